@@ -1,0 +1,4 @@
+"""CPU oracle package -- TEST INFRASTRUCTURE ONLY (see fluca_oracle.c header).
+
+Importable only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+"""

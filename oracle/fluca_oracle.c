@@ -1,0 +1,930 @@
+/*
+ * fluca_oracle.c -- CPU restatement of Fluca's pressure-Poisson path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under fluca_amd/ (the product) may call,
+ * link or import this file.  Only tests/, __graft_entry__.smoke() and the
+ * `cpu_baseline` leg of bench.py use it, and only as the checker / the timed
+ * CPU baseline -- never as the thing shipped.
+ *
+ * What it restates (file:line relative to /root/reference/):
+ *   - staggered divergence  D    fluca/src/ns/impl/linearcn/cnlinearcart3d.c:2314-2408
+ *   - staggered gradient    Gst  cnlinearcart3d.c:2410-2600 (rows), scaled by
+ *                                dt/rho at cnlinearcart3d.c:2907
+ *   - Gst boundary vector        cnlinearcart3d.c:2602-2805
+ *   - cell pressure gradient G   cnlinearcart3d.c:4-217 (x block shown; y,z alike)
+ *   - 1-D stencil rows           fluca/src/ns/utils/cartdiscret.c:3-137,425-476
+ *   - Schur complement S = D((-T)G - (-R)) == -kappa D Gst   (Ainv = ID)
+ *                                fluca/src/ns/utils/abfpc/abfpc.c:150-171
+ *   - PCApply_ABF stage 1/2      abfpc.c:71-101
+ *   - constant null space        abfpc.c:173-177, nsbasic.c:214-244
+ *
+ * PARITY PIN STATUS
+ *   operator coefficients : pinned by the reference's own FlucaFD golden files
+ *                           (fluca/tests/fd/output/<case>.out, copied as data into
+ *                           tests/golden/flucafd/), see tests/test_oracle_golden.py
+ *   Krylov solve          : PARITY UNPINNED.  The solve runs inside PETSc
+ *                           (>= 3.23, fluca/CMakeLists.txt:9-11) which is not
+ *                           vendored, not installed here and cannot be built
+ *                           (no network).  KSPCG / KSPBCGS / KSPCHEBYSHEV /
+ *                           PCJACOBI / MatNullSpaceRemove below are restated
+ *                           from PETSc's published algorithms and documented
+ *                           defaults ("unverified vs PETSc source").
+ *
+ * Layouts (all fp64, x fastest):
+ *   cell  (i,j,k)            -> (k*N + j)*M + i
+ *   x-face(i,j,k) i in [0,Fx) -> (k*N + j)*Fx + i        Fx = M+1, or M if periodic
+ *   y-face(i,j,k) j in [0,Fy) -> (k*Fy + j)*M + i        Fy = N+1 / N
+ *   z-face(i,j,k) k in [0,Fz) -> (k*N + j)*M + i         Fz = P+1 / P
+ *   Face f along an axis sits between cells f-1 and f (DMSTAG_LEFT/DOWN/BACK of
+ *   cell f).  On a periodic axis face 0 is also the right face of cell n-1.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+enum { FO_BC_NONE = 0, FO_BC_VELOCITY = 1, FO_BC_PRESSURE_OUTLET = 2, FO_BC_PERIODIC = 3, FO_BC_SYMMETRY = 4 }; /* flucansbc.h:5-11 */
+
+typedef struct {
+  int     n[3];
+  int     periodic[3];
+  int     bc[6]; /* 0 left 1 right 2 down 3 up 4 back 5 front  (cart.c:564-591) */
+  double  kappa; /* dt/rho */
+  double *xf[3]; /* n+1 face coordinates (arrc[i][iprev]) */
+  double *xcbuf[3];
+  double *xc[3]; /* centres, valid for index -1..n (ghosts only meaningful when periodic) */
+  int     nf[3]; /* faces per grid line */
+  int64_t ncell;
+  int64_t nface[3];
+} fo_grid;
+
+typedef struct {
+  int64_t  nrow, nnz;
+  int64_t *rowptr;
+  int32_t *col;
+  double  *val;
+} fo_csr;
+
+/* ------------------------------------------------------------------ grid */
+
+fo_grid *fo_grid_create(const int n[3], const double *xf0, const double *xf1, const double *xf2, const double *xc0, const double *xc1, const double *xc2, const int bc[6], double kappa)
+{
+  const double *xfin[3] = {xf0, xf1, xf2};
+  const double *xcin[3] = {xc0, xc1, xc2};
+  fo_grid      *g       = (fo_grid *)calloc(1, sizeof(*g));
+  for (int d = 0; d < 3; ++d) {
+    int lo = bc[2 * d], hi = bc[2 * d + 1];
+    if ((lo == FO_BC_PERIODIC) != (hi == FO_BC_PERIODIC) || n[d] < 1) {
+      free(g);
+      return NULL;
+    }
+    g->n[d]        = n[d];
+    g->periodic[d] = (lo == FO_BC_PERIODIC);
+    g->bc[2 * d]   = lo;
+    g->bc[2 * d + 1] = hi;
+    g->nf[d]       = n[d] + (g->periodic[d] ? 0 : 1);
+    g->xf[d]       = (double *)malloc(sizeof(double) * (n[d] + 1));
+    memcpy(g->xf[d], xfin[d], sizeof(double) * (n[d] + 1));
+    g->xcbuf[d] = (double *)malloc(sizeof(double) * (n[d] + 2));
+    g->xc[d]    = g->xcbuf[d] + 1;
+    /* cell centres: midpoints (cart.c:136) unless the caller gives them (uniform product coordinates) */
+    for (int i = 0; i < n[d]; ++i) g->xc[d][i] = xcin[d] ? xcin[d][i] : (g->xf[d][i] + g->xf[d][i + 1]) / 2.;
+    double L       = g->xf[d][n[d]] - g->xf[d][0];
+    g->xc[d][-1]   = g->xc[d][n[d] - 1] - L; /* periodic ghost centres */
+    g->xc[d][n[d]] = g->xc[d][0] + L;
+  }
+  g->kappa    = kappa;
+  g->ncell    = (int64_t)n[0] * n[1] * n[2];
+  g->nface[0] = (int64_t)g->nf[0] * n[1] * n[2];
+  g->nface[1] = (int64_t)n[0] * g->nf[1] * n[2];
+  g->nface[2] = (int64_t)n[0] * n[1] * g->nf[2];
+  return g;
+}
+
+void fo_grid_destroy(fo_grid *g)
+{
+  if (!g) return;
+  for (int d = 0; d < 3; ++d) {
+    free(g->xf[d]);
+    free(g->xcbuf[d]);
+  }
+  free(g);
+}
+
+int64_t fo_grid_ncell(const fo_grid *g) { return g->ncell; }
+int64_t fo_grid_nface(const fo_grid *g, int d) { return g->nface[d]; }
+
+/* ------------------------------------------------- 1-D stencil rows (cartdiscret.c) */
+
+/* NSComputeFaceNormalFirstDerivCentralDiff_Cart, cartdiscret.c:444-457 */
+static void facenormal_central(int f, double xW, double xP, int *nc, int col[2], double v[2])
+{
+  v[0]   = -1. / (xP - xW);
+  v[1]   = 1. / (xP - xW);
+  col[0] = f - 1;
+  col[1] = f;
+  *nc    = 2;
+}
+/* NSComputeFaceNormalFirstDerivForwardDiffDirichletCond_Cart, cartdiscret.c:425-442 */
+static void facenormal_fwd_dirichlet(int f, double xw, double xP, double xE, int *nc, int col[2], double v[2])
+{
+  double h1 = xP - xw, h2 = xE - xw;
+  v[0]   = -h2 / (h1 * (h1 - h2));
+  v[1]   = h1 / (h2 * (h1 - h2));
+  col[0] = f;
+  col[1] = f + 1;
+  *nc    = 2;
+}
+/* NSComputeFaceNormalFirstDerivBackwardDiffDirichletCond_Cart, cartdiscret.c:459-476 */
+static void facenormal_bwd_dirichlet(int f, double xWW, double xW, double xw, int *nc, int col[2], double v[2])
+{
+  double h1 = xw - xW, h2 = xw - xWW;
+  v[0]   = -h1 / (h2 * (h1 - h2));
+  v[1]   = h2 / (h1 * (h1 - h2));
+  col[0] = f - 2;
+  col[1] = f - 1;
+  *nc    = 2;
+}
+
+/*
+ * One row of the (unscaled) staggered pressure gradient along axis d at face f.
+ * Follows cnlinearcart3d.c:2446-2480 (x; y at :2499-2533, z at :2552-2586).
+ * Columns are UNWRAPPED cell indices along the axis (-1 on a periodic face 0,
+ * exactly what the reference's stencil holds before DMStag wraps it).
+ * Returns ncols (0 on a VELOCITY/SYMMETRY wall: zero pressure gradient), -1 on
+ * an unsupported BC.
+ */
+int fo_gst_row_1d(const fo_grid *g, int d, int f, int col[2], double v[2])
+{
+  const double *xf = g->xf[d], *xc = g->xc[d];
+  int           n = g->n[d], nc = 0;
+  if (f == 0) {
+    switch (g->bc[2 * d]) {
+    case FO_BC_VELOCITY:
+    case FO_BC_SYMMETRY:
+      break;
+    case FO_BC_PRESSURE_OUTLET:
+      facenormal_fwd_dirichlet(f, xf[f], xc[f], xc[f + 1], &nc, col, v);
+      break;
+    case FO_BC_PERIODIC:
+      facenormal_central(f, xc[f - 1], xc[f], &nc, col, v);
+      break;
+    default:
+      return -1;
+    }
+  } else if (f == n) {
+    switch (g->bc[2 * d + 1]) {
+    case FO_BC_VELOCITY:
+    case FO_BC_SYMMETRY:
+      break;
+    case FO_BC_PRESSURE_OUTLET:
+      facenormal_bwd_dirichlet(f, xc[f - 2], xc[f - 1], xf[f], &nc, col, v);
+      break;
+    default: /* PERIODIC cannot happen: face n does not exist */
+      return -1;
+    }
+  } else {
+    facenormal_central(f, xc[f - 1], xc[f], &nc, col, v);
+  }
+  return nc;
+}
+
+/* Coefficient of the boundary pressure p_b in the Gst boundary vector,
+ * cnlinearcart3d.c:2643-2646 (low side) and :2671-2674 (high side). */
+double fo_gst_bc_coeff_1d(const fo_grid *g, int d, int side)
+{
+  const double *xf = g->xf[d], *xc = g->xc[d];
+  int           n = g->n[d];
+  if (g->bc[2 * d + side] != FO_BC_PRESSURE_OUTLET) return 0.;
+  if (side == 0) {
+    double h1 = xc[0] - xf[0], h2 = xc[1] - xf[0];
+    return -(h1 + h2) / (h1 * h2);
+  } else {
+    double h1 = xf[n] - xc[n - 1], h2 = xf[n] - xc[n - 2];
+    return (h1 + h2) / (h1 * h2);
+  }
+}
+
+/* Divergence row of cell i along axis d: -1/dx on the left face, +1/dx on the
+ * right face (cnlinearcart3d.c:2348-2362).  Faces are UNWRAPPED (i and i+1). */
+void fo_div_row_1d(const fo_grid *g, int d, int i, int face[2], double v[2])
+{
+  double dx = g->xf[d][i + 1] - g->xf[d][i];
+  face[0]   = i;
+  face[1]   = i + 1;
+  v[0]      = -1. / dx;
+  v[1]      = 1. / dx;
+}
+
+/* cell-centred first derivative rows (cartdiscret.c:3-137) used by G */
+static int cellgrad_row_1d(const fo_grid *g, int d, int i, int col[3], double v[3])
+{
+  const double *xf = g->xf[d], *xc = g->xc[d];
+  int           n = g->n[d];
+  double        h1, h2;
+  if (i == 0 && g->bc[2 * d] != FO_BC_PERIODIC) {
+    switch (g->bc[2 * d]) {
+    case FO_BC_VELOCITY: /* NSComputeFirstDerivForwardDiffNoCond_Cart :3-24 */
+      h1 = xc[1] - xc[0];
+      h2 = xc[2] - xc[0];
+      v[0] = -(h1 + h2) / (h1 * h2);
+      v[1] = -h2 / (h1 * (h1 - h2));
+      v[2] = h1 / (h2 * (h1 - h2));
+      col[0] = 0; col[1] = 1; col[2] = 2;
+      return 3;
+    case FO_BC_PRESSURE_OUTLET: /* ...ForwardDiffDirichletCond :26-43 */
+      h1 = xc[0] - xf[0];
+      h2 = xc[1] - xc[0];
+      v[0] = (h2 - h1) / (h1 * h2);
+      v[1] = h1 / (h2 * (h1 + h2));
+      col[0] = 0; col[1] = 1;
+      return 2;
+    case FO_BC_SYMMETRY: /* ...ForwardDiffNeumannCond :45-62 */
+      h1 = xc[0] - xf[0];
+      h2 = xc[1] - xc[0];
+      v[0] = -2. * h1 / (h2 * (2. * h1 + h2));
+      v[1] = 2. * h1 / (h2 * (2. * h1 + h2));
+      col[0] = 0; col[1] = 1;
+      return 2;
+    default:
+      return -1;
+    }
+  } else if (i == n - 1 && g->bc[2 * d + 1] != FO_BC_PERIODIC) {
+    switch (g->bc[2 * d + 1]) {
+    case FO_BC_VELOCITY: /* ...BackwardDiffNoCond :79-100 */
+      h1 = xc[i] - xc[i - 1];
+      h2 = xc[i] - xc[i - 2];
+      v[0] = -h1 / (h2 * (h1 - h2));
+      v[1] = h2 / (h1 * (h1 - h2));
+      v[2] = (h1 + h2) / (h1 * h2);
+      col[0] = i - 2; col[1] = i - 1; col[2] = i;
+      return 3;
+    case FO_BC_PRESSURE_OUTLET: /* ...BackwardDiffDirichletCond :102-119 */
+      h1 = xf[i + 1] - xc[i];
+      h2 = xc[i] - xc[i - 1];
+      v[0] = -h1 / (h2 * (h1 + h2));
+      v[1] = (h1 - h2) / (h1 * h2);
+      col[0] = i - 1; col[1] = i;
+      return 2;
+    case FO_BC_SYMMETRY: /* ...BackwardDiffNeumannCond :120-137 */
+      h1 = xf[i + 1] - xc[i];
+      h2 = xc[i] - xc[i - 1];
+      v[0] = -2. * h1 / (h2 * (2. * h1 + h2));
+      v[1] = 2. * h1 / (h2 * (2. * h1 + h2));
+      col[0] = i - 1; col[1] = i;
+      return 2;
+    default:
+      return -1;
+    }
+  }
+  /* NSComputeFirstDerivCentralDiff_Cart :64-77 (interior and periodic) */
+  v[0]   = -1. / (xc[i + 1] - xc[i - 1]);
+  v[1]   = 1. / (xc[i + 1] - xc[i - 1]);
+  col[0] = i - 1;
+  col[1] = i + 1;
+  return 2;
+}
+
+/* --------------------------------------------------------- index helpers */
+
+static inline int wrap(int i, int n) { return i < 0 ? i + n : (i >= n ? i - n : i); }
+
+static inline int64_t cell_index(const fo_grid *g, int i, int j, int k) { return ((int64_t)k * g->n[1] + j) * g->n[0] + i; }
+
+static inline int64_t face_index(const fo_grid *g, int d, int i, int j, int k)
+{
+  /* (i,j,k) with the d-th entry being the face number, already wrapped */
+  switch (d) {
+  case 0:
+    return ((int64_t)k * g->n[1] + j) * g->nf[0] + i;
+  case 1:
+    return ((int64_t)k * g->nf[1] + j) * g->n[0] + i;
+  default:
+    return ((int64_t)k * g->n[1] + j) * g->n[0] + i;
+  }
+}
+
+/* ------------------------------------------- S = D * (-kappa Gst), assembled CSR */
+
+/*
+ * Builds S exactly the way the reference gets it (abfpc.c:150-171 with
+ * Ainv = ID): row of D (6 entries) times the rows of tmp = -(kappa*Gst).
+ * The (-T)G - (-R) detour of the reference cancels to -kappa*Gst up to
+ * round-off; its O(eps) ghost entries at i+-2 are not reproduced.
+ */
+fo_csr *fo_assemble_S(const fo_grid *g)
+{
+  fo_csr *A  = (fo_csr *)calloc(1, sizeof(*A));
+  A->nrow    = g->ncell;
+  A->rowptr  = (int64_t *)malloc(sizeof(int64_t) * (A->nrow + 1));
+  int64_t cap = A->nrow * 7 + 16;
+  A->col     = (int32_t *)malloc(sizeof(int32_t) * cap);
+  A->val     = (double *)malloc(sizeof(double) * cap);
+  int64_t nnz = 0;
+  for (int k = 0; k < g->n[2]; ++k)
+    for (int j = 0; j < g->n[1]; ++j)
+      for (int i = 0; i < g->n[0]; ++i) {
+        int     idx[3] = {i, j, k};
+        int64_t ecol[12];
+        double  eval[12];
+        int     ne  = 0;
+        int64_t row = cell_index(g, i, j, k);
+        A->rowptr[row] = nnz;
+        for (int d = 0; d < 3; ++d) {
+          int    face[2];
+          double dv[2];
+          fo_div_row_1d(g, d, idx[d], face, dv);
+          for (int s = 0; s < 2; ++s) {
+            int    gc[2], nc;
+            double gv[2];
+            int    f = face[s];
+            if (g->periodic[d] && f == g->n[d]) f = 0; /* right face of the last cell is face 0 */
+            nc = fo_gst_row_1d(g, d, f, gc, gv);
+            for (int c = 0; c < nc; ++c) {
+              int cidx[3] = {i, j, k};
+              int cc      = gc[c];
+              /* face f==0 reached as the right face of cell n-1: its stencil cells are (-1,0) == (n-1, 0) */
+              cidx[d]     = wrap(cc, g->n[d]);
+              ecol[ne]    = cell_index(g, cidx[0], cidx[1], cidx[2]);
+              eval[ne]    = dv[s] * (-(g->kappa * gv[c]));
+              ++ne;
+            }
+          }
+        }
+        /* sort by column, merge duplicates */
+        for (int a = 1; a < ne; ++a) {
+          int64_t c = ecol[a];
+          double  v = eval[a];
+          int     b = a - 1;
+          while (b >= 0 && ecol[b] > c) {
+            ecol[b + 1] = ecol[b];
+            eval[b + 1] = eval[b];
+            --b;
+          }
+          ecol[b + 1] = c;
+          eval[b + 1] = v;
+        }
+        for (int a = 0; a < ne;) {
+          int64_t c = ecol[a];
+          double  v = 0.;
+          while (a < ne && ecol[a] == c) v += eval[a++];
+          if (nnz >= cap) {
+            cap    = cap * 2;
+            A->col = (int32_t *)realloc(A->col, sizeof(int32_t) * cap);
+            A->val = (double *)realloc(A->val, sizeof(double) * cap);
+          }
+          A->col[nnz] = (int32_t)c;
+          A->val[nnz] = v;
+          ++nnz;
+        }
+      }
+  A->rowptr[A->nrow] = nnz;
+  A->nnz             = nnz;
+  return A;
+}
+
+void fo_csr_destroy(fo_csr *A)
+{
+  if (!A) return;
+  free(A->rowptr);
+  free(A->col);
+  free(A->val);
+  free(A);
+}
+int64_t        fo_csr_nnz(const fo_csr *A) { return A->nnz; }
+int64_t        fo_csr_nrow(const fo_csr *A) { return A->nrow; }
+const int64_t *fo_csr_rowptr(const fo_csr *A) { return A->rowptr; }
+const int32_t *fo_csr_col(const fo_csr *A) { return A->col; }
+const double  *fo_csr_val(const fo_csr *A) { return A->val; }
+
+void fo_csr_mult(const fo_csr *A, const double *x, double *y)
+{
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < A->nrow; ++r) {
+    double s = 0.;
+    for (int64_t p = A->rowptr[r]; p < A->rowptr[r + 1]; ++p) s += A->val[p] * x[A->col[p]];
+    y[r] = s;
+  }
+}
+
+void fo_csr_diag(const fo_csr *A, double *d)
+{
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < A->nrow; ++r) {
+    double s = 0.;
+    for (int64_t p = A->rowptr[r]; p < A->rowptr[r + 1]; ++p)
+      if (A->col[p] == r) s = A->val[p];
+    d[r] = s;
+  }
+}
+
+/* ------------------------------------------- matrix-free pieces of PCApply_ABF */
+
+/* b = contrhs - D V   (abfpc.c:75-76; contrhs may be NULL == 0, cnlinearcart3d.c:3035) */
+void fo_rhs(const fo_grid *g, const double *Vx, const double *Vy, const double *Vz, const double *contrhs, double *b)
+{
+  const double *V[3] = {Vx, Vy, Vz};
+#pragma omp parallel for schedule(static)
+  for (int k = 0; k < g->n[2]; ++k)
+    for (int j = 0; j < g->n[1]; ++j)
+      for (int i = 0; i < g->n[0]; ++i) {
+        int    idx[3] = {i, j, k};
+        double s      = 0.;
+        for (int d = 0; d < 3; ++d) {
+          int    face[2], fi[3];
+          double dv[2];
+          fo_div_row_1d(g, d, idx[d], face, dv);
+          for (int t = 0; t < 2; ++t) {
+            fi[0] = i; fi[1] = j; fi[2] = k;
+            fi[d] = (g->periodic[d] && face[t] == g->n[d]) ? 0 : face[t];
+            s += dv[t] * V[d][face_index(g, d, fi[0], fi[1], fi[2])];
+          }
+        }
+        int64_t c = cell_index(g, i, j, k);
+        b[c]      = (contrhs ? contrhs[c] : 0.) - s;
+      }
+}
+
+/* G_d = kappa * Gst p on the faces of axis d (homogeneous part, MatScale at cnlinearcart3d.c:2907) */
+void fo_apply_gst(const fo_grid *g, const double *p, double *Gx, double *Gy, double *Gz)
+{
+  double *G[3] = {Gx, Gy, Gz};
+  for (int d = 0; d < 3; ++d) {
+    int nn[3] = {g->n[0], g->n[1], g->n[2]};
+    nn[d]     = g->nf[d];
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < nn[2]; ++k)
+      for (int j = 0; j < nn[1]; ++j)
+        for (int i = 0; i < nn[0]; ++i) {
+          int    fi[3] = {i, j, k}, col[2], nc;
+          double v[2], s = 0.;
+          nc = fo_gst_row_1d(g, d, fi[d], col, v);
+          for (int c = 0; c < nc; ++c) {
+            int ci[3] = {i, j, k};
+            ci[d]     = wrap(col[c], g->n[d]);
+            s += g->kappa * v[c] * p[cell_index(g, ci[0], ci[1], ci[2])];
+          }
+          G[d][face_index(g, d, i, j, k)] = s;
+        }
+  }
+}
+
+/* w_d = kappa * (G p)_d at cell centres, d = 0,1,2 (cnlinearcart3d.c:4-217, MatScale :2890) */
+int fo_apply_G(const fo_grid *g, const double *p, double *wx, double *wy, double *wz)
+{
+  double *W[3] = {wx, wy, wz};
+  int     err  = 0;
+  for (int d = 0; d < 3; ++d) {
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < g->n[2]; ++k)
+      for (int j = 0; j < g->n[1]; ++j)
+        for (int i = 0; i < g->n[0]; ++i) {
+          int    ci[3] = {i, j, k}, col[3], nc;
+          double v[3], s = 0.;
+          nc = cellgrad_row_1d(g, d, ci[d], col, v);
+          if (nc < 0) {
+            err = 1;
+            continue;
+          }
+          for (int c = 0; c < nc; ++c) {
+            int cc[3] = {i, j, k};
+            cc[d]     = wrap(col[c], g->n[d]);
+            s += g->kappa * v[c] * p[cell_index(g, cc[0], cc[1], cc[2])];
+          }
+          W[d][cell_index(g, i, j, k)] = s;
+        }
+  }
+  return err;
+}
+
+/* ------------------------------------------------------------------- KSP */
+
+enum { FO_KSP_CG = 0, FO_KSP_BCGS = 1, FO_KSP_CHEBYSHEV = 2 };
+enum { FO_PC_NONE = 0, FO_PC_JACOBI = 1 };
+enum { FO_NORM_PRECONDITIONED = 0, FO_NORM_UNPRECONDITIONED = 1, FO_NORM_NATURAL = 2, FO_NORM_NONE = 3 };
+/* KSPConvergedReason values (petscksp.h) */
+enum {
+  FO_CONVERGED_RTOL          = 2,
+  FO_CONVERGED_ATOL          = 3,
+  FO_CONVERGED_ITS           = 4,
+  FO_DIVERGED_ITS            = -3,
+  FO_DIVERGED_DTOL           = -4,
+  FO_DIVERGED_BREAKDOWN      = -5,
+  FO_DIVERGED_INDEFINITE_PC  = -8,
+  FO_DIVERGED_NANORINF       = -9,
+  FO_DIVERGED_INDEFINITE_MAT = -10
+};
+
+typedef struct {
+  int    type, pc, norm_type;
+  int    remove_nullspace; /* constant null space attached to S (abfpc.c:173-177) */
+  int    maxit;
+  double rtol, atol, dtol;
+  double emin, emax; /* Chebyshev bounds of the preconditioned operator; both 0 -> Gershgorin estimate * (0.1, 1.1) */
+} fo_ksp_opts;
+
+typedef struct {
+  int    iters, reason;
+  double rnorm0, rnorm, seconds;
+} fo_ksp_stats;
+
+static double now_seconds(void)
+{
+#ifdef _OPENMP
+  return omp_get_wtime();
+#else
+  return 0.;
+#endif
+}
+
+int fo_num_threads(void)
+{
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+/* deterministic for a given thread count: static schedule + ordered combine */
+static double vdot(int64_t n, const double *a, const double *b)
+{
+  double s = 0.;
+#pragma omp parallel for schedule(static) reduction(+ : s)
+  for (int64_t i = 0; i < n; ++i) s += a[i] * b[i];
+  return s;
+}
+static double vsum(int64_t n, const double *a)
+{
+  double s = 0.;
+#pragma omp parallel for schedule(static) reduction(+ : s)
+  for (int64_t i = 0; i < n; ++i) s += a[i];
+  return s;
+}
+static void vaxpy(int64_t n, double a, const double *x, double *y)
+{
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) y[i] += a * x[i];
+}
+static void vaypx(int64_t n, double a, const double *x, double *y) /* y = x + a y */
+{
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) y[i] = x[i] + a * y[i];
+}
+static void vcopy(int64_t n, const double *x, double *y)
+{
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) y[i] = x[i];
+}
+static void vset(int64_t n, double a, double *y)
+{
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) y[i] = a;
+}
+
+/* MatNullSpaceRemove for the constant null space: y -= mean(y) */
+void fo_remove_constant(int64_t n, double *y)
+{
+  double m = vsum(n, y) / (double)n;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) y[i] -= m;
+}
+
+/* KSP_PCApply: z = B r, then null-space removal */
+static void pc_apply(const fo_ksp_opts *o, int64_t n, const double *dinv, const double *r, double *z)
+{
+  if (o->pc == FO_PC_JACOBI) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) z[i] = r[i] * dinv[i]; /* PCJACOBI: VecPointwiseMult with the stored inverse diagonal */
+  } else {
+    vcopy(n, r, z);
+  }
+  if (o->remove_nullspace) fo_remove_constant(n, z);
+}
+
+/* KSPConvergedDefault (zero initial guess): ttol = max(rtol*rnorm0, atol) */
+static int converged_default(const fo_ksp_opts *o, int it, double rnorm, double *rnorm0, double *ttol)
+{
+  if (it == 0) {
+    *rnorm0 = rnorm;
+    *ttol   = fmax(o->rtol * rnorm, o->atol);
+  }
+  if (isnan(rnorm) || isinf(rnorm)) return FO_DIVERGED_NANORINF;
+  if (rnorm <= *ttol) return (rnorm < o->atol) ? FO_CONVERGED_ATOL : FO_CONVERGED_RTOL;
+  if (rnorm >= o->dtol * *rnorm0) return FO_DIVERGED_DTOL;
+  return 0;
+}
+
+/* Gershgorin bound of the Jacobi-preconditioned operator: max_i sum_j |a_ij| / |a_ii| */
+double fo_gershgorin_dinvA(const fo_csr *A, int pc)
+{
+  double m = 0.;
+  for (int64_t r = 0; r < A->nrow; ++r) {
+    double s = 0., d = 1.;
+    for (int64_t p = A->rowptr[r]; p < A->rowptr[r + 1]; ++p) {
+      s += fabs(A->val[p]);
+      if (A->col[p] == r) d = fabs(A->val[p]);
+    }
+    if (pc != FO_PC_JACOBI) d = 1.;
+    if (s / d > m) m = s / d;
+  }
+  return m;
+}
+
+/*
+ * KSPSolve(kspS, b, x) with zero initial guess (abfpc.c:77).
+ * hist (may be NULL) receives the monitored norm of iterations 0..iters, at most nhist entries.
+ */
+int fo_ksp_solve(const fo_csr *A, const double *b, double *x, const fo_ksp_opts *o, fo_ksp_stats *st, double *hist, int nhist)
+{
+  int64_t n    = A->nrow;
+  double *dinv = (double *)malloc(sizeof(double) * n);
+  double  t0, rnorm0 = 0., ttol = 0., dp = 0.;
+  int     it = 0, reason = 0;
+
+  fo_csr_diag(A, dinv);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) dinv[i] = 1. / dinv[i];
+  vset(n, 0., x);
+  t0 = now_seconds();
+
+  if (o->type == FO_KSP_CG) {
+    /* KSPCG, Hestenes-Stiefel, left preconditioning */
+    double *r = (double *)malloc(sizeof(double) * n), *z = (double *)malloc(sizeof(double) * n);
+    double *p = (double *)malloc(sizeof(double) * n), *w = (double *)malloc(sizeof(double) * n);
+    double  beta, betaold = 1., a, dpi;
+    vcopy(n, b, r); /* r = b - A*0 */
+    pc_apply(o, n, dinv, r, z);
+    beta = vdot(n, r, z);
+    switch (o->norm_type) {
+    case FO_NORM_PRECONDITIONED: dp = sqrt(vdot(n, z, z)); break;
+    case FO_NORM_UNPRECONDITIONED: dp = sqrt(vdot(n, r, r)); break;
+    case FO_NORM_NATURAL: dp = sqrt(fabs(beta)); break;
+    default: dp = 0.;
+    }
+    if (hist && 0 < nhist) hist[0] = dp;
+    reason = converged_default(o, 0, dp, &rnorm0, &ttol);
+    while (!reason) {
+      if (it >= o->maxit) {
+        reason = FO_DIVERGED_ITS;
+        break;
+      }
+      if (beta < 0.) {
+        reason = FO_DIVERGED_INDEFINITE_PC;
+        break;
+      }
+      if (it == 0) vcopy(n, z, p);
+      else vaypx(n, beta / betaold, z, p); /* p = z + (beta/betaold) p */
+      betaold = beta;
+      fo_csr_mult(A, p, w);
+      dpi = vdot(n, p, w);
+      if (dpi <= 0.) {
+        reason = FO_DIVERGED_INDEFINITE_MAT;
+        break;
+      }
+      a = beta / dpi;
+      vaxpy(n, a, p, x);
+      vaxpy(n, -a, w, r);
+      pc_apply(o, n, dinv, r, z);
+      beta = vdot(n, r, z);
+      switch (o->norm_type) {
+      case FO_NORM_PRECONDITIONED: dp = sqrt(vdot(n, z, z)); break;
+      case FO_NORM_UNPRECONDITIONED: dp = sqrt(vdot(n, r, r)); break;
+      case FO_NORM_NATURAL: dp = sqrt(fabs(beta)); break;
+      default: dp = 0.;
+      }
+      ++it;
+      if (hist && it < nhist) hist[it] = dp;
+      reason = converged_default(o, it, dp, &rnorm0, &ttol);
+    }
+    free(r); free(z); free(p); free(w);
+  } else if (o->type == FO_KSP_BCGS) {
+    /* KSPBCGS (van der Vorst), left preconditioning: iterates on B A, shadow residual = initial residual */
+    double *R = (double *)malloc(sizeof(double) * n), *RP = (double *)malloc(sizeof(double) * n);
+    double *P = (double *)calloc(n, sizeof(double)), *V = (double *)calloc(n, sizeof(double));
+    double *S = (double *)malloc(sizeof(double) * n), *T = (double *)malloc(sizeof(double) * n), *tmp = (double *)malloc(sizeof(double) * n);
+    double  rho, rhoold = 1., alpha = 1., omega, omegaold = 1., beta, d1, d2;
+    pc_apply(o, n, dinv, b, R); /* R = B (b - A*0) */
+    dp = sqrt(vdot(n, R, R));
+    if (hist && 0 < nhist) hist[0] = dp;
+    reason = converged_default(o, 0, dp, &rnorm0, &ttol);
+    vcopy(n, R, RP);
+    while (!reason) {
+      if (it >= o->maxit) {
+        reason = FO_DIVERGED_ITS;
+        break;
+      }
+      rho = vdot(n, R, RP);
+      if (rho == 0.) {
+        reason = FO_DIVERGED_BREAKDOWN;
+        break;
+      }
+      beta = (rho / rhoold) * (alpha / omegaold);
+#pragma omp parallel for schedule(static)
+      for (int64_t i = 0; i < n; ++i) P[i] = R[i] - omegaold * beta * V[i] + beta * P[i]; /* VecAXPBYPCZ */
+      fo_csr_mult(A, P, tmp);
+      pc_apply(o, n, dinv, tmp, V);
+      d1 = vdot(n, V, RP);
+      if (d1 == 0.) {
+        reason = FO_DIVERGED_BREAKDOWN;
+        break;
+      }
+      alpha = rho / d1;
+#pragma omp parallel for schedule(static)
+      for (int64_t i = 0; i < n; ++i) S[i] = R[i] - alpha * V[i]; /* VecWAXPY */
+      fo_csr_mult(A, S, tmp);
+      pc_apply(o, n, dinv, tmp, T);
+      d1 = vdot(n, S, T);
+      d2 = vdot(n, T, T);
+      if (d2 == 0.) {
+        /* S == 0: x + alpha P is the solution */
+        vaxpy(n, alpha, P, x);
+        ++it;
+        dp = 0.;
+        if (hist && it < nhist) hist[it] = dp;
+        reason = FO_CONVERGED_RTOL;
+        break;
+      }
+      omega = d1 / d2;
+#pragma omp parallel for schedule(static)
+      for (int64_t i = 0; i < n; ++i) {
+        x[i] += alpha * P[i] + omega * S[i]; /* VecAXPBYPCZ */
+        R[i] = S[i] - omega * T[i];          /* VecWAXPY */
+      }
+      dp       = sqrt(vdot(n, R, R));
+      rhoold   = rho;
+      omegaold = omega;
+      ++it;
+      if (hist && it < nhist) hist[it] = dp;
+      reason = converged_default(o, it, dp, &rnorm0, &ttol);
+    }
+    free(R); free(RP); free(P); free(V); free(S); free(T); free(tmp);
+  } else if (o->type == FO_KSP_CHEBYSHEV) {
+    /* KSPCHEBYSHEV three-term recurrence, left preconditioning */
+    double  emin = o->emin, emax = o->emax;
+    double *pkm1 = (double *)malloc(sizeof(double) * n), *pk = (double *)malloc(sizeof(double) * n), *pkp1 = (double *)malloc(sizeof(double) * n);
+    double *r = (double *)malloc(sizeof(double) * n), *z = (double *)malloc(sizeof(double) * n);
+    double  scale, alpha, Gamma, mu, omegaprod, ckm1, ck, ckp1, omega;
+    if (emin == 0. && emax == 0.) {
+      double lam = fo_gershgorin_dinvA(A, o->pc);
+      emin       = 0.1 * lam; /* -ksp_chebyshev_esteig 0,0.1,0,1.1 applied to the bound */
+      emax       = 1.1 * lam;
+    }
+    scale     = 2. / (emax + emin);
+    alpha     = 1. - scale * emin;
+    Gamma     = 1.;
+    mu        = 1. / alpha;
+    omegaprod = 2. / alpha;
+    ckm1      = 1.;
+    ck        = mu;
+    vset(n, 0., pkm1);      /* p[km1] = x = 0 */
+    pc_apply(o, n, dinv, b, z); /* z = B (b - A x) */
+    switch (o->norm_type) {
+    case FO_NORM_PRECONDITIONED: dp = sqrt(vdot(n, z, z)); break;
+    case FO_NORM_UNPRECONDITIONED: dp = sqrt(vdot(n, b, b)); break;
+    default: dp = 0.;
+    }
+    if (hist && 0 < nhist) hist[0] = dp;
+    reason = (o->norm_type == FO_NORM_NONE) ? 0 : converged_default(o, 0, dp, &rnorm0, &ttol);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) pk[i] = scale * z[i] + pkm1[i]; /* VecAYPX(p[k], scale, p[km1]) */
+    if (!reason && o->maxit <= 0) reason = (o->norm_type == FO_NORM_NONE) ? FO_CONVERGED_ITS : FO_DIVERGED_ITS;
+    while (!reason) {
+      double *t;
+      ++it;
+      /* r = b - A p[k] */
+      fo_csr_mult(A, pk, r);
+#pragma omp parallel for schedule(static)
+      for (int64_t i = 0; i < n; ++i) r[i] = b[i] - r[i];
+      pc_apply(o, n, dinv, r, z);
+      if (o->norm_type != FO_NORM_NONE) {
+        dp = (o->norm_type == FO_NORM_UNPRECONDITIONED) ? sqrt(vdot(n, r, r)) : sqrt(vdot(n, z, z));
+        if (hist && it < nhist) hist[it] = dp;
+        reason = converged_default(o, it, dp, &rnorm0, &ttol);
+        if (reason) break; /* solution is p[k] */
+      }
+      if (it >= o->maxit) {
+        reason = (o->norm_type == FO_NORM_NONE) ? FO_CONVERGED_ITS : FO_DIVERGED_ITS;
+        break;
+      }
+      ckp1  = 2. * mu * ck - ckm1;
+      omega = omegaprod * ck / ckp1;
+#pragma omp parallel for schedule(static)
+      for (int64_t i = 0; i < n; ++i) pkp1[i] = (1. - omega) * pkm1[i] + omega * pk[i] + omega * Gamma * scale * z[i];
+      ckm1 = ck;
+      ck   = ckp1;
+      t    = pkm1;
+      pkm1 = pk;
+      pk   = pkp1;
+      pkp1 = t;
+    }
+    vcopy(n, pk, x);
+    free(pkm1); free(pk); free(pkp1); free(r); free(z);
+  } else {
+    free(dinv);
+    return -1;
+  }
+  st->seconds = now_seconds() - t0;
+  st->iters   = it;
+  st->reason  = reason;
+  st->rnorm0  = rnorm0;
+  st->rnorm   = dp;
+  free(dinv);
+  return 0;
+}
+
+/* ----------------------------------------------------------------- IBM (own spec; no reference counterpart) */
+
+enum { FO_DELTA_PESKIN4 = 0, FO_DELTA_ROMA3 = 1 };
+
+static double phi_peskin4(double r)
+{
+  r = fabs(r);
+  if (r <= 1.) return (3. - 2. * r + sqrt(1. + 4. * r - 4. * r * r)) / 8.;
+  if (r <= 2.) return (5. - 2. * r - sqrt(-7. + 12. * r - 4. * r * r)) / 8.;
+  return 0.;
+}
+static double phi_roma3(double r)
+{
+  r = fabs(r);
+  if (r <= 0.5) return (1. + sqrt(1. - 3. * r * r)) / 3.;
+  if (r <= 1.5) return (5. - 3. * r - sqrt(1. - 3. * (1. - r) * (1. - r))) / 6.;
+  return 0.;
+}
+
+/* support of marker coordinate X along axis d: first cell index i0 and weights w[0..S) (phi only, the
+ * 1/h of delta_h cancels against the h of the quadrature); S = 4 or 3.  Uniform spacing required. */
+static int ibm_weights_1d(const fo_grid *g, int d, int kind, double X, int *i0, double w[4])
+{
+  int    S  = (kind == FO_DELTA_PESKIN4) ? 4 : 3;
+  double h  = (g->xf[d][g->n[d]] - g->xf[d][0]) / g->n[d];
+  double s  = (X - g->xf[d][0]) / h - 0.5; /* position in cell-centre index units */
+  int    i  = (kind == FO_DELTA_PESKIN4) ? (int)floor(s) - 1 : (int)floor(s + 0.5) - 1;
+  for (int a = 0; a < S; ++a) {
+    double r = s - (double)(i + a);
+    w[a]     = (kind == FO_DELTA_PESKIN4) ? phi_peskin4(r) : phi_roma3(r);
+  }
+  *i0 = i;
+  return S;
+}
+
+/* U_l = sum_x u(x) delta_h(x - X_l) h^3 ; u has ncomp components, component-major u[c*ncell + cell].
+ * Cells outside a non-periodic domain contribute nothing. */
+void fo_ibm_interp(const fo_grid *g, int kind, int64_t L, const double *X, const double *Y, const double *Z, int ncomp, const double *u, double *U)
+{
+#pragma omp parallel for schedule(static)
+  for (int64_t l = 0; l < L; ++l) {
+    int    i0[3], S;
+    double w[3][4];
+    S = ibm_weights_1d(g, 0, kind, X[l], &i0[0], w[0]);
+    ibm_weights_1d(g, 1, kind, Y[l], &i0[1], w[1]);
+    ibm_weights_1d(g, 2, kind, Z[l], &i0[2], w[2]);
+    for (int c = 0; c < ncomp; ++c) {
+      double s = 0.;
+      for (int c3 = 0; c3 < S; ++c3)
+        for (int b = 0; b < S; ++b)
+          for (int a = 0; a < S; ++a) {
+            int ii = i0[0] + a, jj = i0[1] + b, kk = i0[2] + c3;
+            if (g->periodic[0]) ii = ((ii % g->n[0]) + g->n[0]) % g->n[0];
+            if (g->periodic[1]) jj = ((jj % g->n[1]) + g->n[1]) % g->n[1];
+            if (g->periodic[2]) kk = ((kk % g->n[2]) + g->n[2]) % g->n[2];
+            if (ii < 0 || ii >= g->n[0] || jj < 0 || jj >= g->n[1] || kk < 0 || kk >= g->n[2]) continue;
+            s += w[0][a] * w[1][b] * w[2][c3] * u[(int64_t)c * g->ncell + cell_index(g, ii, jj, kk)];
+          }
+      U[(int64_t)c * L + l] = s;
+    }
+  }
+}
+
+/* f(x) += sum_l F_l delta_h(x - X_l) dV_l ; delta_h = prod phi(r_d)/h_d.  Serial over markers (deterministic). */
+void fo_ibm_spread(const fo_grid *g, int kind, int64_t L, const double *X, const double *Y, const double *Z, const double *dV, int ncomp, const double *F, double *f)
+{
+  double hx = (g->xf[0][g->n[0]] - g->xf[0][0]) / g->n[0];
+  double hy = (g->xf[1][g->n[1]] - g->xf[1][0]) / g->n[1];
+  double hz = (g->xf[2][g->n[2]] - g->xf[2][0]) / g->n[2];
+  double ih = 1. / (hx * hy * hz);
+  for (int64_t l = 0; l < L; ++l) {
+    int    i0[3], S;
+    double w[3][4];
+    S = ibm_weights_1d(g, 0, kind, X[l], &i0[0], w[0]);
+    ibm_weights_1d(g, 1, kind, Y[l], &i0[1], w[1]);
+    ibm_weights_1d(g, 2, kind, Z[l], &i0[2], w[2]);
+    for (int c3 = 0; c3 < S; ++c3)
+      for (int b = 0; b < S; ++b)
+        for (int a = 0; a < S; ++a) {
+          int ii = i0[0] + a, jj = i0[1] + b, kk = i0[2] + c3;
+          if (g->periodic[0]) ii = ((ii % g->n[0]) + g->n[0]) % g->n[0];
+          if (g->periodic[1]) jj = ((jj % g->n[1]) + g->n[1]) % g->n[1];
+          if (g->periodic[2]) kk = ((kk % g->n[2]) + g->n[2]) % g->n[2];
+          if (ii < 0 || ii >= g->n[0] || jj < 0 || jj >= g->n[1] || kk < 0 || kk >= g->n[2]) continue;
+          double wt = w[0][a] * w[1][b] * w[2][c3] * ih * dV[l];
+          for (int c = 0; c < ncomp; ++c) f[(int64_t)c * g->ncell + cell_index(g, ii, jj, kk)] += wt * F[(int64_t)c * L + l];
+        }
+  }
+}
+
+double fo_ibm_phi(int kind, double r) { return kind == FO_DELTA_PESKIN4 ? phi_peskin4(r) : phi_roma3(r); }

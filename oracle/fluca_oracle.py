@@ -1,0 +1,245 @@
+"""ctypes front end of oracle/libfluca_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+The product package (fluca_amd/) must never import this module.  See the header
+of fluca_oracle.c for what is restated and for the parity-pin status
+(operator coefficients: pinned by the FlucaFD goldens; Krylov solve: PARITY
+UNPINNED -- PETSc is absent).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+BC_NONE, BC_VELOCITY, BC_PRESSURE_OUTLET, BC_PERIODIC, BC_SYMMETRY = range(5)
+KSP_CG, KSP_BCGS, KSP_CHEBYSHEV = range(3)
+PC_NONE, PC_JACOBI = range(2)
+NORM_PRECONDITIONED, NORM_UNPRECONDITIONED, NORM_NATURAL, NORM_NONE = range(4)
+DELTA_PESKIN4, DELTA_ROMA3 = range(2)
+
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+
+
+class KspOpts(C.Structure):
+    _fields_ = [("type", C.c_int), ("pc", C.c_int), ("norm_type", C.c_int), ("remove_nullspace", C.c_int),
+                ("maxit", C.c_int), ("rtol", C.c_double), ("atol", C.c_double), ("dtol", C.c_double),
+                ("emin", C.c_double), ("emax", C.c_double)]
+
+
+class KspStats(C.Structure):
+    _fields_ = [("iters", C.c_int), ("reason", C.c_int), ("rnorm0", C.c_double), ("rnorm", C.c_double),
+                ("seconds", C.c_double)]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libfluca_oracle.so")
+    src = os.path.join(_HERE, "fluca_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libfluca_oracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        ip3 = C.POINTER(C.c_int)
+        L.fo_grid_create.restype = C.c_void_p
+        L.fo_grid_create.argtypes = [ip3] + [C.c_void_p] * 6 + [ip3, C.c_double]
+        L.fo_grid_destroy.argtypes = [C.c_void_p]
+        L.fo_grid_ncell.restype = C.c_int64
+        L.fo_grid_ncell.argtypes = [C.c_void_p]
+        L.fo_grid_nface.restype = C.c_int64
+        L.fo_grid_nface.argtypes = [C.c_void_p, C.c_int]
+        L.fo_gst_row_1d.restype = C.c_int
+        L.fo_gst_row_1d.argtypes = [C.c_void_p, C.c_int, C.c_int, ip3, C.POINTER(C.c_double)]
+        L.fo_gst_bc_coeff_1d.restype = C.c_double
+        L.fo_gst_bc_coeff_1d.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.fo_div_row_1d.argtypes = [C.c_void_p, C.c_int, C.c_int, ip3, C.POINTER(C.c_double)]
+        L.fo_assemble_S.restype = C.c_void_p
+        L.fo_assemble_S.argtypes = [C.c_void_p]
+        L.fo_csr_destroy.argtypes = [C.c_void_p]
+        for f in ("fo_csr_nnz", "fo_csr_nrow"):
+            getattr(L, f).restype = C.c_int64
+            getattr(L, f).argtypes = [C.c_void_p]
+        for f in ("fo_csr_rowptr", "fo_csr_col", "fo_csr_val"):
+            getattr(L, f).restype = C.c_void_p
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.fo_csr_mult.argtypes = [C.c_void_p, _dp, _dp]
+        L.fo_csr_diag.argtypes = [C.c_void_p, _dp]
+        L.fo_rhs.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_void_p, _dp]
+        L.fo_apply_gst.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
+        L.fo_apply_G.restype = C.c_int
+        L.fo_apply_G.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
+        L.fo_remove_constant.argtypes = [C.c_int64, _dp]
+        L.fo_gershgorin_dinvA.restype = C.c_double
+        L.fo_gershgorin_dinvA.argtypes = [C.c_void_p, C.c_int]
+        L.fo_ksp_solve.restype = C.c_int
+        L.fo_ksp_solve.argtypes = [C.c_void_p, _dp, _dp, C.POINTER(KspOpts), C.POINTER(KspStats), C.c_void_p, C.c_int]
+        L.fo_num_threads.restype = C.c_int
+        L.fo_ibm_interp.argtypes = [C.c_void_p, C.c_int, C.c_int64, _dp, _dp, _dp, C.c_int, _dp, _dp]
+        L.fo_ibm_spread.argtypes = [C.c_void_p, C.c_int, C.c_int64, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp]
+        L.fo_ibm_phi.restype = C.c_double
+        L.fo_ibm_phi.argtypes = [C.c_int, C.c_double]
+        _LIB = L
+    return _LIB
+
+
+def uniform_coords(n, lo, hi):
+    """DMStagSetUniformCoordinatesProduct: face = lo + i*h, centre = lo + (i+0.5)*h (PETSc docs; unverified vs source)."""
+    h = (hi - lo) / n
+    xf = lo + np.arange(n + 1, dtype=np.float64) * h
+    xc = lo + (np.arange(n, dtype=np.float64) + 0.5) * h
+    return xf, xc
+
+
+class Grid:
+    """Cartesian grid + NS boundary conditions + kappa = dt/rho."""
+
+    def __init__(self, n, xf, bc, kappa=1.0, xc=None):
+        L = lib()
+        self.n = tuple(int(v) for v in n)
+        self.xf = [np.ascontiguousarray(a, dtype=np.float64) for a in xf]
+        self.xc = [None if (xc is None or xc[d] is None) else np.ascontiguousarray(xc[d], dtype=np.float64) for d in range(3)]
+        self.bc = tuple(int(b) for b in bc)
+        self.kappa = float(kappa)
+        for d in range(3):
+            assert self.xf[d].shape == (self.n[d] + 1,)
+        n3 = (C.c_int * 3)(*self.n)
+        bc6 = (C.c_int * 6)(*self.bc)
+        ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        self.h = L.fo_grid_create(n3, ptr(self.xf[0]), ptr(self.xf[1]), ptr(self.xf[2]), ptr(self.xc[0]), ptr(self.xc[1]),
+                                  ptr(self.xc[2]), bc6, self.kappa)
+        if not self.h:
+            raise ValueError("invalid grid / boundary conditions")
+        self.periodic = tuple(self.bc[2 * d] == BC_PERIODIC for d in range(3))
+        self.nf = tuple(self.n[d] + (0 if self.periodic[d] else 1) for d in range(3))
+        self.ncell = L.fo_grid_ncell(self.h)
+        self.nface = tuple(L.fo_grid_nface(self.h, d) for d in range(3))
+
+    @classmethod
+    def uniform(cls, n, box, bc, kappa=1.0):
+        xf, xc = zip(*[uniform_coords(n[d], box[d][0], box[d][1]) for d in range(3)])
+        return cls(n, xf, bc, kappa, xc)
+
+    def __del__(self):
+        try:
+            lib().fo_grid_destroy(self.h)
+        except Exception:
+            pass
+
+    # 1-D rows -----------------------------------------------------------
+    def gst_row(self, d, f):
+        col = (C.c_int * 2)()
+        v = (C.c_double * 2)()
+        nc = lib().fo_gst_row_1d(self.h, d, f, col, v)
+        return [(col[i], v[i]) for i in range(nc)]
+
+    def gst_bc_coeff(self, d, side):
+        return lib().fo_gst_bc_coeff_1d(self.h, d, side)
+
+    def div_row(self, d, i):
+        col = (C.c_int * 2)()
+        v = (C.c_double * 2)()
+        lib().fo_div_row_1d(self.h, d, i, col, v)
+        return [(col[0], v[0]), (col[1], v[1])]
+
+    # operators ----------------------------------------------------------
+    def assemble_S(self):
+        return Csr(lib().fo_assemble_S(self.h))
+
+    def rhs(self, Vx, Vy, Vz, contrhs=None):
+        b = np.empty(self.ncell)
+        cp = None if contrhs is None else np.ascontiguousarray(contrhs, dtype=np.float64).ctypes.data_as(C.c_void_p)
+        lib().fo_rhs(self.h, Vx, Vy, Vz, cp, b)
+        return b
+
+    def apply_gst(self, p):
+        G = [np.empty(self.nface[d]) for d in range(3)]
+        lib().fo_apply_gst(self.h, p, *G)
+        return G
+
+    def apply_G(self, p):
+        W = [np.empty(self.ncell) for _ in range(3)]
+        if lib().fo_apply_G(self.h, p, *W):
+            raise ValueError("unsupported BC in G")
+        return W
+
+    # IBM ----------------------------------------------------------------
+    def ibm_interp(self, kind, X, u):
+        X = [np.ascontiguousarray(a, dtype=np.float64) for a in X]
+        u = np.ascontiguousarray(u, dtype=np.float64).reshape(-1, self.ncell)
+        U = np.empty((u.shape[0], X[0].size))
+        lib().fo_ibm_interp(self.h, kind, X[0].size, X[0], X[1], X[2], u.shape[0], u, U)
+        return U
+
+    def ibm_spread(self, kind, X, dV, F, f=None):
+        X = [np.ascontiguousarray(a, dtype=np.float64) for a in X]
+        F = np.ascontiguousarray(F, dtype=np.float64).reshape(-1, X[0].size)
+        dV = np.ascontiguousarray(np.broadcast_to(dV, X[0].shape), dtype=np.float64)
+        if f is None:
+            f = np.zeros((F.shape[0], self.ncell))
+        lib().fo_ibm_spread(self.h, kind, X[0].size, X[0], X[1], X[2], dV, F.shape[0], F, f)
+        return f
+
+
+class Csr:
+    def __init__(self, h):
+        self.h = h
+        L = lib()
+        self.nrow = L.fo_csr_nrow(h)
+        self.nnz = L.fo_csr_nnz(h)
+
+    def __del__(self):
+        try:
+            lib().fo_csr_destroy(self.h)
+        except Exception:
+            pass
+
+    def arrays(self):
+        L = lib()
+        rp = np.ctypeslib.as_array(C.cast(L.fo_csr_rowptr(self.h), C.POINTER(C.c_int64)), (self.nrow + 1,)).copy()
+        col = np.ctypeslib.as_array(C.cast(L.fo_csr_col(self.h), C.POINTER(C.c_int32)), (self.nnz,)).copy()
+        val = np.ctypeslib.as_array(C.cast(L.fo_csr_val(self.h), C.POINTER(C.c_double)), (self.nnz,)).copy()
+        return rp, col, val
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        rp, col, val = self.arrays()
+        return sp.csr_matrix((val, col, rp), shape=(self.nrow, self.nrow))
+
+    def mult(self, x):
+        y = np.empty(self.nrow)
+        lib().fo_csr_mult(self.h, np.ascontiguousarray(x, dtype=np.float64), y)
+        return y
+
+    def diag(self):
+        d = np.empty(self.nrow)
+        lib().fo_csr_diag(self.h, d)
+        return d
+
+    def gershgorin(self, pc=PC_JACOBI):
+        return lib().fo_gershgorin_dinvA(self.h, pc)
+
+    def solve(self, b, ksp=KSP_CG, pc=PC_JACOBI, norm=NORM_PRECONDITIONED, nullspace=True, rtol=1e-5, atol=1e-50,
+              dtol=1e5, maxit=10000, emin=0.0, emax=0.0, history=True):
+        """KSPSolve(kspS, b, x) with PETSc defaults (rtol 1e-5, atol 1e-50, dtol 1e5, maxit 1e4, zero guess)."""
+        o = KspOpts(ksp, pc, norm, int(nullspace), int(maxit), rtol, atol, dtol, emin, emax)
+        st = KspStats()
+        x = np.empty(self.nrow)
+        hist = np.full(int(maxit) + 2, np.nan) if history else None
+        rc = lib().fo_ksp_solve(self.h, np.ascontiguousarray(b, dtype=np.float64), x, C.byref(o), C.byref(st),
+                                None if hist is None else hist.ctypes.data_as(C.c_void_p), 0 if hist is None else hist.size)
+        if rc:
+            raise ValueError("unknown KSP type")
+        info = dict(iters=st.iters, reason=st.reason, rnorm0=st.rnorm0, rnorm=st.rnorm, seconds=st.seconds)
+        if history:
+            info["history"] = hist[:st.iters + 1].copy()
+        return x, info
+
+
+def num_threads():
+    return lib().fo_num_threads()
