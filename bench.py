@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""bench.py -- pressure-Poisson Krylov iterations/s on MI355X (BASELINE.json metric).
+
+A "step" is ONE Jacobi-PCG iteration of KSPSolve(kspS) (fluca/src/ns/utils/abfpc/abfpc.c:77) on the cavity-flow
+Schur complement (BCs of fluca/tests/cavity_flow/cavity_flow_3d.c:72-77, box [0,1]x[0,1]x[0,0.5], kappa = dt/rho = 1e-3)
+with a 512^3 block of cells per GPU (weak scaling: N GPUs hold a (512 rx) x (512 ry) x (512 rz) grid, split like the
+reference's -cart_ranks_{x,y,z}).  Right-hand side: SURVEY 8d micro-benchmark b = S p*, p* seeded uniform(-1,1); fixed
+iteration count (rtol = atol = 0), inputs resident in HBM before the timed region.
+
+One JSON line on rank 0.  value = (cells of the whole job / 512^3) * K / seconds  ==  iterations/s of a 512^3 grid at N=1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); measured streaming peak ~6290 GB/s
+B_ITER_ALGO = 88               # algorithmic bytes / cell / PCG iteration
+B_KERNEL_A_ALGO = 64           # of those, the textbook steps k_cg_A fuses: direction 24 + SpMV/dot 16 + x-update 24
+B_KERNEL_A_REAL = 48           # what k_cg_A actually moves: reads r,p,x  writes p,q,x
+RANK_GRIDS = {1: (1, 1, 1), 2: (1, 1, 2), 4: (1, 2, 2), 8: (2, 2, 2)}
+
+
+def cpu_baseline(sample_n, iters):
+    """The oracle (CPU restatement: assembled CSR + PETSc-style PCG, OpenMP) timed on this box's host cores."""
+    from oracle import fluca_oracle as fo
+    bc = [fo.BC_VELOCITY] * 4 + [fo.BC_SYMMETRY, fo.BC_VELOCITY]
+    n = (sample_n,) * 3
+    g = fo.Grid.uniform(n, [(0, 1), (0, 1), (0, 0.5)], bc, 1e-3)
+    S = g.assemble_S()
+    rng = np.random.default_rng(20260313)
+    p = rng.uniform(-1, 1, g.ncell)
+    p -= p.mean()
+    b = S.mult(p)
+    _, info = S.solve(b, rtol=0.0, atol=0.0, maxit=iters, history=False)
+    its_per_s = info["iters"] / info["seconds"]
+    return {"value": its_per_s * (sample_n ** 3) / 512.0 ** 3, "unit": "512^3-equivalent PCG iterations/s",
+            "cores": fo.num_threads(), "kind": "port",
+            "sample": f"{sample_n}^3 cavity grid (1/{(512 // sample_n) ** 3} of the cells), {info['iters']} Jacobi-PCG iterations, "
+                      f"assembled CSR (AIJ cost model), {info['seconds']:.2f} s, raw {its_per_s:.3f} it/s on the sample",
+            "host_GBps_at_104B_per_row": 104.0 * sample_n ** 3 * its_per_s / 1e9}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--n", type=int, default=512, help="cells per axis per GPU")
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--cpu-n", type=int, default=256)
+    ap.add_argument("--cpu-iters", type=int, default=40)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    assert args.gpus in RANK_GRIDS, "supported: 1, 2, 4, 8 GPUs"
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)   # control plane only; data path = RCCL inside the library
+
+    from fluca_amd import poisson as flp
+    from fluca_amd.capi import BC_SYMMETRY, BC_VELOCITY
+
+    ranks = RANK_GRIDS[args.gpus]
+    n = tuple(args.n * r for r in ranks)
+    bc = [BC_VELOCITY] * 4 + [BC_SYMMETRY, BC_VELOCITY]
+    box = [(0.0, 1.0), (0.0, 1.0), (0.0, 0.5)]
+    dec = flp.default_decomp(n, ranks, rank) if world > 1 else None
+    P = flp.Poisson.uniform(n, box, bc, 1e-3, decomp=dec, device=local)
+    if world > 1:
+        idb = [flp.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(idb, src=0)
+        P.comm_init_rccl(idb[0], rank, world)
+    stream = torch.cuda.Stream()
+    P.set_stream(stream)
+
+    gen = torch.Generator(device="cuda").manual_seed(20260313 + rank)
+    pstar = torch.rand(P.ncell, generator=gen, dtype=torch.float64, device="cuda") * 2 - 1
+    stream.wait_stream(torch.cuda.current_stream())
+    b = P.apply(pstar)           # b = S p*  (consistent by construction; exercises the halo exchange when N > 1)
+    x = P.empty()
+    P.synchronize()
+
+    def run(iters, profile):
+        return P.solve(b, x=x, rtol=0.0, atol=0.0, maxit=iters, variant=args.variant, profile=int(profile), check_every=64)[1]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        run(args.warmup, False)
+    barrier()
+    t0 = time.perf_counter()
+    info = run(args.steps, True)
+    P.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    assert info["iters"] == args.steps, info
+
+    cells_job = float(P.ncell) * world
+    value = cells_job / 512.0 ** 3 * args.steps / dt
+    ka_ms = info["kernel_ms"]
+    achieved = B_KERNEL_A_ALGO * P.ncell / (ka_ms * 1e-3) / 1e9 if ka_ms > 0 else None
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_k_cg_A.json")     # written from a rocprofv3 --pmc pass (see profiles/README.md)
+    if os.path.exists(pmc) and args.n == 512:
+        try:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "pressure-Poisson Jacobi-PCG iterations/s, 512^3 cells per GPU",
+        "value": value, "unit": "512^3-equivalent PCG iterations/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{n[0]}x{n[1]}x{n[2]} lid-driven-cavity Schur complement S=-kappa*D*Gst (7-pt, Neumann), "
+                               f"matrix-free Jacobi-PCG with constant-null-space removal, b=S*p* seeded, fixed {args.steps} iterations",
+                   "cells_per_gpu": int(P.ncell), "rank_grid": list(ranks), "variant": "fused" if args.variant == 0 else "unfused",
+                   "halo": "RCCL Send/Recv" if world > 1 else "none"},
+        "iteration_algorithmic_GBps_per_gpu": B_ITER_ALGO * P.ncell * args.steps / dt / 1e9,
+        "solve_seconds_device": info["seconds"],
+        "roofline": {"bound": "hbm", "kernel": "k_cg_A (p-update + S*p + dot + deferred x-update)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                     "algorithmic_bytes_per_cell": B_KERNEL_A_ALGO, "moved_bytes_per_cell": B_KERNEL_A_REAL,
+                     "avg_launch_ms": ka_ms, "launches_timed": info["kernel_launches"],
+                     "moved_GBps": (B_KERNEL_A_REAL * P.ncell / (ka_ms * 1e-3) / 1e9) if ka_ms > 0 else None},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_iters)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    P.close()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

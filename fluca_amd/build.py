@@ -1,0 +1,49 @@
+"""Builds libflucahip.so (HIP kernels + C-ABI) in-tree with hipcc for gfx950.
+
+No fallback: if hipcc is missing or the compile fails this raises.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libflucahip.so")
+SOURCES = ["fl_coeff.cpp", "fl_kernels.hip", "fl_api.hip", "fl_ksp.hip", "fl_ibm.hip"]
+HEADERS = ["fl_internal.h", os.path.join("..", "..", "include", "fluca_hip.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-Wno-unused-result"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    objs = []
+    for s in srcs:
+        o = os.path.join(LIBDIR, os.path.basename(s) + ".o")
+        if force or _stale(o, [s] + hdrs):
+            cmd = [HIPCC] + FLAGS + (["-x", "hip"] if s.endswith(".hip") else []) + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        objs.append(o)
+    if force or _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-Wl,-rpath,/opt/rocm/lib", "-ldl"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

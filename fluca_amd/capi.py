@@ -1,0 +1,99 @@
+"""ctypes binding of include/fluca_hip.h (the C-ABI).  Loads fluca_amd/lib/libflucahip.so; raises if it is absent.
+
+torch is imported first on purpose: libflucahip.so needs libamdhip64.so.7, and inside a torch process the copy torch
+already loaded must be the one that resolves (one HIP runtime per process).
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (loads the process-wide HIP runtime first)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libflucahip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `python -m fluca_amd.build` (hipcc --offload-arch=gfx950). "
+        "There is no CPU fallback for the product path.")
+
+lib = C.CDLL(LIB_PATH)
+
+BC_NONE, BC_VELOCITY, BC_PRESSURE_OUTLET, BC_PERIODIC, BC_SYMMETRY = range(5)
+KSP_CG, KSP_BCGS, KSP_CHEBYSHEV = range(3)
+PC_NONE, PC_JACOBI = range(2)
+NORM_PRECONDITIONED, NORM_UNPRECONDITIONED, NORM_NATURAL, NORM_NONE = range(4)
+DELTA_PESKIN4, DELTA_ROMA3 = range(2)
+UNIQUE_ID_BYTES = 128
+
+ERRORS = {0: "FL_SUCCESS", -55: "FL_ERR_MEM", -56: "FL_ERR_SUP", -60: "FL_ERR_ARG_SIZ", -62: "FL_ERR_ARG_WRONG",
+          -63: "FL_ERR_ARG_OUTOFRANGE", -73: "FL_ERR_ARG_WRONGSTATE", -76: "FL_ERR_LIB", -85: "FL_ERR_ARG_NULL",
+          -91: "FL_ERR_NOT_CONVERGED", -97: "FL_ERR_GPU"}
+
+
+class FlucaError(RuntimeError):
+    def __init__(self, rc, what):
+        super().__init__(f"{what} -> {ERRORS.get(rc, rc)} ({rc})")
+        self.rc = rc
+
+
+def check(rc, what="libflucahip"):
+    if rc != 0:
+        raise FlucaError(rc, what)
+
+
+class fl_grid(C.Structure):
+    _fields_ = [("n", C.c_int64 * 3), ("xf", C.c_void_p * 3), ("xc", C.c_void_p * 3)]
+
+
+class fl_decomp(C.Structure):
+    _fields_ = [("ranks", C.c_int * 3), ("coord", C.c_int * 3), ("lo", C.c_int64 * 3), ("len", C.c_int64 * 3)]
+
+
+class fl_ksp_opts(C.Structure):
+    _fields_ = [("type", C.c_int), ("pc", C.c_int), ("norm_type", C.c_int), ("remove_nullspace", C.c_int),
+                ("maxit", C.c_int), ("rtol", C.c_double), ("atol", C.c_double), ("dtol", C.c_double),
+                ("emin", C.c_double), ("emax", C.c_double), ("variant", C.c_int), ("check_every", C.c_int),
+                ("profile", C.c_int), ("history", C.POINTER(C.c_double)), ("nhistory", C.c_int)]
+
+
+class fl_ksp_stats(C.Structure):
+    _fields_ = [("iters", C.c_int), ("reason", C.c_int), ("rnorm0", C.c_double), ("rnorm", C.c_double),
+                ("seconds", C.c_double), ("kernel_ms", C.c_double), ("kernel_launches", C.c_int)]
+
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                          C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64))
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
+
+# every symbol include/fluca_hip.h declares (tests/test_capi_symbols.py checks the header against this table)
+_P = C.c_void_p
+PROTOTYPES = {
+    "fl_poisson_create": (C.c_int, [C.POINTER(fl_grid), C.POINTER(C.c_int), C.c_double, C.POINTER(fl_decomp), C.c_int, C.POINTER(_P)]),
+    "fl_poisson_destroy": (C.c_int, [_P]),
+    "fl_poisson_set_stream": (C.c_int, [_P, _P]),
+    "fl_poisson_synchronize": (C.c_int, [_P]),
+    "fl_poisson_sizes": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "fl_ksp_opts_default": (None, [C.POINTER(fl_ksp_opts)]),
+    "fl_version": (C.c_char_p, []),
+    "fl_poisson_apply": (C.c_int, [_P, _P, _P]),
+    "fl_poisson_diagonal": (C.c_int, [_P, _P]),
+    "fl_poisson_solve": (C.c_int, [_P, _P, _P, C.POINTER(fl_ksp_opts), C.POINTER(fl_ksp_stats)]),
+    "fl_poisson_rhs": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "fl_poisson_project": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "fl_poisson_gst_bc": (C.c_int, [_P, C.c_int, _P, _P]),
+    "fl_pressure_update": (C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
+    "fl_comm_unique_id": (C.c_int, [_P]),
+    "fl_poisson_comm_init_rccl": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "fl_poisson_comm_init_host": (C.c_int, [_P, EXCHANGE_FN, ALLREDUCE_FN, _P, C.c_int, C.c_int]),
+    "fl_decomp_default": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int), C.c_int, C.POINTER(fl_decomp)]),
+    "fl_decomp_neighbor": (C.c_int, [C.POINTER(fl_decomp), C.POINTER(C.c_int), C.c_int]),
+    "fl_ibm_create": (C.c_int, [_P, C.c_int, C.c_int64, _P, _P, _P, C.POINTER(_P)]),
+    "fl_ibm_update": (C.c_int, [_P, _P, _P, _P]),
+    "fl_ibm_interp": (C.c_int, [_P, C.c_int, _P, _P]),
+    "fl_ibm_spread": (C.c_int, [_P, C.c_int, _P, _P, _P]),
+    "fl_ibm_destroy": (C.c_int, [_P]),
+}
+for _name, (_res, _args) in PROTOTYPES.items():
+    _f = getattr(lib, _name)  # AttributeError if the library lacks a declared symbol
+    _f.restype = _res
+    _f.argtypes = _args

@@ -1,0 +1,604 @@
+// fl_api.hip -- C-ABI entry points of libflucahip.so (see include/fluca_hip.h), handle management, the Krylov drivers
+// and the two halo transports (RCCL Send/Recv; host-staged callbacks).
+#include "fl_handle.h"
+
+int fl_dev_alloc(fl_poisson *h, void **p, size_t bytes, bool zero)
+{
+  FL_HIP(hipMalloc(p, bytes ? bytes : 8));
+  if (zero) FL_HIP(hipMemsetAsync(*p, 0, bytes ? bytes : 8, h->stream));
+  return 0;
+}
+
+template <class T>
+static int upload_table(fl_poisson *h, const std::vector<T> &host, const T **dev, int shift)
+{
+  void *p = nullptr;
+  FL_HIP(hipMalloc(&p, sizeof(T) * std::max<size_t>(host.size(), 1)));
+  FL_HIP(hipMemcpy(p, host.data(), sizeof(T) * host.size(), hipMemcpyHostToDevice));
+  h->tables.push_back(p);
+  *dev = (const T *)p + shift;
+  return 0;
+}
+
+static int face_count(const fl_poisson *h, int d) { return d == 0 ? h->g.fx : (d == 1 ? h->g.fy : h->g.fz); }
+static int plane_size(const fl_poisson *h, int d)
+{
+  const GridP &g = h->g;
+  return d == 0 ? g.ny * g.nz : (d == 1 ? g.nx * g.nz : g.nx * g.ny);
+}
+
+extern "C" const char *fl_version(void) { return "fluca_amd 0.1 (gfx950)"; }
+
+extern "C" void fl_ksp_opts_default(fl_ksp_opts *o)
+{
+  if (!o) return;
+  std::memset(o, 0, sizeof(*o));
+  o->type             = FL_KSP_CG;
+  o->pc               = FL_PC_JACOBI;
+  o->norm_type        = FL_NORM_PRECONDITIONED;
+  o->remove_nullspace = 1;
+  o->maxit            = 10000;
+  o->rtol             = 1e-5;
+  o->atol             = 1e-50;
+  o->dtol             = 1e5;
+  o->check_every      = 16;
+}
+
+extern "C" int fl_poisson_create(const fl_grid *grid, const int bc[6], double kappa, const fl_decomp *decomp, int device, fl_poisson **out)
+{
+  if (!grid || !bc || !out) return FL_ERR_ARG_NULL;
+  *out = nullptr;
+  for (int d = 0; d < 3; ++d)
+    if (grid->n[d] < 1 || grid->n[d] > (int64_t)1 << 30 || !grid->xf[d]) return FL_ERR_ARG_OUTOFRANGE;
+  if (!(kappa > 0.) || !std::isfinite(kappa)) return FL_ERR_ARG_OUTOFRANGE;
+  fl_poisson *h = new fl_poisson();
+  h->device     = device;
+  h->kappa      = kappa;
+  std::memcpy(h->bc, bc, sizeof(int) * 6);
+  for (int d = 0; d < 3; ++d) {
+    int rc = build_axis(h->ax[d], grid->n[d], grid->xf[d], grid->xc[d], bc[2 * d], bc[2 * d + 1], kappa);
+    if (rc) {
+      delete h;
+      return rc;
+    }
+  }
+  if (decomp) h->dec = *decomp;
+  else
+    for (int d = 0; d < 3; ++d) {
+      h->dec.ranks[d] = 1;
+      h->dec.coord[d] = 0;
+      h->dec.lo[d]    = 0;
+      h->dec.len[d]   = grid->n[d];
+    }
+  int periodic[3];
+  for (int d = 0; d < 3; ++d) {
+    const fl_decomp &D = h->dec;
+    periodic[d]        = h->ax[d].periodic;
+    if (D.ranks[d] < 1 || D.coord[d] < 0 || D.coord[d] >= D.ranks[d] || D.len[d] < 1 || D.lo[d] < 0 || D.lo[d] + D.len[d] > grid->n[d] || D.len[d] > 100000) {
+      delete h;
+      return FL_ERR_ARG_OUTOFRANGE;
+    }
+    if ((D.coord[d] == 0) != (D.lo[d] == 0) || (D.coord[d] == D.ranks[d] - 1) != (D.lo[d] + D.len[d] == grid->n[d])) {
+      delete h;
+      return FL_ERR_ARG_WRONG;
+    }
+    h->wrap_local[d] = periodic[d] && D.ranks[d] == 1;
+  }
+  h->multi = h->dec.ranks[0] * h->dec.ranks[1] * h->dec.ranks[2] > 1;
+  for (int b = 0; b < 6; ++b) h->nbr[b] = h->multi ? fl_decomp_neighbor(&h->dec, periodic, b) : -1;
+
+  FL_HIP(hipSetDevice(device));
+  FL_HIP(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+  h->stream = h->own_stream;
+  FL_HIP(hipEventCreate(&h->ev0));
+  FL_HIP(hipEventCreate(&h->ev1));
+
+  // ---- local tables ---------------------------------------------------------------------------------------------
+  GridP &g = h->g;
+  std::memset(&g, 0, sizeof(g));
+  g.nx = (int)h->dec.len[0];
+  g.ny = (int)h->dec.len[1];
+  g.nz = (int)h->dec.len[2];
+  int fl_[3];
+  for (int d = 0; d < 3; ++d) {
+    const bool last = h->dec.coord[d] == h->dec.ranks[d] - 1;
+    fl_[d]          = (int)h->dec.len[d] + ((last && !h->ax[d].periodic) ? 1 : 0);
+  }
+  g.fx    = fl_[0];
+  g.fy    = fl_[1];
+  g.fz    = fl_[2];
+  g.sx    = ((PADX + g.nx + 1 + 15) / 16) * 16;
+  g.sxy   = (int64_t)g.sx * (g.ny + 2);
+  g.off0  = g.sxy + g.sx + PADX;
+  g.kappa = kappa;
+  h->padlen = (size_t)g.sxy * (g.nz + 2) + 256;
+  h->ncell  = (int64_t)g.nx * g.ny * g.nz;
+  h->nface[0] = (int64_t)g.fx * g.ny * g.nz;
+  h->nface[1] = (int64_t)g.nx * g.fy * g.nz;
+  h->nface[2] = (int64_t)g.nx * g.ny * g.fz;
+  const double inf = std::numeric_limits<double>::infinity();
+  for (int d = 0; d < 3; ++d) {
+    const Axis   &A  = h->ax[d];
+    const int64_t lo = h->dec.lo[d], len = h->dec.len[d], n = A.n;
+    std::vector<double> sl(len + 2), sc(len + 2), sh(len + 2), idx(len);
+    for (int64_t i = -1; i <= len; ++i) {
+      int64_t gi = lo + i;
+      bool    in = true;
+      if (gi < 0 || gi >= n) {
+        if (A.periodic) gi = (gi + n) % n;
+        else in = false;
+      }
+      sl[i + 1] = in ? A.sl[gi] : 0.;
+      sc[i + 1] = in ? A.sc[gi] : inf;  // wall ghost: 1/diag = 0
+      sh[i + 1] = in ? A.sh[gi] : 0.;
+    }
+    for (int64_t i = 0; i < len; ++i) idx[i] = A.idx[lo + i];
+    std::vector<double> ga0(fl_[d]), ga1(fl_[d]);
+    std::vector<int>    gc0(fl_[d]);
+    for (int f = 0; f < fl_[d]; ++f) {
+      ga0[f] = A.ga0[lo + f];
+      ga1[f] = A.ga1[lo + f];
+      gc0[f] = (int)(A.gc0[lo + f] - lo);
+    }
+    std::vector<int>    Gs(len);
+    std::vector<double> Gv0(len), Gv1(len), Gv2(len);
+    for (int64_t i = 0; i < len; ++i) {
+      Gs[i]  = (int)(A.Gs[lo + i] - lo);
+      Gv0[i] = A.Gv0[lo + i];
+      Gv1[i] = A.Gv1[lo + i];
+      Gv2[i] = A.Gv2[lo + i];
+      if (Gs[i] < -1 || Gs[i] + (Gv2[i] != 0. ? 2 : 1) > len) {
+        // a one-sided wall row that leaves the block + its single ghost layer
+        fl_poisson_destroy(h);
+        return FL_ERR_SUP;
+      }
+    }
+    int rc = 0;
+    rc |= upload_table(h, sl, &g.sl[d], 1);
+    rc |= upload_table(h, sc, &g.sc[d], 1);
+    rc |= upload_table(h, sh, &g.sh[d], 1);
+    rc |= upload_table(h, idx, &g.idx[d], 0);
+    rc |= upload_table(h, ga0, &g.ga0[d], 0);
+    rc |= upload_table(h, ga1, &g.ga1[d], 0);
+    rc |= upload_table(h, gc0, &g.gc0[d], 0);
+    rc |= upload_table(h, Gs, &g.Gs[d], 0);
+    rc |= upload_table(h, Gv0, &g.Gv0[d], 0);
+    rc |= upload_table(h, Gv1, &g.Gv1[d], 0);
+    rc |= upload_table(h, Gv2, &g.Gv2[d], 0);
+    if (rc) {
+      fl_poisson_destroy(h);
+      return FL_ERR_GPU;
+    }
+  }
+  FL_HIP(hipMalloc((void **)&h->scal, sizeof(KspScal)));
+  FL_HIP(hipHostMalloc((void **)&h->scal_host, sizeof(KspScal)));
+  FL_HIP(hipMalloc((void **)&h->sums, sizeof(double) * NSLOT));
+  *out = h;
+  return FL_SUCCESS;
+}
+
+extern "C" int fl_poisson_destroy(fl_poisson *h)
+{
+  if (!h) return FL_SUCCESS;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  h->comm.destroy();
+  for (void *p : h->tables) (void)hipFree(p);
+  for (double *p : {h->r, h->P0, h->P1, h->q, h->xp, h->w0, h->w1, h->w2, h->partial, h->sums, h->hist})
+    if (p) (void)hipFree(p);
+  for (int b = 0; b < 6; ++b) {
+    if (h->fsend[b]) (void)hipFree(h->fsend[b]);
+    if (h->frecv[b]) (void)hipFree(h->frecv[b]);
+  }
+  for (int d = 0; d < 3; ++d) {
+    if (h->hiface[d]) (void)hipFree(h->hiface[d]);
+    if (h->loface_send[d]) (void)hipFree(h->loface_send[d]);
+  }
+  if (h->scal) (void)hipFree(h->scal);
+  if (h->scal_host) (void)hipHostFree(h->scal_host);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+  return FL_SUCCESS;
+}
+
+extern "C" int fl_poisson_set_stream(fl_poisson *h, void *hip_stream)
+{
+  if (!h) return FL_ERR_ARG_NULL;
+  h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+  return FL_SUCCESS;
+}
+
+extern "C" int fl_poisson_synchronize(fl_poisson *h)
+{
+  if (!h) return FL_ERR_ARG_NULL;
+  FL_HIP(hipStreamSynchronize(h->stream));
+  return FL_SUCCESS;
+}
+
+extern "C" int fl_poisson_sizes(const fl_poisson *h, int64_t out[4])
+{
+  if (!h || !out) return FL_ERR_ARG_NULL;
+  out[0] = h->ncell;
+  out[1] = h->nface[0];
+  out[2] = h->nface[1];
+  out[3] = h->nface[2];
+  return FL_SUCCESS;
+}
+
+// ------------------------------------------------------------------------------------------------ workspace / ghosts
+
+int fl_ensure_vec(fl_poisson *h, double **v)
+{
+  if (*v) return 0;
+  return fl_dev_alloc(h, (void **)v, sizeof(double) * h->padlen, true);
+}
+
+int fl_ensure_hist(fl_poisson *h, int nhist)
+{
+  if (h->hist_cap >= nhist) return 0;
+  if (h->hist) {
+    FL_HIP(hipStreamSynchronize(h->stream));
+    FL_HIP(hipFree(h->hist));
+    h->hist = nullptr;
+  }
+  FL_CHK(fl_dev_alloc(h, (void **)&h->hist, sizeof(double) * nhist, true));
+  h->hist_cap = nhist;
+  return 0;
+}
+
+int fl_ensure_partials(fl_poisson *h, int nblocks)
+{
+  const int want = std::max(nblocks, (int)MAX_PARTIAL_BLOCKS);
+  if (h->partial && h->partial_stride >= want) return 0;
+  if (h->partial) {
+    FL_HIP(hipStreamSynchronize(h->stream));
+    FL_HIP(hipFree(h->partial));
+    h->partial = nullptr;
+  }
+  FL_CHK(fl_dev_alloc(h, (void **)&h->partial, sizeof(double) * (size_t)want * NSLOT, true));
+  h->partial_stride = want;
+  return 0;
+}
+
+static int ensure_facebufs(fl_poisson *h)
+{
+  for (int b = 0; b < 6; ++b) {
+    if (h->nbr[b] < 0 || h->wrap_local[b / 2] || h->fsend[b]) continue;
+    const size_t n = (size_t)plane_size(h, b / 2);
+    FL_CHK(fl_dev_alloc(h, (void **)&h->fsend[b], sizeof(double) * n, true));
+    FL_CHK(fl_dev_alloc(h, (void **)&h->frecv[b], sizeof(double) * n, true));
+  }
+  return 0;
+}
+
+// ghosts of a padded vector: local periodic images + neighbour ranks' boundary cells (DMGlobalToLocal of the reference)
+int fl_fill_ghosts(fl_poisson *h, double *v)
+{
+  const GridP &g = h->g;
+  for (int d = 0; d < 3; ++d)
+    if (h->wrap_local[d]) launch_wrap(h->stream, g, v, d);
+  if (!h->multi) return 0;
+  if (h->comm.kind == Comm::NONE) return FL_ERR_ARG_WRONGSTATE;
+  FL_CHK(ensure_facebufs(h));
+  std::vector<Msg> msgs;
+  for (int d = 0; d < 3; ++d) {
+    if (h->wrap_local[d]) continue;
+    const int lo = h->nbr[2 * d], hi = h->nbr[2 * d + 1];
+    const int64_t n = plane_size(h, d);
+    // step 1: my high face -> high neighbour's low ghost; my low ghost <- low neighbour's high face
+    // step 2: my low face  -> low neighbour's high ghost; my high ghost <- high neighbour's low face
+    // (posting order matters for RCCL: messages between one pair of ranks match in order)
+    if (hi >= 0) launch_pack(h->stream, g, v, h->fsend[2 * d + 1], d, 1);
+    if (lo >= 0) launch_pack(h->stream, g, v, h->fsend[2 * d], d, 0);
+    if (hi >= 0 && lo >= 0 && hi == lo) {
+      msgs.push_back({hi, h->fsend[2 * d + 1], h->frecv[2 * d], n, 2 * d + 1, 2 * d + 1});
+      msgs.push_back({lo, h->fsend[2 * d], h->frecv[2 * d + 1], n, 2 * d, 2 * d});
+    } else {
+      if (hi >= 0) msgs.push_back({hi, h->fsend[2 * d + 1], h->frecv[2 * d + 1], n, 2 * d + 1, 2 * d});
+      if (lo >= 0) msgs.push_back({lo, h->fsend[2 * d], h->frecv[2 * d], n, 2 * d, 2 * d + 1});
+    }
+  }
+  FL_CHK(h->comm.exchange(h->stream, msgs));
+  for (int d = 0; d < 3; ++d) {
+    if (h->wrap_local[d]) continue;
+    if (h->nbr[2 * d] >= 0) launch_unpack(h->stream, g, v, h->frecv[2 * d], d, 0);
+    if (h->nbr[2 * d + 1] >= 0) launch_unpack(h->stream, g, v, h->frecv[2 * d + 1], d, 1);
+  }
+  return 0;
+}
+
+bool fl_any_ghost_exchange(const fl_poisson *h) { return h->multi || h->wrap_local[0] || h->wrap_local[1] || h->wrap_local[2]; }
+
+// ------------------------------------------------------------------------------------------------ operator entry points
+
+extern "C" int fl_poisson_apply(fl_poisson *h, const double *x_dev, double *y_dev)
+{
+  if (!h || !x_dev || !y_dev) return FL_ERR_ARG_NULL;
+  FL_HIP(hipSetDevice(h->device));
+  FL_CHK(fl_ensure_vec(h, &h->w0));
+  launch_pad_copy(h->stream, h->g, x_dev, h->w0);
+  FL_CHK(fl_fill_ghosts(h, h->w0));
+  launch_apply(h->stream, h->g, h->w0, y_dev, 0);
+  FL_HIP(hipGetLastError());
+  return FL_SUCCESS;
+}
+
+extern "C" int fl_poisson_diagonal(fl_poisson *h, double *d_dev)
+{
+  if (!h || !d_dev) return FL_ERR_ARG_NULL;
+  FL_HIP(hipSetDevice(h->device));
+  launch_diagonal(h->stream, h->g, d_dev);
+  FL_HIP(hipGetLastError());
+  return FL_SUCCESS;
+}
+
+extern "C" int fl_poisson_rhs(fl_poisson *h, const double *Vx, const double *Vy, const double *Vz, const double *contrhs, double *b)
+{
+  if (!h || !Vx || !Vy || !Vz || !b) return FL_ERR_ARG_NULL;
+  FL_HIP(hipSetDevice(h->device));
+  const GridP  &g    = h->g;
+  const double *V[3] = {Vx, Vy, Vz};
+  // the high face of the last owned cell belongs to the next rank (or is the periodic image of face 0)
+  std::vector<Msg> msgs;
+  for (int d = 0; d < 3; ++d) {
+    const int len = d == 0 ? g.nx : (d == 1 ? g.ny : g.nz);
+    if (face_count(h, d) > len) continue;  // this rank owns its high boundary face
+    const size_t n = (size_t)plane_size(h, d);
+    if (!h->hiface[d]) FL_CHK(fl_dev_alloc(h, (void **)&h->hiface[d], sizeof(double) * n, true));
+    if (h->wrap_local[d]) launch_face_plane0(h->stream, g, V[d], h->hiface[d], d);
+    else if (h->comm.kind == Comm::NONE) return FL_ERR_ARG_WRONGSTATE;
+  }
+  if (h->multi) {
+    // every rank with a low neighbour ships its first face plane there (send only); every rank with a high neighbour
+    // receives that plane as the high face of its last cells (receive only)
+    for (int d = 0; d < 3; ++d) {
+      if (h->wrap_local[d]) continue;
+      const int     lo = h->nbr[2 * d], hi = h->nbr[2 * d + 1];
+      const int64_t n  = plane_size(h, d);
+      if (lo >= 0) {
+        if (!h->loface_send[d]) FL_CHK(fl_dev_alloc(h, (void **)&h->loface_send[d], sizeof(double) * n, true));
+        launch_face_plane0(h->stream, g, V[d], h->loface_send[d], d);
+      }
+      if (lo >= 0 && lo == hi) {
+        msgs.push_back({lo, h->loface_send[d], h->hiface[d], n, 6 + d, 6 + d});
+      } else {
+        if (lo >= 0) msgs.push_back({lo, h->loface_send[d], nullptr, n, 6 + d, 6 + d});
+        if (hi >= 0) msgs.push_back({hi, nullptr, h->hiface[d], n, 6 + d, 6 + d});
+      }
+    }
+    FL_CHK(h->comm.exchange(h->stream, msgs));
+  }
+  launch_rhs(h->stream, g, Vx, Vy, Vz, h->hiface[0], h->hiface[1], h->hiface[2], contrhs, b);
+  FL_HIP(hipGetLastError());
+  return FL_SUCCESS;
+}
+
+extern "C" int fl_poisson_project(fl_poisson *h, const double *p_dev, double *vx, double *vy, double *vz, double *Vx, double *Vy, double *Vz)
+{
+  if (!h || !p_dev) return FL_ERR_ARG_NULL;
+  FL_HIP(hipSetDevice(h->device));
+  FL_CHK(fl_ensure_vec(h, &h->w0));
+  launch_pad_copy(h->stream, h->g, p_dev, h->w0);
+  FL_CHK(fl_fill_ghosts(h, h->w0));
+  double *v[3] = {vx, vy, vz}, *V[3] = {Vx, Vy, Vz};
+  for (int d = 0; d < 3; ++d) {
+    if (v[d]) launch_project_cells(h->stream, h->g, h->w0, v[d], d);
+    if (V[d]) launch_project_faces(h->stream, h->g, h->w0, V[d], d);
+  }
+  FL_HIP(hipGetLastError());
+  return FL_SUCCESS;
+}
+
+extern "C" int fl_poisson_gst_bc(fl_poisson *h, int boundary, const double *pb_dev, double *V_dev)
+{
+  if (!h || !pb_dev || !V_dev) return FL_ERR_ARG_NULL;
+  if (boundary < 0 || boundary > 5) return FL_ERR_ARG_OUTOFRANGE;
+  const int d = boundary / 2, side = boundary % 2;
+  if (h->bc[boundary] != FL_BC_PRESSURE_OUTLET) return FL_SUCCESS;
+  const bool touches = side ? (h->dec.coord[d] == h->dec.ranks[d] - 1) : (h->dec.coord[d] == 0);
+  if (!touches) return FL_SUCCESS;
+  FL_HIP(hipSetDevice(h->device));
+  launch_gst_bc(h->stream, h->g, pb_dev, V_dev, d, side, side ? h->ax[d].bcc_hi : h->ax[d].bcc_lo);
+  FL_HIP(hipGetLastError());
+  return FL_SUCCESS;
+}
+
+extern "C" int fl_pressure_update(fl_poisson *h, int first, const double *dp, const double *p0, double *phalf, double *p)
+{
+  if (!h || !dp || !phalf || !p || (first && !p0)) return FL_ERR_ARG_NULL;
+  FL_HIP(hipSetDevice(h->device));
+  launch_pressure_update(h->stream, h->ncell, first, dp, p0, phalf, p);
+  FL_HIP(hipGetLastError());
+  return FL_SUCCESS;
+}
+
+// ------------------------------------------------------------------------------------------------ KSPSolve
+
+int fl_poll_scal(fl_poisson *h)
+{
+  FL_HIP(hipMemcpyAsync(h->scal_host, h->scal, sizeof(KspScal), hipMemcpyDeviceToHost, h->stream));
+  FL_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// partial sums -> KspScal update.  Single rank: one kernel.  Multi rank: reduce, all-reduce, then the scalar kernel.
+static int cg_fin(fl_poisson *h, int mode, int nblocks, int nslot, double *hist, int nhist)
+{
+  if (!h->multi) {
+    launch_cg_fin(h->stream, mode, h->partial, nblocks, h->partial_stride, nullptr, h->scal, hist, nhist);
+    return 0;
+  }
+  launch_reduce(h->stream, h->partial, nblocks, h->partial_stride, nslot, h->sums);
+  FL_CHK(h->comm.allreduce(h->stream, h->sums, NSLOT));
+  launch_cg_fin(h->stream, mode, nullptr, 0, 0, h->sums, h->scal, hist, nhist);
+  return 0;
+}
+
+static int solve_cg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *o, fl_ksp_stats *st)
+{
+  const GridP &g   = h->g;
+  const bool   jac = o->pc == FL_PC_JACOBI;
+  FL_CHK(fl_ensure_vec(h, &h->r));
+  FL_CHK(fl_ensure_vec(h, &h->P0));
+  FL_CHK(fl_ensure_vec(h, &h->P1));
+  FL_CHK(fl_ensure_vec(h, &h->q));
+  FL_CHK(fl_ensure_vec(h, &h->xp));
+  const PlanA plan = plan_cg_A(g, 0, 0);
+  const int   nsb  = stream_blocks(g);
+  const int   nab  = o->variant == 1 ? apply_dot_blocks(g) : plan.nblocks;
+  FL_CHK(fl_ensure_partials(h, std::max(nsb, nab)));
+  const int nhist = o->maxit + 1;
+  FL_CHK(fl_ensure_hist(h, nhist));
+  hipStream_t s = h->stream;
+
+  KspScal &S = *h->scal_host;
+  std::memset(&S, 0, sizeof(S));
+  S.rtol         = o->rtol;
+  S.atol         = o->atol;
+  S.dtol         = o->dtol;
+  S.ncell_global = (double)h->ax[0].n * (double)h->ax[1].n * (double)h->ax[2].n;
+  S.maxit        = o->maxit;
+  S.norm_type    = o->norm_type;
+  S.nullspace    = o->remove_nullspace;
+  S.rz_old       = 1.;
+
+  FL_HIP(hipEventRecord(h->ev0, s));
+  FL_HIP(hipMemcpyAsync(h->scal, h->scal_host, sizeof(KspScal), hipMemcpyHostToDevice, s));
+  FL_HIP(hipMemsetAsync(h->P0, 0, sizeof(double) * h->padlen, s));
+  FL_HIP(hipMemsetAsync(h->P1, 0, sizeof(double) * h->padlen, s));
+  FL_HIP(hipMemsetAsync(h->xp, 0, sizeof(double) * h->padlen, s));
+  launch_cg_init(s, g, jac, b, h->r, h->partial, h->partial_stride, nsb);
+  FL_CHK(cg_fin(h, 0, nsb, 5, h->hist, nhist));
+  const bool ghosts = fl_any_ghost_exchange(h);
+  if (ghosts) FL_CHK(fl_fill_ghosts(h, h->r));
+
+  std::vector<hipEvent_t> pev;
+  if (o->profile) {
+    pev.resize(2 * (size_t)std::min(o->maxit, 4096));
+    for (auto &e : pev) FL_HIP(hipEventCreate(&e));
+  }
+
+  const int every = o->check_every > 0 ? o->check_every : 16;
+  int       it    = 0;
+  int       hostcur = 0;  // host's view of KspScal::cur (exact while the device has not stopped)
+  bool      done  = false;
+  while (!done) {
+    const int stop = std::min(o->maxit, it + every);
+    for (; it < stop; ++it) {
+      const bool prof = o->profile && (size_t)(2 * it + 1) < pev.size();
+      if (o->variant == 1) {
+        launch_cg_pupdate(s, g, jac, h->r, h->P0, h->P1, h->scal);
+        if (ghosts) FL_CHK(fl_fill_ghosts(h, hostcur ? h->P0 : h->P1));
+        if (prof) FL_HIP(hipEventRecord(pev[2 * it], s));
+        launch_cg_apply_dot(s, g, h->P0, h->P1, h->q, h->xp, h->scal, h->partial);
+        if (prof) FL_HIP(hipEventRecord(pev[2 * it + 1], s));
+      } else {
+        if (prof) FL_HIP(hipEventRecord(pev[2 * it], s));
+        launch_cg_A(s, g, jac, plan, h->r, h->P0, h->P1, h->q, h->xp, h->scal, h->partial);
+        if (prof) FL_HIP(hipEventRecord(pev[2 * it + 1], s));
+      }
+      FL_CHK(cg_fin(h, 1, nab, 1, h->hist, nhist));
+      hostcur ^= 1;
+      launch_cg_B(s, g, jac, h->q, h->r, h->scal, h->partial, h->partial_stride, nsb);
+      FL_CHK(cg_fin(h, 2, nsb, 5, h->hist, nhist));
+      if (ghosts && o->variant != 1) FL_CHK(fl_fill_ghosts(h, h->r));
+    }
+    FL_CHK(fl_poll_scal(h));
+    if (h->scal_host->reason != 0 || it >= o->maxit) done = true;
+  }
+  launch_cg_flush(s, g, h->P0, h->P1, h->xp, h->scal, nsb);
+  launch_unpad_copy(s, g, h->xp, x, nullptr);
+  FL_HIP(hipEventRecord(h->ev1, s));
+  FL_CHK(fl_poll_scal(h));
+  FL_HIP(hipGetLastError());
+  float ms = 0.f;
+  FL_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  const KspScal &R = *h->scal_host;
+  st->iters        = R.it;
+  st->reason       = R.reason ? R.reason : FL_DIVERGED_ITS;
+  st->rnorm0       = R.rnorm0;
+  st->rnorm        = R.dp;
+  st->seconds      = ms * 1e-3;
+  st->kernel_ms    = 0.;
+  st->kernel_launches = 0;
+  if (o->profile) {
+    double tot = 0.;
+    int    cnt = 0;
+    for (int a = 0; a < R.it && (size_t)(2 * a + 1) < pev.size(); ++a) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, pev[2 * a], pev[2 * a + 1]) == hipSuccess) {
+        tot += t;
+        ++cnt;
+      }
+    }
+    st->kernel_ms       = cnt ? tot / cnt : 0.;
+    st->kernel_launches = cnt;
+    for (auto &e : pev) (void)hipEventDestroy(e);
+  }
+  if (o->history && o->nhistory > 0) {
+    const int n = std::min(o->nhistory, R.it + 1);
+    FL_HIP(hipMemcpy(o->history, h->hist, sizeof(double) * n, hipMemcpyDeviceToHost));
+  }
+  return FL_SUCCESS;
+}
+
+extern "C" int fl_poisson_solve(fl_poisson *h, const double *b_dev, double *x_dev, const fl_ksp_opts *opts, fl_ksp_stats *stats)
+{
+  if (!h || !b_dev || !x_dev || !opts || !stats) return FL_ERR_ARG_NULL;
+  if (opts->maxit < 0 || opts->maxit > 10000000) return FL_ERR_ARG_OUTOFRANGE;
+  if (opts->pc != FL_PC_NONE && opts->pc != FL_PC_JACOBI) return FL_ERR_SUP;
+  FL_HIP(hipSetDevice(h->device));
+  std::memset(stats, 0, sizeof(*stats));
+  switch (opts->type) {
+  case FL_KSP_CG:
+    if (opts->norm_type < 0 || opts->norm_type > FL_NORM_NONE) return FL_ERR_ARG_OUTOFRANGE;
+    return solve_cg(h, b_dev, x_dev, opts, stats);
+  default:
+    return FL_ERR_SUP;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ comm init
+
+extern "C" int fl_comm_unique_id(void *out128)
+{
+  if (!out128) return FL_ERR_ARG_NULL;
+  FL_CHK(g_rccl.load());
+  ncclUniqueId id;
+  static_assert(sizeof(ncclUniqueId) == FL_UNIQUE_ID_BYTES, "ncclUniqueId size");
+  FL_NCCL(g_rccl.GetUniqueId(&id));
+  std::memcpy(out128, &id, sizeof(id));
+  return FL_SUCCESS;
+}
+
+extern "C" int fl_poisson_comm_init_rccl(fl_poisson *h, const void *id128, int rank, int nranks)
+{
+  if (!h || !id128) return FL_ERR_ARG_NULL;
+  if (nranks != h->dec.ranks[0] * h->dec.ranks[1] * h->dec.ranks[2] || rank < 0 || rank >= nranks) return FL_ERR_ARG_WRONG;
+  FL_CHK(g_rccl.load());
+  FL_HIP(hipSetDevice(h->device));
+  ncclUniqueId id;
+  std::memcpy(&id, id128, sizeof(id));
+  h->comm.destroy();
+  FL_NCCL(g_rccl.CommInitRank(&h->comm.nccl, nranks, id, rank));
+  h->comm.kind   = Comm::RCCL;
+  h->comm.rank   = rank;
+  h->comm.nranks = nranks;
+  return FL_SUCCESS;
+}
+
+extern "C" int fl_poisson_comm_init_host(fl_poisson *h, fl_exchange_fn xchg, fl_allreduce_fn allred, void *ctx, int rank, int nranks)
+{
+  if (!h || !xchg || !allred) return FL_ERR_ARG_NULL;
+  if (nranks != h->dec.ranks[0] * h->dec.ranks[1] * h->dec.ranks[2] || rank < 0 || rank >= nranks) return FL_ERR_ARG_WRONG;
+  h->comm.destroy();
+  h->comm.kind   = Comm::HOST;
+  h->comm.xchg   = xchg;
+  h->comm.allred = allred;
+  h->comm.ctx    = ctx;
+  h->comm.rank   = rank;
+  h->comm.nranks = nranks;
+  return FL_SUCCESS;
+}

@@ -1,0 +1,210 @@
+// fl_coeff.cpp -- host-side construction of the 1-D operator tables (no GPU code).
+//
+// The reference assembles D, Gst and S = D((-T)G - (-R)) as PETSc AIJ matrices
+// (fluca/src/ns/impl/linearcn/cnlinearcart3d.c:2314-2600, fluca/src/ns/utils/abfpc/abfpc.c:150-171).
+// On a Cartesian product grid every one of those rows is a sum of three independent 1-D rows, so the
+// whole operator is described by O(M+N+P) numbers per axis.  This file computes them once; the HIP
+// kernels never see a matrix.
+#include <cmath>
+#include <limits>
+
+#include "fl_internal.h"
+
+namespace fl {
+
+// Face-normal first derivative at face f of a grid line: the three 1-D rows of
+// fluca/src/ns/utils/cartdiscret.c:425-476, selected as in cnlinearcart3d.c:2446-2480.
+static void gst_row(const Axis &a, int64_t f, double &v0, double &v1, int64_t &c0)
+{
+  const int64_t n = a.n;
+  v0 = v1 = 0.;
+  c0      = f - 1;
+  if (f == 0 && !a.periodic) {
+    if (a.bc_lo == FL_BC_PRESSURE_OUTLET) {
+      // one-sided through (face value, cell 0, cell 1)
+      const double h1 = a.xcc(0) - a.xf[0], h2 = a.xcc(1) - a.xf[0];
+      v0 = -h2 / (h1 * (h1 - h2));
+      v1 = h1 / (h2 * (h1 - h2));
+      c0 = 0;
+    } else {
+      c0 = 0;  // VELOCITY / SYMMETRY wall: zero pressure gradient, empty row
+    }
+  } else if (f == n && !a.periodic) {
+    if (a.bc_hi == FL_BC_PRESSURE_OUTLET) {
+      const double h1 = a.xf[n] - a.xcc(n - 1), h2 = a.xf[n] - a.xcc(n - 2);
+      v0 = -h1 / (h2 * (h1 - h2));
+      v1 = h2 / (h1 * (h1 - h2));
+      c0 = n - 2;
+    } else {
+      c0 = n - 2 < 0 ? 0 : n - 2;
+    }
+  } else {
+    // interior face, or the periodic face 0 (== face n): central difference between the two adjacent centres
+    const int64_t ff = (f == n) ? 0 : f;
+    const double  dc = a.xcc(ff) - a.xcc(ff - 1);
+    v0 = -1. / dc;
+    v1 = 1. / dc;
+    c0 = f - 1;  // unwrapped: -1 on the periodic face 0, n-1 on its alias f == n
+  }
+}
+
+int build_axis(Axis &a, int64_t n, const double *xf, const double *xc, int bc_lo, int bc_hi, double kappa)
+{
+  if (n < 1 || !xf) return FL_ERR_ARG_WRONG;
+  if ((bc_lo == FL_BC_PERIODIC) != (bc_hi == FL_BC_PERIODIC)) return FL_ERR_ARG_WRONG;
+  for (int b : {bc_lo, bc_hi})
+    if (b != FL_BC_VELOCITY && b != FL_BC_PRESSURE_OUTLET && b != FL_BC_PERIODIC && b != FL_BC_SYMMETRY) return FL_ERR_SUP;  // "Unsupported boundary condition type"
+  a.n        = n;
+  a.periodic = (bc_lo == FL_BC_PERIODIC);
+  a.bc_lo    = bc_lo;
+  a.bc_hi    = bc_hi;
+  if ((bc_lo == FL_BC_PRESSURE_OUTLET || bc_hi == FL_BC_PRESSURE_OUTLET || bc_lo == FL_BC_VELOCITY || bc_hi == FL_BC_VELOCITY) && !a.periodic && n < 2) {
+    /* one-sided rows need two cells; a 1-cell axis is only meaningful with walls, where G is not formed */
+    if (bc_lo == FL_BC_PRESSURE_OUTLET || bc_hi == FL_BC_PRESSURE_OUTLET) return FL_ERR_ARG_OUTOFRANGE;
+  }
+  a.xf.assign(xf, xf + n + 1);
+  for (int64_t i = 0; i < n; ++i)
+    if (!(a.xf[i + 1] > a.xf[i])) return FL_ERR_ARG_WRONG;
+  a.xc.resize(n + 2);
+  for (int64_t i = 0; i < n; ++i) a.xc[i + 1] = xc ? xc[i] : (a.xf[i] + a.xf[i + 1]) / 2.;
+  const double L = a.xf[n] - a.xf[0];
+  a.xc[0]        = a.xc[n] - L;  // periodic images of the last / first centre
+  a.xc[n + 1]    = a.xc[1] + L;
+
+  a.ga0.resize(n + 1);
+  a.ga1.resize(n + 1);
+  a.gc0.resize(n + 1);
+  for (int64_t f = 0; f <= n; ++f) gst_row(a, f, a.ga0[f], a.ga1[f], a.gc0[f]);
+
+  a.idx.resize(n);
+  a.sl.assign(n, 0.);
+  a.sc.assign(n, 0.);
+  a.sh.assign(n, 0.);
+  for (int64_t i = 0; i < n; ++i) {
+    const double dx = a.xf[i + 1] - a.xf[i];
+    a.idx[i]        = 1. / dx;
+    // (S p)_i = -kappa (1/dx_i) (g_{i+1} - g_i): scatter both face rows into the slots {i-1, i, i+1}
+    double slot[3] = {0., 0., 0.};
+    for (int s = 0; s < 2; ++s) {
+      const int64_t f    = i + s;
+      const double  sign = s ? -1. : 1.;
+      const int64_t rel  = a.gc0[f] - (i - 1);  // slot of the row's first column
+      if (a.ga0[f] != 0. || a.ga1[f] != 0.) {
+        if (rel < 0 || rel > 1) return FL_ERR_LIB;
+        slot[rel] += sign * kappa * a.idx[i] * a.ga0[f];
+        slot[rel + 1] += sign * kappa * a.idx[i] * a.ga1[f];
+      }
+    }
+    a.sl[i] = slot[0];
+    a.sc[i] = slot[1];
+    a.sh[i] = slot[2];
+  }
+
+  // outlet pressure coefficient of the Gst boundary vector, cnlinearcart3d.c:2643-2646 / :2671-2674
+  a.bcc_lo = a.bcc_hi = 0.;
+  if (bc_lo == FL_BC_PRESSURE_OUTLET) {
+    const double h1 = a.xcc(0) - a.xf[0], h2 = a.xcc(1) - a.xf[0];
+    a.bcc_lo        = -(h1 + h2) / (h1 * h2);
+  }
+  if (bc_hi == FL_BC_PRESSURE_OUTLET) {
+    const double h1 = a.xf[n] - a.xcc(n - 1), h2 = a.xf[n] - a.xcc(n - 2);
+    a.bcc_hi        = (h1 + h2) / (h1 * h2);
+  }
+
+  // cell-centred gradient G (cnlinearcart3d.c:40-84 for x; same per axis), rows of cartdiscret.c:3-137
+  a.Gs.assign(n, 0);
+  a.Gv0.assign(n, 0.);
+  a.Gv1.assign(n, 0.);
+  a.Gv2.assign(n, 0.);
+  for (int64_t i = 0; i < n; ++i) {
+    double h1, h2;
+    if (i == 0 && !a.periodic) {
+      if (bc_lo == FL_BC_VELOCITY) {
+        if (n < 3) continue;  // no 3-point one-sided row on such a line; G is left zero (the reference would index out of range)
+        h1       = a.xcc(1) - a.xcc(0);
+        h2       = a.xcc(2) - a.xcc(0);
+        a.Gs[i]  = 0;
+        a.Gv0[i] = -(h1 + h2) / (h1 * h2);
+        a.Gv1[i] = -h2 / (h1 * (h1 - h2));
+        a.Gv2[i] = h1 / (h2 * (h1 - h2));
+      } else if (bc_lo == FL_BC_PRESSURE_OUTLET) {
+        h1       = a.xcc(0) - a.xf[0];
+        h2       = a.xcc(1) - a.xcc(0);
+        a.Gs[i]  = 0;
+        a.Gv0[i] = (h2 - h1) / (h1 * h2);
+        a.Gv1[i] = h1 / (h2 * (h1 + h2));
+      } else {  // SYMMETRY
+        if (n < 2) continue;
+        h1       = a.xcc(0) - a.xf[0];
+        h2       = a.xcc(1) - a.xcc(0);
+        a.Gs[i]  = 0;
+        a.Gv0[i] = -2. * h1 / (h2 * (2. * h1 + h2));
+        a.Gv1[i] = 2. * h1 / (h2 * (2. * h1 + h2));
+      }
+    } else if (i == n - 1 && !a.periodic) {
+      if (bc_hi == FL_BC_VELOCITY) {
+        if (n < 3) continue;
+        h1       = a.xcc(i) - a.xcc(i - 1);
+        h2       = a.xcc(i) - a.xcc(i - 2);
+        a.Gs[i]  = i - 2;
+        a.Gv0[i] = -h1 / (h2 * (h1 - h2));
+        a.Gv1[i] = h2 / (h1 * (h1 - h2));
+        a.Gv2[i] = (h1 + h2) / (h1 * h2);
+      } else if (bc_hi == FL_BC_PRESSURE_OUTLET) {
+        h1       = a.xf[i + 1] - a.xcc(i);
+        h2       = a.xcc(i) - a.xcc(i - 1);
+        a.Gs[i]  = i - 1;
+        a.Gv0[i] = -h1 / (h2 * (h1 + h2));
+        a.Gv1[i] = (h1 - h2) / (h1 * h2);
+      } else {
+        if (n < 2) continue;
+        h1       = a.xf[i + 1] - a.xcc(i);
+        h2       = a.xcc(i) - a.xcc(i - 1);
+        a.Gs[i]  = i - 1;
+        a.Gv0[i] = -2. * h1 / (h2 * (2. * h1 + h2));
+        a.Gv1[i] = 2. * h1 / (h2 * (2. * h1 + h2));
+      }
+    } else {
+      const double d = a.xcc(i + 1) - a.xcc(i - 1);
+      a.Gs[i]        = i - 1;
+      a.Gv0[i]       = -1. / d;
+      a.Gv2[i]       = 1. / d;
+    }
+  }
+  return FL_SUCCESS;
+}
+
+}  // namespace fl
+
+// ---- host-only decomposition helpers (C-ABI) ------------------------------------------------------------------------
+
+extern "C" int fl_decomp_default(const int64_t n[3], const int ranks[3], int rank, fl_decomp *out)
+{
+  if (!n || !ranks || !out) return FL_ERR_ARG_NULL;
+  const int nr = ranks[0] * ranks[1] * ranks[2];
+  if (ranks[0] < 1 || ranks[1] < 1 || ranks[2] < 1 || rank < 0 || rank >= nr) return FL_ERR_ARG_OUTOFRANGE;
+  // DMStag numbers ranks x-fastest: rank = (rz*ny + ry)*nx + rx
+  int c[3] = {rank % ranks[0], (rank / ranks[0]) % ranks[1], rank / (ranks[0] * ranks[1])};
+  for (int d = 0; d < 3; ++d) {
+    if (n[d] < ranks[d]) return FL_ERR_ARG_OUTOFRANGE;
+    const int64_t q = n[d] / ranks[d], r = n[d] % ranks[d];
+    out->ranks[d] = ranks[d];
+    out->coord[d] = c[d];
+    out->len[d]   = q + (c[d] < r ? 1 : 0);  // the first N%m ranks get one more cell
+    out->lo[d]    = q * c[d] + (c[d] < r ? c[d] : r);
+  }
+  return FL_SUCCESS;
+}
+
+extern "C" int fl_decomp_neighbor(const fl_decomp *d, const int periodic[3], int boundary)
+{
+  if (!d || !periodic || boundary < 0 || boundary > 5) return -1;
+  const int ax = boundary / 2, side = boundary % 2;
+  int       c[3] = {d->coord[0], d->coord[1], d->coord[2]};
+  c[ax] += side ? 1 : -1;
+  if (c[ax] < 0 || c[ax] >= d->ranks[ax]) {
+    if (!periodic[ax]) return -1;
+    c[ax] = (c[ax] + d->ranks[ax]) % d->ranks[ax];
+  }
+  return (c[2] * d->ranks[1] + c[1]) * d->ranks[0] + c[0];
+}

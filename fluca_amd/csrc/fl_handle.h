@@ -1,0 +1,233 @@
+// fl_handle.h -- the fl_poisson handle, the halo transports and the kernel launchers shared by the .hip files.
+#pragma once
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <string>
+
+#include "fl_internal.h"
+
+namespace fl {
+
+// launchers defined in fl_kernels.hip
+void launch_pad_copy(hipStream_t, const GridP &, const double *, double *);
+void launch_unpad_copy(hipStream_t, const GridP &, const double *, double *, const double *);
+void launch_wrap(hipStream_t, const GridP &, double *, int);
+void launch_pack(hipStream_t, const GridP &, const double *, double *, int, int);
+void launch_unpack(hipStream_t, const GridP &, double *, const double *, int, int);
+void launch_apply(hipStream_t, const GridP &, const double *, double *, int);
+void launch_diagonal(hipStream_t, const GridP &, double *);
+void launch_rhs(hipStream_t, const GridP &, const double *, const double *, const double *, const double *, const double *, const double *, const double *, double *);
+void launch_face_plane0(hipStream_t, const GridP &, const double *, double *, int);
+void launch_project_faces(hipStream_t, const GridP &, const double *, double *, int);
+void launch_project_cells(hipStream_t, const GridP &, const double *, double *, int);
+void launch_gst_bc(hipStream_t, const GridP &, const double *, double *, int, int, double);
+void launch_pressure_update(hipStream_t, int64_t, int, const double *, const double *, double *, double *);
+void launch_reduce(hipStream_t, const double *, int, int, int, double *);
+void launch_cg_fin(hipStream_t, int, const double *, int, int, const double *, KspScal *, double *, int);
+int  stream_blocks(const GridP &);
+void launch_cg_init(hipStream_t, const GridP &, bool, const double *, double *, double *, int, int);
+void launch_cg_B(hipStream_t, const GridP &, bool, const double *, double *, const KspScal *, double *, int, int);
+void launch_cg_flush(hipStream_t, const GridP &, const double *, const double *, double *, const KspScal *, int);
+struct PlanA {
+  int ry, tiles_x, tiles_y, nchunk, zc, nblocks;
+};
+PlanA plan_cg_A(const GridP &, int, int);
+void  launch_cg_A(hipStream_t, const GridP &, bool, const PlanA &, const double *, double *, double *, double *, double *, const KspScal *, double *);
+void  launch_cg_pupdate(hipStream_t, const GridP &, bool, const double *, double *, double *, const KspScal *);
+int   apply_dot_blocks(const GridP &);
+void  launch_cg_apply_dot(hipStream_t, const GridP &, const double *, const double *, double *, double *, const KspScal *, double *);
+
+// ------------------------------------------------------------------------------------------------ transports
+
+struct Msg {
+  int     peer;
+  double *send, *recv;  // device
+  int64_t count;
+  int     sendtag, recvtag;
+};
+
+struct Rccl {
+  void *lib = nullptr;
+  decltype(&ncclGetUniqueId)    GetUniqueId    = nullptr;
+  decltype(&ncclCommInitRank)   CommInitRank   = nullptr;
+  decltype(&ncclCommDestroy)    CommDestroy    = nullptr;
+  decltype(&ncclSend)           Send           = nullptr;
+  decltype(&ncclRecv)           Recv           = nullptr;
+  decltype(&ncclAllReduce)      AllReduce      = nullptr;
+  decltype(&ncclGroupStart)     GroupStart     = nullptr;
+  decltype(&ncclGroupEnd)       GroupEnd       = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  int load()
+  {
+    if (lib) return 0;
+    // the soname: inside a process that already loaded torch this resolves to the very RCCL torch.distributed uses
+    lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) {
+      std::fprintf(stderr, "[flucahip] cannot dlopen librccl: %s\n", dlerror());
+      return FL_ERR_LIB;
+    }
+#define FL_SYM(n)                                                \
+  n = (decltype(n))dlsym(lib, "nccl" #n);                        \
+  if (!n) {                                                      \
+    std::fprintf(stderr, "[flucahip] librccl lacks nccl" #n "\n"); \
+    return FL_ERR_LIB;                                           \
+  }
+    FL_SYM(GetUniqueId) FL_SYM(CommInitRank) FL_SYM(CommDestroy) FL_SYM(Send) FL_SYM(Recv) FL_SYM(AllReduce) FL_SYM(GroupStart) FL_SYM(GroupEnd) FL_SYM(GetErrorString)
+#undef FL_SYM
+    return 0;
+  }
+};
+inline Rccl g_rccl;
+
+#define FL_NCCL(call)                                                                                              \
+  do {                                                                                                             \
+    ncclResult_t r_ = (call);                                                                                      \
+    if (r_ != ncclSuccess) {                                                                                       \
+      std::fprintf(stderr, "[flucahip] %s:%d %s -> %s\n", __FILE__, __LINE__, #call, g_rccl.GetErrorString(r_)); \
+      return FL_ERR_LIB;                                                                                           \
+    }                                                                                                              \
+  } while (0)
+
+struct Comm {
+  enum Kind { NONE, RCCL, HOST } kind = NONE;
+  int             rank = 0, nranks = 1;
+  ncclComm_t      nccl = nullptr;
+  fl_exchange_fn  xchg = nullptr;
+  fl_allreduce_fn allred = nullptr;
+  void           *ctx = nullptr;
+  // pinned staging for the host transport
+  std::vector<double *> hsend, hrecv;
+  std::vector<int64_t>  hcap;
+  double               *hred = nullptr;
+
+  int exchange(hipStream_t st, const std::vector<Msg> &m)
+  {
+    if (m.empty()) return 0;
+    if (kind == RCCL) {
+      FL_NCCL(g_rccl.GroupStart());
+      for (const Msg &x : m) {
+        if (x.send) FL_NCCL(g_rccl.Send(x.send, (size_t)x.count, ncclDouble, x.peer, nccl, st));
+        if (x.recv) FL_NCCL(g_rccl.Recv(x.recv, (size_t)x.count, ncclDouble, x.peer, nccl, st));
+      }
+      FL_NCCL(g_rccl.GroupEnd());
+      return 0;
+    }
+    if (kind == HOST) {
+      const int n = (int)m.size();
+      if ((int)hsend.size() < n) {
+        hsend.resize(n, nullptr);
+        hrecv.resize(n, nullptr);
+        hcap.resize(n, 0);
+      }
+      std::vector<int>     peer(n), stag(n), rtag(n);
+      std::vector<void *>  sp(n), rp(n);
+      std::vector<int64_t> nb(n);
+      for (int a = 0; a < n; ++a) {
+        if (hcap[a] < m[a].count) {
+          if (hsend[a]) (void)hipHostFree(hsend[a]);
+          if (hrecv[a]) (void)hipHostFree(hrecv[a]);
+          FL_HIP(hipHostMalloc((void **)&hsend[a], sizeof(double) * m[a].count));
+          FL_HIP(hipHostMalloc((void **)&hrecv[a], sizeof(double) * m[a].count));
+          hcap[a] = m[a].count;
+        }
+        if (m[a].send) FL_HIP(hipMemcpyAsync(hsend[a], m[a].send, sizeof(double) * m[a].count, hipMemcpyDeviceToHost, st));
+        peer[a] = m[a].peer;
+        stag[a] = m[a].sendtag;
+        rtag[a] = m[a].recvtag;
+        sp[a]   = m[a].send ? hsend[a] : nullptr;
+        rp[a]   = m[a].recv ? hrecv[a] : nullptr;
+        nb[a]   = (int64_t)sizeof(double) * m[a].count;
+      }
+      FL_HIP(hipStreamSynchronize(st));
+      if (xchg(ctx, n, peer.data(), stag.data(), rtag.data(), sp.data(), rp.data(), nb.data()) != 0) return FL_ERR_LIB;
+      for (int a = 0; a < n; ++a)
+        if (m[a].recv) FL_HIP(hipMemcpyAsync(m[a].recv, hrecv[a], sizeof(double) * m[a].count, hipMemcpyHostToDevice, st));
+      return 0;
+    }
+    return FL_ERR_ARG_WRONGSTATE;
+  }
+
+  int allreduce(hipStream_t st, double *dev, int n)
+  {
+    if (nranks == 1) return 0;
+    if (kind == RCCL) {
+      FL_NCCL(g_rccl.AllReduce(dev, dev, (size_t)n, ncclDouble, ncclSum, nccl, st));
+      return 0;
+    }
+    if (kind == HOST) {
+      if (!hred) FL_HIP(hipHostMalloc((void **)&hred, sizeof(double) * 64));
+      FL_HIP(hipMemcpyAsync(hred, dev, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+      FL_HIP(hipStreamSynchronize(st));
+      if (allred(ctx, hred, n) != 0) return FL_ERR_LIB;
+      FL_HIP(hipMemcpyAsync(dev, hred, sizeof(double) * n, hipMemcpyHostToDevice, st));
+      return 0;
+    }
+    return FL_ERR_ARG_WRONGSTATE;
+  }
+
+  void destroy()
+  {
+    if (kind == RCCL && nccl) g_rccl.CommDestroy(nccl);
+    for (double *p : hsend)
+      if (p) (void)hipHostFree(p);
+    for (double *p : hrecv)
+      if (p) (void)hipHostFree(p);
+    if (hred) (void)hipHostFree(hred);
+    hsend.clear();
+    hrecv.clear();
+    hcap.clear();
+    hred = nullptr;
+    nccl = nullptr;
+    kind = NONE;
+  }
+};
+
+}  // namespace fl
+
+using namespace fl;
+
+// ------------------------------------------------------------------------------------------------ handle
+
+struct fl_poisson {
+  int         device = 0;
+  hipStream_t stream = nullptr, own_stream = nullptr;
+  Axis        ax[3];
+  int         bc[6];
+  double      kappa = 0.;
+  fl_decomp   dec;
+  int         nbr[6];        // rank across each boundary, -1 = physical boundary
+  bool        wrap_local[3]; // periodic axis held by a single rank: ghosts filled by a local copy
+  bool        multi = false; // more than one rank
+  GridP       g;
+  std::vector<void *> tables;
+  int64_t     ncell = 0, nface[3] = {0, 0, 0};
+  size_t      padlen = 0;
+  // solver workspace (padded vectors)
+  double *r = nullptr, *P0 = nullptr, *P1 = nullptr, *q = nullptr, *xp = nullptr, *w0 = nullptr, *w1 = nullptr, *w2 = nullptr;
+  double *partial = nullptr;
+  int     partial_stride = 0;
+  double *sums = nullptr;
+  KspScal *scal = nullptr, *scal_host = nullptr;
+  double  *hist = nullptr;
+  int      hist_cap = 0;
+  double  *fsend[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, *frecv[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  double  *hiface[3] = {nullptr, nullptr, nullptr}, *loface_send[3] = {nullptr, nullptr, nullptr};
+  Comm     comm;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+
+// shared host helpers (fl_api.hip)
+int  fl_dev_alloc(fl_poisson *h, void **p, size_t bytes, bool zero);
+int  fl_ensure_vec(fl_poisson *h, double **v);
+int  fl_ensure_partials(fl_poisson *h, int nblocks);
+int  fl_ensure_hist(fl_poisson *h, int nhist);
+int  fl_fill_ghosts(fl_poisson *h, double *v);
+bool fl_any_ghost_exchange(const fl_poisson *h);
+int  fl_poll_scal(fl_poisson *h);

@@ -1,0 +1,377 @@
+// fl_ibm.hip -- immersed-boundary delta-function interpolation / spreading.
+//
+// There is NO reference implementation (thecasterian/fluca THEORY_GUIDE.md:130-132 is an empty TODO); the specification
+// is DESIGN.md "IBM":  U_l = sum_x u(x) delta_h(x - X_l) h^3,  f(x) += sum_l F_l delta_h(x - X_l) dV_l,
+// delta_h = prod_d phi(r_d / h_d) / h_d, phi = Peskin 4-point or Roma 3-point, uniform spacing, collocated fields
+// (all velocity components live at cell centres in Fluca, fluca/src/ns/interface/nsbasic.c:180) so one weight set serves
+// every component.
+//
+// Kernels (gfx950, 64-lane wavefronts):
+//   k_ibm_weights   one lane per marker: first support cell and the S 1-D weights per axis
+//   k_ibm_interp    ONE WAVEFRONT PER MARKER, one lane per support cell (4^3 = 64 lanes exactly), fixed-order wave
+//                   reduction -> deterministic
+//   k_ibm_spread    gather form, no atomics: one 256-thread block per 8x8x8 tile of cells; the markers whose support
+//                   touches the tile (per-tile bins built at create/update) are staged in LDS, rank-sorted by marker id
+//                   in LDS so that every cell accumulates in a run-independent order -> bitwise reproducible
+#include "fl_handle.h"
+
+namespace fl {
+
+constexpr int TB       = 8;    // tile edge (cells)
+constexpr int BIN_CHUNK = 256; // markers staged in LDS per pass
+
+__device__ __forceinline__ double phi_peskin4(double r)
+{
+  r = fabs(r);
+  if (r <= 1.) return (3. - 2. * r + sqrt(1. + 4. * r - 4. * r * r)) / 8.;
+  if (r <= 2.) return (5. - 2. * r - sqrt(fmax(-7. + 12. * r - 4. * r * r, 0.))) / 8.;
+  return 0.;
+}
+__device__ __forceinline__ double phi_roma3(double r)
+{
+  r = fabs(r);
+  if (r <= 0.5) return (1. + sqrt(1. - 3. * r * r)) / 3.;
+  if (r <= 1.5) return (5. - 3. * r - sqrt(fmax(1. - 3. * (1. - r) * (1. - r), 0.))) / 6.;
+  return 0.;
+}
+
+struct IbmP {
+  int     kind, S;
+  int64_t L;
+  int     n[3];        // local cells
+  int     lo[3];       // global index of local cell 0
+  int     ng[3];       // global cells
+  int     periodic[3]; // periodic AND held by this rank alone (wrap locally)
+  double  x0[3], h[3]; // global origin, spacing
+  int     nt[3];       // tiles
+};
+
+// i0[d*L + l] = first support cell (LOCAL index, may be out of range); w[(d*4 + a)*L + l] = phi weights
+__global__ void k_ibm_weights(IbmP P, const double *__restrict__ X, const double *__restrict__ Y, const double *__restrict__ Z, int *__restrict__ i0, double *__restrict__ w)
+{
+  const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= P.L) return;
+  const double pos[3] = {X[l], Y[l], Z[l]};
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const double s = (pos[d] - P.x0[d]) / P.h[d] - 0.5;  // position in units of the cell-centre index
+    const int    i = (P.kind == FL_DELTA_PESKIN4) ? (int)floor(s) - 1 : (int)floor(s + 0.5) - 1;
+    for (int a = 0; a < 4; ++a) {
+      const double r          = s - (double)(i + a);
+      w[(d * 4 + a) * P.L + l] = a < P.S ? (P.kind == FL_DELTA_PESKIN4 ? phi_peskin4(r) : phi_roma3(r)) : 0.;
+    }
+    i0[d * P.L + l] = i - P.lo[d];
+  }
+}
+
+// local cell index of support entry a, or -1 when it falls outside this rank's block
+__device__ __forceinline__ int support_cell(const IbmP &P, int d, int i0, int a)
+{
+  int c = i0 + a;
+  if (P.periodic[d]) {
+    if (c < 0) c += P.n[d];
+    else if (c >= P.n[d]) c -= P.n[d];
+  }
+  return (c < 0 || c >= P.n[d]) ? -1 : c;
+}
+
+// the distinct tiles the support touches along each axis: at most 3 (S=4 over 8-cell tiles gives <= 2, a wrap adds one)
+__device__ __forceinline__ int support_tiles(const IbmP &P, int d, int i0, int t[4])
+{
+  int nt = 0;
+  for (int a = 0; a < P.S; ++a) {
+    const int c = support_cell(P, d, i0, a);
+    if (c < 0) continue;
+    const int tt = c / TB;
+    bool      dup = false;
+    for (int b = 0; b < nt; ++b) dup |= (t[b] == tt);
+    if (!dup) t[nt++] = tt;
+  }
+  return nt;
+}
+
+// pass 0: cnt[tile]++ ; pass 1: list[off[tile] + cursor[tile]++] = marker
+__global__ void k_ibm_bin(IbmP P, const int *__restrict__ i0, int *__restrict__ cnt, const int *__restrict__ off, int *__restrict__ list, int pass)
+{
+  const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= P.L) return;
+  int tx[4], ty[4], tz[4];
+  const int nx = support_tiles(P, 0, i0[l], tx), ny = support_tiles(P, 1, i0[P.L + l], ty), nz = support_tiles(P, 2, i0[2 * P.L + l], tz);
+  for (int c = 0; c < nz; ++c)
+    for (int b = 0; b < ny; ++b)
+      for (int a = 0; a < nx; ++a) {
+        const int tile = (tz[c] * P.nt[1] + ty[b]) * P.nt[0] + tx[a];
+        const int pos  = atomicAdd(&cnt[tile], 1);
+        if (pass) list[off[tile] + pos] = (int)l;
+      }
+}
+
+// exclusive scan of cnt[0..n) -> off[0..n], single block
+__global__ void __launch_bounds__(256) k_ibm_scan(const int *__restrict__ cnt, int *__restrict__ off, int n)
+{
+  __shared__ int part[256];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 256 * 16) {
+    int loc[16], sum = 0;
+    for (int a = 0; a < 16; ++a) {
+      const int idx = base + threadIdx.x * 16 + a;
+      loc[a]        = idx < n ? cnt[idx] : 0;
+      sum += loc[a];
+    }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over the 256 per-thread sums
+    for (int o = 1; o < 256; o <<= 1) {
+      const int v = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+      __syncthreads();
+      part[threadIdx.x] += v;
+      __syncthreads();
+    }
+    int run = carry + part[threadIdx.x] - sum;
+    for (int a = 0; a < 16; ++a) {
+      const int idx = base + threadIdx.x * 16 + a;
+      if (idx < n) off[idx] = run;
+      run += loc[a];
+    }
+    __syncthreads();
+    if (threadIdx.x == 255) carry += part[255];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) off[n] = carry;
+}
+
+// U[c*L + l] = sum over the support.  One wavefront per marker, lane = (a,b,c3) of the S^3 support.
+__global__ void __launch_bounds__(256) k_ibm_interp(IbmP P, const int *__restrict__ i0, const double *__restrict__ w, int ncomp, int64_t ncell, const double *__restrict__ u, double *__restrict__ U)
+{
+  const int     lane = threadIdx.x & 63;
+  const int64_t l    = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (l >= P.L) return;
+  const int S = P.S;
+  const int a = lane % S, b = (lane / S) % S, c3 = lane / (S * S);
+  double    wt   = 0.;
+  int64_t   cell = -1;
+  if (c3 < S) {
+    const int ci = support_cell(P, 0, i0[l], a), cj = support_cell(P, 1, i0[P.L + l], b), ck = support_cell(P, 2, i0[2 * P.L + l], c3);
+    if (ci >= 0 && cj >= 0 && ck >= 0) {
+      cell = ((int64_t)ck * P.n[1] + cj) * P.n[0] + ci;
+      wt   = w[(0 * 4 + a) * P.L + l] * w[(1 * 4 + b) * P.L + l] * w[(2 * 4 + c3) * P.L + l];
+    }
+  }
+  for (int c = 0; c < ncomp; ++c) {
+    double v = cell >= 0 ? wt * u[(int64_t)c * ncell + cell] : 0.;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (lane == 0) U[(int64_t)c * P.L + l] = v;
+  }
+}
+
+// f[c*ncell + x] += sum_l w_l(x) F[c*L + l] dV_l / (hx hy hz), gather over the tile's bin, markers in ascending id order
+__global__ void __launch_bounds__(256) k_ibm_spread(IbmP P, const int *__restrict__ i0, const double *__restrict__ w, const int *__restrict__ off, const int *__restrict__ list, int ncomp, int64_t ncell, const double *__restrict__ F,
+                                                      const double *__restrict__ dV, double *__restrict__ f)
+{
+  __shared__ int    sid[BIN_CHUNK], sraw[BIN_CHUNK];
+  __shared__ int    si0[3][BIN_CHUNK];
+  __shared__ double sw[3][4][BIN_CHUNK];
+  __shared__ double sF[3][BIN_CHUNK];
+  const int tile = blockIdx.x;
+  const int beg = off[tile], end = off[tile + 1];
+  if (beg == end) return;
+  const int tx = tile % P.nt[0], ty = (tile / P.nt[0]) % P.nt[1], tz = tile / (P.nt[0] * P.nt[1]);
+  const double ih = 1. / (P.h[0] * P.h[1] * P.h[2]);
+  // this thread's two cells: (ci, cj, ck) and (ci, cj, ck + 4)
+  const int li = threadIdx.x & 7, lj = (threadIdx.x >> 3) & 7, lk = threadIdx.x >> 6;
+  const int ci = tx * TB + li, cj = ty * TB + lj;
+  double    acc[2][3] = {{0., 0., 0.}, {0., 0., 0.}};
+  // the bin is staged in id-sorted chunks; since every chunk is rank-sorted and chunks are visited in list order, the
+  // whole list must already be chunk-monotone -> sort the FULL bin when it fits (the common case), else fall back to
+  // a two-level order (chunk order = list order) which is still deterministic because k_ibm_sort_bins sorted the list.
+  for (int c0 = beg; c0 < end; c0 += BIN_CHUNK) {
+    const int n = min(BIN_CHUNK, end - c0);
+    __syncthreads();
+    if (threadIdx.x < n) sraw[threadIdx.x] = list[c0 + threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < n) {
+      const int m = sraw[threadIdx.x];
+      sid[threadIdx.x] = m;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        si0[d][threadIdx.x] = i0[d * P.L + m];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) sw[d][a][threadIdx.x] = w[(d * 4 + a) * P.L + m];
+      }
+      const double dv = dV[m] * ih;
+      for (int c = 0; c < 3; ++c) sF[c][threadIdx.x] = c < ncomp ? F[(int64_t)c * P.L + m] * dv : 0.;
+    }
+    __syncthreads();
+    if (ci < P.n[0] && cj < P.n[1]) {
+      for (int e = 0; e < n; ++e) {
+        int a = ci - si0[0][e], b = cj - si0[1][e];
+        if (P.periodic[0]) { if (a < 0) a += P.n[0]; else if (a >= P.n[0]) a -= P.n[0]; }
+        if (P.periodic[1]) { if (b < 0) b += P.n[1]; else if (b >= P.n[1]) b -= P.n[1]; }
+        if (a < 0 || a >= P.S || b < 0 || b >= P.S) continue;
+        const double wxy = sw[0][a][e] * sw[1][b][e];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int ck = tz * TB + lk + 4 * half;
+          int       c3 = ck - si0[2][e];
+          if (P.periodic[2]) { if (c3 < 0) c3 += P.n[2]; else if (c3 >= P.n[2]) c3 -= P.n[2]; }
+          if (ck >= P.n[2] || c3 < 0 || c3 >= P.S) continue;
+          const double wt = wxy * sw[2][c3][e];
+          acc[half][0] += wt * sF[0][e];
+          acc[half][1] += wt * sF[1][e];
+          acc[half][2] += wt * sF[2][e];
+        }
+      }
+    }
+  }
+  if (ci < P.n[0] && cj < P.n[1])
+    for (int half = 0; half < 2; ++half) {
+      const int ck = tz * TB + lk + 4 * half;
+      if (ck >= P.n[2]) continue;
+      const int64_t cell = ((int64_t)ck * P.n[1] + cj) * P.n[0] + ci;
+      for (int c = 0; c < ncomp && c < 3; ++c)
+        if (acc[half][c] != 0.) f[(int64_t)c * ncell + cell] += acc[half][c];
+    }
+}
+
+// in-place ascending sort of every bin (marker ids are unique within a bin): rank sort, one block per tile
+__global__ void __launch_bounds__(256) k_ibm_sort_bins(const int *__restrict__ off, int *__restrict__ list, int *__restrict__ scratch)
+{
+  const int beg = off[blockIdx.x], end = off[blockIdx.x + 1], n = end - beg;
+  if (n <= 1) return;
+  for (int e = threadIdx.x; e < n; e += 256) {
+    const int v = list[beg + e];
+    int       rank = 0;
+    for (int o = 0; o < n; ++o) rank += list[beg + o] < v;
+    scratch[beg + rank] = v;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < n; e += 256) list[beg + e] = scratch[beg + e];
+}
+
+}  // namespace fl
+
+using namespace fl;
+
+struct fl_ibm {
+  fl_poisson *gp = nullptr;
+  IbmP        P;
+  double     *X = nullptr, *Y = nullptr, *Z = nullptr, *w = nullptr;
+  int        *i0 = nullptr, *cnt = nullptr, *off = nullptr, *list = nullptr, *scratch = nullptr;
+  int         ntiles = 0, listcap = 0;
+};
+
+static int ibm_rebin(fl_ibm *m)
+{
+  fl_poisson *h = m->gp;
+  hipStream_t s = h->stream;
+  const IbmP &P = m->P;
+  const int   nb = (int)((P.L + 255) / 256);
+  hipLaunchKernelGGL(k_ibm_weights, dim3(nb), dim3(256), 0, s, P, m->X, m->Y, m->Z, m->i0, m->w);
+  FL_HIP(hipMemsetAsync(m->cnt, 0, sizeof(int) * (m->ntiles + 1), s));
+  hipLaunchKernelGGL(k_ibm_bin, dim3(nb), dim3(256), 0, s, P, m->i0, m->cnt, m->off, m->list, 0);
+  hipLaunchKernelGGL(k_ibm_scan, dim3(1), dim3(256), 0, s, m->cnt, m->off, m->ntiles);
+  FL_HIP(hipMemsetAsync(m->cnt, 0, sizeof(int) * (m->ntiles + 1), s));
+  hipLaunchKernelGGL(k_ibm_bin, dim3(nb), dim3(256), 0, s, P, m->i0, m->cnt, m->off, m->list, 1);
+  hipLaunchKernelGGL(k_ibm_sort_bins, dim3(m->ntiles), dim3(256), 0, s, m->off, m->list, m->scratch);
+  FL_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int fl_ibm_create(fl_poisson *h, int kind, int64_t L, const double *X, const double *Y, const double *Z, fl_ibm **out)
+{
+  if (!h || !X || !Y || !Z || !out) return FL_ERR_ARG_NULL;
+  if (kind != FL_DELTA_PESKIN4 && kind != FL_DELTA_ROMA3) return FL_ERR_ARG_OUTOFRANGE;
+  if (L < 1 || L > (int64_t)1 << 27) return FL_ERR_ARG_OUTOFRANGE;
+  *out = nullptr;
+  FL_HIP(hipSetDevice(h->device));
+  fl_ibm *m = new fl_ibm();
+  m->gp     = h;
+  IbmP &P   = m->P;
+  P.kind    = kind;
+  P.S       = kind == FL_DELTA_PESKIN4 ? 4 : 3;
+  P.L       = L;
+  for (int d = 0; d < 3; ++d) {
+    const Axis &A = h->ax[d];
+    P.n[d]        = (int)h->dec.len[d];
+    P.lo[d]       = (int)h->dec.lo[d];
+    P.ng[d]       = (int)A.n;
+    P.periodic[d] = h->wrap_local[d] ? 1 : 0;
+    P.x0[d]       = A.xf[0];
+    P.h[d]        = (A.xf[A.n] - A.xf[0]) / (double)A.n;
+    // the delta function is only defined on uniformly spaced grids
+    for (int64_t i = 0; i < A.n; ++i)
+      if (std::fabs((A.xf[i + 1] - A.xf[i]) - P.h[d]) > 1e-10 * P.h[d]) {
+        delete m;
+        return FL_ERR_SUP;
+      }
+    if (P.periodic[d] && P.n[d] < P.S) {
+      delete m;
+      return FL_ERR_ARG_OUTOFRANGE;
+    }
+    P.nt[d] = (P.n[d] + TB - 1) / TB;
+  }
+  m->ntiles  = P.nt[0] * P.nt[1] * P.nt[2];
+  m->listcap = (int)std::min<int64_t>(L * 27, (int64_t)1 << 30);
+  int rc     = 0;
+  rc |= fl_dev_alloc(h, (void **)&m->X, sizeof(double) * L, false);
+  rc |= fl_dev_alloc(h, (void **)&m->Y, sizeof(double) * L, false);
+  rc |= fl_dev_alloc(h, (void **)&m->Z, sizeof(double) * L, false);
+  rc |= fl_dev_alloc(h, (void **)&m->w, sizeof(double) * 12 * L, false);
+  rc |= fl_dev_alloc(h, (void **)&m->i0, sizeof(int) * 3 * L, false);
+  rc |= fl_dev_alloc(h, (void **)&m->cnt, sizeof(int) * (m->ntiles + 1), true);
+  rc |= fl_dev_alloc(h, (void **)&m->off, sizeof(int) * (m->ntiles + 1), true);
+  rc |= fl_dev_alloc(h, (void **)&m->list, sizeof(int) * m->listcap, true);
+  rc |= fl_dev_alloc(h, (void **)&m->scratch, sizeof(int) * m->listcap, true);
+  if (rc) {
+    fl_ibm_destroy(m);
+    return FL_ERR_MEM;
+  }
+  *out = m;
+  return fl_ibm_update(m, X, Y, Z);
+}
+
+extern "C" int fl_ibm_update(fl_ibm *m, const double *X, const double *Y, const double *Z)
+{
+  if (!m || !X || !Y || !Z) return FL_ERR_ARG_NULL;
+  fl_poisson *h = m->gp;
+  FL_HIP(hipSetDevice(h->device));
+  FL_HIP(hipMemcpyAsync(m->X, X, sizeof(double) * m->P.L, hipMemcpyDeviceToDevice, h->stream));
+  FL_HIP(hipMemcpyAsync(m->Y, Y, sizeof(double) * m->P.L, hipMemcpyDeviceToDevice, h->stream));
+  FL_HIP(hipMemcpyAsync(m->Z, Z, sizeof(double) * m->P.L, hipMemcpyDeviceToDevice, h->stream));
+  return ibm_rebin(m);
+}
+
+extern "C" int fl_ibm_interp(fl_ibm *m, int ncomp, const double *u, double *U)
+{
+  if (!m || !u || !U) return FL_ERR_ARG_NULL;
+  if (ncomp < 1) return FL_ERR_ARG_OUTOFRANGE;
+  fl_poisson *h = m->gp;
+  FL_HIP(hipSetDevice(h->device));
+  hipLaunchKernelGGL(k_ibm_interp, dim3((unsigned)((m->P.L + 3) / 4)), dim3(256), 0, h->stream, m->P, m->i0, m->w, ncomp, h->ncell, u, U);
+  FL_HIP(hipGetLastError());
+  return FL_SUCCESS;
+}
+
+extern "C" int fl_ibm_spread(fl_ibm *m, int ncomp, const double *F, const double *dV, double *f)
+{
+  if (!m || !F || !dV || !f) return FL_ERR_ARG_NULL;
+  if (ncomp < 1 || ncomp > 3) return FL_ERR_ARG_OUTOFRANGE;
+  fl_poisson *h = m->gp;
+  FL_HIP(hipSetDevice(h->device));
+  hipLaunchKernelGGL(k_ibm_spread, dim3(m->ntiles), dim3(256), 0, h->stream, m->P, m->i0, m->w, m->off, m->list, ncomp, h->ncell, F, dV, f);
+  FL_HIP(hipGetLastError());
+  return FL_SUCCESS;
+}
+
+extern "C" int fl_ibm_destroy(fl_ibm *m)
+{
+  if (!m) return FL_SUCCESS;
+  if (m->gp) (void)hipStreamSynchronize(m->gp->stream);
+  for (void *p : {(void *)m->X, (void *)m->Y, (void *)m->Z, (void *)m->w, (void *)m->i0, (void *)m->cnt, (void *)m->off, (void *)m->list, (void *)m->scratch})
+    if (p) (void)hipFree(p);
+  delete m;
+  return FL_SUCCESS;
+}

@@ -1,0 +1,182 @@
+"""Host-side mirror of the reference's Poisson call sites on top of the C-ABI (device memory through torch).
+
+`Poisson` plays the role of PC_ABF's Schur-complement half (fluca/src/ns/utils/abfpc/abfpc.c): set-up builds S from the
+grid + NS boundary conditions, `.solve` is KSPSolve(kspS), `.rhs` / `.project` are the MatMult chains around it.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import capi
+from .capi import check, lib
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous(), "need a contiguous fp64 device tensor"
+    return C.c_void_p(t.data_ptr())
+
+
+def default_decomp(n, ranks, rank):
+    """DMStag's default ownership ranges (MeshCartGetOwnershipRanges, cart.c:420-430)."""
+    d = capi.fl_decomp()
+    check(lib.fl_decomp_default((C.c_int64 * 3)(*n), (C.c_int * 3)(*ranks), int(rank), C.byref(d)), "fl_decomp_default")
+    return d
+
+
+class KspOptions:
+    """The -ns_abf_schur_ksp_* / -ns_abf_schur_pc_type knobs, PETSc defaults."""
+
+    def __init__(self, **kw):
+        self.o = capi.fl_ksp_opts()
+        lib.fl_ksp_opts_default(C.byref(self.o))
+        for k, v in kw.items():
+            if not hasattr(self.o, k):
+                raise TypeError(f"unknown KSP option {k}")
+            setattr(self.o, k, v)
+
+
+class Poisson:
+    def __init__(self, n, xf, bc, kappa, xc=None, decomp=None, device=0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("fluca_amd needs a HIP device; there is no CPU path")
+        self.n = tuple(int(v) for v in n)
+        self.device = torch.device("cuda", device)
+        self._xf = [np.ascontiguousarray(a, dtype=np.float64) for a in xf]
+        self._xc = [None if (xc is None or xc[d] is None) else np.ascontiguousarray(xc[d], dtype=np.float64) for d in range(3)]
+        g = capi.fl_grid()
+        for d in range(3):
+            assert self._xf[d].shape == (self.n[d] + 1,)
+            g.n[d] = self.n[d]
+            g.xf[d] = self._xf[d].ctypes.data
+            g.xc[d] = None if self._xc[d] is None else self._xc[d].ctypes.data
+        self.bc = tuple(int(b) for b in bc)
+        self.kappa = float(kappa)
+        self.decomp = decomp
+        h = C.c_void_p()
+        check(lib.fl_poisson_create(C.byref(g), (C.c_int * 6)(*self.bc), self.kappa,
+                                    None if decomp is None else C.byref(decomp), device, C.byref(h)), "fl_poisson_create")
+        self.h = h
+        sz = (C.c_int64 * 4)()
+        check(lib.fl_poisson_sizes(self.h, sz))
+        self.ncell, self.nface = sz[0], (sz[1], sz[2], sz[3])
+        self._cb = None
+
+    @classmethod
+    def uniform(cls, n, box, bc, kappa, **kw):
+        xf, xc = [], []
+        for d in range(3):
+            lo, hi = box[d]
+            h = (hi - lo) / n[d]
+            xf.append(lo + np.arange(n[d] + 1, dtype=np.float64) * h)       # DMStagSetUniformCoordinatesProduct
+            xc.append(lo + (np.arange(n[d], dtype=np.float64) + 0.5) * h)
+        return cls(n, xf, bc, kappa, xc=xc, **kw)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.fl_poisson_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream):
+        check(lib.fl_poisson_set_stream(self.h, None if stream is None else C.c_void_p(stream.cuda_stream)))
+
+    def synchronize(self):
+        check(lib.fl_poisson_synchronize(self.h))
+
+    def empty(self, n=None):
+        return torch.empty(self.ncell if n is None else n, dtype=torch.float64, device=self.device)
+
+    # ---- MatMult(S) -------------------------------------------------------------------------------------------
+    def apply(self, x, y=None):
+        y = self.empty() if y is None else y
+        check(lib.fl_poisson_apply(self.h, _ptr(x), _ptr(y)), "fl_poisson_apply")
+        return y
+
+    def diagonal(self):
+        d = self.empty()
+        check(lib.fl_poisson_diagonal(self.h, _ptr(d)), "fl_poisson_diagonal")
+        return d
+
+    # ---- KSPSolve(kspS, b, x) ---------------------------------------------------------------------------------
+    def solve(self, b, x=None, opts=None, history=False, **kw):
+        opts = opts or KspOptions(**kw)
+        o = opts.o
+        x = self.empty() if x is None else x
+        hist = None
+        if history:
+            hist = np.full(o.maxit + 1, np.nan)
+            o.history = hist.ctypes.data_as(C.POINTER(C.c_double))
+            o.nhistory = hist.size
+        st = capi.fl_ksp_stats()
+        check(lib.fl_poisson_solve(self.h, _ptr(b), _ptr(x), C.byref(o), C.byref(st)), "fl_poisson_solve")
+        info = dict(iters=st.iters, reason=st.reason, rnorm0=st.rnorm0, rnorm=st.rnorm, seconds=st.seconds,
+                    kernel_ms=st.kernel_ms, kernel_launches=st.kernel_launches)
+        if history:
+            info["history"] = hist[:st.iters + 1].copy()
+            o.history = None
+            o.nhistory = 0
+        return x, info
+
+    # ---- PCApply_ABF pieces ------------------------------------------------------------------------------------
+    def rhs(self, Vx, Vy, Vz, contrhs=None, b=None):
+        b = self.empty() if b is None else b
+        check(lib.fl_poisson_rhs(self.h, _ptr(Vx), _ptr(Vy), _ptr(Vz), _ptr(contrhs), _ptr(b)), "fl_poisson_rhs")
+        return b
+
+    def project(self, p, v=(None, None, None), V=(None, None, None)):
+        check(lib.fl_poisson_project(self.h, _ptr(p), _ptr(v[0]), _ptr(v[1]), _ptr(v[2]), _ptr(V[0]), _ptr(V[1]), _ptr(V[2])),
+              "fl_poisson_project")
+
+    def gst_bc(self, boundary, pb, V):
+        check(lib.fl_poisson_gst_bc(self.h, int(boundary), _ptr(pb), _ptr(V)), "fl_poisson_gst_bc")
+
+    def pressure_update(self, first, dp, p0, phalf, p):
+        check(lib.fl_pressure_update(self.h, int(bool(first)), _ptr(dp), _ptr(p0), _ptr(phalf), _ptr(p)), "fl_pressure_update")
+
+    # ---- multi-GPU ---------------------------------------------------------------------------------------------
+    def comm_init_rccl(self, id_bytes, rank, nranks):
+        buf = (C.c_char * capi.UNIQUE_ID_BYTES).from_buffer_copy(id_bytes)
+        check(lib.fl_poisson_comm_init_rccl(self.h, buf, rank, nranks), "fl_poisson_comm_init_rccl")
+
+    def comm_init_host(self, exchange, allreduce, rank, nranks):
+        """exchange(list of (peer, sendtag, recvtag, send_ndarray|None, recv_ndarray|None)); allreduce(ndarray) in place."""
+        def _x(ctx, n, peer, stag, rtag, send, recv, nbytes):
+            try:
+                msgs = []
+                for a in range(n):
+                    cnt = nbytes[a] // 8
+                    s = None if not send[a] else np.ctypeslib.as_array(C.cast(send[a], C.POINTER(C.c_double)), (cnt,))
+                    r = None if not recv[a] else np.ctypeslib.as_array(C.cast(recv[a], C.POINTER(C.c_double)), (cnt,))
+                    msgs.append((peer[a], stag[a], rtag[a], s, r))
+                exchange(msgs)
+                return 0
+            except Exception:  # pragma: no cover
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def _r(ctx, vals, n):
+            try:
+                allreduce(np.ctypeslib.as_array(vals, (n,)))
+                return 0
+            except Exception:  # pragma: no cover
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._cb = (capi.EXCHANGE_FN(_x), capi.ALLREDUCE_FN(_r))
+        check(lib.fl_poisson_comm_init_host(self.h, self._cb[0], self._cb[1], None, rank, nranks), "fl_poisson_comm_init_host")
+
+
+def rccl_unique_id():
+    buf = (C.c_char * capi.UNIQUE_ID_BYTES)()
+    check(lib.fl_comm_unique_id(buf), "fl_comm_unique_id")
+    return bytes(buf)

@@ -1,0 +1,176 @@
+/*
+ * fluca_hip.h -- C-ABI of libflucahip.so: the MI355X (gfx950) replacement for the
+ * pressure-Poisson path of Fluca's PCABF preconditioner.
+ *
+ * Plain C, no PETSc / torch / C++ types.  Every function returns int: 0 = success,
+ * negative = -(PETSC_ERR_* class) so a PETSc-side caller can SETERRQ(-rc).
+ * Device pointers are raw HIP device addresses owned by the caller unless stated.
+ * A handle is driven by one host thread; different handles (one per GPU / process)
+ * are independent.  All arithmetic is IEEE fp64 (PetscScalar = double).
+ *
+ * Reference interfaces replaced (file:line relative to thecasterian/fluca):
+ *   fl_poisson_create    PCSetUp_ABF: S = D((-T)Ainv G - (-R)), Ainv = ID         fluca/src/ns/utils/abfpc/abfpc.c:113-182
+ *                        + D / Gst row definitions                                 fluca/src/ns/impl/linearcn/cnlinearcart3d.c:2314-2600
+ *                        + Mesh_Cart decomposition (N, nRanks, ownership l[])      fluca/include/fluca/private/meshcartimpl.h:8-17
+ *   fl_poisson_apply     MatMult(S, x, y) inside KSPSolve(kspS)                    abfpc.c:77,180
+ *   fl_poisson_solve     KSPSolve(abf->kspS, abf->Srhs, p)                         abfpc.c:77
+ *   fl_poisson_rhs       MatMult(D, Vstar, Srhs); VecAYPX(Srhs, -1, contrhs)       abfpc.c:75-76
+ *   fl_poisson_project   stage 2: v = v* - G p ; V = V* + (-T)Gp - (-R)p           abfpc.c:80-101
+ *   fl_poisson_gst_bc    ComputeStaggeredPressureGradientBoundaryConditionVector   cnlinearcart3d.c:2602-2805
+ *   fl_pressure_update   p = phalf + 1.5 dp ; phalf += dp (first step p0 + 2dp)    cnlinearcart3d.c:2846-2854
+ *   fl_ksp_opts          -ns_abf_schur_ksp_* / -ns_abf_schur_pc_type options       abfpc.c:42,206,248-249
+ *   fl_bc                NSBoundaryConditionType                                   fluca/include/flucansbc.h:5-11
+ *   fl_ibm_*             no reference counterpart (THEORY_GUIDE.md:130-132 is a TODO); specified in DESIGN.md
+ *
+ * Array layouts (x fastest, block-contiguous per rank, exactly one rank's OWNED part):
+ *   cell  (i,j,k) -> (k*ny + j)*nx + i                     nx,ny,nz = decomp.len (or grid.n)
+ *   x-face(i,j,k) -> (k*ny + j)*fx + i ,  i in [0,fx)      fx = nx+1 on the last rank of a non-periodic axis, else nx
+ *   y-face(i,j,k) -> (k*fy + j)*nx + i ,  fy likewise      (DMStag: the extra face belongs to the last rank)
+ *   z-face(i,j,k) -> (k*ny + j)*nx + i ,  k in [0,fz)
+ *   Face f of an axis lies between cells f-1 and f.
+ */
+#ifndef FLUCA_HIP_H
+#define FLUCA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes: -(PETSC_ERR_*) ------------------------------------------------------------ */
+#define FL_SUCCESS 0
+#define FL_ERR_MEM (-55)            /* PETSC_ERR_MEM */
+#define FL_ERR_SUP (-56)            /* PETSC_ERR_SUP */
+#define FL_ERR_ARG_SIZ (-60)        /* PETSC_ERR_ARG_SIZ */
+#define FL_ERR_ARG_WRONG (-62)      /* PETSC_ERR_ARG_WRONG */
+#define FL_ERR_ARG_OUTOFRANGE (-63) /* PETSC_ERR_ARG_OUTOFRANGE */
+#define FL_ERR_ARG_WRONGSTATE (-73) /* PETSC_ERR_ARG_WRONGSTATE */
+#define FL_ERR_LIB (-76)            /* PETSC_ERR_LIB (RCCL) */
+#define FL_ERR_ARG_NULL (-85)       /* PETSC_ERR_ARG_NULL */
+#define FL_ERR_NOT_CONVERGED (-91)  /* PETSC_ERR_NOT_CONVERGED */
+#define FL_ERR_GPU (-97)            /* PETSC_ERR_GPU */
+
+/* ---- types ----------------------------------------------------------------------------------- */
+
+/* = NSBoundaryConditionType, flucansbc.h:5-11.  Index order of bc[6]: 0 left(-x) 1 right 2 down(-y) 3 up 4 back(-z) 5 front
+ * (MeshCartGetBoundaryIndex, fluca/src/mesh/impl/cart/cart.c:564-591). */
+typedef enum { FL_BC_NONE = 0, FL_BC_VELOCITY = 1, FL_BC_PRESSURE_OUTLET = 2, FL_BC_PERIODIC = 3, FL_BC_SYMMETRY = 4 } fl_bc;
+
+/* GLOBAL grid.  xf[d]: n[d]+1 face coordinates (arrc[i][iprev]); xc[d]: n[d] cell centres (arrc[i][ielem]) or NULL for
+ * midpoints (cart.c:136).  Host pointers, copied at create. */
+typedef struct fl_grid {
+  int64_t       n[3];
+  const double *xf[3];
+  const double *xc[3];
+} fl_grid;
+
+/* One rank's block of the m x n x p rank grid (DMStagCreate3d ownership, cart.c:88-104).  NULL = whole grid on one GPU. */
+typedef struct fl_decomp {
+  int     ranks[3];
+  int     coord[3];
+  int64_t lo[3], len[3];
+} fl_decomp;
+
+typedef enum { FL_KSP_CG = 0, FL_KSP_BCGS = 1, FL_KSP_CHEBYSHEV = 2 } fl_ksp_type;             /* -ksp_type cg|bcgs|chebyshev */
+typedef enum { FL_PC_NONE = 0, FL_PC_JACOBI = 1 } fl_pc_type;                                   /* -pc_type none|jacobi */
+typedef enum { FL_NORM_PRECONDITIONED = 0, FL_NORM_UNPRECONDITIONED = 1, FL_NORM_NATURAL = 2, FL_NORM_NONE = 3 } fl_norm_type; /* -ksp_norm_type */
+
+/* KSPConvergedReason values */
+#define FL_CONVERGED_RTOL 2
+#define FL_CONVERGED_ATOL 3
+#define FL_CONVERGED_ITS 4
+#define FL_DIVERGED_ITS (-3)
+#define FL_DIVERGED_DTOL (-4)
+#define FL_DIVERGED_BREAKDOWN (-5)
+#define FL_DIVERGED_INDEFINITE_PC (-8)
+#define FL_DIVERGED_NANORINF (-9)
+#define FL_DIVERGED_INDEFINITE_MAT (-10)
+
+typedef struct fl_ksp_opts {
+  int     type;             /* fl_ksp_type */
+  int     pc;               /* fl_pc_type */
+  int     norm_type;        /* fl_norm_type */
+  int     remove_nullspace; /* constant null space attached to S (abfpc.c:173-177): y -= mean(y) after every PC apply */
+  int     maxit;            /* -ksp_max_it   (PETSc default 10000) */
+  double  rtol, atol, dtol; /* -ksp_rtol 1e-5, -ksp_atol 1e-50, -ksp_divtol 1e5 */
+  double  emin, emax;       /* Chebyshev bounds of the preconditioned operator; 0,0 = Gershgorin bound * (0.1, 1.1) */
+  int     variant;          /* 0 = fused kernels (default), 1 = one kernel per BLAS-1/SpMV step (A/B + debugging) */
+  int     check_every;      /* host polls the device-side convergence flag every this many iterations (0 = default 16) */
+  int     profile;          /* 1: bracket the dominant kernel of every iteration with HIP events -> stats.kernel_ms */
+  double *history;          /* optional host array, receives the monitored norm of iterations 0..iters */
+  int     nhistory;
+} fl_ksp_opts;
+
+typedef struct fl_ksp_stats {
+  int    iters;
+  int    reason; /* KSPConvergedReason */
+  double rnorm0, rnorm;
+  double seconds;         /* wall time of the solve measured with HIP events on the handle's stream */
+  double kernel_ms;       /* profile=1: mean duration of the dominant kernel (HIP events), else 0 */
+  int    kernel_launches; /* number of launches averaged in kernel_ms */
+} fl_ksp_stats;
+
+typedef struct fl_poisson fl_poisson;
+typedef struct fl_ibm     fl_ibm;
+
+/* ---- life cycle ------------------------------------------------------------------------------ */
+
+/* bc[6] as fl_bc.  kappa = dt/rho (MatScale at cnlinearcart3d.c:2890,2907).  device = HIP device ordinal. */
+int fl_poisson_create(const fl_grid *grid, const int bc[6], double kappa, const fl_decomp *decomp, int device, fl_poisson **out);
+int fl_poisson_destroy(fl_poisson *h);
+/* Run on a caller-owned hipStream_t (pass as void*); NULL = the handle's own stream. */
+int fl_poisson_set_stream(fl_poisson *h, void *hip_stream);
+int fl_poisson_synchronize(fl_poisson *h);
+/* sizes of this rank's arrays: out[0]=cells, out[1..3]=x,y,z faces */
+int fl_poisson_sizes(const fl_poisson *h, int64_t out[4]);
+void fl_ksp_opts_default(fl_ksp_opts *o); /* PETSc defaults + cg/jacobi/preconditioned norm */
+const char *fl_version(void);
+
+/* ---- operator -------------------------------------------------------------------------------- */
+int fl_poisson_apply(fl_poisson *h, const double *x_dev, double *y_dev);  /* y = S x */
+int fl_poisson_diagonal(fl_poisson *h, double *d_dev);                    /* MatGetDiagonal(S) */
+int fl_poisson_solve(fl_poisson *h, const double *b_dev, double *x_dev, const fl_ksp_opts *opts, fl_ksp_stats *stats);
+/* b = contrhs - D V   (contrhs_dev may be NULL = 0) */
+int fl_poisson_rhs(fl_poisson *h, const double *Vx_dev, const double *Vy_dev, const double *Vz_dev, const double *contrhs_dev, double *b_dev);
+/* v_d -= kappa (G p)_d at cell centres (any v*_dev may be NULL), V_d -= kappa (Gst p)_d on faces (any V*_dev may be NULL) */
+int fl_poisson_project(fl_poisson *h, const double *p_dev, double *vx_dev, double *vy_dev, double *vz_dev, double *Vx_dev, double *Vy_dev, double *Vz_dev);
+/* boundary = 0..5; pb_dev: boundary pressures on that boundary's faces of this rank (plane, x fastest); writes
+ * coeff*pb into the boundary faces of V_dev (face array of the boundary's axis), INSERT_VALUES semantics.  No-op (success)
+ * unless bc[boundary] is PRESSURE_OUTLET and this rank touches the boundary. */
+int fl_poisson_gst_bc(fl_poisson *h, int boundary, const double *pb_dev, double *V_dev);
+/* first != 0: p = p0 + 2 dp, phalf = p0 + dp ; else p = phalf + 1.5 dp, phalf += dp */
+int fl_pressure_update(fl_poisson *h, int first, const double *dp_dev, const double *p0_dev, double *phalf_dev, double *p_dev);
+
+/* ---- multi-GPU: one process per GPU, halo exchange + scalar all-reduce ----------------------- */
+#define FL_UNIQUE_ID_BYTES 128
+/* rank 0 calls this, the host broadcasts the bytes (torch.distributed / MPI), every rank calls ..._comm_init_rccl */
+int fl_comm_unique_id(void *out128);
+int fl_poisson_comm_init_rccl(fl_poisson *h, const void *id128, int rank, int nranks);
+/* Host-staged transport for tests / hosts without RCCL (e.g. gloo): the library stages faces through pinned host memory.
+ * exchange: nmsg messages; peer[m] = rank to swap with; send[m]/recv[m] host buffers of nbytes[m]; tag[m] disambiguates
+ * two messages between the same pair.  allreduce: in-place sum of n doubles. */
+typedef int (*fl_exchange_fn)(void *ctx, int nmsg, const int *peer, const int *sendtag, const int *recvtag, void *const *send, void *const *recv, const int64_t *nbytes);
+typedef int (*fl_allreduce_fn)(void *ctx, double *vals, int n);
+int fl_poisson_comm_init_host(fl_poisson *h, fl_exchange_fn xchg, fl_allreduce_fn allred, void *ctx, int rank, int nranks);
+
+/* Host-only helper = DMStag's default ownership split (N/m cells each, the first N%m ranks get one more). */
+int fl_decomp_default(const int64_t n[3], const int ranks[3], int rank, fl_decomp *out);
+/* rank of the neighbour across boundary 0..5 of this block, -1 if physical (non-periodic) boundary */
+int fl_decomp_neighbor(const fl_decomp *d, const int periodic[3], int boundary);
+
+/* ---- immersed boundary (build-defined; no reference function) -------------------------------- */
+typedef enum { FL_DELTA_PESKIN4 = 0, FL_DELTA_ROMA3 = 1 } fl_delta_kind;
+/* markers X,Y,Z (device, length L) are binned per cell at create / update */
+int fl_ibm_create(fl_poisson *grid_from, int kind, int64_t L, const double *X_dev, const double *Y_dev, const double *Z_dev, fl_ibm **out);
+int fl_ibm_update(fl_ibm *m, const double *X_dev, const double *Y_dev, const double *Z_dev);
+/* U[c*L + l] = sum_x u[c*ncell + x] delta_h(x - X_l) h^3 */
+int fl_ibm_interp(fl_ibm *m, int ncomp, const double *u_dev, double *U_dev);
+/* f[c*ncell + x] += sum_l F[c*L + l] delta_h(x - X_l) dV_l */
+int fl_ibm_spread(fl_ibm *m, int ncomp, const double *F_dev, const double *dV_dev, double *f_dev);
+int fl_ibm_destroy(fl_ibm *m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLUCA_HIP_H */

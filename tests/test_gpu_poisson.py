@@ -1,0 +1,218 @@
+"""-m gpu: the HIP path, called through the C-ABI, against the CPU oracle on the same seeded inputs.
+
+Tolerances (fp64, stated per SURVEY 8d):
+  apply / rhs / project : |diff| <= 1e-13 * ||S||_inf * ||x||_inf  (different summation order, FMA contraction)
+  solve                 : same convergence reason, iteration count within +-2 of the oracle, monitored-norm history
+                          within 1e-6 relative (early iterations 1e-9), true residual <= 1.05*rtol*||b|| + noise
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fluca_oracle as fo
+from tests.gpu_common import CAVITY, CAVITY_BOX, O, PER, SYM, V, dev, host, make_pair, mean_free_rhs
+
+pytestmark = pytest.mark.gpu
+
+GRIDS = [
+    # n, bc, nonuniform
+    ((6, 5, 4), [V] * 6, False),
+    ((17, 9, 11), CAVITY, False),
+    ((16, 16, 8), [PER, PER, V, V, V, V], False),
+    ((12, 10, 9), [PER] * 6, False),
+    ((9, 12, 7), [V, O, V, V, PER, PER], False),          # "channel": inlet velocity, pressure outlet, periodic span
+    ((11, 7, 13), [O, V, SYM, V, V, O], True),
+    ((130, 37, 20), CAVITY, False),                        # > 1 tile in x and y, 2 z-chunks (RY=1)
+    ((136, 70, 12), [PER, PER, V, V, PER, PER], False),    # RY=2 tiles, periodic wrap through the ghost layer
+    ((132, 260, 9), [V, O, V, V, V, V], True),             # RY=4 tiles, odd nz
+    ((7, 5, 6), [V] * 6, True),                            # odd nx: scalar tail of the paired loads
+]
+
+
+@pytest.mark.parametrize("n,bc,nonuni", GRIDS)
+def test_apply_matches_assembled_S(n, bc, nonuni):
+    P, g = make_pair(n, bc, kappa=0.37, nonuniform=nonuni)
+    S = g.assemble_S()
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal(g.ncell)
+    y = host(P.apply(dev(x)))
+    ref = S.mult(x)
+    scale = abs(S.arrays()[2]).max() * 7 * abs(x).max()
+    assert abs(y - ref).max() <= 1e-13 * scale
+    d = host(P.diagonal())
+    assert np.allclose(d, S.diag(), rtol=1e-14, atol=0)
+    P.close()
+
+
+@pytest.mark.parametrize("n,bc,nonuni", GRIDS)
+def test_rhs_and_projection(n, bc, nonuni):
+    P, g = make_pair(n, bc, kappa=0.5, nonuniform=nonuni)
+    rng = np.random.default_rng(3)
+    Vf = [rng.standard_normal(nf) for nf in g.nface]
+    cr = rng.standard_normal(g.ncell)
+    assert tuple(P.nface) == tuple(g.nface)
+    b = host(P.rhs(*[dev(a) for a in Vf], contrhs=dev(cr)))
+    ref = g.rhs(*Vf, contrhs=cr)
+    assert abs(b - ref).max() <= 1e-12 * max(1.0, abs(ref).max())
+    b0 = host(P.rhs(*[dev(a) for a in Vf]))
+    assert abs(b0 - g.rhs(*Vf)).max() <= 1e-12 * max(1.0, abs(ref).max())
+    # stage 2 of PCApply_ABF: V = V* - kappa Gst p ; v = v* - kappa G p
+    p = rng.standard_normal(g.ncell)
+    Vd = [dev(a) for a in Vf]
+    vs = [rng.standard_normal(g.ncell) for _ in range(3)]
+    vd = [dev(a) for a in vs]
+    P.project(dev(p), v=vd, V=Vd)
+    Gst = g.apply_gst(p)
+    for d in range(3):
+        ref = Vf[d] - Gst[d]
+        assert abs(host(Vd[d]) - ref).max() <= 1e-12 * max(1.0, abs(ref).max())
+    if min(n) >= 3:
+        Gc = g.apply_G(p)
+        for d in range(3):
+            ref = vs[d] - Gc[d]
+            assert abs(host(vd[d]) - ref).max() <= 1e-12 * max(1.0, abs(ref).max())
+    P.close()
+
+
+def _check_solve(P, g, b, ksp=None, variant=0, rtol=1e-5, nullspace=True, norm=fo.NORM_PRECONDITIONED, pc=fo.PC_JACOBI, maxit=10000):
+    S = g.assemble_S()
+    xo, io = S.solve(b, ksp=fo.KSP_CG, pc=pc, norm=norm, nullspace=nullspace, rtol=rtol, maxit=maxit)
+    xg, ig = P.solve(dev(b), history=True, type=0, pc=pc, norm_type=norm, remove_nullspace=int(nullspace), rtol=rtol,
+                     maxit=maxit, variant=variant, check_every=7)
+    xg = host(xg)
+    assert ig["reason"] == io["reason"], (ig, io["reason"])
+    assert abs(ig["iters"] - io["iters"]) <= 2, (ig["iters"], io["iters"])
+    m = min(len(ig["history"]), len(io["history"]))
+    ho, hg = io["history"][:m], ig["history"][:m]
+    assert np.allclose(hg[: min(m, 5)], ho[: min(m, 5)], rtol=1e-9, atol=0)
+    assert np.allclose(hg, ho, rtol=1e-6, atol=1e-300)
+    # true residual and solution agreement
+    bn = np.linalg.norm(b)
+    rres = np.linalg.norm(b - S.mult(xg))
+    ores = np.linalg.norm(b - S.mult(xo))
+    assert rres <= 1.5 * ores + 1e-12 * bn
+    if nullspace:
+        xg = xg - xg.mean()
+        xo = xo - xo.mean()
+    assert np.linalg.norm(xg - xo) <= 50 * rtol * np.linalg.norm(xo) + 1e-14
+    return ig, io
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("n,bc", [((6, 5, 4), [V] * 6), ((17, 9, 11), CAVITY), ((16, 16, 8), [PER, PER, V, V, V, V]),
+                                   ((12, 10, 9), [PER] * 6), ((130, 37, 20), CAVITY), ((136, 70, 12), [PER, PER, V, V, PER, PER])])
+def test_cg_neumann_matches_oracle(n, bc, variant):
+    P, g = make_pair(n, bc, kappa=1e-3)
+    _, b = mean_free_rhs(g.assemble_S(), g.ncell)
+    _check_solve(P, g, b, variant=variant)
+    P.close()
+
+
+@pytest.mark.parametrize("n", [(9, 12, 7), (132, 260, 9)])
+def test_cg_outlet_nonsingular(n):
+    """uniform grid + pressure outlet: S symmetric positive definite, no null space (nsbasic.c:214-231)"""
+    P, g = make_pair(n, [V, O, V, V, PER, PER], kappa=1e-3)
+    rng = np.random.default_rng(5)
+    b = rng.standard_normal(g.ncell)
+    _check_solve(P, g, b, nullspace=False, rtol=1e-8)
+    P.close()
+
+
+@pytest.mark.parametrize("norm", [fo.NORM_UNPRECONDITIONED, fo.NORM_NATURAL])
+@pytest.mark.parametrize("pc", [fo.PC_NONE, fo.PC_JACOBI])
+def test_cg_norm_types_and_pc(norm, pc):
+    P, g = make_pair((17, 9, 11), CAVITY, kappa=2e-3)
+    _, b = mean_free_rhs(g.assemble_S(), g.ncell, seed=11)
+    _check_solve(P, g, b, norm=norm, pc=pc, rtol=1e-7)
+    P.close()
+
+
+def test_cg_edge_cases():
+    P, g = make_pair((10, 8, 6), CAVITY)
+    S = g.assemble_S()
+    # zero right-hand side: converged at iteration 0 by atol (KSPConvergedDefault), x = 0
+    x, info = P.solve(dev(np.zeros(g.ncell)))
+    assert info["iters"] == 0 and info["reason"] == 3 and float(x.abs().max()) == 0.0
+    # iteration cap: reason DIVERGED_ITS exactly at maxit, same as the oracle
+    _, b = mean_free_rhs(S, g.ncell)
+    _check_solve(P, g, b, rtol=1e-14, maxit=5)
+    # maxit = 0
+    x, info = P.solve(dev(b), maxit=0)
+    assert info["iters"] == 0 and info["reason"] == -3
+    # NaN in b -> DIVERGED_NANORINF, no hang
+    bn = b.copy()
+    bn[3] = np.nan
+    x, info = P.solve(dev(bn), maxit=20)
+    assert info["reason"] == -9
+    P.close()
+
+
+def test_manufactured_cavity_solution():
+    """p = cos(pi x) cos(pi y) cos(2 pi z) on the cavity_flow_3d box: recover it from b = S p."""
+    n = (32, 32, 16)
+    P, g = make_pair(n, [V] * 6, kappa=1e-3)
+    xc = [0.5 * (a[1:] + a[:-1]) for a in g.xf]
+    Z, Y, X = np.meshgrid(xc[2], xc[1], xc[0], indexing="ij")
+    p = (np.cos(np.pi * X) * np.cos(np.pi * Y) * np.cos(2 * np.pi * Z)).ravel()
+    p -= p.mean()
+    b = g.assemble_S().mult(p)
+    x, info = P.solve(dev(b), rtol=1e-10)
+    x = host(x)
+    assert info["reason"] == 2
+    assert abs((x - x.mean()) - p).max() < 1e-6
+    P.close()
+
+
+def test_full_size_properties_256():
+    """Size-independent checks at a BASELINE.json size (256^3): S 1 = 0, symmetry <Sx,y> = <x,Sy>, and the CG residual
+    of the benchmark RHS drops monotonically in the natural norm."""
+    from fluca_amd.poisson import Poisson
+    n = (256, 256, 256)
+    P = Poisson.uniform(n, CAVITY_BOX, CAVITY, 1e-3)
+    N = P.ncell
+    one = torch.ones(N, dtype=torch.float64, device="cuda")
+    s1 = P.apply(one)
+    d = P.diagonal()
+    assert float(s1.abs().max()) <= 1e-12 * float(d.max())
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.rand(N, generator=g, dtype=torch.float64, device="cuda") - 0.5
+    y = torch.rand(N, generator=g, dtype=torch.float64, device="cuda") - 0.5
+    a = float(torch.dot(P.apply(x), y))
+    b = float(torch.dot(x, P.apply(y)))
+    assert abs(a - b) <= 1e-10 * max(abs(a), abs(b), 1.0)
+    assert float(torch.dot(x, P.apply(x))) > 0
+    rhs = P.apply(x - x.mean())
+    sol, info = P.solve(rhs, history=True, norm_type=fo.NORM_NATURAL, rtol=1e-6, maxit=3000)
+    h = info["history"]
+    assert info["reason"] == 2
+    assert (np.diff(h) < 0).mean() > 0.9                        # energy norm of CG decreases (allow round-off wiggles)
+    res = rhs - P.apply(sol)
+    assert float(res.norm()) <= 1e-4 * float(rhs.norm())
+    # variant 0 (fused) and variant 1 (one kernel per step) are the same algorithm
+    sol1, info1 = P.solve(rhs, norm_type=fo.NORM_NATURAL, rtol=1e-6, maxit=3000, variant=1)
+    assert abs(info1["iters"] - info["iters"]) <= 2
+    assert float((sol1 - sol).norm()) <= 1e-4 * float(sol.norm())
+    P.close()
+
+
+def test_pressure_update_and_outlet_bc_vector():
+    P, g = make_pair((9, 12, 7), [V, O, V, V, PER, PER], kappa=0.25)
+    rng = np.random.default_rng(2)
+    dp, p0 = rng.standard_normal(g.ncell), rng.standard_normal(g.ncell)
+    phalf, p = P.empty(), P.empty()
+    P.pressure_update(True, dev(dp), dev(p0), phalf, p)           # cnlinearcart3d.c:2848-2849
+    assert np.array_equal(host(p), 2.0 * dp + p0) and np.array_equal(host(phalf), dp + p0)
+    ph0 = host(phalf).copy()
+    P.pressure_update(False, dev(dp), None, phalf, p)             # :2852-2853
+    assert np.array_equal(host(p), 1.5 * dp + ph0) and np.array_equal(host(phalf), ph0 + dp)
+    # Gst boundary vector on the outlet (right, boundary 1): coeff * p_b on faces i = M, zero elsewhere
+    pb = rng.standard_normal(12 * 7)
+    Vx = torch.zeros(g.nface[0], dtype=torch.float64, device="cuda")
+    P.gst_bc(1, dev(pb), Vx)
+    Vx = host(Vx).reshape(7, 12, 10)
+    assert np.allclose(Vx[:, :, 9].ravel(), g.gst_bc_coeff(0, 1) * pb, rtol=1e-15)
+    assert abs(Vx[:, :, :9]).max() == 0.0
+    Vy = torch.zeros(g.nface[1], dtype=torch.float64, device="cuda")
+    P.gst_bc(2, dev(rng.standard_normal(9 * 7)), Vy)             # not an outlet: no-op
+    assert float(Vy.abs().max()) == 0.0
+    P.close()
