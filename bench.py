@@ -32,6 +32,8 @@ RANK_GRIDS = {1: (1, 1, 1), 2: (1, 1, 2), 4: (1, 2, 2), 8: (2, 2, 2)}
 def cpu_baseline(sample_n, iters):
     """The oracle (CPU restatement: assembled CSR + PETSc-style PCG, OpenMP) timed on this box's host cores."""
     from oracle import fluca_oracle as fo
+    # a one-GPU box's CPU share is 16 cores; never spawn more OpenMP threads than that (or than the affinity mask)
+    fo.set_num_threads(min(16, len(os.sched_getaffinity(0)), fo.num_threads()))
     bc = [fo.BC_VELOCITY] * 4 + [fo.BC_SYMMETRY, fo.BC_VELOCITY]
     n = (sample_n,) * 3
     g = fo.Grid.uniform(n, [(0, 1), (0, 1), (0, 0.5)], bc, 1e-3)

@@ -271,7 +271,7 @@ __device__ __forceinline__ double cg_norms(KspScal *s, const double *sum, double
   const double zz   = sum[1] - N * mean * mean;
   s->zshift         = mean;
   switch (s->norm_type) {
-  case FL_NORM_PRECONDITIONED: return sqrt(fmax(zz, 0.));
+  case FL_NORM_PRECONDITIONED: return sqrt(zz < 0. ? 0. : zz);  // keeps a NaN a NaN
   case FL_NORM_UNPRECONDITIONED: return sqrt(sum[4]);
   case FL_NORM_NATURAL: return sqrt(fabs(rz));
   default: return 0.;

@@ -63,6 +63,10 @@ class Poisson:
         check(lib.fl_poisson_sizes(self.h, sz))
         self.ncell, self.nface = sz[0], (sz[1], sz[2], sz[3])
         self._cb = None
+        # the library works on its own HIP stream; order it against torch's current stream around every call
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._ext_stream = False
+        check(lib.fl_poisson_set_stream(self.h, C.c_void_p(self.stream.cuda_stream)))
 
     @classmethod
     def uniform(cls, n, box, bc, kappa, **kw):
@@ -86,7 +90,18 @@ class Poisson:
             pass
 
     def set_stream(self, stream):
-        check(lib.fl_poisson_set_stream(self.h, None if stream is None else C.c_void_p(stream.cuda_stream)))
+        """Run on a caller-managed torch stream: the caller orders it against other streams (bench.py does)."""
+        self.stream = stream
+        self._ext_stream = True
+        check(lib.fl_poisson_set_stream(self.h, C.c_void_p(stream.cuda_stream)))
+
+    def _pre(self):
+        if not self._ext_stream:
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+
+    def _post(self):
+        if not self._ext_stream:
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)
 
     def synchronize(self):
         check(lib.fl_poisson_synchronize(self.h))
@@ -97,12 +112,16 @@ class Poisson:
     # ---- MatMult(S) -------------------------------------------------------------------------------------------
     def apply(self, x, y=None):
         y = self.empty() if y is None else y
+        self._pre()
         check(lib.fl_poisson_apply(self.h, _ptr(x), _ptr(y)), "fl_poisson_apply")
+        self._post()
         return y
 
     def diagonal(self):
         d = self.empty()
+        self._pre()
         check(lib.fl_poisson_diagonal(self.h, _ptr(d)), "fl_poisson_diagonal")
+        self._post()
         return d
 
     # ---- KSPSolve(kspS, b, x) ---------------------------------------------------------------------------------
@@ -116,7 +135,9 @@ class Poisson:
             o.history = hist.ctypes.data_as(C.POINTER(C.c_double))
             o.nhistory = hist.size
         st = capi.fl_ksp_stats()
+        self._pre()
         check(lib.fl_poisson_solve(self.h, _ptr(b), _ptr(x), C.byref(o), C.byref(st)), "fl_poisson_solve")
+        self._post()
         info = dict(iters=st.iters, reason=st.reason, rnorm0=st.rnorm0, rnorm=st.rnorm, seconds=st.seconds,
                     kernel_ms=st.kernel_ms, kernel_launches=st.kernel_launches)
         if history:
@@ -128,18 +149,26 @@ class Poisson:
     # ---- PCApply_ABF pieces ------------------------------------------------------------------------------------
     def rhs(self, Vx, Vy, Vz, contrhs=None, b=None):
         b = self.empty() if b is None else b
+        self._pre()
         check(lib.fl_poisson_rhs(self.h, _ptr(Vx), _ptr(Vy), _ptr(Vz), _ptr(contrhs), _ptr(b)), "fl_poisson_rhs")
+        self._post()
         return b
 
     def project(self, p, v=(None, None, None), V=(None, None, None)):
+        self._pre()
         check(lib.fl_poisson_project(self.h, _ptr(p), _ptr(v[0]), _ptr(v[1]), _ptr(v[2]), _ptr(V[0]), _ptr(V[1]), _ptr(V[2])),
               "fl_poisson_project")
+        self._post()
 
     def gst_bc(self, boundary, pb, V):
+        self._pre()
         check(lib.fl_poisson_gst_bc(self.h, int(boundary), _ptr(pb), _ptr(V)), "fl_poisson_gst_bc")
+        self._post()
 
     def pressure_update(self, first, dp, p0, phalf, p):
+        self._pre()
         check(lib.fl_pressure_update(self.h, int(bool(first)), _ptr(dp), _ptr(p0), _ptr(phalf), _ptr(p)), "fl_pressure_update")
+        self._post()
 
     # ---- multi-GPU ---------------------------------------------------------------------------------------------
     def comm_init_rccl(self, id_bytes, rank, nranks):

@@ -541,6 +541,15 @@ static double now_seconds(void)
 #endif
 }
 
+void fo_set_num_threads(int n)
+{
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 int fo_num_threads(void)
 {
 #ifdef _OPENMP

@@ -80,6 +80,7 @@ def lib():
         L.fo_ksp_solve.restype = C.c_int
         L.fo_ksp_solve.argtypes = [C.c_void_p, _dp, _dp, C.POINTER(KspOpts), C.POINTER(KspStats), C.c_void_p, C.c_int]
         L.fo_num_threads.restype = C.c_int
+        L.fo_set_num_threads.argtypes = [C.c_int]
         L.fo_ibm_interp.argtypes = [C.c_void_p, C.c_int, C.c_int64, _dp, _dp, _dp, C.c_int, _dp, _dp]
         L.fo_ibm_spread.argtypes = [C.c_void_p, C.c_int, C.c_int64, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp]
         L.fo_ibm_phi.restype = C.c_double
@@ -243,3 +244,7 @@ class Csr:
 
 def num_threads():
     return lib().fo_num_threads()
+
+
+def set_num_threads(n):
+    lib().fo_set_num_threads(int(n))

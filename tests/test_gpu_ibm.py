@@ -26,16 +26,21 @@ class Ibm:
         self.L = X[0].size
         self.Xd = [dev(a) for a in X]
         h = C.c_void_p()
+        P._pre()
         check(lib.fl_ibm_create(P.h, kind, self.L, *[C.c_void_p(t.data_ptr()) for t in self.Xd], C.byref(h)), "fl_ibm_create")
         self.h = h
 
     def interp(self, u, ncomp):
         U = torch.empty(ncomp * self.L, dtype=torch.float64, device="cuda")
+        self.P._pre()
         self.check(self.lib.fl_ibm_interp(self.h, ncomp, C.c_void_p(u.data_ptr()), C.c_void_p(U.data_ptr())))
+        self.P._post()
         return U
 
     def spread(self, F, dV, f, ncomp):
+        self.P._pre()
         self.check(self.lib.fl_ibm_spread(self.h, ncomp, C.c_void_p(F.data_ptr()), C.c_void_p(dV.data_ptr()), C.c_void_p(f.data_ptr())))
+        self.P._post()
         return f
 
     def close(self):
