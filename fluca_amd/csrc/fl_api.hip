@@ -184,7 +184,8 @@ extern "C" int fl_poisson_destroy(fl_poisson *h)
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   h->comm.destroy();
   for (void *p : h->tables) (void)hipFree(p);
-  for (double *p : {h->r, h->P0, h->P1, h->q, h->xp, h->w0, h->w1, h->w2, h->partial, h->sums, h->hist})
+  for (void *p : h->vec_bases) (void)hipFree(p);
+  for (double *p : {h->partial, h->sums, h->hist})
     if (p) (void)hipFree(p);
   for (int b = 0; b < 6; ++b) {
     if (h->fsend[b]) (void)hipFree(h->fsend[b]);
@@ -229,10 +230,24 @@ extern "C" int fl_poisson_sizes(const fl_poisson *h, int64_t out[4])
 
 // ------------------------------------------------------------------------------------------------ workspace / ghosts
 
+// Padded solver vectors.  Each one starts at a different offset inside its allocation (multiples of FLUCA_SKEW bytes,
+// default 0): the hot kernels touch the same logical index of up to six vectors at the same time, and identical
+// low address bits put those six streams on the same HBM channel.
 int fl_ensure_vec(fl_poisson *h, double **v)
 {
   if (*v) return 0;
-  return fl_dev_alloc(h, (void **)v, sizeof(double) * h->padlen, true);
+  static const long skew = []() {
+    const char *e = std::getenv("FLUCA_SKEW");
+    long        s = e ? std::atol(e) : 0;
+    return (s / 128) * 128;
+  }();
+  const int    k     = h->nvec++;
+  const size_t extra = (size_t)skew * 16;
+  void        *base  = nullptr;
+  FL_CHK(fl_dev_alloc(h, &base, sizeof(double) * h->padlen + extra, true));
+  h->vec_bases.push_back(base);
+  *v = (double *)((char *)base + (size_t)skew * (k % 16));
+  return 0;
 }
 
 int fl_ensure_hist(fl_poisson *h, int nhist)
@@ -445,10 +460,10 @@ static int solve_cg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts
   FL_CHK(fl_ensure_vec(h, &h->P1));
   FL_CHK(fl_ensure_vec(h, &h->q));
   FL_CHK(fl_ensure_vec(h, &h->xp));
-  const PlanA plan = plan_cg_A(g, 0, 0);
+  const PlanA plan = plan_cg_A(g, 0, 0), planB = plan_cg_B(g);
   const int   nsb  = stream_blocks(g);
   const int   nab  = o->variant == 1 ? apply_dot_blocks(g) : plan.nblocks;
-  FL_CHK(fl_ensure_partials(h, std::max(nsb, nab)));
+  FL_CHK(fl_ensure_partials(h, std::max(std::max(nsb, nab), planB.nblocks)));
   const int nhist = o->maxit + 1;
   FL_CHK(fl_ensure_hist(h, nhist));
   hipStream_t s = h->stream;
@@ -501,8 +516,8 @@ static int solve_cg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts
       }
       FL_CHK(cg_fin(h, 1, nab, 1, h->hist, nhist));
       hostcur ^= 1;
-      launch_cg_B(s, g, jac, h->q, h->r, h->scal, h->partial, h->partial_stride, nsb);
-      FL_CHK(cg_fin(h, 2, nsb, 5, h->hist, nhist));
+      launch_cg_B(s, g, jac, planB, h->q, h->r, h->scal, h->partial, h->partial_stride);
+      FL_CHK(cg_fin(h, 2, planB.nblocks, 5, h->hist, nhist));
       if (ghosts && o->variant != 1) FL_CHK(fl_fill_ghosts(h, h->r));
     }
     FL_CHK(fl_poll_scal(h));
@@ -600,5 +615,56 @@ extern "C" int fl_poisson_comm_init_host(fl_poisson *h, fl_exchange_fn xchg, fl_
   h->comm.ctx    = ctx;
   h->comm.rank   = rank;
   h->comm.nranks = nranks;
+  return FL_SUCCESS;
+}
+
+// ------------------------------------------------------------------------------------------------ kernel micro-bench (tools/kbench.py)
+// Not part of the public C-ABI (not declared in fluca_hip.h): times one hot kernel in isolation with HIP events.
+//   kernel 0: k_cg_A (ry, pf, nchunk)   1: k_cg_B (ry, nchunk)   2: streaming reference with ry reads / pf writes
+extern "C" int fldbg_bench(fl_poisson *h, int kernel, int ry, int pf, int nchunk, int reps, const double *src_dev, double *ms_out, int *nblocks_out)
+{
+  if (!h || !ms_out) return FL_ERR_ARG_NULL;
+  FL_HIP(hipSetDevice(h->device));
+  const GridP &g = h->g;
+  for (double **v : {&h->r, &h->P0, &h->P1, &h->q, &h->xp, &h->w0}) FL_CHK(fl_ensure_vec(h, v));
+  hipStream_t s = h->stream;
+  if (src_dev) {
+    launch_pad_copy(s, g, src_dev, h->r);
+    launch_pad_copy(s, g, src_dev, h->P0);
+    launch_pad_copy(s, g, src_dev, h->xp);
+    launch_pad_copy(s, g, src_dev, h->q);
+  }
+  // ry = 10*RY + NW(4|8) ; pf = 100*remap + 10*PF + NT
+  PlanA plan = (kernel <= 1) ? plan_tiles(g, ry / 10, ry % 10, nchunk, 512) : plan_cg_A(g, 0, 0);
+  if (kernel <= 1) {
+    plan.remap = pf / 100;
+    plan.pf    = (pf / 10) % 10;
+    plan.nt    = pf % 10;
+  }
+  FL_CHK(fl_ensure_partials(h, plan.nblocks));
+  KspScal &S = *h->scal_host;
+  std::memset(&S, 0, sizeof(S));
+  S.beta = 0.5; S.alpha = 1e-3; S.zshift = 1e-4; S.ncell_global = (double)h->ncell; S.maxit = 1 << 30; S.pending_x = 1; S.nullspace = 1; S.rz = 1.;
+  FL_HIP(hipMemcpyAsync(h->scal, h->scal_host, sizeof(KspScal), hipMemcpyHostToDevice, s));
+  auto once = [&]() {
+    if (kernel == 0) launch_cg_A(s, g, true, plan, h->r, h->P0, h->P1, h->q, h->xp, h->scal, h->partial);
+    else if (kernel == 1) launch_cg_B(s, g, true, plan, h->q, h->r, h->scal, h->partial, h->partial_stride);
+    else if (kernel == 2) launch_stream_ref(s, ry, pf, (int64_t)(h->padlen - 256) / 2, h->r, h->P0, h->xp, h->P1, h->q, h->w0);
+    else {
+      // kernel 3: parametric stream.  ry = 10*NR + NW, pf = 10*U + NT, nchunk = blocks
+      launch_stream_par(s, ry / 10, ry % 10, pf / 10, pf % 10, nchunk, (int64_t)(h->padlen - 256) / 2, h->r, h->P0, h->xp, h->P1, h->q, h->w0);
+    }
+  };
+  once();
+  once();
+  FL_HIP(hipEventRecord(h->ev0, s));
+  for (int a = 0; a < reps; ++a) once();
+  FL_HIP(hipEventRecord(h->ev1, s));
+  FL_HIP(hipStreamSynchronize(s));
+  FL_HIP(hipGetLastError());
+  float ms = 0.f;
+  FL_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  *ms_out = ms / reps;
+  if (nblocks_out) *nblocks_out = plan.nblocks;
   return FL_SUCCESS;
 }

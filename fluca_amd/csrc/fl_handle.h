@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -31,13 +32,17 @@ void launch_reduce(hipStream_t, const double *, int, int, int, double *);
 void launch_cg_fin(hipStream_t, int, const double *, int, int, const double *, KspScal *, double *, int);
 int  stream_blocks(const GridP &);
 void launch_cg_init(hipStream_t, const GridP &, bool, const double *, double *, double *, int, int);
-void launch_cg_B(hipStream_t, const GridP &, bool, const double *, double *, const KspScal *, double *, int, int);
 void launch_cg_flush(hipStream_t, const GridP &, const double *, const double *, double *, const KspScal *, int);
 struct PlanA {
-  int ry, tiles_x, tiles_y, nchunk, zc, nblocks;
+  int ry, nw, tiles_x, tiles_y, nchunk, zc, nblocks, pf, nt, remap;
 };
+PlanA plan_tiles(const GridP &, int ry, int nw, int nchunk_force, int target_blocks);
 PlanA plan_cg_A(const GridP &, int, int);
+PlanA plan_cg_B(const GridP &);
 void  launch_cg_A(hipStream_t, const GridP &, bool, const PlanA &, const double *, double *, double *, double *, double *, const KspScal *, double *);
+void  launch_cg_B(hipStream_t, const GridP &, bool, const PlanA &, const double *, double *, const KspScal *, double *, int);
+void  launch_stream_ref(hipStream_t, int, int, int64_t, const double *, const double *, const double *, double *, double *, double *);
+void  launch_stream_par(hipStream_t, int, int, int, int, int, int64_t, const double *, const double *, const double *, double *, double *, double *);
 void  launch_cg_pupdate(hipStream_t, const GridP &, bool, const double *, double *, double *, const KspScal *);
 int   apply_dot_blocks(const GridP &);
 void  launch_cg_apply_dot(hipStream_t, const GridP &, const double *, const double *, double *, double *, const KspScal *, double *);
@@ -210,6 +215,8 @@ struct fl_poisson {
   size_t      padlen = 0;
   // solver workspace (padded vectors)
   double *r = nullptr, *P0 = nullptr, *P1 = nullptr, *q = nullptr, *xp = nullptr, *w0 = nullptr, *w1 = nullptr, *w2 = nullptr;
+  std::vector<void *> vec_bases;
+  int                 nvec = 0;
   double *partial = nullptr;
   int     partial_stride = 0;
   double *sums = nullptr;

@@ -27,6 +27,28 @@ __device__ __forceinline__ double wave_sum(double v)
   return v;
 }
 
+typedef double v2d __attribute__((ext_vector_type(2)));
+// 16-B accesses with an optional non-temporal hint (streams that are not re-read before they would be evicted anyway)
+template <int NT>
+__device__ __forceinline__ double2 ld2(const double *p)
+{
+  if (NT) {
+    const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(p));
+    return make_double2(v.x, v.y);
+  }
+  return *reinterpret_cast<const double2 *>(p);
+}
+template <int NT>
+__device__ __forceinline__ void st2(double *p, double2 v)
+{
+  if (NT) {
+    v2d t;
+    t.x = v.x;
+    t.y = v.y;
+    __builtin_nontemporal_store(t, reinterpret_cast<v2d *>(p));
+  } else *reinterpret_cast<double2 *>(p) = v;
+}
+
 // sum over the 256-thread block; result valid in thread 0.  Fixed order -> deterministic.
 template <int NV>
 __device__ __forceinline__ void block_sum(double (&v)[NV], double *red /* [NV][4] */)
@@ -371,65 +393,80 @@ __global__ void __launch_bounds__(256) k_cg_init(GridP g, const double *__restri
     for (int a = 0; a < 5; ++a) partial[(int64_t)a * stride + blockIdx.x] = acc[a];
 }
 
-// r -= alpha q ; partial sums of the new r.  24 B/cell.
-template <bool JAC>
-__global__ void __launch_bounds__(256) k_cg_B(GridP g, const double *__restrict__ q, double *__restrict__ r, const KspScal *__restrict__ s, double *__restrict__ partial, int stride)
+// r -= alpha q ; partial sums of the new r.  24 B/cell.  Same 128 x (4*RY) x zc tiling as k_cg_A (no integer division in
+// the loop); loads are unconditional on clamped, always-valid addresses so that the compiler can count them (a load
+// inside a divergent branch costs an s_waitcnt vmcnt(0)); only the stores and the sums are masked.
+template <int RY, bool JAC, int NT>
+__global__ void __launch_bounds__(256) k_cg_B(GridP g, const double *__restrict__ q, double *__restrict__ r, const KspScal *__restrict__ s, double *__restrict__ partial, int stride, int nchunk, int zc, int tiles_x)
 {
   __shared__ double red[5 * 4];
   if (s->reason != 0) return;
-  const double  alpha = s->alpha;
-  const int     lane  = threadIdx.x & 63;
-  const int     nxs   = (g.nx + 127) / 128;
-  const int64_t nseg  = (int64_t)nxs * g.ny * g.nz;
-  const int64_t step  = (int64_t)gridDim.x * 4;
-  double        acc[5] = {0., 0., 0., 0., 0.};
-  for (int64_t seg0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); seg0 < nseg; seg0 += 2 * step) {
-    // two independent segments per trip: more bytes in flight
-    double2 qv[2], rv[2];
-    int64_t off[2];
-    int     ii[2], jj[2], kk[2];
-    bool    ok[2];
+  const double alpha = s->alpha;
+  const int    b = blockIdx.x, chunk = b % nchunk, tile = b / nchunk;
+  const int    i0 = (tile % tiles_x) * 128, j0 = (tile / tiles_x) * (4 * RY);
+  const int    k0 = chunk * zc, k1 = min(k0 + zc, g.nz);
+  const int    lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int    i = i0 + 2 * lane, il = min(i, g.nx & ~1);
+  const bool   own0 = i < g.nx, own1 = i + 1 < g.nx;
+  const double xc0 = g.sc[0][min(i, g.nx)], xc1 = g.sc[0][min(i + 1, g.nx)];
+  int64_t      ro[RY];
+  bool         rown[RY];
+  double       yc[RY];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int64_t seg = seg0 + u * step;
-      ok[u]             = seg < nseg;
-      const int64_t sg  = ok[u] ? seg : 0;
-      const int     xs  = (int)(sg % nxs);
-      const int64_t R   = sg / nxs;
-      jj[u]             = (int)(R % g.ny);
-      kk[u]             = (int)(R / g.ny);
-      ii[u]             = xs * 128 + 2 * lane;
-      ok[u]             = ok[u] && ii[u] < g.nx;
-      off[u]            = pidx(g, ii[u], jj[u], kk[u]);
-      if (ok[u]) {
-        qv[u] = *reinterpret_cast<const double2 *>(q + off[u]);
-        rv[u] = *reinterpret_cast<const double2 *>(r + off[u]);
-      }
+  for (int m = 0; m < RY; ++m) {
+    const int j = j0 + w * RY + m;
+    rown[m]     = j < g.ny;
+    ro[m]       = g.off0 + (int64_t)min(j, g.ny) * g.sx;  // wave-uniform; the lane adds il
+    yc[m]       = g.sc[1][min(j, g.ny)];
+  }
+  double acc[5] = {0., 0., 0., 0., 0.};
+  struct Raw {
+    double2 q[RY], r[RY];
+    double  zc;
+  };
+  // loads of plane k (clamped into the chunk: the trip past the end re-reads a cached plane instead of branching)
+  auto load = [&](int k, Raw &R) {
+    const int     kc = min(k, k1 - 1);
+    const int64_t pl = (int64_t)kc * g.sxy;
+#pragma unroll
+    for (int m = 0; m < RY; ++m) {
+      R.q[m] = ld2<NT>(q + ro[m] + pl + il);
+      R.r[m] = ld2<NT>(r + ro[m] + pl + il);
     }
+    R.zc = g.sc[2][kc];
+  };
+  // one plane: prefetch k+1 into N, work on C.  Called with (A,B) then (B,A): the two register sets ping-pong, so no
+  // register copy ever has to wait for a load in flight.
+  auto step = [&](int k, const Raw &C, Raw &N) {
+    load(k + 1, N);
+    const int64_t pc = (int64_t)k * g.sxy;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      if (!ok[u]) continue;
-      const double dyz = g.sc[1][jj[u]] + g.sc[2][kk[u]];
-      double2      rn;
-      rn.x = rv[u].x - alpha * qv[u].x;
-      rn.y = rv[u].y - alpha * qv[u].y;
-      if (ii[u] + 1 < g.nx) {
-        *reinterpret_cast<double2 *>(r + off[u]) = rn;
-        const double z1 = JAC ? rn.y / (g.sc[0][ii[u] + 1] + dyz) : rn.y;
-        acc[0] += rn.y * z1;
-        acc[1] += z1 * z1;
-        acc[2] += z1;
-        acc[3] += rn.y;
-        acc[4] += rn.y * rn.y;
-      } else {
-        r[off[u]] = rn.x;  // odd nx: the pair's second entry is the ghost column, leave it alone
+    for (int m = 0; m < RY; ++m) {
+      double2 rn;
+      rn.x = C.r[m].x - alpha * C.q[m].x;
+      rn.y = C.r[m].y - alpha * C.q[m].y;
+      const double dyz = yc[m] + C.zc;
+      const double z0 = JAC ? rn.x / (xc0 + dyz) : rn.x;
+      const double z1 = JAC ? rn.y / (xc1 + dyz) : rn.y;
+      if (rown[m]) {
+        if (own1) st2<NT>(r + ro[m] + pc + il, rn);
+        else if (own0) r[ro[m] + pc + il] = rn.x;
       }
-      const double z0 = JAC ? rn.x / (g.sc[0][ii[u]] + dyz) : rn.x;
-      acc[0] += rn.x * z0;
-      acc[1] += z0 * z0;
-      acc[2] += z0;
-      acc[3] += rn.x;
-      acc[4] += rn.x * rn.x;
+      const double m0 = (rown[m] && own0) ? 1. : 0., m1 = (rown[m] && own1) ? 1. : 0.;
+      const double r0 = m0 * rn.x, r1 = m1 * rn.y, zz0 = m0 * z0, zz1 = m1 * z1;
+      acc[0] += r0 * zz0 + r1 * zz1;
+      acc[1] += zz0 * zz0 + zz1 * zz1;
+      acc[2] += zz0 + zz1;
+      acc[3] += r0 + r1;
+      acc[4] += r0 * r0 + r1 * r1;
+    }
+  };
+  if (k0 < k1) {
+    Raw A, B;
+    load(k0, A);
+    for (int k = k0; k < k1; k += 2) {
+      step(k, A, B);
+      if (k + 1 < k1) step(k + 1, B, A);
     }
   }
   block_sum<5>(acc, red);
@@ -464,19 +501,29 @@ __global__ void __launch_bounds__(256) k_cg_flush(GridP g, const double *__restr
 
 // ------------------------------------------------------------------------------------------------ CG: the fused stencil kernel
 
-template <int RY>
+template <int RY, int NW>
 struct TileA {
-  static constexpr int TX = 128, TY = 4 * RY, LX = TX + 4, LY = TY + 2;
+  static constexpr int TX = 128, TY = NW * RY, LX = TX + 4, LY = TY + 2;
 };
 
-template <int RY, bool JAC>
-__global__ void __launch_bounds__(256, 2) k_cg_A(GridP g, const double *__restrict__ r, double *__restrict__ P0, double *__restrict__ P1, double *__restrict__ q, double *__restrict__ x, const KspScal *__restrict__ s,
-                                                  double *__restrict__ partial, int nchunk, int zc, int tiles_x)
+// blockIdx -> logical block.  Blocks are dealt round-robin over the 8 XCDs, so physical blocks b, b+8, ... share an L2.
+// Give each XCD a contiguous range of logical blocks (= neighbouring tiles of one z-chunk): the halo rows / columns a
+// tile re-reads were just fetched into the same L2 by its neighbour.  Speed only; any mapping is correct.
+__device__ __forceinline__ int xcd_remap(int b, int nblocks) { return (nblocks & 7) ? b : (b & 7) * (nblocks >> 3) + (b >> 3); }
+
+// RY rows per wave, NW waves per block (tile 128 x NW*RY), PF prefetch mode, NT: 0 plain, 1 non-temporal stores,
+// 2 non-temporal stores and tile loads (halo loads stay plain: they are meant to hit in L2)
+template <int RY, int NW, bool JAC, int PF, int NT>
+__global__ void __launch_bounds__(64 * NW, 2) k_cg_A(GridP g, const double *__restrict__ r, double *__restrict__ P0, double *__restrict__ P1, double *__restrict__ q, double *__restrict__ x, const KspScal *__restrict__ s,
+                                                      double *__restrict__ partial, int nchunk, int zc, int tiles_x, int tiles, int remap)
 {
-  using T               = TileA<RY>;
+  using T               = TileA<RY, NW>;
   constexpr int TX = T::TX, TY = T::TY, LX = T::LX, LY = T::LY;
-  __shared__ __attribute__((aligned(16))) double lds[2][LY][LX];
-  __shared__ double                              red[4];
+  constexpr int NTL = NT >= 2, NTS = NT >= 1;
+  // three staged p' planes: kk (being written), kk-1 (stencil centre + in-plane neighbours), kk-2 (z-low neighbour).
+  // Keeping the two older planes in LDS instead of registers frees 32 VGPRs for the load prefetch.
+  __shared__ __attribute__((aligned(16))) double lds[3][LY][LX];
+  __shared__ double                              red[NW];
   if (s->reason != 0) return;
 
   const int     cur        = s->cur;
@@ -484,189 +531,218 @@ __global__ void __launch_bounds__(256, 2) k_cg_A(GridP g, const double *__restri
   double       *pnew       = cur ? P0 : P1;
   const double  beta       = s->beta;
   const double  zs         = s->zshift;
-  const double  alpha_prev = s->alpha;
-  const bool    pend       = s->pending_x != 0;
+  const double  alpha_prev = s->alpha;  // 0 on the first iteration (and p_old = 0): the deferred x-update is a no-op then
 
-  const int b     = blockIdx.x;
-  const int chunk = b % nchunk, tile = b / nchunk;
+  const int b     = remap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int chunk = b / tiles, tile = b % tiles;  // chunk-major: consecutive logical blocks are neighbouring tiles
   const int i0 = (tile % tiles_x) * TX, j0 = (tile / tiles_x) * TY;
   const int k0 = chunk * zc, k1 = min(k0 + zc, g.nz);
   if (k0 >= k1) return;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w  = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: rows, row offsets and y-coefficients live in SGPRs
   const int i  = i0 + 2 * lane;  // first of this lane's two cells
   const int jb = j0 + w * RY;    // first of this wave's RY rows
 
-  // column state ------------------------------------------------------------------------------------------------
-  const bool act  = i <= g.nx;      // pair holds at least one active (owned or high-ghost) cell -> load it
+  // Every load below is unconditional and goes to a clamped, always-valid address: a load inside a divergent branch
+  // makes hipcc wait vmcnt(0) at its use, which would also drain the next plane's prefetch.  Masks apply to stores only.
   const bool own0 = i < g.nx, own1 = i + 1 < g.nx;
   const bool gh0 = i == g.nx, gh1 = i + 1 == g.nx;  // high ghost column inside the tile
+  const int  il  = min(i, g.nx & ~1);               // clamped pair start (16-B aligned, inside the padded row)
   const int  ic0 = min(i, g.nx), ic1 = min(i + 1, g.nx);
   const double xl0 = g.sl[0][ic0], xc0 = g.sc[0][ic0], xh0 = g.sh[0][ic0];
   const double xl1 = g.sl[0][ic1], xc1 = g.sc[0][ic1], xh1 = g.sh[0][ic1];
+  int64_t rob[RY];  // wave-uniform offset of (0, clamped row, plane 0); the lane adds il
+  bool    rown[RY], rgh[RY];
+  double  yl[RY], yc[RY], yh[RY];
+#pragma unroll
+  for (int m = 0; m < RY; ++m) {
+    const int j  = jb + m, jc = min(j, g.ny);
+    rown[m]      = j < g.ny;
+    rgh[m]       = j == g.ny;
+    rob[m]       = g.off0 + (int64_t)jc * g.sx;
+    yl[m]        = g.sl[1][jc];
+    yc[m]        = g.sc[1][jc];
+    yh[m]        = g.sh[1][jc];
+  }
+#define RO(m) (rob[m] + il)
 
   // halo cells of this thread -----------------------------------------------------------------------------------
-  // A: rows jj = -1 (tid < 128) / TY (tid >= 128), column ii = tid & 127
+  // A: rows jj = -1 (tid < 128) / TY (128 <= tid < 256), column ii = tid & 127
+  // B: columns ii = -1 / TX, jj = (tid - HB0) >> 1 for HB0 <= tid < HB0 + 2*TY; a 512-thread block gives A and B to
+  //    different threads (HB0 = 256), a 256-thread block gives some threads one of each
+  constexpr int HB0 = NW > 4 ? 256 : 0;
+  const int  tb  = tid - HB0;
   const int  hAi = i0 + (tid & 127), hAj = j0 + (tid < 128 ? -1 : TY);
-  const bool hAok = hAi < g.nx && hAj <= g.ny;
+  const bool hAok = tid < 256 && hAi < g.nx && hAj <= g.ny;
   const bool hAgh = hAok && (hAj == -1 || hAj == g.ny);
-  // B: columns ii = -1 / TX for tid < 2*TY: jj = tid >> 1
-  const int  hBi = i0 + ((tid & 1) ? TX : -1), hBj = j0 + (tid >> 1);
-  const bool hBok = tid < 2 * TY && hBj < g.ny && hBi <= g.nx;
+  const int  hBi = i0 + ((tb & 1) ? TX : -1), hBj = j0 + (tb >> 1);
+  const bool hBok = tb >= 0 && tb < 2 * TY && hBj < g.ny && hBi <= g.nx;
   const bool hBgh = hBok && (hBi == -1 || hBi == g.nx);
-  const double hAdxy = hAok ? g.sc[0][hAi] + g.sc[1][hAj] : 1.;
-  const double hBdxy = hBok ? g.sc[0][hBi] + g.sc[1][hBj] : 1.;
-  const int hAr = (tid < 128 ? 0 : TY + 1), hAc = (tid & 127) + 2;
-  const int hBr = (tid >> 1) + 1, hBc = (tid & 1) ? TX + 2 : 1;
+  const int64_t tbase = g.off0 + (int64_t)j0 * g.sx + i0;  // uniform; halo cells are 32-bit offsets from it
+  const int     hAo   = hAok ? (hAj - j0) * g.sx + (hAi - i0) : 0;
+  const int     hBo   = hBok ? (hBj - j0) * g.sx + (hBi - i0) : 0;
+  const double  hAdxy = hAok ? g.sc[0][hAi] + g.sc[1][hAj] : 1.;
+  const double  hBdxy = hBok ? g.sc[0][hBi] + g.sc[1][hBj] : 1.;
+  const int hAr = hAok ? (tid < 128 ? 0 : TY + 1) : 0, hAc = hAok ? (tid & 127) + 2 : 0;  // (0,0) is a dead corner slot
+  const int hBr = hBok ? (tb >> 1) + 1 : 0, hBc = hBok ? ((tb & 1) ? TX + 2 : 1) : 0;
 
-  double2 pprev[RY], pcur[RY], pnext[RY];
-  double2 ra[RY], pa[RY], xa[RY];  // raw values of the plane being processed
-  double  hrA = 0., hpA = 0., hrB = 0., hpB = 0.;
+  double2 pnext[RY];
   double  dot = 0.;
-#pragma unroll
-  for (int m = 0; m < RY; ++m) pprev[m] = pcur[m] = pnext[m] = ra[m] = pa[m] = xa[m] = make_double2(0., 0.);
+  double  zlc = 0., zcc = 0., zhc = 0.;  // z-row of plane kk-1 (the plane whose q is formed)
 
-  // plane loader (issued one plane ahead of its use)
-  auto load_plane = [&](int kk, double2 (&rr)[RY], double2 (&pp)[RY], double2 (&xx)[RY], double &r_a, double &p_a, double &r_b, double &p_b) {
-    const bool pown = kk >= k0 && kk < k1;
+  // raw inputs of one plane, fetched one trip ahead
+  struct Raw {
+    double2 r[RY], p[RY], x[RY];
+    double  hrA, hpA, hrB, hpB;
+    double  zl, zc, zh;  // z-row of that plane: prefetched with it so that no load sits between prefetch and use
+  };
+  auto load = [&](int kn_, Raw &R) {
+    // clamped to k1 (the trip past the end re-reads a cached plane instead of branching)
+    const int     kn = min(kn_, k1);
+    const int64_t pl = (int64_t)kn * g.sxy;
 #pragma unroll
     for (int m = 0; m < RY; ++m) {
-      const int j = jb + m;
-      if (act && j <= g.ny) {
-        const int64_t o = pidx(g, i, j, kk);
-        rr[m]           = *reinterpret_cast<const double2 *>(r + o);
-        pp[m]           = *reinterpret_cast<const double2 *>(pold + o);
-        if (pend && pown && j < g.ny) xx[m] = *reinterpret_cast<const double2 *>(x + o);
-      }
+      R.r[m] = ld2<NTL>(r + RO(m) + pl);
+      R.p[m] = ld2<NTL>(pold + RO(m) + pl);
     }
-    if (pown) {
-      if (hAok) {
-        const int64_t o = pidx(g, hAi, hAj, kk);
-        r_a             = r[o];
-        p_a             = pold[o];
-      }
-      if (hBok) {
-        const int64_t o = pidx(g, hBi, hBj, kk);
-        r_b             = r[o];
-        p_b             = pold[o];
+    {
+      // x only exists on owned planes: the two extra trips re-read a cached plane instead of branching
+      const int64_t px = (int64_t)min(max(kn_, k0), k1 - 1) * g.sxy;
+#pragma unroll
+      for (int m = 0; m < RY; ++m) R.x[m] = ld2<NTL>(x + RO(m) + px);
+    }
+    R.hrA = r[tbase + pl + hAo];
+    R.hpA = pold[tbase + pl + hAo];
+    R.hrB = r[tbase + pl + hBo];
+    R.hpB = pold[tbase + pl + hBo];
+    R.zl  = g.sl[2][kn];
+    R.zc  = g.sc[2][kn];
+    R.zh  = g.sh[2][kn];
+  };
+
+  // one plane: prefetch kk+1 into N, work on C.  Called alternately with (A,B) and (B,A): the two register sets
+  // ping-pong, so no register copy ever has to wait for a load in flight.
+  // PF == 1: called alternately with (A,B) / (B,A), prefetch at the top.  PF == 0: C and N are the same set; the
+  // next plane is fetched as soon as p' and the x-update have consumed the current one (fewer VGPRs, shorter flight).
+  // deferred x-update of plane kk:  x += alpha_prev * p_old
+  auto xupdate = [&](int kk, int64_t pl, bool pown, const Raw &C, const double2 *xv) {
+    if (!pown) return;
+#pragma unroll
+    for (int m = 0; m < RY; ++m) {
+      double2 xn;
+      xn.x = xv[m].x + alpha_prev * C.p[m].x;
+      xn.y = xv[m].y + alpha_prev * C.p[m].y;
+      if (rown[m]) {
+        if (own1) st2<NTS>(x + RO(m) + pl, xn);
+        else if (own0) x[RO(m) + pl] = xn.x;
       }
     }
   };
 
-  load_plane(k0 - 1, ra, pa, xa, hrA, hpA, hrB, hpB);
+  auto step = [&](int kk, Raw &C, Raw &N) {
+    if (PF == 1) load(kk + 1, N);
+    const double nzl = C.zl, nzc = C.zc, nzh = C.zh;
 
-  for (int kk = k0 - 1; kk <= k1; ++kk) {
-    double2 rb[RY], pb[RY], xb[RY];
-    double  nrA = 0., npA = 0., nrB = 0., npB = 0.;
-#pragma unroll
-    for (int m = 0; m < RY; ++m) rb[m] = pb[m] = xb[m] = make_double2(0., 0.);
-    if (kk + 1 <= k1) load_plane(kk + 1, rb, pb, xb, nrA, npA, nrB, npB);
-
-    const bool   pown = kk >= k0 && kk < k1;          // plane owned by this chunk: its p', x are stored here
-    const bool   pgh  = kk == -1 || kk == g.nz;        // z-ghost plane: p' of the owned columns is stored too
-    const double dz   = g.sc[2][kk];
-    const int    buf  = kk & 1;
+    const bool    pown = kk >= k0 && kk < k1;    // plane owned by this chunk: its p', x are stored here
+    const bool    pgh  = kk == -1 || kk == g.nz;  // z-ghost plane: p' of the owned columns is stored too
+    const double  dz   = C.zc;
+    const int     buf  = (kk + 3) % 3;  // kk >= -1
+    const int64_t pl   = (int64_t)kk * g.sxy;
 
     // p' of plane kk ------------------------------------------------------------------------------------------------
 #pragma unroll
     for (int m = 0; m < RY; ++m) {
-      const int j = jb + m;
-      double2   pn = make_double2(0., 0.);
-      if (act && j <= g.ny) {
-        const double dy = g.sc[1][j] + dz;
-        const double z0 = JAC ? ra[m].x / (xc0 + dy) : ra[m].x;
-        const double z1 = JAC ? ra[m].y / (xc1 + dy) : ra[m].y;
-        pn.x            = (z0 - zs) + beta * pa[m].x;
-        pn.y            = (z1 - zs) + beta * pa[m].y;
-        const int64_t o = pidx(g, i, j, kk);
-        const bool    rown = j < g.ny;
-        if (pown || (pgh && rown)) {
-          // store the owned cells, and (owned planes only) the high ghost row / column living inside the tile
-          const bool st0 = rown ? (own0 || (gh0 && pown)) : (own0 && pown);
-          const bool st1 = rown ? (own1 || (gh1 && pown)) : (own1 && pown);
-          if (st0 && st1) *reinterpret_cast<double2 *>(pnew + o) = pn;
-          else if (st0) pnew[o] = pn.x;
-          else if (st1) pnew[o + 1] = pn.y;
-        }
-        if (pend && pown && rown) {
-          double2 xn;
-          xn.x = xa[m].x + alpha_prev * pa[m].x;
-          xn.y = xa[m].y + alpha_prev * pa[m].y;
-          if (own1) *reinterpret_cast<double2 *>(x + o) = xn;
-          else if (own0) x[o] = xn.x;
-        }
-      }
+      const double dy = yc[m] + dz;
+      const double z0 = JAC ? C.r[m].x / (xc0 + dy) : C.r[m].x;
+      const double z1 = JAC ? C.r[m].y / (xc1 + dy) : C.r[m].y;
+      double2      pn;
+      pn.x = (z0 - zs) + beta * C.p[m].x;
+      pn.y = (z1 - zs) + beta * C.p[m].y;
       pnext[m] = pn;
+      // owned cells always; on owned planes also the high ghost row / column that lives inside the tile
+      const bool st0 = rown[m] ? ((own0 && (pown || pgh)) || (gh0 && pown)) : (rgh[m] && own0 && pown);
+      const bool st1 = rown[m] ? ((own1 && (pown || pgh)) || (gh1 && pown)) : (rgh[m] && own1 && pown);
+      if (st0 && st1) st2<NTS>(pnew + RO(m) + pl, pn);
+      else if (st0) pnew[RO(m) + pl] = pn.x;
+      else if (st1) pnew[RO(m) + pl + 1] = pn.y;
     }
-    double hnA = 0., hnB = 0.;
+    const double hnA = ((JAC ? C.hrA / (hAdxy + dz) : C.hrA) - zs) + beta * C.hpA;
+    const double hnB = ((JAC ? C.hrB / (hBdxy + dz) : C.hrB) - zs) + beta * C.hpB;
     if (pown) {
-      if (hAok) {
-        const double z = JAC ? hrA / (hAdxy + dz) : hrA;
-        hnA            = (z - zs) + beta * hpA;
-        if (hAgh) pnew[pidx(g, hAi, hAj, kk)] = hnA;
-      }
-      if (hBok) {
-        const double z = JAC ? hrB / (hBdxy + dz) : hrB;
-        hnB            = (z - zs) + beta * hpB;
-        if (hBgh) pnew[pidx(g, hBi, hBj, kk)] = hnB;
-      }
+      if (hAgh) pnew[tbase + pl + hAo] = hnA;
+      if (hBgh) pnew[tbase + pl + hBo] = hnB;
+    }
+    if (PF == 0) {
+      xupdate(kk, pl, pown, C, C.x);
+      load(kk + 1, N);  // N aliases C: every value of the old plane has been consumed
     }
 
-    // q of plane kc = kk-1 (its in-plane neighbours were staged in lds[kc&1] one trip ago) -------------------------------
+    // q of plane kc = kk-1: centre, in-plane neighbours from lds[kc%3] (staged one trip ago), z-low from lds[(kc-1)%3] ------
     const int kc = kk - 1;
     if (kc >= k0) {
-      const double zl = g.sl[2][kc], zh = g.sh[2][kc], dzc = g.sc[2][kc];
-      const int    bc = kc & 1;
+      const int     bc = (kc + 3) % 3, bp = (kc + 2) % 3;
+      const int64_t pc = (int64_t)kc * g.sxy;
+      const int     lc = 2 * lane + 2;
 #pragma unroll
       for (int m = 0; m < RY; ++m) {
-        const int j = jb + m;
-        if (own0 && j < g.ny) {
-          const int    lr = w * RY + m + 1, lc = 2 * lane + 2;
-          const double west = lds[bc][lr][lc - 1], east = lds[bc][lr][lc + 2];
-          double2      south, north;
-          if (m > 0) south = pcur[m - 1];
-          else south = *reinterpret_cast<const double2 *>(&lds[bc][lr - 1][lc]);
-          if (m < RY - 1) north = pcur[m + 1];
-          else north = *reinterpret_cast<const double2 *>(&lds[bc][lr + 1][lc]);
-          const double yl = g.sl[1][j], yh = g.sh[1][j], dyc = g.sc[1][j] + dzc;
-          double2      qq;
-          qq.x = (xc0 + dyc) * pcur[m].x + xl0 * west + xh0 * pcur[m].y + yl * south.x + yh * north.x + zl * pprev[m].x + zh * pnext[m].x;
-          qq.y = (xc1 + dyc) * pcur[m].y + xl1 * pcur[m].x + xh1 * east + yl * south.y + yh * north.y + zl * pprev[m].y + zh * pnext[m].y;
-          const int64_t o = pidx(g, i, j, kc);
-          dot += pcur[m].x * qq.x;
+        const int     lr = w * RY + m + 1;
+        const double2 cen   = *reinterpret_cast<const double2 *>(&lds[bc][lr][lc]);
+        const double2 south = *reinterpret_cast<const double2 *>(&lds[bc][lr - 1][lc]);
+        const double2 north = *reinterpret_cast<const double2 *>(&lds[bc][lr + 1][lc]);
+        const double2 below = *reinterpret_cast<const double2 *>(&lds[bp][lr][lc]);
+        const double  west = lds[bc][lr][lc - 1], east = lds[bc][lr][lc + 2];
+        const double  dyc = yc[m] + zcc;
+        double2       qq;
+        qq.x = (xc0 + dyc) * cen.x + xl0 * west + xh0 * cen.y + yl[m] * south.x + yh[m] * north.x + zlc * below.x + zhc * pnext[m].x;
+        qq.y = (xc1 + dyc) * cen.y + xl1 * cen.x + xh1 * east + yl[m] * south.y + yh[m] * north.y + zlc * below.y + zhc * pnext[m].y;
+        if (rown[m]) {
           if (own1) {
-            *reinterpret_cast<double2 *>(q + o) = qq;
-            dot += pcur[m].y * qq.y;
-          } else {
-            q[o] = qq.x;
+            st2<NTS>(q + RO(m) + pc, qq);
+            dot += cen.x * qq.x + cen.y * qq.y;
+          } else if (own0) {
+            q[RO(m) + pc] = qq.x;
+            dot += cen.x * qq.x;
           }
         }
       }
     }
 
-    // stage plane kk for the next trip ------------------------------------------------------------------------------------
-    if (pown) {
-#pragma unroll
-      for (int m = 0; m < RY; ++m) *reinterpret_cast<double2 *>(&lds[buf][w * RY + m + 1][2 * lane + 2]) = pnext[m];
-      if (hAok) lds[buf][hAr][hAc] = hnA;
-      if (hBok) lds[buf][hBr][hBc] = hnB;
-    }
-    __syncthreads();
+    if (PF == 1) xupdate(kk, pl, pown, C, C.x);
 
+    // stage plane kk for the next trip ------------------------------------------------------------------------------------
 #pragma unroll
-    for (int m = 0; m < RY; ++m) {
-      pprev[m] = pcur[m];
-      pcur[m]  = pnext[m];
-      ra[m]    = rb[m];
-      pa[m]    = pb[m];
-      xa[m]    = xb[m];
+    for (int m = 0; m < RY; ++m) *reinterpret_cast<double2 *>(&lds[buf][w * RY + m + 1][2 * lane + 2]) = pnext[m];
+    lds[buf][hAr][hAc] = hnA;
+    lds[buf][hBr][hBc] = hnB;
+    __syncthreads();
+    zlc = nzl;
+    zcc = nzc;
+    zhc = nzh;
+  };
+
+  if (PF == 1) {
+    Raw A, B;
+    load(k0 - 1, A);
+    for (int kk = k0 - 1; kk <= k1; kk += 2) {
+      step(kk, A, B);
+      if (kk + 1 <= k1) step(kk + 1, B, A);
     }
-    hrA = nrA; hpA = npA; hrB = nrB; hpB = npB;
+  } else {
+    Raw A;
+    load(k0 - 1, A);
+    for (int kk = k0 - 1; kk <= k1; ++kk) step(kk, A, A);
   }
 
+#undef RO
   dot = wave_sum(dot);
   if (lane == 0) red[w] = dot;
   __syncthreads();
-  if (tid == 0) partial[b] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (tid == 0) {
+    double t = 0.;
+#pragma unroll
+    for (int a = 0; a < NW; ++a) t += red[a];
+    partial[b] = t;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ unfused CG pieces (variant 1)
@@ -709,6 +785,76 @@ __global__ void __launch_bounds__(256) k_cg_apply_dot(GridP g, const double *__r
     if ((lin & 63) == 0) red[lin >> 6] = t;
     __syncthreads();
     if (lin == 0) partial[((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ bandwidth reference
+// NR input streams, NW output streams, 16 B per lane per access, grid-stride: the realistic HBM ceiling for a kernel with
+// this read:write mix on this box (profiles/ and DESIGN.md quote it next to the solver kernels).
+template <int NR, int NW>
+__global__ void __launch_bounds__(256) k_stream_ref(int64_t n2, const double2 *__restrict__ a, const double2 *__restrict__ b, const double2 *__restrict__ c, double2 *__restrict__ o0, double2 *__restrict__ o1, double2 *__restrict__ o2)
+{
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n2; t += 2 * step) {
+    const int64_t t2 = min(t + step, n2 - 1);
+    double2       v = a[t], w = a[t2];
+    if (NR > 1) { const double2 u = b[t], u2 = b[t2]; v.x += u.x; v.y += u.y; w.x += u2.x; w.y += u2.y; }
+    if (NR > 2) { const double2 u = c[t], u2 = c[t2]; v.x += u.x; v.y += u.y; w.x += u2.x; w.y += u2.y; }
+    o0[t] = v;
+    if (t + step < n2) o0[t2] = w;
+    if (NW > 1) { o1[t] = v; if (t + step < n2) o1[t2] = w; }
+    if (NW > 2) { o2[t] = v; if (t + step < n2) o2[t2] = w; }
+  }
+}
+
+// parametric variant: U accesses of 16 B per lane per stream in flight, optional non-temporal hints
+template <int NR, int NW, int U, bool NT>
+__global__ void __launch_bounds__(256) k_stream_par(int64_t n2, const double2 *__restrict__ a, const double2 *__restrict__ b, const double2 *__restrict__ c, double2 *__restrict__ o0, double2 *__restrict__ o1, double2 *__restrict__ o2)
+{
+  const int64_t tile = 256 * U;
+  for (int64_t base = (int64_t)blockIdx.x * tile; base < n2; base += (int64_t)gridDim.x * tile) {
+    double2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t t = min(base + u * 256 + threadIdx.x, n2 - 1);
+      if (NT) {
+        v[u].x = __builtin_nontemporal_load(&a[t].x);
+        v[u].y = __builtin_nontemporal_load(&a[t].y);
+      } else v[u] = a[t];
+    }
+    if (NR > 1) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t t = min(base + u * 256 + threadIdx.x, n2 - 1);
+        double2       w;
+        if (NT) { w.x = __builtin_nontemporal_load(&b[t].x); w.y = __builtin_nontemporal_load(&b[t].y); } else w = b[t];
+        v[u].x += w.x; v[u].y += w.y;
+      }
+    }
+    if (NR > 2) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t t = min(base + u * 256 + threadIdx.x, n2 - 1);
+        double2       w;
+        if (NT) { w.x = __builtin_nontemporal_load(&c[t].x); w.y = __builtin_nontemporal_load(&c[t].y); } else w = c[t];
+        v[u].x += w.x; v[u].y += w.y;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t t = base + u * 256 + threadIdx.x;
+      if (t < n2) {
+        if (NT) {
+          __builtin_nontemporal_store(v[u].x, &o0[t].x); __builtin_nontemporal_store(v[u].y, &o0[t].y);
+          if (NW > 1) { __builtin_nontemporal_store(v[u].x, &o1[t].x); __builtin_nontemporal_store(v[u].y, &o1[t].y); }
+          if (NW > 2) { __builtin_nontemporal_store(v[u].x, &o2[t].x); __builtin_nontemporal_store(v[u].y, &o2[t].y); }
+        } else {
+          o0[t] = v[u];
+          if (NW > 1) o1[t] = v[u];
+          if (NW > 2) o2[t] = v[u];
+        }
+      }
+    }
   }
 }
 
@@ -785,46 +931,139 @@ void launch_cg_init(hipStream_t st, const GridP &g, bool jac, const double *b, d
   if (jac) hipLaunchKernelGGL(k_cg_init<true>, dim3(nblocks), dim3(256), 0, st, g, b, r, partial, stride);
   else hipLaunchKernelGGL(k_cg_init<false>, dim3(nblocks), dim3(256), 0, st, g, b, r, partial, stride);
 }
-void launch_cg_B(hipStream_t st, const GridP &g, bool jac, const double *q, double *r, const KspScal *s, double *partial, int stride, int nblocks)
-{
-  if (jac) hipLaunchKernelGGL(k_cg_B<true>, dim3(nblocks), dim3(256), 0, st, g, q, r, s, partial, stride);
-  else hipLaunchKernelGGL(k_cg_B<false>, dim3(nblocks), dim3(256), 0, st, g, q, r, s, partial, stride);
-}
 void launch_cg_flush(hipStream_t st, const GridP &g, const double *P0, const double *P1, double *x, const KspScal *s, int nblocks) { hipLaunchKernelGGL(k_cg_flush, dim3(nblocks), dim3(256), 0, st, g, P0, P1, x, s); }
 
 // tiling of k_cg_A: returns the number of blocks
 struct PlanA {
-  int ry, tiles_x, tiles_y, nchunk, zc, nblocks;
+  int ry, nw, tiles_x, tiles_y, nchunk, zc, nblocks, pf, nt, remap;
 };
-PlanA plan_cg_A(const GridP &g, int ry_force, int nchunk_force)
+// tiling of k_cg_A / k_cg_B (K_B always runs 4-wave blocks: it reuses ry, nchunk, zc with nw = 4)
+PlanA plan_tiles(const GridP &g, int ry, int nw, int nchunk_force, int target_blocks)
 {
   PlanA p;
-  p.ry = ry_force > 0 ? ry_force : (g.ny >= 256 ? 4 : (g.ny >= 64 ? 2 : 1));
+  p.ry = ry;
+  p.nw = nw;
+  p.pf = 0;
+  p.nt = 0;
+  p.remap   = 1;
   p.tiles_x = (g.nx + 127) / 128;
-  p.tiles_y = (g.ny + 4 * p.ry - 1) / (4 * p.ry);
+  p.tiles_y = (g.ny + nw * ry - 1) / (nw * ry);
   const int tiles = p.tiles_x * p.tiles_y;
-  int       nchunk = nchunk_force > 0 ? nchunk_force : std::max(1, (512 + tiles / 2) / tiles);  // ~2 resident blocks per CU
-  nchunk           = std::min(nchunk, std::max(1, g.nz / 8));                                    // keep the 2-plane chunk prologue <= 25 %
-  nchunk           = std::max(1, std::min(nchunk, g.nz));
-  p.zc             = (g.nz + nchunk - 1) / nchunk;
-  p.nchunk         = (g.nz + p.zc - 1) / p.zc;
-  p.nblocks        = tiles * p.nchunk;
+  int       nchunk = nchunk_force > 0 ? nchunk_force : std::max(1, (target_blocks + tiles / 2) / tiles);
+  if (nchunk_force <= 0) nchunk = std::min(nchunk, std::max(1, g.nz / 8));  // keep the 2-plane chunk prologue <= 25 %
+  nchunk    = std::max(1, std::min(nchunk, g.nz));
+  p.zc      = (g.nz + nchunk - 1) / nchunk;
+  p.nchunk  = (g.nz + p.zc - 1) / p.zc;
+  p.nblocks = tiles * p.nchunk;
+  return p;
+}
+// Defaults from the tools/kbench.py sweeps on MI355X at 512^3 (profiles/r01_kbench*.txt, three different boxes): 128 x 16
+// tiles of 8 waves x 2 rows, two ping-pong prefetch sets, non-temporal tile loads and stores, XCD-contiguous
+// chunk-major block order.  Small grids fall back to 4-wave tiles.
+PlanA plan_cg_A(const GridP &g, int ry_force, int nchunk_force)
+{
+  const int ry = ry_force > 0 ? ry_force : (g.ny >= 8 ? 2 : 1);
+  const int nw = (ry == 2 && g.ny >= 32) ? 8 : 4;
+  PlanA     p  = plan_tiles(g, ry, nw, nchunk_force, 512);
+  p.pf         = 1;
+  p.nt         = 2;
+  return p;
+}
+PlanA plan_cg_B(const GridP &g)
+{
+  const int ry = g.ny >= 32 ? 4 : (g.ny >= 8 ? 2 : 1);
+  PlanA     p  = plan_tiles(g, ry, 4, 0, 1024);
+  p.nt         = 1;
   return p;
 }
 
-template <int RY>
-static void launch_cg_A_ry(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const double *r, double *P0, double *P1, double *q, double *x, const KspScal *s, double *partial)
+template <int RY, int NW, int PF, int NT>
+static void launch_cg_A_t(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const double *r, double *P0, double *P1, double *q, double *x, const KspScal *s, double *partial)
 {
-  if (jac) hipLaunchKernelGGL((k_cg_A<RY, true>), dim3(p.nblocks), dim3(256), 0, st, g, r, P0, P1, q, x, s, partial, p.nchunk, p.zc, p.tiles_x);
-  else hipLaunchKernelGGL((k_cg_A<RY, false>), dim3(p.nblocks), dim3(256), 0, st, g, r, P0, P1, q, x, s, partial, p.nchunk, p.zc, p.tiles_x);
+  const int tiles = p.tiles_x * p.tiles_y;
+  if (jac) hipLaunchKernelGGL((k_cg_A<RY, NW, true, PF, NT>), dim3(p.nblocks), dim3(64 * NW), 0, st, g, r, P0, P1, q, x, s, partial, p.nchunk, p.zc, p.tiles_x, tiles, p.remap);
+  else hipLaunchKernelGGL((k_cg_A<RY, NW, false, PF, NT>), dim3(p.nblocks), dim3(64 * NW), 0, st, g, r, P0, P1, q, x, s, partial, p.nchunk, p.zc, p.tiles_x, tiles, p.remap);
+}
+template <int RY, int NW>
+static void launch_cg_A_v(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const double *r, double *P0, double *P1, double *q, double *x, const KspScal *s, double *partial)
+{
+  switch (p.pf * 10 + p.nt) {
+  case 0: launch_cg_A_t<RY, NW, 0, 0>(st, g, jac, p, r, P0, P1, q, x, s, partial); break;
+  case 1: launch_cg_A_t<RY, NW, 0, 1>(st, g, jac, p, r, P0, P1, q, x, s, partial); break;
+  case 2: launch_cg_A_t<RY, NW, 0, 2>(st, g, jac, p, r, P0, P1, q, x, s, partial); break;
+  case 10: launch_cg_A_t<RY, NW, 1, 0>(st, g, jac, p, r, P0, P1, q, x, s, partial); break;
+  case 11: launch_cg_A_t<RY, NW, 1, 1>(st, g, jac, p, r, P0, P1, q, x, s, partial); break;
+  default: launch_cg_A_t<RY, NW, 1, 2>(st, g, jac, p, r, P0, P1, q, x, s, partial); break;
+  }
 }
 void launch_cg_A(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const double *r, double *P0, double *P1, double *q, double *x, const KspScal *s, double *partial)
 {
-  switch (p.ry) {
-  case 4: launch_cg_A_ry<4>(st, g, jac, p, r, P0, P1, q, x, s, partial); break;
-  case 2: launch_cg_A_ry<2>(st, g, jac, p, r, P0, P1, q, x, s, partial); break;
-  default: launch_cg_A_ry<1>(st, g, jac, p, r, P0, P1, q, x, s, partial); break;
+  switch (p.ry * 10 + p.nw) {
+  case 48: launch_cg_A_v<4, 8>(st, g, jac, p, r, P0, P1, q, x, s, partial); break;
+  case 44: launch_cg_A_v<4, 4>(st, g, jac, p, r, P0, P1, q, x, s, partial); break;
+  case 28: launch_cg_A_v<2, 8>(st, g, jac, p, r, P0, P1, q, x, s, partial); break;
+  case 24: launch_cg_A_v<2, 4>(st, g, jac, p, r, P0, P1, q, x, s, partial); break;
+  default: launch_cg_A_v<1, 4>(st, g, jac, p, r, P0, P1, q, x, s, partial); break;
   }
+}
+
+template <int RY>
+static void launch_cg_B_ry(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const double *q, double *r, const KspScal *s, double *partial, int stride)
+{
+  const dim3 gr(p.nblocks), bl(256);
+  if (p.nt) {
+    if (jac) hipLaunchKernelGGL((k_cg_B<RY, true, 1>), gr, bl, 0, st, g, q, r, s, partial, stride, p.nchunk, p.zc, p.tiles_x);
+    else hipLaunchKernelGGL((k_cg_B<RY, false, 1>), gr, bl, 0, st, g, q, r, s, partial, stride, p.nchunk, p.zc, p.tiles_x);
+  } else {
+    if (jac) hipLaunchKernelGGL((k_cg_B<RY, true, 0>), gr, bl, 0, st, g, q, r, s, partial, stride, p.nchunk, p.zc, p.tiles_x);
+    else hipLaunchKernelGGL((k_cg_B<RY, false, 0>), gr, bl, 0, st, g, q, r, s, partial, stride, p.nchunk, p.zc, p.tiles_x);
+  }
+}
+void launch_cg_B(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const double *q, double *r, const KspScal *s, double *partial, int stride)
+{
+  switch (p.ry) {
+  case 4: launch_cg_B_ry<4>(st, g, jac, p, q, r, s, partial, stride); break;
+  case 2: launch_cg_B_ry<2>(st, g, jac, p, q, r, s, partial, stride); break;
+  default: launch_cg_B_ry<1>(st, g, jac, p, q, r, s, partial, stride); break;
+  }
+}
+
+void launch_stream_ref(hipStream_t st, int nr, int nw, int64_t n2, const double *a, const double *b, const double *c, double *o0, double *o1, double *o2)
+{
+  const dim3 gr(2048), bl(256);
+  const double2 *A = (const double2 *)a, *B = (const double2 *)b, *C = (const double2 *)c;
+  double2       *O0 = (double2 *)o0, *O1 = (double2 *)o1, *O2 = (double2 *)o2;
+  switch (nr * 10 + nw) {
+  case 11: hipLaunchKernelGGL((k_stream_ref<1, 1>), gr, bl, 0, st, n2, A, B, C, O0, O1, O2); break;
+  case 21: hipLaunchKernelGGL((k_stream_ref<2, 1>), gr, bl, 0, st, n2, A, B, C, O0, O1, O2); break;
+  case 22: hipLaunchKernelGGL((k_stream_ref<2, 2>), gr, bl, 0, st, n2, A, B, C, O0, O1, O2); break;
+  case 32: hipLaunchKernelGGL((k_stream_ref<3, 2>), gr, bl, 0, st, n2, A, B, C, O0, O1, O2); break;
+  default: hipLaunchKernelGGL((k_stream_ref<3, 3>), gr, bl, 0, st, n2, A, B, C, O0, O1, O2); break;
+  }
+}
+
+template <int NR, int NW>
+static void stream_par_t(hipStream_t st, int u, int nt, int nblocks, int64_t n2, const double2 *A, const double2 *B, const double2 *C, double2 *O0, double2 *O1, double2 *O2)
+{
+  const dim3 gr(nblocks), bl(256);
+  switch (u * 10 + nt) {
+  case 10: hipLaunchKernelGGL((k_stream_par<NR, NW, 1, false>), gr, bl, 0, st, n2, A, B, C, O0, O1, O2); break;
+  case 11: hipLaunchKernelGGL((k_stream_par<NR, NW, 1, true>), gr, bl, 0, st, n2, A, B, C, O0, O1, O2); break;
+  case 20: hipLaunchKernelGGL((k_stream_par<NR, NW, 2, false>), gr, bl, 0, st, n2, A, B, C, O0, O1, O2); break;
+  case 21: hipLaunchKernelGGL((k_stream_par<NR, NW, 2, true>), gr, bl, 0, st, n2, A, B, C, O0, O1, O2); break;
+  case 40: hipLaunchKernelGGL((k_stream_par<NR, NW, 4, false>), gr, bl, 0, st, n2, A, B, C, O0, O1, O2); break;
+  case 41: hipLaunchKernelGGL((k_stream_par<NR, NW, 4, true>), gr, bl, 0, st, n2, A, B, C, O0, O1, O2); break;
+  case 80: hipLaunchKernelGGL((k_stream_par<NR, NW, 8, false>), gr, bl, 0, st, n2, A, B, C, O0, O1, O2); break;
+  default: hipLaunchKernelGGL((k_stream_par<NR, NW, 8, true>), gr, bl, 0, st, n2, A, B, C, O0, O1, O2); break;
+  }
+}
+void launch_stream_par(hipStream_t st, int nr, int nw, int u, int nt, int nblocks, int64_t n2, const double *a, const double *b, const double *c, double *o0, double *o1, double *o2)
+{
+  const double2 *A = (const double2 *)a, *B = (const double2 *)b, *C = (const double2 *)c;
+  double2       *O0 = (double2 *)o0, *O1 = (double2 *)o1, *O2 = (double2 *)o2;
+  if (nr == 1 && nw == 1) stream_par_t<1, 1>(st, u, nt, nblocks, n2, A, B, C, O0, O1, O2);
+  else if (nr == 2 && nw == 1) stream_par_t<2, 1>(st, u, nt, nblocks, n2, A, B, C, O0, O1, O2);
+  else stream_par_t<3, 3>(st, u, nt, nblocks, n2, A, B, C, O0, O1, O2);
 }
 
 void launch_cg_pupdate(hipStream_t st, const GridP &g, bool jac, const double *r, double *P0, double *P1, const KspScal *s)
