@@ -335,7 +335,7 @@ extern "C" int fl_poisson_apply(fl_poisson *h, const double *x_dev, double *y_de
   FL_CHK(fl_ensure_vec(h, &h->w0));
   launch_pad_copy(h->stream, h->g, x_dev, h->w0);
   FL_CHK(fl_fill_ghosts(h, h->w0));
-  launch_apply(h->stream, h->g, h->w0, y_dev, 0);
+  FL_CHK(fl_apply_tiled(h, h->w0, y_dev, 1));
   FL_HIP(hipGetLastError());
   return FL_SUCCESS;
 }
@@ -570,6 +570,13 @@ extern "C" int fl_poisson_solve(fl_poisson *h, const double *b_dev, double *x_de
   case FL_KSP_CG:
     if (opts->norm_type < 0 || opts->norm_type > FL_NORM_NONE) return FL_ERR_ARG_OUTOFRANGE;
     return solve_cg(h, b_dev, x_dev, opts, stats);
+  case FL_KSP_BCGS:
+    // KSPBCGS: left preconditioning, preconditioned residual norm only
+    if (opts->norm_type != FL_NORM_PRECONDITIONED) return FL_ERR_SUP;
+    return fl_solve_bcgs(h, b_dev, x_dev, opts, stats);
+  case FL_KSP_CHEBYSHEV:
+    if (opts->norm_type < 0 || opts->norm_type > FL_NORM_NONE) return FL_ERR_ARG_OUTOFRANGE;
+    return fl_solve_cheb(h, b_dev, x_dev, opts, stats);
   default:
     return FL_ERR_SUP;
   }

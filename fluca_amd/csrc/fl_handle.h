@@ -238,3 +238,7 @@ int  fl_ensure_hist(fl_poisson *h, int nhist);
 int  fl_fill_ghosts(fl_poisson *h, double *v);
 bool fl_any_ghost_exchange(const fl_poisson *h);
 int  fl_poll_scal(fl_poisson *h);
+// fl_ksp.hip
+int fl_apply_tiled(fl_poisson *h, const double *xpad, double *y, int unpadded_y);
+int fl_solve_bcgs(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *o, fl_ksp_stats *st);
+int fl_solve_cheb(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *o, fl_ksp_stats *st);

@@ -1,0 +1,712 @@
+// fl_ksp.hip -- KSPBCGS and KSPCHEBYSHEV restatements for the Schur complement (the other -ns_abf_schur_ksp_type values a
+// Fluca user reaches for: BiCGStab because S is non-symmetric on stretched grids, cnlinearcart3d.c:2348-2361; Chebyshev
+// as the Jacobi smoother of BASELINE.json config 3).  Same conventions as the CG path in fl_kernels.hip: padded vectors,
+// scalars in device memory (KspScal), fixed-order partial sums, lazy constant-null-space removal.
+#include "fl_handle.h"
+
+namespace fl {
+
+__device__ __forceinline__ int64_t pidx(const GridP &g, int i, int j, int k) { return g.off0 + (int64_t)k * g.sxy + (int64_t)j * g.sx + i; }
+__device__ __forceinline__ double  wave_sum(double v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double *red)
+{
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int a = 0; a < NV; ++a) {
+    v[a] = wave_sum(v[a]);
+    if (lane == 0) red[a * 4 + w] = v[a];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int a = 0; a < NV; ++a) v[a] = (red[a * 4 + 0] + red[a * 4 + 1]) + (red[a * 4 + 2] + red[a * 4 + 3]);
+  }
+}
+__device__ __forceinline__ void reduce_partials(const double *__restrict__ partial, int nblocks, int stride, int nslot, double *out, double *red)
+{
+  double v[NSLOT];
+#pragma unroll
+  for (int a = 0; a < NSLOT; ++a) {
+    v[a] = 0.;
+    if (a < nslot)
+      for (int b = threadIdx.x; b < nblocks; b += 256) v[a] += partial[(int64_t)a * stride + b];
+  }
+  block_sum<NSLOT>(v, red);
+  if (threadIdx.x == 0)
+    for (int a = 0; a < NSLOT; ++a) out[a] = v[a];
+  __syncthreads();
+}
+__device__ __forceinline__ int converged_default(const KspScal *s, double dp)
+{
+  if (isnan(dp) || isinf(dp)) return FL_DIVERGED_NANORINF;
+  if (dp <= s->ttol) return dp < s->atol ? FL_CONVERGED_ATOL : FL_CONVERGED_RTOL;
+  if (dp >= s->dtol * s->rnorm0) return FL_DIVERGED_DTOL;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ tile walker
+// 128 x 4*RY x zc tiles like k_cg_B: lane = pair of x-adjacent cells, wave = RY rows, march in z.
+
+struct Tile {
+  int  i, il, k0, k1, lane, w, j0w;
+  bool own0, own1;
+};
+template <int RY>
+__device__ __forceinline__ Tile make_tile(const GridP &g, int nchunk, int zc, int tiles_x)
+{
+  Tile      t;
+  const int b = blockIdx.x, chunk = b % nchunk, tile = b / nchunk;
+  const int i0 = (tile % tiles_x) * 128, j0 = (tile / tiles_x) * (4 * RY);
+  t.k0   = chunk * zc;
+  t.k1   = min(t.k0 + zc, g.nz);
+  t.lane = threadIdx.x & 63;
+  t.w    = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  t.i    = i0 + 2 * t.lane;
+  t.il   = min(t.i, g.nx & ~1);
+  t.own0 = t.i < g.nx;
+  t.own1 = t.i + 1 < g.nx;
+  t.j0w  = j0 + t.w * RY;
+  return t;
+}
+
+// ------------------------------------------------------------------------------------------------ generic fused SpMV
+// y = M (S x) with M = 1/diag (JAC) or 1, x padded with valid ghosts, y padded.  Optional second output and dots:
+//   partial slots: 0 sum y   1 y.o (o may be NULL)   2 x.y   3 y.y
+// MODE 0: plain.  MODE 1 (Chebyshev step): see k_cheb below (separate kernel).
+template <int RY, bool JAC>
+__global__ void __launch_bounds__(256) k_apply_pc(GridP g, const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ o, const KspScal *__restrict__ s, double *__restrict__ partial, int stride, int nchunk,
+                                                  int zc, int tiles_x, int unpadded_y)
+{
+  __shared__ double red[4 * 4];
+  if (s && s->reason != 0) return;
+  const Tile   t = make_tile<RY>(g, nchunk, zc, tiles_x);
+  const double xl0 = g.sl[0][min(t.i, g.nx)], xc0 = g.sc[0][min(t.i, g.nx)], xh0 = g.sh[0][min(t.i, g.nx)];
+  const double xl1 = g.sl[0][min(t.i + 1, g.nx)], xc1 = g.sc[0][min(t.i + 1, g.nx)], xh1 = g.sh[0][min(t.i + 1, g.nx)];
+  double       acc[4] = {0., 0., 0., 0.};
+  if (t.k0 < t.k1) {
+    double2 prev[RY], cur[RY], nxt[RY];
+#pragma unroll
+    for (int m = 0; m < RY; ++m) {
+      const int64_t ro = g.off0 + (int64_t)min(t.j0w + m, g.ny) * g.sx + t.il;
+      prev[m] = *reinterpret_cast<const double2 *>(x + ro + (int64_t)(t.k0 - 1) * g.sxy);
+      cur[m]  = *reinterpret_cast<const double2 *>(x + ro + (int64_t)t.k0 * g.sxy);
+    }
+    for (int k = t.k0; k < t.k1; ++k) {
+      const int64_t pc = (int64_t)k * g.sxy;
+      const double  zl = g.sl[2][k], zcc = g.sc[2][k], zh = g.sh[2][k];
+      double2       south, north;
+      double        west[RY], east[RY];
+      {
+        const int64_t rs = g.off0 + (int64_t)min(t.j0w - 1, g.ny) * g.sx + t.il + pc;
+        const int64_t rn = g.off0 + (int64_t)min(t.j0w + RY, g.ny + 0) * g.sx + t.il + pc;
+        south = *reinterpret_cast<const double2 *>(x + rs);
+        north = *reinterpret_cast<const double2 *>(x + rn);
+      }
+#pragma unroll
+      for (int m = 0; m < RY; ++m) {
+        const int64_t ro = g.off0 + (int64_t)min(t.j0w + m, g.ny) * g.sx + t.il;
+        nxt[m]  = *reinterpret_cast<const double2 *>(x + ro + pc + g.sxy);
+        west[m] = x[ro + pc - 1];
+        east[m] = x[ro + pc + 2];
+      }
+#pragma unroll
+      for (int m = 0; m < RY; ++m) {
+        const int     j  = t.j0w + m, jc = min(j, g.ny);
+        const double  yl = g.sl[1][jc], ycc = g.sc[1][jc], yh = g.sh[1][jc];
+        const double2 so = m > 0 ? cur[m - 1] : south, no = m < RY - 1 ? cur[m + 1] : north;
+        const double  dyz = ycc + zcc;
+        double2       v;
+        v.x = (xc0 + dyz) * cur[m].x + xl0 * west[m] + xh0 * cur[m].y + yl * so.x + yh * no.x + zl * prev[m].x + zh * nxt[m].x;
+        v.y = (xc1 + dyz) * cur[m].y + xl1 * cur[m].x + xh1 * east[m] + yl * so.y + yh * no.y + zl * prev[m].y + zh * nxt[m].y;
+        if (JAC) {
+          v.x /= (xc0 + dyz);
+          v.y /= (xc1 + dyz);
+        }
+        if (j < g.ny) {
+          const int64_t ro = g.off0 + (int64_t)j * g.sx + t.il + pc;
+          double2       ov = make_double2(0., 0.);
+          if (o) ov = *reinterpret_cast<const double2 *>(o + ro);
+          if (unpadded_y) {
+            const int64_t u = ((int64_t)k * g.ny + j) * g.nx + t.i;
+            if (t.own0) y[u] = v.x;
+            if (t.own1) y[u + 1] = v.y;
+          } else {
+            if (t.own1) *reinterpret_cast<double2 *>(y + ro) = v;
+            else if (t.own0) y[ro] = v.x;
+          }
+          if (t.own0) {
+            acc[0] += v.x;
+            acc[1] += v.x * ov.x;
+            acc[2] += cur[m].x * v.x;
+            acc[3] += v.x * v.x;
+          }
+          if (t.own1) {
+            acc[0] += v.y;
+            acc[1] += v.y * ov.y;
+            acc[2] += cur[m].y * v.y;
+            acc[3] += v.y * v.y;
+          }
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < RY; ++m) {
+        prev[m] = cur[m];
+        cur[m]  = nxt[m];
+      }
+    }
+  }
+  if (partial) {
+    block_sum<4>(acc, red);
+    if (threadIdx.x == 0)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) partial[(int64_t)a * stride + blockIdx.x] = acc[a];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ pointwise kernels
+// OP 0 (BiCGStab P):  P = R - (omega_old*beta) (V0 - vshift) + beta P
+// OP 1 (BiCGStab S):  S0 = R - alpha V0                       sums: 0 sum S0
+// OP 2 (BiCGStab X,R): X += alpha P + omega (S0 - sshift) ; R = (S0 - sshift) - omega (T0 - tshift)
+//                      sums: 0 R.R  1 R.RP  2 sum R
+// OP 3 (init):        R = M b (unpadded b) ; RP = R (after the shift is known: see OP 4)   sums: 0 sum R0  1 R0.R0
+// OP 4:               R -= shift ; RP = R
+template <int RY, int OP, bool JAC>
+__global__ void __launch_bounds__(256) k_bcgs_pw(GridP g, const double *__restrict__ a0, const double *__restrict__ a1, const double *__restrict__ a2, const double *__restrict__ a3, double *__restrict__ w0, double *__restrict__ w1,
+                                                 const KspScal *__restrict__ s, double *__restrict__ partial, int stride, int nchunk, int zc, int tiles_x)
+{
+  __shared__ double red[3 * 4];
+  if (OP != 3 && OP != 4 && s->reason != 0) return;
+  const Tile   t = make_tile<RY>(g, nchunk, zc, tiles_x);
+  const double xc0 = g.sc[0][min(t.i, g.nx)], xc1 = g.sc[0][min(t.i + 1, g.nx)];
+  double       acc[3] = {0., 0., 0.};
+  const double alpha = s->alpha, omega = s->omega, beta = s->beta, ob = s->omega_old * s->beta, vsh = s->vshift, ssh = s->rshift, tsh = s->tshift, sh0 = s->zshift;
+  for (int k = t.k0; k < t.k1; ++k) {
+#pragma unroll
+    for (int m = 0; m < RY; ++m) {
+      const int j = t.j0w + m;
+      if (j >= g.ny || !t.own0) continue;
+      const int64_t ro = g.off0 + (int64_t)j * g.sx + t.il + (int64_t)k * g.sxy;
+      const bool    two = t.own1;
+      auto L = [&](const double *p) { return two ? *reinterpret_cast<const double2 *>(p + ro) : make_double2(p[ro], 0.); };
+      auto W = [&](double *p, double2 v) {
+        if (two) *reinterpret_cast<double2 *>(p + ro) = v;
+        else p[ro] = v.x;
+      };
+      if (OP == 0) {
+        const double2 R = L(a0), V = L(a1), P = L(w0);
+        double2       o;
+        o.x = R.x - ob * (V.x - vsh) + beta * P.x;
+        o.y = R.y - ob * (V.y - vsh) + beta * P.y;
+        W(w0, o);
+      } else if (OP == 1) {
+        const double2 R = L(a0), V = L(a1);
+        double2       o;
+        o.x = R.x - alpha * V.x;
+        o.y = R.y - alpha * V.y;
+        W(w0, o);
+        acc[0] += o.x + (two ? o.y : 0.);
+      } else if (OP == 2) {
+        const double2 P = L(a0), S0 = L(a1), T0 = L(a2), RP = L(a3), X = L(w0);
+        double2       xs, rn;
+        const double  s0 = S0.x - ssh, s1 = S0.y - ssh;
+        xs.x = X.x + alpha * P.x + omega * s0;
+        xs.y = X.y + alpha * P.y + omega * s1;
+        rn.x = s0 - omega * (T0.x - tsh);
+        rn.y = s1 - omega * (T0.y - tsh);
+        W(w0, xs);
+        W(w1, rn);
+        acc[0] += rn.x * rn.x + (two ? rn.y * rn.y : 0.);
+        acc[1] += rn.x * RP.x + (two ? rn.y * RP.y : 0.);
+        acc[2] += rn.x + (two ? rn.y : 0.);
+      } else if (OP == 3) {
+        const int64_t u = ((int64_t)k * g.ny + j) * g.nx + t.i;
+        const double  dyz = g.sc[1][j] + g.sc[2][k];
+        double2       o;
+        o.x = JAC ? a0[u] / (xc0 + dyz) : a0[u];
+        o.y = two ? (JAC ? a0[u + 1] / (xc1 + dyz) : a0[u + 1]) : 0.;
+        W(w0, o);
+        acc[0] += o.x + o.y;
+        acc[1] += o.x * o.x + o.y * o.y;
+      } else {
+        double2 R = L(w0);
+        R.x -= sh0;
+        R.y -= sh0;
+        W(w0, R);
+        W(w1, R);
+      }
+    }
+  }
+  if (OP == 1 || OP == 2 || OP == 3) {
+    block_sum<3>(acc, red);
+    if (threadIdx.x == 0)
+#pragma unroll
+      for (int a = 0; a < 3; ++a) partial[(int64_t)a * stride + blockIdx.x] = acc[a];
+  }
+}
+
+// BiCGStab scalar updates.  mode: 0 init (after OP 3)  1 after V0 = M S P   2 after S0   3 after T0 = M S S0   4 after OP 2
+__global__ void __launch_bounds__(256) k_bcgs_fin(int mode, const double *__restrict__ partial, int nblocks, int stride, const double *__restrict__ sums, KspScal *__restrict__ s, double *__restrict__ hist, int nhist)
+{
+  __shared__ double out[NSLOT], red[NSLOT * 4];
+  if (mode != 0 && s->reason != 0) return;
+  if (nblocks > 0) reduce_partials(partial, nblocks, stride, 4, out, red);
+  else {
+    if (threadIdx.x < NSLOT) out[threadIdx.x] = sums[threadIdx.x];
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  const double N  = s->ncell_global;
+  const bool   ns = s->nullspace != 0;
+  if (mode == 0) {
+    // R0 = M b: shift = mean, ||R||^2 = sum R0^2 - N mean^2 ; rho_0 = R.RP = ||R||^2
+    const double m  = ns ? out[0] / N : 0.;
+    const double rr = out[1] - N * m * m;
+    s->zshift       = m;
+    const double dp = sqrt(rr < 0. ? 0. : rr);
+    s->rho          = rr;
+    s->rho_old = s->alpha = s->omega_old = s->omega = 1.;
+    s->beta   = 0.;
+    s->vshift = s->rshift = s->tshift = 0.;
+    s->it     = 0;
+    s->rnorm0 = s->dp = dp;
+    s->ttol   = fmax(s->rtol * dp, s->atol);
+    if (hist && nhist > 0) hist[0] = dp;
+    int reason = converged_default(s, dp);
+    if (!reason && s->maxit <= 0) reason = FL_DIVERGED_ITS;
+    if (!reason && s->rho == 0.) reason = FL_DIVERGED_BREAKDOWN;
+    s->reason = reason;
+    // first iteration: beta = (rho/1)(1/1) = rho, P = R - 1*beta*0 + beta*0 -> handled by P = V = 0 and the general formula
+    s->beta = (s->rho / s->rho_old) * (s->alpha / s->omega_old);
+  } else if (mode == 1) {
+    // slots: 0 sum V0, 1 V0.RP (RP has zero mean: the shift drops out)
+    s->vshift = ns ? out[0] / N : 0.;
+    const double d1 = out[1];
+    if (d1 == 0. || isnan(d1)) {
+      s->reason = isnan(d1) ? FL_DIVERGED_NANORINF : FL_DIVERGED_BREAKDOWN;
+      return;
+    }
+    s->alpha = s->rho / d1;
+  } else if (mode == 2) {
+    // S = S0 - rshift with S0 = R - alpha V0, V = V0 - vshift  ->  rshift = -alpha * vshift ; keep sum S0
+    s->rshift = -s->alpha * s->vshift;
+    s->d1     = out[0];  // sum S0
+  } else if (mode == 3) {
+    // slots: 0 sum T0, 2 S0.T0 (x.y), 3 T0.T0
+    const double tb = ns ? out[0] / N : 0.;
+    s->tshift       = tb;
+    const double sb = s->rshift, sumS0 = s->d1, sumT0 = out[0];
+    const double st = out[2] - sb * sumT0 - tb * sumS0 + N * sb * tb;
+    const double tt = out[3] - 2. * tb * sumT0 + N * tb * tb;
+    if (tt == 0.) {
+      // S == 0: x + alpha P is the solution (handled by omega = 0 in the X update)
+      s->omega = 0.;
+      s->d2    = 0.;
+    } else {
+      s->omega = st / tt;
+      s->d2    = tt;
+    }
+  } else {
+    // slots: 0 R.R, 1 R.RP
+    const double dp = s->d2 == 0. ? 0. : sqrt(out[0]);
+    s->rho_old   = s->rho;
+    s->rho       = out[1];
+    s->omega_old = s->omega;
+    s->it += 1;
+    s->dp = dp;
+    if (hist && s->it < nhist) hist[s->it] = dp;
+    int reason = s->d2 == 0. ? FL_CONVERGED_RTOL : converged_default(s, dp);
+    if (!reason) {
+      if (s->it >= s->maxit) reason = FL_DIVERGED_ITS;
+      else if (s->rho == 0.) reason = FL_DIVERGED_BREAKDOWN;
+    }
+    s->reason = reason;
+    s->beta   = (s->rho / s->rho_old) * (s->alpha / s->omega_old);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ Chebyshev
+// One fused step: z = M (b - S x) ; d = rho d + c z ; x' = x + d   (x -> the other buffer, d in place)
+// sums: 0 sum z  1 z.z  2 r.r
+template <int RY, bool JAC>
+__global__ void __launch_bounds__(256) k_cheb(GridP g, const double *X0, const double *X1, double *X0w, double *X1w, const double *__restrict__ b, double *__restrict__ d,
+                                              const KspScal *__restrict__ s, double *__restrict__ partial, int stride, int nchunk, int zc, int tiles_x)
+{
+  __shared__ double red[3 * 4];
+  if (s->reason != 0) return;
+  const double *x  = s->cur ? X1 : X0;
+  double       *xn = s->cur ? X0w : X1w;
+  const double  rho = s->cheb_rho, cc = s->cheb_c;
+  const Tile    t = make_tile<RY>(g, nchunk, zc, tiles_x);
+  const double  xl0 = g.sl[0][min(t.i, g.nx)], xc0 = g.sc[0][min(t.i, g.nx)], xh0 = g.sh[0][min(t.i, g.nx)];
+  const double  xl1 = g.sl[0][min(t.i + 1, g.nx)], xc1 = g.sc[0][min(t.i + 1, g.nx)], xh1 = g.sh[0][min(t.i + 1, g.nx)];
+  double        acc[3] = {0., 0., 0.};
+  if (t.k0 < t.k1) {
+    double2 prev[RY], cur[RY], nxt[RY];
+#pragma unroll
+    for (int m = 0; m < RY; ++m) {
+      const int64_t ro = g.off0 + (int64_t)min(t.j0w + m, g.ny) * g.sx + t.il;
+      prev[m] = *reinterpret_cast<const double2 *>(x + ro + (int64_t)(t.k0 - 1) * g.sxy);
+      cur[m]  = *reinterpret_cast<const double2 *>(x + ro + (int64_t)t.k0 * g.sxy);
+    }
+    for (int k = t.k0; k < t.k1; ++k) {
+      const int64_t pc = (int64_t)k * g.sxy;
+      const double  zl = g.sl[2][k], zcc = g.sc[2][k], zh = g.sh[2][k];
+      double2       south, north;
+      double        west[RY], east[RY];
+      south = *reinterpret_cast<const double2 *>(x + g.off0 + (int64_t)min(t.j0w - 1, g.ny) * g.sx + t.il + pc);
+      north = *reinterpret_cast<const double2 *>(x + g.off0 + (int64_t)min(t.j0w + RY, g.ny) * g.sx + t.il + pc);
+#pragma unroll
+      for (int m = 0; m < RY; ++m) {
+        const int64_t ro = g.off0 + (int64_t)min(t.j0w + m, g.ny) * g.sx + t.il;
+        nxt[m]  = *reinterpret_cast<const double2 *>(x + ro + pc + g.sxy);
+        west[m] = x[ro + pc - 1];
+        east[m] = x[ro + pc + 2];
+      }
+#pragma unroll
+      for (int m = 0; m < RY; ++m) {
+        const int     j  = t.j0w + m, jc = min(j, g.ny);
+        const double  yl = g.sl[1][jc], ycc = g.sc[1][jc], yh = g.sh[1][jc];
+        const double2 so = m > 0 ? cur[m - 1] : south, no = m < RY - 1 ? cur[m + 1] : north;
+        const double  dyz = ycc + zcc;
+        double2       v;
+        v.x = (xc0 + dyz) * cur[m].x + xl0 * west[m] + xh0 * cur[m].y + yl * so.x + yh * no.x + zl * prev[m].x + zh * nxt[m].x;
+        v.y = (xc1 + dyz) * cur[m].y + xl1 * cur[m].x + xh1 * east[m] + yl * so.y + yh * no.y + zl * prev[m].y + zh * nxt[m].y;
+        if (j < g.ny && t.own0) {
+          const int64_t ro = g.off0 + (int64_t)j * g.sx + t.il + pc;
+          const bool    two = t.own1;
+          const double2 bv = two ? *reinterpret_cast<const double2 *>(b + ro) : make_double2(b[ro], 0.);
+          const double2 dv = two ? *reinterpret_cast<const double2 *>(d + ro) : make_double2(d[ro], 0.);
+          const double  r0 = bv.x - v.x, r1 = two ? bv.y - v.y : 0.;
+          const double  z0 = JAC ? r0 / (xc0 + dyz) : r0, z1 = two ? (JAC ? r1 / (xc1 + dyz) : r1) : 0.;
+          double2       dn, xo;
+          dn.x = rho * dv.x + cc * z0;
+          dn.y = rho * dv.y + cc * z1;
+          xo.x = cur[m].x + dn.x;
+          xo.y = cur[m].y + dn.y;
+          if (two) {
+            *reinterpret_cast<double2 *>(d + ro)  = dn;
+            *reinterpret_cast<double2 *>(xn + ro) = xo;
+          } else {
+            d[ro]  = dn.x;
+            xn[ro] = xo.x;
+          }
+          acc[0] += z0 + z1;
+          acc[1] += z0 * z0 + z1 * z1;
+          acc[2] += r0 * r0 + r1 * r1;
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < RY; ++m) {
+        prev[m] = cur[m];
+        cur[m]  = nxt[m];
+      }
+    }
+  }
+  block_sum<3>(acc, red);
+  if (threadIdx.x == 0)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) partial[(int64_t)a * stride + blockIdx.x] = acc[a];
+}
+
+// after launch j of k_cheb: convergence test on the residual of x_j, then either stop (answer = old buffer, x_j) or accept
+// the update (flip) and prepare rho, c of the next step.
+__global__ void __launch_bounds__(256) k_cheb_fin(const double *__restrict__ partial, int nblocks, int stride, const double *__restrict__ sums, KspScal *__restrict__ s, double *__restrict__ hist, int nhist)
+{
+  __shared__ double out[NSLOT], red[NSLOT * 4];
+  if (s->reason != 0) return;
+  if (nblocks > 0) reduce_partials(partial, nblocks, stride, 3, out, red);
+  else {
+    if (threadIdx.x < NSLOT) out[threadIdx.x] = sums[threadIdx.x];
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  const double N = s->ncell_global;
+  const double m = s->nullspace ? out[0] / N : 0.;
+  const int    j = s->it;  // index of the step just executed
+  if (s->norm_type != FL_NORM_NONE) {
+    const double zz = out[1] - N * m * m;
+    const double dp = s->norm_type == FL_NORM_UNPRECONDITIONED ? sqrt(out[2]) : sqrt(zz < 0. ? 0. : zz);
+    if (j == 0) {
+      s->rnorm0 = dp;
+      s->ttol   = fmax(s->rtol * dp, s->atol);
+    }
+    s->dp = dp;
+    if (hist && j < nhist) hist[j] = dp;
+    int reason = converged_default(s, dp);
+    if (!reason && j >= s->maxit) reason = FL_DIVERGED_ITS;
+    if (reason) {
+      s->reason = reason;  // answer: x_j in the buffer this step read (cur not flipped), constant shift xshift
+      return;
+    }
+  }
+  // accept x_{j+1} = x_j + d_{j+1};  lazy null-space bookkeeping: d_true = d - dshift, x_true = x - xshift
+  s->dshift = s->cheb_rho * s->dshift + s->cheb_c * m;
+  s->xshift += s->dshift;
+  s->cur ^= 1;
+  s->it = j + 1;
+  if (s->norm_type == FL_NORM_NONE && s->it >= s->maxit) {
+    s->reason = FL_CONVERGED_ITS;
+    return;
+  }
+  // next step: c_{k+1} = 2 mu c_k - c_{k-1}; omega = omegaprod c_k / c_{k+1}; d' = (omega-1) d + omega*scale z
+  const double ckp1  = 2. * s->mu * s->ck - s->ckm1;
+  const double omega = s->omegaprod * s->ck / ckp1;
+  s->ckm1            = s->ck;
+  s->ck              = ckp1;
+  s->cheb_rho        = omega - 1.;
+  s->cheb_c          = omega * s->scale;
+}
+
+}  // namespace fl
+
+using namespace fl;
+
+// ------------------------------------------------------------------------------------------------ drivers
+
+namespace {
+
+struct TP {
+  int ry, nchunk, zc, tiles_x, nblocks;
+};
+TP tile_plan(const GridP &g)
+{
+  TP t;
+  t.ry = g.ny >= 16 ? 2 : 1;
+  t.tiles_x = (g.nx + 127) / 128;
+  const int tiles_y = (g.ny + 4 * t.ry - 1) / (4 * t.ry), tiles = t.tiles_x * tiles_y;
+  int       nchunk = std::max(1, (1024 + tiles / 2) / tiles);
+  nchunk   = std::max(1, std::min(std::min(nchunk, std::max(1, g.nz / 8)), g.nz));
+  t.zc     = (g.nz + nchunk - 1) / nchunk;
+  t.nchunk = (g.nz + t.zc - 1) / t.zc;
+  t.nblocks = tiles * t.nchunk;
+  return t;
+}
+
+template <int RY, bool JAC>
+void apply_pc_t(fl_poisson *h, const TP &tp, const double *x, double *y, const double *o, const KspScal *s, double *partial, int unpadded_y)
+{
+  hipLaunchKernelGGL((k_apply_pc<RY, JAC>), dim3(tp.nblocks), dim3(256), 0, h->stream, h->g, x, y, o, s, partial, h->partial_stride, tp.nchunk, tp.zc, tp.tiles_x, unpadded_y);
+}
+void launch_apply_pc(fl_poisson *h, const TP &tp, bool jac, const double *x, double *y, const double *o, const KspScal *s, double *partial, int unpadded_y)
+{
+  if (jac) {
+    if (tp.ry == 2) apply_pc_t<2, true>(h, tp, x, y, o, s, partial, unpadded_y);
+    else apply_pc_t<1, true>(h, tp, x, y, o, s, partial, unpadded_y);
+  } else {
+    if (tp.ry == 2) apply_pc_t<2, false>(h, tp, x, y, o, s, partial, unpadded_y);
+    else apply_pc_t<1, false>(h, tp, x, y, o, s, partial, unpadded_y);
+  }
+}
+
+template <int RY, int OP, bool JAC>
+void pw_t(fl_poisson *h, const TP &tp, const double *a0, const double *a1, const double *a2, const double *a3, double *w0, double *w1)
+{
+  hipLaunchKernelGGL((k_bcgs_pw<RY, OP, JAC>), dim3(tp.nblocks), dim3(256), 0, h->stream, h->g, a0, a1, a2, a3, w0, w1, h->scal, h->partial, h->partial_stride, tp.nchunk, tp.zc, tp.tiles_x);
+}
+template <int OP>
+void launch_pw(fl_poisson *h, const TP &tp, bool jac, const double *a0, const double *a1, const double *a2, const double *a3, double *w0, double *w1)
+{
+  if (jac) {
+    if (tp.ry == 2) pw_t<2, OP, true>(h, tp, a0, a1, a2, a3, w0, w1);
+    else pw_t<1, OP, true>(h, tp, a0, a1, a2, a3, w0, w1);
+  } else {
+    if (tp.ry == 2) pw_t<2, OP, false>(h, tp, a0, a1, a2, a3, w0, w1);
+    else pw_t<1, OP, false>(h, tp, a0, a1, a2, a3, w0, w1);
+  }
+}
+
+template <int RY, bool JAC>
+void cheb_t(fl_poisson *h, const TP &tp, double *X0, double *X1, const double *B, double *D)
+{
+  hipLaunchKernelGGL((k_cheb<RY, JAC>), dim3(tp.nblocks), dim3(256), 0, h->stream, h->g, X0, X1, X0, X1, B, D, h->scal, h->partial, h->partial_stride, tp.nchunk, tp.zc, tp.tiles_x);
+}
+void launch_cheb(fl_poisson *h, const TP &tp, bool jac, double *X0, double *X1, const double *B, double *D)
+{
+  if (jac) {
+    if (tp.ry == 2) cheb_t<2, true>(h, tp, X0, X1, B, D);
+    else cheb_t<1, true>(h, tp, X0, X1, B, D);
+  } else {
+    if (tp.ry == 2) cheb_t<2, false>(h, tp, X0, X1, B, D);
+    else cheb_t<1, false>(h, tp, X0, X1, B, D);
+  }
+}
+
+// partial sums -> scalar kernel, with the all-reduce in between when there is more than one rank
+template <class F>
+int fin_step(fl_poisson *h, int nblocks, int nslot, F &&launch_fin)
+{
+  if (!h->multi) {
+    launch_fin(h->partial, nblocks, h->partial_stride, (const double *)nullptr);
+    return 0;
+  }
+  launch_reduce(h->stream, h->partial, nblocks, h->partial_stride, nslot, h->sums);
+  FL_CHK(h->comm.allreduce(h->stream, h->sums, NSLOT));
+  launch_fin((const double *)nullptr, 0, 0, (const double *)h->sums);
+  return 0;
+}
+
+void init_scal(fl_poisson *h, const fl_ksp_opts *o)
+{
+  KspScal &S = *h->scal_host;
+  std::memset(&S, 0, sizeof(S));
+  S.rtol         = o->rtol;
+  S.atol         = o->atol;
+  S.dtol         = o->dtol;
+  S.ncell_global = (double)h->ax[0].n * (double)h->ax[1].n * (double)h->ax[2].n;
+  S.maxit        = o->maxit;
+  S.norm_type    = o->norm_type;
+  S.nullspace    = o->remove_nullspace;
+}
+
+int finish_stats(fl_poisson *h, const fl_ksp_opts *o, fl_ksp_stats *st)
+{
+  FL_HIP(hipEventRecord(h->ev1, h->stream));
+  FL_CHK(fl_poll_scal(h));
+  FL_HIP(hipGetLastError());
+  float ms = 0.f;
+  FL_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  const KspScal &R = *h->scal_host;
+  st->iters        = R.it;
+  st->reason       = R.reason ? R.reason : FL_DIVERGED_ITS;
+  st->rnorm0       = R.rnorm0;
+  st->rnorm        = R.dp;
+  st->seconds      = ms * 1e-3;
+  if (o->history && o->nhistory > 0) {
+    const int n = std::min(o->nhistory, R.it + 1);
+    FL_HIP(hipMemcpy(o->history, h->hist, sizeof(double) * n, hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
+}  // namespace
+
+int fl_apply_tiled(fl_poisson *h, const double *xpad, double *y, int unpadded_y)
+{
+  const TP tp = tile_plan(h->g);
+  launch_apply_pc(h, tp, false, xpad, y, nullptr, nullptr, nullptr, unpadded_y);
+  return 0;
+}
+
+int fl_solve_bcgs(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *o, fl_ksp_stats *st)
+{
+  const GridP &g   = h->g;
+  const bool   jac = o->pc == FL_PC_JACOBI;
+  // vectors: r=R, P0=RP, P1=P, q=V0, xp=X, w0=S0, w1=T0
+  for (double **v : {&h->r, &h->P0, &h->P1, &h->q, &h->xp, &h->w0, &h->w1}) FL_CHK(fl_ensure_vec(h, v));
+  const TP tp = tile_plan(g);
+  FL_CHK(fl_ensure_partials(h, tp.nblocks));
+  const int nhist = o->maxit + 1;
+  FL_CHK(fl_ensure_hist(h, nhist));
+  hipStream_t s = h->stream;
+  init_scal(h, o);
+  FL_HIP(hipEventRecord(h->ev0, s));
+  FL_HIP(hipMemcpyAsync(h->scal, h->scal_host, sizeof(KspScal), hipMemcpyHostToDevice, s));
+  for (double *v : {h->P1, h->q, h->xp}) FL_HIP(hipMemsetAsync(v, 0, sizeof(double) * h->padlen, s));
+  double *R = h->r, *RP = h->P0, *P = h->P1, *V0 = h->q, *X = h->xp, *S0 = h->w0, *T0 = h->w1;
+  auto    fin = [&](int mode) {
+    return [=](const double *partial, int nb, int stride, const double *sums) { hipLaunchKernelGGL(k_bcgs_fin, dim3(1), dim3(256), 0, s, mode, partial, nb, stride, sums, h->scal, h->hist, nhist); };
+  };
+  launch_pw<3>(h, tp, jac, b, nullptr, nullptr, nullptr, R, nullptr);
+  FL_CHK(fin_step(h, tp.nblocks, 3, fin(0)));
+  launch_pw<4>(h, tp, jac, nullptr, nullptr, nullptr, nullptr, R, RP);
+  const bool ghosts = fl_any_ghost_exchange(h);
+  const int  every  = o->check_every > 0 ? o->check_every : 16;
+  int        it = 0;
+  bool       done = false;
+  while (!done) {
+    const int stop = std::min(o->maxit, it + every);
+    for (; it < stop; ++it) {
+      launch_pw<0>(h, tp, jac, R, V0, nullptr, nullptr, P, nullptr);
+      if (ghosts) FL_CHK(fl_fill_ghosts(h, P));
+      launch_apply_pc(h, tp, jac, P, V0, RP, h->scal, h->partial, 0);
+      FL_CHK(fin_step(h, tp.nblocks, 4, fin(1)));
+      launch_pw<1>(h, tp, jac, R, V0, nullptr, nullptr, S0, nullptr);
+      FL_CHK(fin_step(h, tp.nblocks, 3, fin(2)));
+      if (ghosts) FL_CHK(fl_fill_ghosts(h, S0));
+      launch_apply_pc(h, tp, jac, S0, T0, nullptr, h->scal, h->partial, 0);
+      FL_CHK(fin_step(h, tp.nblocks, 4, fin(3)));
+      launch_pw<2>(h, tp, jac, P, S0, T0, RP, X, R);
+      FL_CHK(fin_step(h, tp.nblocks, 3, fin(4)));
+    }
+    FL_CHK(fl_poll_scal(h));
+    if (h->scal_host->reason != 0 || it >= o->maxit) done = true;
+  }
+  launch_unpad_copy(s, g, X, x, nullptr);
+  return finish_stats(h, o, st);
+}
+
+int fl_solve_cheb(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *o, fl_ksp_stats *st)
+{
+  const GridP &g   = h->g;
+  const bool   jac = o->pc == FL_PC_JACOBI;
+  if (o->norm_type == FL_NORM_NATURAL) return FL_ERR_SUP;
+  // vectors: xp=X0, P0=X1, r=b (padded), q=d
+  for (double **v : {&h->r, &h->P0, &h->q, &h->xp}) FL_CHK(fl_ensure_vec(h, v));
+  const TP tp = tile_plan(g);
+  FL_CHK(fl_ensure_partials(h, std::max(tp.nblocks, 1024)));
+  const int nhist = o->maxit + 2;
+  FL_CHK(fl_ensure_hist(h, nhist));
+  hipStream_t s = h->stream;
+  double emin = o->emin, emax = o->emax;
+  if (emin == 0. && emax == 0.) {
+    // Upper bound of the spectrum of M S from the GLOBAL 1-D tables (identical on every rank):
+    //   Jacobi: sum_d a_d / sum_d c_d <= max_d max_i a_d(i)/c_d(i)   (mediant inequality), a = |sl|+|sc|+|sh|, c = |sc|
+    //   none  : sum_d max_i a_d(i)
+    // For the uniform Neumann / periodic Laplacian this is the exact Gershgorin value 2.
+    double lam = 0.;
+    for (int d = 0; d < 3; ++d) {
+      const Axis &A = h->ax[d];
+      double      md = 0.;
+      for (int64_t i = 0; i < A.n; ++i) {
+        const double a = std::fabs(A.sl[i]) + std::fabs(A.sc[i]) + std::fabs(A.sh[i]);
+        md             = std::max(md, jac ? a / std::fabs(A.sc[i]) : a);
+      }
+      lam = jac ? std::max(lam, md) : lam + md;
+    }
+    emin = 0.1 * lam;  // -ksp_chebyshev_esteig 0,0.1,0,1.1 applied to the bound
+    emax = 1.1 * lam;
+  }
+  init_scal(h, o);
+  KspScal &S = *h->scal_host;
+  S.scale     = 2. / (emax + emin);
+  const double alpha = 1. - S.scale * emin;
+  S.mu        = 1. / alpha;
+  S.omegaprod = 2. / alpha;
+  S.ckm1      = 1.;
+  S.ck        = S.mu;
+  S.cheb_rho  = 0.;        // step 0: d_1 = scale * z_0
+  S.cheb_c    = S.scale;
+  FL_HIP(hipEventRecord(h->ev0, s));
+  FL_HIP(hipMemcpyAsync(h->scal, h->scal_host, sizeof(KspScal), hipMemcpyHostToDevice, s));
+  for (double *v : {h->P0, h->q, h->xp}) FL_HIP(hipMemsetAsync(v, 0, sizeof(double) * h->padlen, s));
+  launch_pad_copy(s, g, b, h->r);
+  double    *X0 = h->xp, *X1 = h->P0, *B = h->r, *D = h->q;
+  const bool ghosts = fl_any_ghost_exchange(h);
+  const int  every  = o->check_every > 0 ? o->check_every : 16;
+  const int  total  = o->norm_type == FL_NORM_NONE ? o->maxit : o->maxit + 1;  // with a norm, launch maxit is only the final check
+  auto       finl   = [=](const double *partial, int nb, int stride, const double *sums) { hipLaunchKernelGGL(k_cheb_fin, dim3(1), dim3(256), 0, s, partial, nb, stride, sums, h->scal, h->hist, nhist); };
+  int        j = 0, hostcur = 0;
+  bool       done = total <= 0;
+  while (!done) {
+    const int stop = std::min(total, j + every);
+    for (; j < stop; ++j) {
+      if (ghosts && j > 0) FL_CHK(fl_fill_ghosts(h, hostcur ? X1 : X0));
+      launch_cheb(h, tp, jac, X0, X1, B, D);
+      FL_CHK(fin_step(h, tp.nblocks, 3, finl));
+      hostcur ^= 1;
+    }
+    FL_CHK(fl_poll_scal(h));
+    if (h->scal_host->reason != 0 || j >= total) done = true;
+  }
+  FL_CHK(fl_poll_scal(h));
+  const KspScal &R = *h->scal_host;
+  // answer: buffer `cur`, minus the accumulated constant (null-space removal done lazily)
+  launch_unpad_copy(s, g, R.cur ? X1 : X0, x, R.nullspace ? &h->scal->xshift : nullptr);
+  return finish_stats(h, o, st);
+}

@@ -1,0 +1,99 @@
+"""-m gpu: BiCGStab and Chebyshev through the C-ABI against the CPU oracle (PARITY UNPINNED vs PETSc)."""
+import numpy as np
+import pytest
+
+from oracle import fluca_oracle as fo
+from tests.gpu_common import CAVITY, O, PER, SYM, V, dev, host, make_pair, mean_free_rhs
+
+pytestmark = pytest.mark.gpu
+
+
+def _common(ig, io, hist_rtol=1e-6, iters_tol=2):
+    assert ig["reason"] == io["reason"], (ig["reason"], io["reason"], ig["iters"], io["iters"])
+    assert abs(ig["iters"] - io["iters"]) <= iters_tol, (ig["iters"], io["iters"])
+    m = min(len(ig["history"]), len(io["history"]))
+    assert np.allclose(ig["history"][: min(m, 4)], io["history"][: min(m, 4)], rtol=1e-9, atol=0)
+    assert np.allclose(ig["history"][:m], io["history"][:m], rtol=hist_rtol, atol=1e-300)
+
+
+@pytest.mark.parametrize("n,bc,nonuni,nullspace", [
+    ((17, 9, 11), CAVITY, False, True),
+    ((12, 10, 9), [PER] * 6, False, True),
+    ((9, 12, 7), [V, O, V, V, PER, PER], False, False),
+    ((11, 7, 13), [O, V, SYM, V, V, O], True, False),       # stretched grid: S non-symmetric, CG is not valid here
+    ((130, 37, 20), CAVITY, True, True),
+    ((136, 70, 12), [PER, PER, V, V, PER, PER], False, True),
+])
+@pytest.mark.parametrize("pc", [fo.PC_JACOBI, fo.PC_NONE])
+def test_bcgs_matches_oracle(n, bc, nonuni, nullspace, pc):
+    P, g = make_pair(n, bc, kappa=1e-3, nonuniform=nonuni)
+    S = g.assemble_S()
+    if nullspace:
+        _, b = mean_free_rhs(S, g.ncell)
+    else:
+        b = np.random.default_rng(5).standard_normal(g.ncell)
+    rtol = 1e-6
+    xo, io = S.solve(b, ksp=fo.KSP_BCGS, pc=pc, nullspace=nullspace, rtol=rtol, maxit=2000)
+    xg, ig = P.solve(dev(b), history=True, type=1, pc=pc, remove_nullspace=int(nullspace), rtol=rtol, maxit=2000, check_every=5)
+    # BiCGStab amplifies round-off differences (reduction order, FMA): compare the early history tightly, the rest loosely
+    assert ig["reason"] == io["reason"]
+    m = min(len(ig["history"]), len(io["history"]))
+    assert np.allclose(ig["history"][:3], io["history"][:3], rtol=1e-9)
+    k = min(m, 10)
+    assert np.allclose(ig["history"][:k], io["history"][:k], rtol=1e-5)
+    assert abs(ig["iters"] - io["iters"]) <= max(3, io["iters"] // 10)
+    xg = host(xg)
+    res = np.linalg.norm(b - S.mult(xg)) / np.linalg.norm(b)
+    ores = np.linalg.norm(b - S.mult(xo)) / np.linalg.norm(b)
+    assert res <= 20 * max(ores, rtol)
+    if nullspace:
+        xg, xo = xg - xg.mean(), xo - xo.mean()
+    assert np.linalg.norm(xg - xo) <= 1e-3 * np.linalg.norm(xo)
+    P.close()
+
+
+@pytest.mark.parametrize("n,bc,nullspace", [
+    ((17, 9, 11), CAVITY, True),
+    ((12, 10, 9), [PER] * 6, True),
+    ((9, 12, 7), [V, O, V, V, PER, PER], False),
+    ((130, 37, 20), CAVITY, True),
+])
+@pytest.mark.parametrize("norm", [fo.NORM_PRECONDITIONED, fo.NORM_UNPRECONDITIONED, fo.NORM_NONE])
+def test_chebyshev_jacobi_matches_oracle(n, bc, nullspace, norm):
+    """KSPCHEBYSHEV + PCJACOBI with the SAME explicit eigenvalue bounds on both sides (oracle Gershgorin x (0.1, 1.1))."""
+    P, g = make_pair(n, bc, kappa=1e-3)
+    S = g.assemble_S()
+    if nullspace:
+        _, b = mean_free_rhs(S, g.ncell)
+    else:
+        b = np.random.default_rng(5).standard_normal(g.ncell)
+    lam = S.gershgorin(fo.PC_JACOBI)
+    emin, emax = 0.1 * lam, 1.1 * lam
+    maxit = 60
+    xo, io = S.solve(b, ksp=fo.KSP_CHEBYSHEV, pc=fo.PC_JACOBI, norm=norm, nullspace=nullspace, rtol=1e-3, maxit=maxit, emin=emin, emax=emax)
+    xg, ig = P.solve(dev(b), history=(norm != fo.NORM_NONE), type=2, pc=fo.PC_JACOBI, norm_type=norm, remove_nullspace=int(nullspace),
+                     rtol=1e-3, maxit=maxit, emin=emin, emax=emax, check_every=7)
+    assert ig["reason"] == io["reason"] and ig["iters"] == io["iters"], (ig["reason"], io["reason"], ig["iters"], io["iters"])
+    if norm != fo.NORM_NONE:
+        m = min(len(ig["history"]), len(io["history"]))
+        assert np.allclose(ig["history"][:m], io["history"][:m], rtol=1e-8, atol=1e-300)
+    xg = host(xg)
+    # the oracle removes the constant after every PC apply, the GPU path once at the end: identical up to round-off
+    assert np.linalg.norm(xg - xo) <= 1e-9 * max(np.linalg.norm(xo), 1e-300)
+    P.close()
+
+
+def test_chebyshev_default_bounds_smooth():
+    """Default bounds (separable Gershgorin bound x (0.1,1.1)): 20 fixed steps must damp the residual like the oracle's default."""
+    P, g = make_pair((32, 24, 16), CAVITY, kappa=1e-3)
+    S = g.assemble_S()
+    _, b = mean_free_rhs(S, g.ncell)
+    xg, ig = P.solve(dev(b), type=2, norm_type=fo.NORM_NONE, maxit=20)
+    assert ig["reason"] == 4 and ig["iters"] == 20             # KSP_CONVERGED_ITS
+    xo, io = S.solve(b, ksp=fo.KSP_CHEBYSHEV, norm=fo.NORM_NONE, maxit=20)
+    xg = host(xg)
+    rg = np.linalg.norm(b - S.mult(xg))
+    ro = np.linalg.norm(b - S.mult(xo))
+    assert rg <= 1.0001 * ro + 1e-12 * np.linalg.norm(b)        # uniform Neumann grid: both bounds equal 2 -> same polynomial
+    assert np.linalg.norm(xg - xo) <= 1e-9 * np.linalg.norm(xo)
+    P.close()
