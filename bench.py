@@ -61,6 +61,9 @@ def main():
     ap.add_argument("--cpu-n", type=int, default=256)
     ap.add_argument("--cpu-iters", type=int, default=40)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--transport", choices=["rccl", "host"], default="rccl",
+                    help="halo transport for N > 1: RCCL Send/Recv (production) or the host-staged gloo callbacks "
+                         "(rehearsal on a box with fewer GPUs than ranks; never used for a reported number)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -68,6 +71,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"WORLD_SIZE {world} != --gpus {args.gpus}"
     assert args.gpus in RANK_GRIDS, "supported: 1, 2, 4, 8 GPUs"
+    ndev = torch.cuda.device_count()
+    if args.transport == "rccl":
+        assert world <= ndev, f"{world} ranks need {world} GPUs for the RCCL transport (found {ndev})"
+    local = local % max(ndev, 1)
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -82,10 +89,13 @@ def main():
     box = [(0.0, 1.0), (0.0, 1.0), (0.0, 0.5)]
     dec = flp.default_decomp(n, ranks, rank) if world > 1 else None
     P = flp.Poisson.uniform(n, box, bc, 1e-3, decomp=dec, device=local)
-    if world > 1:
+    if world > 1 and args.transport == "rccl":
         idb = [flp.rccl_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(idb, src=0)
         P.comm_init_rccl(idb[0], rank, world)
+    elif world > 1:
+        from tests import mp_common as mpc
+        P.comm_init_host(mpc.gloo_exchange, mpc.gloo_allreduce, rank, world)
     stream = torch.cuda.Stream()
     P.set_stream(stream)
 
@@ -137,7 +147,7 @@ def main():
         "config": {"workload": f"{n[0]}x{n[1]}x{n[2]} lid-driven-cavity Schur complement S=-kappa*D*Gst (7-pt, Neumann), "
                                f"matrix-free Jacobi-PCG with constant-null-space removal, b=S*p* seeded, fixed {args.steps} iterations",
                    "cells_per_gpu": int(P.ncell), "rank_grid": list(ranks), "variant": "fused" if args.variant == 0 else "unfused",
-                   "halo": "RCCL Send/Recv" if world > 1 else "none"},
+                   "halo": ("RCCL Send/Recv" if args.transport == "rccl" else "host-staged gloo (rehearsal)") if world > 1 else "none"},
         "iteration_algorithmic_GBps_per_gpu": B_ITER_ALGO * P.ncell * args.steps / dt / 1e9,
         "solve_seconds_device": info["seconds"],
         "roofline": {"bound": "hbm", "kernel": "k_cg_A (p-update + S*p + dot + deferred x-update)",

@@ -61,6 +61,10 @@ class fl_ksp_stats(C.Structure):
                 ("seconds", C.c_double), ("kernel_ms", C.c_double), ("kernel_launches", C.c_int)]
 
 
+class fl_halo_msg(C.Structure):
+    _fields_ = [("peer", C.c_int), ("send_boundary", C.c_int), ("recv_boundary", C.c_int), ("sendtag", C.c_int), ("recvtag", C.c_int)]
+
+
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                           C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64))
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
@@ -85,6 +89,7 @@ PROTOTYPES = {
     "fl_comm_unique_id": (C.c_int, [_P]),
     "fl_poisson_comm_init_rccl": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "fl_poisson_comm_init_host": (C.c_int, [_P, EXCHANGE_FN, ALLREDUCE_FN, _P, C.c_int, C.c_int]),
+    "fl_halo_plan": (C.c_int, [C.POINTER(fl_decomp), C.POINTER(C.c_int), C.POINTER(fl_halo_msg)]),
     "fl_decomp_default": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int), C.c_int, C.POINTER(fl_decomp)]),
     "fl_decomp_neighbor": (C.c_int, [C.POINTER(fl_decomp), C.POINTER(C.c_int), C.c_int]),
     "fl_ibm_create": (C.c_int, [_P, C.c_int, C.c_int64, _P, _P, _P, C.POINTER(_P)]),

@@ -297,23 +297,15 @@ int fl_fill_ghosts(fl_poisson *h, double *v)
   if (!h->multi) return 0;
   if (h->comm.kind == Comm::NONE) return FL_ERR_ARG_WRONGSTATE;
   FL_CHK(ensure_facebufs(h));
+  int periodic[3];
+  for (int d = 0; d < 3; ++d) periodic[d] = h->ax[d].periodic;
+  fl_halo_msg plan[12];
+  const int   np = fl_halo_plan(&h->dec, periodic, plan);
   std::vector<Msg> msgs;
-  for (int d = 0; d < 3; ++d) {
-    if (h->wrap_local[d]) continue;
-    const int lo = h->nbr[2 * d], hi = h->nbr[2 * d + 1];
-    const int64_t n = plane_size(h, d);
-    // step 1: my high face -> high neighbour's low ghost; my low ghost <- low neighbour's high face
-    // step 2: my low face  -> low neighbour's high ghost; my high ghost <- high neighbour's low face
-    // (posting order matters for RCCL: messages between one pair of ranks match in order)
-    if (hi >= 0) launch_pack(h->stream, g, v, h->fsend[2 * d + 1], d, 1);
-    if (lo >= 0) launch_pack(h->stream, g, v, h->fsend[2 * d], d, 0);
-    if (hi >= 0 && lo >= 0 && hi == lo) {
-      msgs.push_back({hi, h->fsend[2 * d + 1], h->frecv[2 * d], n, 2 * d + 1, 2 * d + 1});
-      msgs.push_back({lo, h->fsend[2 * d], h->frecv[2 * d + 1], n, 2 * d, 2 * d});
-    } else {
-      if (hi >= 0) msgs.push_back({hi, h->fsend[2 * d + 1], h->frecv[2 * d + 1], n, 2 * d + 1, 2 * d});
-      if (lo >= 0) msgs.push_back({lo, h->fsend[2 * d], h->frecv[2 * d], n, 2 * d, 2 * d + 1});
-    }
+  for (int a = 0; a < np; ++a) {
+    const int sb = plan[a].send_boundary, rb = plan[a].recv_boundary;
+    launch_pack(h->stream, g, v, h->fsend[sb], sb / 2, sb % 2);
+    msgs.push_back({plan[a].peer, h->fsend[sb], h->frecv[rb], (int64_t)plane_size(h, sb / 2), plan[a].sendtag, plan[a].recvtag});
   }
   FL_CHK(h->comm.exchange(h->stream, msgs));
   for (int d = 0; d < 3; ++d) {

@@ -208,3 +208,23 @@ extern "C" int fl_decomp_neighbor(const fl_decomp *d, const int periodic[3], int
   }
   return (c[2] * d->ranks[1] + c[1]) * d->ranks[0] + c[0];
 }
+
+extern "C" int fl_halo_plan(const fl_decomp *d, const int periodic[3], fl_halo_msg out[12])
+{
+  if (!d || !periodic || !out) return FL_ERR_ARG_NULL;
+  int n = 0;
+  for (int ax = 0; ax < 3; ++ax) {
+    if (d->ranks[ax] == 1) continue;  // a periodic axis held by one rank is wrapped locally, a wall has no neighbour
+    const int lo = fl_decomp_neighbor(d, periodic, 2 * ax), hi = fl_decomp_neighbor(d, periodic, 2 * ax + 1);
+    if (hi >= 0 && hi == lo) {
+      // two ranks on a periodic axis: both faces go to the same peer.  Order: (my high face -> its low ghost) first,
+      // then (my low face -> its high ghost); the peer posts the same order, so in-order matching pairs them correctly.
+      out[n++] = {hi, 2 * ax + 1, 2 * ax, 2 * ax + 1, 2 * ax + 1};
+      out[n++] = {lo, 2 * ax, 2 * ax + 1, 2 * ax, 2 * ax};
+    } else {
+      if (hi >= 0) out[n++] = {hi, 2 * ax + 1, 2 * ax + 1, 2 * ax + 1, 2 * ax};
+      if (lo >= 0) out[n++] = {lo, 2 * ax, 2 * ax, 2 * ax, 2 * ax + 1};
+    }
+  }
+  return n;
+}

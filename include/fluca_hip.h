@@ -154,6 +154,15 @@ typedef int (*fl_exchange_fn)(void *ctx, int nmsg, const int *peer, const int *s
 typedef int (*fl_allreduce_fn)(void *ctx, double *vals, int n);
 int fl_poisson_comm_init_host(fl_poisson *h, fl_exchange_fn xchg, fl_allreduce_fn allred, void *ctx, int rank, int nranks);
 
+/* The ghost-exchange plan of one rank (host-only, no GPU): what fl_poisson_* does before every stencil application, the
+ * analogue of DMGlobalToLocal on the reference's star-stencil DMStag (cart.c:66,91).  For each message: swap with `peer`;
+ * send the owned cell layer at boundary `send_boundary` (0..5, -1 = nothing), receive into the ghost layer at
+ * `recv_boundary` (-1 = nothing).  Messages between one pair of ranks must be matched in array order (RCCL) or by tag. */
+typedef struct fl_halo_msg {
+  int peer, send_boundary, recv_boundary, sendtag, recvtag;
+} fl_halo_msg;
+int fl_halo_plan(const fl_decomp *d, const int periodic[3], fl_halo_msg out[12]); /* returns the number of messages (<= 12) */
+
 /* Host-only helper = DMStag's default ownership split (N/m cells each, the first N%m ranks get one more). */
 int fl_decomp_default(const int64_t n[3], const int ranks[3], int rank, fl_decomp *out);
 /* rank of the neighbour across boundary 0..5 of this block, -1 if physical (non-periodic) boundary */

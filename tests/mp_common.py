@@ -1,0 +1,103 @@
+"""Helpers shared by the multi-process tests (CPU gloo and GPU): process spawning, the gloo halo transport, block slicing."""
+import ctypes as C
+import os
+import socket
+import traceback
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _entry(rank, world, port, fn, args, errq):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        fn(rank, world, *args)
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:  # pragma: no cover
+        errq.put((rank, traceback.format_exc()))
+        raise
+
+
+def run_ranks(world, fn, *args, timeout=600):
+    """Run fn(rank, world, *args) in `world` processes joined by a gloo group on 127.0.0.1; re-raise the first failure."""
+    ctx = mp.get_context("spawn")
+    errq = ctx.SimpleQueue()
+    port = free_port()
+    procs = [ctx.Process(target=_entry, args=(r, world, port, fn, args, errq)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout)
+    failed = [p for p in procs if p.exitcode != 0]
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+    if failed or not errq.empty():
+        msgs = []
+        while not errq.empty():
+            r, tb = errq.get()
+            msgs.append(f"--- rank {r} ---\n{tb}")
+        raise AssertionError("multi-process test failed:\n" + "\n".join(msgs) + f"\nexit codes {[p.exitcode for p in procs]}")
+
+
+def gloo_exchange(msgs):
+    """msgs: list of (peer, sendtag, recvtag, send ndarray | None, recv ndarray | None) -- the fl_exchange_fn contract."""
+    reqs, keep = [], []
+    for peer, stag, rtag, s, r in msgs:
+        if r is not None:
+            t = torch.from_numpy(r)
+            reqs.append(dist.irecv(t, src=int(peer), tag=int(rtag)))
+        if s is not None:
+            t = torch.from_numpy(np.ascontiguousarray(s).copy())
+            keep.append(t)
+            reqs.append(dist.isend(t, dst=int(peer), tag=int(stag)))
+    for q in reqs:
+        q.wait()
+
+
+def gloo_allreduce(vals):
+    t = torch.from_numpy(vals)
+    dist.all_reduce(t)
+
+
+def decomp_of(capi, n, ranks, rank):
+    d = capi.fl_decomp()
+    rc = capi.lib.fl_decomp_default((C.c_int64 * 3)(*n), (C.c_int * 3)(*ranks), rank, C.byref(d))
+    assert rc == 0
+    return d
+
+
+def halo_plan(capi, d, periodic):
+    out = (capi.fl_halo_msg * 12)()
+    n = capi.lib.fl_halo_plan(C.byref(d), (C.c_int * 3)(*[int(p) for p in periodic]), out)
+    assert 0 <= n <= 12
+    return [(out[i].peer, out[i].send_boundary, out[i].recv_boundary, out[i].sendtag, out[i].recvtag) for i in range(n)]
+
+
+def block(d):
+    """slices (z, y, x) of this rank's owned cells in a global (nz, ny, nx) array"""
+    return tuple(slice(d.lo[a], d.lo[a] + d.len[a]) for a in (2, 1, 0))
+
+
+def face_block(d, axis, periodic):
+    """slices of the owned faces of `axis` in the global face array (nz, ny, nx) with the face axis extended"""
+    sl = []
+    for a in (2, 1, 0):
+        n = d.len[a]
+        if a == axis and d.coord[a] == d.ranks[a] - 1 and not periodic[a]:
+            n += 1
+        sl.append(slice(d.lo[a], d.lo[a] + n))
+    return tuple(sl)
