@@ -56,11 +56,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--n", type=int, default=512, help="cells per axis per GPU")
+    ap.add_argument("--cells", type=int, default=512, help="cells per axis per GPU")
     ap.add_argument("--variant", type=int, default=0)
-    ap.add_argument("--cpu-n", type=int, default=256)
+    ap.add_argument("--cpu-cells", type=int, default=256)
     ap.add_argument("--cpu-iters", type=int, default=40)
-    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--transport", choices=["rccl", "host"], default="rccl",
                     help="halo transport for N > 1: RCCL Send/Recv (production) or the host-staged gloo callbacks "
                          "(rehearsal on a box with fewer GPUs than ranks; never used for a reported number)")
@@ -84,7 +84,7 @@ def main():
     from fluca_amd.capi import BC_SYMMETRY, BC_VELOCITY
 
     ranks = RANK_GRIDS[args.gpus]
-    n = tuple(args.n * r for r in ranks)
+    n = tuple(args.cells * r for r in ranks)
     bc = [BC_VELOCITY] * 4 + [BC_SYMMETRY, BC_VELOCITY]
     box = [(0.0, 1.0), (0.0, 1.0), (0.0, 0.5)]
     dec = flp.default_decomp(n, ranks, rank) if world > 1 else None
@@ -134,7 +134,7 @@ def main():
     achieved = B_KERNEL_A_ALGO * P.ncell / (ka_ms * 1e-3) / 1e9 if ka_ms > 0 else None
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_k_cg_A.json")     # written from a rocprofv3 --pmc pass (see profiles/README.md)
-    if os.path.exists(pmc) and args.n == 512:
+    if os.path.exists(pmc) and args.cells == 512:
         try:
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         except Exception:
@@ -157,8 +157,8 @@ def main():
                      "avg_launch_ms": ka_ms, "launches_timed": info["kernel_launches"],
                      "moved_GBps": (B_KERNEL_A_REAL * P.ncell / (ka_ms * 1e-3) / 1e9) if ka_ms > 0 else None},
     }
-    if rank == 0 and world == 1 and not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_iters)
+    if rank == 0 and world == 1 and not args.skip_cpu:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_cells, args.cpu_iters)
     elif rank == 0:
         out["cpu_baseline"] = None
     P.close()

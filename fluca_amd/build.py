@@ -42,7 +42,24 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    build_host(force, verbose)
     return LIB
+
+
+HOST_LIB = os.path.join(LIBDIR, "libfluca_host.so")
+
+
+def build_host(force=False, verbose=False):
+    """The C host mirror (gcc): links against libflucahip.so through its C-ABI only."""
+    src = os.path.join(HERE, "host", "fluca_host.c")
+    hdrs = [os.path.normpath(os.path.join(HERE, "..", "include", h)) for h in ("fluca_host.h", "fluca_hip.h")]
+    if force or _stale(HOST_LIB, [src, LIB] + hdrs):
+        cmd = [os.environ.get("CC", "gcc"), "-std=gnu99", "-O2", "-fPIC", "-shared", "-Wall", "-o", HOST_LIB, src,
+               "-L" + LIBDIR, "-lflucahip", "-Wl,-rpath,$ORIGIN", "-lm"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return HOST_LIB
 
 
 if __name__ == "__main__":

@@ -79,6 +79,10 @@ PROTOTYPES = {
     "fl_poisson_sizes": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "fl_ksp_opts_default": (None, [C.POINTER(fl_ksp_opts)]),
     "fl_version": (C.c_char_p, []),
+    "fl_malloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(_P)]),
+    "fl_free": (C.c_int, [C.c_int, _P]),
+    "fl_memcpy_h2d": (C.c_int, [C.c_int, _P, _P, C.c_size_t]),
+    "fl_memcpy_d2h": (C.c_int, [C.c_int, _P, _P, C.c_size_t]),
     "fl_poisson_apply": (C.c_int, [_P, _P, _P]),
     "fl_poisson_diagonal": (C.c_int, [_P, _P]),
     "fl_poisson_solve": (C.c_int, [_P, _P, _P, C.POINTER(fl_ksp_opts), C.POINTER(fl_ksp_stats)]),

@@ -574,6 +574,40 @@ extern "C" int fl_poisson_solve(fl_poisson *h, const double *b_dev, double *x_de
   }
 }
 
+// ------------------------------------------------------------------------------------------------ plain device memory
+
+extern "C" int fl_malloc(int device, size_t bytes, void **dev_out)
+{
+  if (!dev_out) return FL_ERR_ARG_NULL;
+  *dev_out = nullptr;
+  FL_HIP(hipSetDevice(device));
+  if (hipMalloc(dev_out, bytes ? bytes : 8) != hipSuccess) return FL_ERR_MEM;
+  FL_HIP(hipMemset(*dev_out, 0, bytes ? bytes : 8));
+  return FL_SUCCESS;
+}
+extern "C" int fl_free(int device, void *dev)
+{
+  if (!dev) return FL_SUCCESS;
+  FL_HIP(hipSetDevice(device));
+  FL_HIP(hipFree(dev));
+  return FL_SUCCESS;
+}
+extern "C" int fl_memcpy_h2d(int device, void *dev, const void *host, size_t bytes)
+{
+  if (!dev || !host) return FL_ERR_ARG_NULL;
+  FL_HIP(hipSetDevice(device));
+  FL_HIP(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice));
+  return FL_SUCCESS;
+}
+extern "C" int fl_memcpy_d2h(int device, void *host, const void *dev, size_t bytes)
+{
+  if (!dev || !host) return FL_ERR_ARG_NULL;
+  FL_HIP(hipSetDevice(device));
+  FL_HIP(hipDeviceSynchronize());
+  FL_HIP(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
+  return FL_SUCCESS;
+}
+
 // ------------------------------------------------------------------------------------------------ comm init
 
 extern "C" int fl_comm_unique_id(void *out128)

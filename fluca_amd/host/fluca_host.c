@@ -1,0 +1,746 @@
+/*
+ * fluca_host.c -- C host mirror of Fluca's Mesh / NS plugin surface in front of the pressure-Poisson path
+ * (include/fluca_host.h lists the reference interfaces).  Pure C99; reaches the GPU only through the C-ABI of
+ * include/fluca_hip.h (libflucahip.so).  No PETSc, no MPI: one process per GPU, rank/size set explicitly.
+ */
+#include "../../include/fluca_host.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* positive PETSC_ERR_* values */
+enum { E_MEM = 55, E_SUP = 56, E_ARG_WRONG = 62, E_ARG_OUTOFRANGE = 63, E_ARG_WRONGSTATE = 73, E_ARG_NULL = 85, E_ARG_UNKNOWN_TYPE = 86, E_ARG_TYPENOTSET = 89 };
+
+#define FLCHK(call)             \
+  do {                          \
+    FlErrorCode e_ = (call);    \
+    if (e_) return e_;          \
+  } while (0)
+/* C-ABI calls return -(PETSC_ERR_*) */
+#define FLABI(call)             \
+  do {                          \
+    int r_ = (call);            \
+    if (r_) return -r_;         \
+  } while (0)
+
+/* ------------------------------------------------------------------------------------------------ registries */
+
+#define MAXTYPES 16
+typedef struct {
+  char name[32];
+  void *create;
+} TypeEntry;
+static TypeEntry MeshList[MAXTYPES], NSList[MAXTYPES];
+static int       nMeshTypes = 0, nNSTypes = 0, registered = 0;
+
+static FlErrorCode MeshCreate_Cart(Mesh);
+static FlErrorCode NSCreate_CNLinear(NS);
+
+static void RegisterAll(void)
+{
+  if (registered) return;
+  registered = 1;
+  MeshRegister(MESHCART, MeshCreate_Cart); /* meshreg.c */
+  NSRegister(NSCNLINEAR, NSCreate_CNLinear); /* nsreg.c:17 */
+}
+
+static const char *opt_find(int argc, char **argv, const char *name)
+{
+  for (int i = 1; i + 1 < argc; ++i)
+    if (argv[i] && !strcmp(argv[i], name)) return argv[i + 1];
+  return NULL;
+}
+static int opt_int64(int argc, char **argv, const char *name, int64_t *v)
+{
+  const char *s = opt_find(argc, argv, name);
+  if (!s) return 0;
+  *v = strtoll(s, NULL, 10);
+  return 1;
+}
+static int opt_real(int argc, char **argv, const char *name, double *v)
+{
+  const char *s = opt_find(argc, argv, name);
+  if (!s) return 0;
+  *v = strtod(s, NULL);
+  return 1;
+}
+
+/* ------------------------------------------------------------------------------------------------ Mesh */
+
+typedef struct {
+  int64_t              N[3];
+  int                  nRanks[3];
+  int64_t             *l[3]; /* ownership ranges */
+  MeshCartBoundaryType bndTypes[3];
+  double              *xf[3], *xc[3]; /* global coordinates, set by MeshSetUp / SetUniformCoordinates */
+} Mesh_Cart; /* = fluca/include/fluca/private/meshcartimpl.h:8-17 */
+
+struct _p_Mesh {
+  struct _MeshOps ops[1];
+  char            type_name[32];
+  int             dim, rank, size, setupcalled;
+  fl_decomp       decomp;
+  void           *data;
+};
+
+FlErrorCode MeshRegister(const char name[], FlErrorCode (*create)(Mesh))
+{
+  if (nMeshTypes >= MAXTYPES) return E_MEM;
+  snprintf(MeshList[nMeshTypes].name, sizeof(MeshList[0].name), "%s", name);
+  MeshList[nMeshTypes++].create = (void *)create;
+  return 0;
+}
+
+FlErrorCode MeshCreate(Mesh *mesh)
+{
+  if (!mesh) return E_ARG_NULL;
+  RegisterAll();
+  Mesh m = (Mesh)calloc(1, sizeof(*m));
+  if (!m) return E_MEM;
+  m->dim  = 3;
+  m->size = 1;
+  *mesh   = m;
+  return 0;
+}
+
+FlErrorCode MeshSetType(Mesh mesh, MeshType type)
+{
+  if (!mesh || !type) return E_ARG_NULL;
+  for (int i = 0; i < nMeshTypes; ++i)
+    if (!strcmp(MeshList[i].name, type)) {
+      if (mesh->ops->destroy) FLCHK(mesh->ops->destroy(mesh));
+      memset(mesh->ops, 0, sizeof(mesh->ops));
+      snprintf(mesh->type_name, sizeof(mesh->type_name), "%s", type);
+      return ((FlErrorCode(*)(Mesh))MeshList[i].create)(mesh);
+    }
+  return E_ARG_UNKNOWN_TYPE; /* "Unknown mesh type" */
+}
+
+FlErrorCode MeshSetRank(Mesh mesh, int rank, int size)
+{
+  if (!mesh) return E_ARG_NULL;
+  if (mesh->setupcalled) return E_ARG_WRONGSTATE;
+  if (size < 1 || rank < 0 || rank >= size) return E_ARG_OUTOFRANGE;
+  mesh->rank = rank;
+  mesh->size = size;
+  return 0;
+}
+
+static FlErrorCode MeshSetFromOptions_Cart(Mesh mesh, int argc, char **argv)
+{
+  Mesh_Cart *cart = (Mesh_Cart *)mesh->data;
+  char       opt[64];
+  for (int d = 0; d < 3; ++d) { /* cart.c:21-36 */
+    int64_t v;
+    snprintf(opt, sizeof(opt), "-cart_grid_%c", 'x' + d);
+    if (opt_int64(argc, argv, opt, &v)) {
+      if (v < 1) return E_ARG_OUTOFRANGE;
+      cart->N[d] = v;
+    }
+    snprintf(opt, sizeof(opt), "-cart_ranks_%c", 'x' + d);
+    if (opt_int64(argc, argv, opt, &v)) cart->nRanks[d] = (int)v;
+    snprintf(opt, sizeof(opt), "-cart_boundary_type_%c", 'x' + d);
+    const char *s = opt_find(argc, argv, opt);
+    if (s) {
+      if (!strcasecmp(s, "none")) cart->bndTypes[d] = MESHCART_BOUNDARY_NONE;
+      else if (!strcasecmp(s, "periodic")) cart->bndTypes[d] = MESHCART_BOUNDARY_PERIODIC;
+      else return E_ARG_WRONG;
+    }
+  }
+  return 0;
+}
+
+/* PETSC_DECIDE rank grid: like DMStag, as cubic as the factorisation of `size` allows, larger factors on longer axes */
+static void decide_ranks(int size, const int64_t N[3], int ranks[3])
+{
+  int fixed = 1, nfree = 0;
+  for (int d = 0; d < 3; ++d)
+    if (ranks[d] > 0) fixed *= ranks[d];
+    else ++nfree;
+  int rest = size / (fixed > 0 ? fixed : 1);
+  for (int d = 0; d < 3; ++d)
+    if (ranks[d] <= 0) ranks[d] = 1;
+  for (int f = 2; rest > 1;) {
+    if (rest % f) {
+      ++f;
+      continue;
+    }
+    /* give the factor to the free axis with the most cells per rank */
+    int best = -1;
+    double bestv = -1.;
+    for (int d = 2; d >= 0; --d) {
+      (void)nfree;
+      double v = (double)N[d] / ranks[d];
+      if (v > bestv) {
+        bestv = v;
+        best  = d;
+      }
+    }
+    ranks[best] *= f;
+    rest /= f;
+  }
+}
+
+static FlErrorCode MeshSetUp_Cart(Mesh mesh)
+{
+  Mesh_Cart *cart = (Mesh_Cart *)mesh->data;
+  int        want[3] = {cart->nRanks[0], cart->nRanks[1], cart->nRanks[2]};
+  decide_ranks(mesh->size, cart->N, want);
+  if (want[0] * want[1] * want[2] != mesh->size) return E_ARG_WRONG; /* rank grid does not match the job size */
+  for (int d = 0; d < 3; ++d) cart->nRanks[d] = want[d];
+  FLABI(fl_decomp_default(cart->N, cart->nRanks, mesh->rank, &mesh->decomp));
+  for (int d = 0; d < 3; ++d) {
+    if (cart->l[d]) { /* user ownership ranges (MeshCartSetOwnershipRanges, cart.c:399-418) */
+      int64_t lo = 0, sum = 0;
+      for (int r = 0; r < cart->nRanks[d]; ++r) {
+        if (r < mesh->decomp.coord[d]) lo += cart->l[d][r];
+        sum += cart->l[d][r];
+      }
+      if (sum != cart->N[d]) return E_ARG_WRONG;
+      mesh->decomp.lo[d]  = lo;
+      mesh->decomp.len[d] = cart->l[d][mesh->decomp.coord[d]];
+    } else {
+      cart->l[d] = (int64_t *)malloc(sizeof(int64_t) * cart->nRanks[d]);
+      for (int r = 0; r < cart->nRanks[d]; ++r) {
+        int64_t q = cart->N[d] / cart->nRanks[d], rem = cart->N[d] % cart->nRanks[d];
+        cart->l[d][r] = q + (r < rem ? 1 : 0);
+      }
+    }
+  }
+  mesh->setupcalled = 1;
+  /* DMStagSetUniformCoordinatesProduct(sdm, 0, 1, 0, 1, 0, 1)  (cart.c:128) */
+  return MeshCartSetUniformCoordinates(mesh, 0., 1., 0., 1., 0., 1.);
+}
+
+static FlErrorCode MeshDestroy_Cart(Mesh mesh)
+{
+  Mesh_Cart *cart = (Mesh_Cart *)mesh->data;
+  if (!cart) return 0;
+  for (int d = 0; d < 3; ++d) {
+    free(cart->l[d]);
+    free(cart->xf[d]);
+    free(cart->xc[d]);
+  }
+  free(cart);
+  mesh->data = NULL;
+  return 0;
+}
+
+static FlErrorCode MeshGetNumberBoundaries_Cart(Mesh mesh, int *nb)
+{
+  *nb = 2 * mesh->dim;
+  return 0;
+}
+
+static FlErrorCode MeshCreate_Cart(Mesh mesh) /* cart.c:262-288 */
+{
+  Mesh_Cart *cart = (Mesh_Cart *)calloc(1, sizeof(*cart));
+  if (!cart) return E_MEM;
+  for (int d = 0; d < 3; ++d) {
+    cart->N[d]      = -1;
+    cart->nRanks[d] = FL_DECIDE;
+  }
+  mesh->data                     = cart;
+  mesh->ops->setfromoptions      = MeshSetFromOptions_Cart;
+  mesh->ops->setup               = MeshSetUp_Cart;
+  mesh->ops->destroy             = MeshDestroy_Cart;
+  mesh->ops->getnumberboundaries = MeshGetNumberBoundaries_Cart;
+  return 0;
+}
+
+FlErrorCode MeshCartCreate3d(MeshCartBoundaryType bndx, MeshCartBoundaryType bndy, MeshCartBoundaryType bndz, int64_t M, int64_t N, int64_t P, int m, int n, int p, const int64_t *lx, const int64_t *ly, const int64_t *lz, Mesh *mesh)
+{
+  FLCHK(MeshCreate(mesh));
+  FLCHK(MeshSetType(*mesh, MESHCART));
+  Mesh_Cart     *cart = (Mesh_Cart *)(*mesh)->data;
+  const int64_t *l[3] = {lx, ly, lz};
+  const int      r[3] = {m, n, p};
+  cart->N[0] = M; cart->N[1] = N; cart->N[2] = P;
+  cart->bndTypes[0] = bndx; cart->bndTypes[1] = bndy; cart->bndTypes[2] = bndz;
+  for (int d = 0; d < 3; ++d) {
+    cart->nRanks[d] = r[d];
+    if (l[d]) {
+      if (r[d] <= 0) return E_ARG_WRONGSTATE; /* "Cannot set ownership ranges before setting number of procs" */
+      cart->l[d] = (int64_t *)malloc(sizeof(int64_t) * r[d]);
+      memcpy(cart->l[d], l[d], sizeof(int64_t) * r[d]);
+    }
+  }
+  return 0;
+}
+
+FlErrorCode MeshSetFromOptions(Mesh mesh, int argc, char **argv)
+{
+  if (!mesh) return E_ARG_NULL;
+  if (mesh->setupcalled) return E_ARG_WRONGSTATE;
+  if (!mesh->type_name[0]) FLCHK(MeshSetType(mesh, MESHCART));
+  return mesh->ops->setfromoptions ? mesh->ops->setfromoptions(mesh, argc, argv) : 0;
+}
+
+FlErrorCode MeshSetUp(Mesh mesh)
+{
+  if (!mesh) return E_ARG_NULL;
+  if (mesh->setupcalled) return 0;
+  if (!mesh->type_name[0]) return E_ARG_TYPENOTSET;
+  Mesh_Cart *cart = (Mesh_Cart *)mesh->data;
+  for (int d = 0; d < 3; ++d)
+    if (cart->N[d] < 1) return E_ARG_WRONGSTATE;
+  return mesh->ops->setup(mesh);
+}
+
+FlErrorCode MeshCartSetUniformCoordinates(Mesh mesh, double xmin, double xmax, double ymin, double ymax, double zmin, double zmax)
+{
+  if (!mesh) return E_ARG_NULL;
+  if (!mesh->setupcalled) return E_ARG_WRONGSTATE; /* "This function must be called after MeshSetUp()" cart.c:462 */
+  Mesh_Cart   *cart = (Mesh_Cart *)mesh->data;
+  const double lo[3] = {xmin, ymin, zmin}, hi[3] = {xmax, ymax, zmax};
+  for (int d = 0; d < 3; ++d) {
+    if (!(hi[d] > lo[d])) return E_ARG_WRONG;
+    const int64_t n = cart->N[d];
+    const double  h = (hi[d] - lo[d]) / (double)n;
+    free(cart->xf[d]);
+    free(cart->xc[d]);
+    cart->xf[d] = (double *)malloc(sizeof(double) * (n + 1));
+    cart->xc[d] = (double *)malloc(sizeof(double) * n);
+    /* DMStagSetUniformCoordinatesProduct: prev = min + i h, element = min + (i + 1/2) h */
+    for (int64_t i = 0; i <= n; ++i) cart->xf[d][i] = lo[d] + (double)i * h;
+    for (int64_t i = 0; i < n; ++i) cart->xc[d][i] = lo[d] + ((double)i + 0.5) * h;
+  }
+  return 0;
+}
+
+FlErrorCode MeshCartSetCoordinates(Mesh mesh, const double *xf, const double *yf, const double *zf)
+{
+  if (!mesh || !xf || !yf || !zf) return E_ARG_NULL;
+  if (!mesh->setupcalled) return E_ARG_WRONGSTATE;
+  Mesh_Cart    *cart = (Mesh_Cart *)mesh->data;
+  const double *in[3] = {xf, yf, zf};
+  for (int d = 0; d < 3; ++d) {
+    const int64_t n = cart->N[d];
+    free(cart->xf[d]);
+    free(cart->xc[d]);
+    cart->xf[d] = (double *)malloc(sizeof(double) * (n + 1));
+    cart->xc[d] = (double *)malloc(sizeof(double) * n);
+    memcpy(cart->xf[d], in[d], sizeof(double) * (n + 1));
+    for (int64_t i = 0; i < n; ++i) cart->xc[d][i] = (in[d][i] + in[d][i + 1]) / 2.; /* cart.c:136 */
+  }
+  return 0;
+}
+
+#define MESH_CART(mesh)                      \
+  if (!(mesh)) return E_ARG_NULL;            \
+  Mesh_Cart *cart = (Mesh_Cart *)(mesh)->data; \
+  if (!cart) return E_ARG_TYPENOTSET
+
+FlErrorCode MeshCartGetGlobalSizes(Mesh mesh, int64_t *M, int64_t *N, int64_t *P)
+{
+  MESH_CART(mesh);
+  if (M) *M = cart->N[0];
+  if (N) *N = cart->N[1];
+  if (P) *P = cart->N[2];
+  return 0;
+}
+FlErrorCode MeshCartGetNumRanks(Mesh mesh, int *m, int *n, int *p)
+{
+  MESH_CART(mesh);
+  if (m) *m = cart->nRanks[0];
+  if (n) *n = cart->nRanks[1];
+  if (p) *p = cart->nRanks[2];
+  return 0;
+}
+FlErrorCode MeshCartGetCorners(Mesh mesh, int64_t *x, int64_t *y, int64_t *z, int64_t *m, int64_t *n, int64_t *p)
+{
+  if (!mesh) return E_ARG_NULL;
+  if (!mesh->setupcalled) return E_ARG_WRONGSTATE;
+  const fl_decomp *d = &mesh->decomp;
+  if (x) *x = d->lo[0];
+  if (y) *y = d->lo[1];
+  if (z) *z = d->lo[2];
+  if (m) *m = d->len[0];
+  if (n) *n = d->len[1];
+  if (p) *p = d->len[2];
+  return 0;
+}
+FlErrorCode MeshCartGetIsFirstRank(Mesh mesh, int *fx, int *fy, int *fz)
+{
+  if (!mesh) return E_ARG_NULL;
+  if (!mesh->setupcalled) return E_ARG_WRONGSTATE;
+  if (fx) *fx = mesh->decomp.coord[0] == 0;
+  if (fy) *fy = mesh->decomp.coord[1] == 0;
+  if (fz) *fz = mesh->decomp.coord[2] == 0;
+  return 0;
+}
+FlErrorCode MeshCartGetIsLastRank(Mesh mesh, int *lx, int *ly, int *lz)
+{
+  if (!mesh) return E_ARG_NULL;
+  if (!mesh->setupcalled) return E_ARG_WRONGSTATE;
+  if (lx) *lx = mesh->decomp.coord[0] == mesh->decomp.ranks[0] - 1;
+  if (ly) *ly = mesh->decomp.coord[1] == mesh->decomp.ranks[1] - 1;
+  if (lz) *lz = mesh->decomp.coord[2] == mesh->decomp.ranks[2] - 1;
+  return 0;
+}
+FlErrorCode MeshCartGetBoundaryIndex(Mesh mesh, MeshCartBoundaryLocation loc, int *index)
+{
+  if (!mesh || !index) return E_ARG_NULL;
+  if ((int)loc < 0 || (int)loc > 5) return E_ARG_WRONG; /* "Invalid boundary location" cart.c:587 */
+  *index = (int)loc;                                     /* LEFT 0, RIGHT 1, DOWN 2, UP 3, BACK 4, FRONT 5  cart.c:568-586 */
+  return 0;
+}
+FlErrorCode MeshGetNumberBoundaries(Mesh mesh, int *nb)
+{
+  if (!mesh || !nb) return E_ARG_NULL;
+  if (!mesh->ops->getnumberboundaries) return E_ARG_TYPENOTSET;
+  return mesh->ops->getnumberboundaries(mesh, nb);
+}
+FlErrorCode MeshDestroy(Mesh *mesh)
+{
+  if (!mesh || !*mesh) return 0;
+  if ((*mesh)->ops->destroy) (*mesh)->ops->destroy(*mesh);
+  free(*mesh);
+  *mesh = NULL;
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ NS */
+
+struct _p_NS {
+  struct _NSOps        ops[1];
+  char                 type_name[32];
+  double               rho, mu, dt, t;
+  int64_t              step, max_steps;
+  Mesh                 mesh;
+  NSBoundaryCondition *bcs;
+  int                  nb, device, setupcalled;
+  fl_poisson          *poisson; /* plays PC_ABF's kspS + S */
+  fl_ksp_opts          schur;   /* -ns_abf_schur_* */
+  void                *data;
+};
+
+FlErrorCode NSRegister(const char name[], FlErrorCode (*create)(NS))
+{
+  if (nNSTypes >= MAXTYPES) return E_MEM;
+  snprintf(NSList[nNSTypes].name, sizeof(NSList[0].name), "%s", name);
+  NSList[nNSTypes++].create = (void *)create;
+  return 0;
+}
+
+FlErrorCode NSCreate(NS *ns)
+{
+  if (!ns) return E_ARG_NULL;
+  RegisterAll();
+  NS n = (NS)calloc(1, sizeof(*n));
+  if (!n) return E_MEM;
+  n->rho = 1.; /* nsbasic.c:31-35 defaults */
+  n->mu  = 1.;
+  n->dt  = 0.;
+  n->max_steps = -1;
+  fl_ksp_opts_default(&n->schur);
+  *ns = n;
+  return 0;
+}
+
+FlErrorCode NSSetType(NS ns, NSType type)
+{
+  if (!ns || !type) return E_ARG_NULL;
+  for (int i = 0; i < nNSTypes; ++i)
+    if (!strcmp(NSList[i].name, type)) {
+      if (ns->ops->destroy) FLCHK(ns->ops->destroy(ns));
+      memset(ns->ops, 0, sizeof(ns->ops));
+      snprintf(ns->type_name, sizeof(ns->type_name), "%s", type);
+      return ((FlErrorCode(*)(NS))NSList[i].create)(ns);
+    }
+  return E_ARG_UNKNOWN_TYPE;
+}
+FlErrorCode NSGetType(NS ns, NSType *type)
+{
+  if (!ns || !type) return E_ARG_NULL;
+  *type = ns->type_name[0] ? ns->type_name : NULL;
+  return 0;
+}
+
+FlErrorCode NSSetMesh(NS ns, Mesh mesh)
+{
+  if (!ns || !mesh) return E_ARG_NULL;
+  if (ns->setupcalled) return E_ARG_WRONGSTATE;
+  int nb;
+  FLCHK(MeshGetNumberBoundaries(mesh, &nb));
+  free(ns->bcs);
+  ns->bcs  = (NSBoundaryCondition *)calloc((size_t)nb, sizeof(NSBoundaryCondition)); /* all NS_BC_NONE, nsopts.c:19-22 */
+  ns->nb   = nb;
+  ns->mesh = mesh;
+  return 0;
+}
+FlErrorCode NSSetDevice(NS ns, int device)
+{
+  if (!ns) return E_ARG_NULL;
+  if (ns->setupcalled) return E_ARG_WRONGSTATE;
+  ns->device = device;
+  return 0;
+}
+FlErrorCode NSSetDensity(NS ns, double rho)
+{
+  if (!ns) return E_ARG_NULL;
+  if (!(rho > 0.)) return E_ARG_OUTOFRANGE;
+  ns->rho = rho;
+  return 0;
+}
+FlErrorCode NSSetViscosity(NS ns, double mu)
+{
+  if (!ns) return E_ARG_NULL;
+  if (!(mu > 0.)) return E_ARG_OUTOFRANGE;
+  ns->mu = mu;
+  return 0;
+}
+FlErrorCode NSSetTimeStepSize(NS ns, double dt)
+{
+  if (!ns) return E_ARG_NULL;
+  if (!(dt > 0.)) return E_ARG_OUTOFRANGE;
+  ns->dt = dt;
+  return 0;
+}
+FlErrorCode NSSetMaxSteps(NS ns, int64_t max_steps)
+{
+  if (!ns) return E_ARG_NULL;
+  ns->max_steps = max_steps;
+  return 0;
+}
+FlErrorCode NSSetBoundaryCondition(NS ns, int index, NSBoundaryCondition bc)
+{
+  if (!ns) return E_ARG_NULL;
+  if (!ns->mesh) return E_ARG_WRONGSTATE; /* "Mesh not set" */
+  if (index < 0 || index >= ns->nb) return E_ARG_OUTOFRANGE;
+  ns->bcs[index] = bc;
+  return 0;
+}
+FlErrorCode NSGetBoundaryCondition(NS ns, int index, NSBoundaryCondition *bc)
+{
+  if (!ns || !bc) return E_ARG_NULL;
+  if (index < 0 || index >= ns->nb) return E_ARG_OUTOFRANGE;
+  *bc = ns->bcs[index];
+  return 0;
+}
+
+FlErrorCode NSSetFromOptions(NS ns, int argc, char **argv)
+{
+  if (!ns) return E_ARG_NULL;
+  const char *s;
+  double      v;
+  int64_t     iv;
+  if ((s = opt_find(argc, argv, "-ns_type"))) FLCHK(NSSetType(ns, s));
+  if (!ns->type_name[0]) FLCHK(NSSetType(ns, NSCNLINEAR));
+  if (opt_real(argc, argv, "-ns_density", &v)) FLCHK(NSSetDensity(ns, v)); /* nsopts.c:180-186 */
+  if (opt_real(argc, argv, "-ns_viscosity", &v)) FLCHK(NSSetViscosity(ns, v));
+  if (opt_real(argc, argv, "-ns_time_step_size", &v)) FLCHK(NSSetTimeStepSize(ns, v));
+  if (opt_int64(argc, argv, "-ns_max_steps", &iv)) ns->max_steps = iv;
+  /* sub-KSP of the Schur complement: prefix ns_ + abf_schur_ (nssol.c:19, abfpc.c:206) */
+  if ((s = opt_find(argc, argv, "-ns_abf_schur_ksp_type"))) {
+    if (!strcmp(s, "cg")) ns->schur.type = FL_KSP_CG;
+    else if (!strcmp(s, "bcgs")) ns->schur.type = FL_KSP_BCGS;
+    else if (!strcmp(s, "chebyshev")) ns->schur.type = FL_KSP_CHEBYSHEV;
+    else return E_ARG_UNKNOWN_TYPE; /* PETSc: "Unable to find requested KSP type" */
+  }
+  if ((s = opt_find(argc, argv, "-ns_abf_schur_pc_type"))) {
+    if (!strcmp(s, "jacobi")) ns->schur.pc = FL_PC_JACOBI;
+    else if (!strcmp(s, "none")) ns->schur.pc = FL_PC_NONE;
+    else return E_ARG_UNKNOWN_TYPE;
+  }
+  if ((s = opt_find(argc, argv, "-ns_abf_schur_ksp_norm_type"))) {
+    if (!strcmp(s, "preconditioned")) ns->schur.norm_type = FL_NORM_PRECONDITIONED;
+    else if (!strcmp(s, "unpreconditioned")) ns->schur.norm_type = FL_NORM_UNPRECONDITIONED;
+    else if (!strcmp(s, "natural")) ns->schur.norm_type = FL_NORM_NATURAL;
+    else if (!strcmp(s, "none")) ns->schur.norm_type = FL_NORM_NONE;
+    else return E_ARG_UNKNOWN_TYPE;
+  }
+  if (opt_real(argc, argv, "-ns_abf_schur_ksp_rtol", &v)) ns->schur.rtol = v;
+  if (opt_real(argc, argv, "-ns_abf_schur_ksp_atol", &v)) ns->schur.atol = v;
+  if (opt_real(argc, argv, "-ns_abf_schur_ksp_divtol", &v)) ns->schur.dtol = v;
+  if (opt_int64(argc, argv, "-ns_abf_schur_ksp_max_it", &iv)) ns->schur.maxit = (int)iv;
+  if ((s = opt_find(argc, argv, "-ns_abf_schur_ksp_chebyshev_eigenvalues"))) {
+    if (sscanf(s, "%lf,%lf", &ns->schur.emin, &ns->schur.emax) != 2) return E_ARG_WRONG;
+  }
+  if ((s = opt_find(argc, argv, "-ns_pc_abf_schur_ainv_type"))) /* abfpc.c:246: only ID is built */
+    if (strcmp(s, "ID") && strcmp(s, "id")) return E_SUP;
+  return ns->ops->setfromoptions ? ns->ops->setfromoptions(ns, argc, argv) : 0;
+}
+
+FlErrorCode NSSetUp(NS ns) /* nsbasic.c:153-274, restricted to what the Poisson path needs */
+{
+  if (!ns) return E_ARG_NULL;
+  if (ns->setupcalled) return 0;
+  if (!ns->type_name[0]) FLCHK(NSSetType(ns, NSCNLINEAR)); /* "Set default type" */
+  if (!ns->mesh) return E_ARG_WRONGSTATE;                   /* "Mesh not set" */
+  if (!ns->mesh->setupcalled) return E_ARG_WRONGSTATE;
+  if (!(ns->dt > 0.)) return E_ARG_WRONGSTATE;
+  Mesh_Cart *cart = (Mesh_Cart *)ns->mesh->data;
+  int        bc[6], needs = 1;
+  for (int b = 0; b < 6; ++b) {
+    bc[b] = (int)ns->bcs[b].type;
+    /* the mesh's periodic axes and the NS periodic BCs must agree */
+    if ((cart->bndTypes[b / 2] == MESHCART_BOUNDARY_PERIODIC) != (ns->bcs[b].type == NS_BC_PERIODIC)) return E_ARG_WRONG;
+    switch (ns->bcs[b].type) { /* nsbasic.c:217-231 */
+    case NS_BC_VELOCITY:
+    case NS_BC_PERIODIC:
+    case NS_BC_SYMMETRY: break;
+    case NS_BC_PRESSURE_OUTLET: needs = 0; break;
+    default: return E_SUP; /* "Unsupported boundary condition type" */
+    }
+  }
+  ns->schur.remove_nullspace = needs;
+  fl_grid g;
+  for (int d = 0; d < 3; ++d) {
+    g.n[d]  = cart->N[d];
+    g.xf[d] = cart->xf[d];
+    g.xc[d] = cart->xc[d];
+  }
+  FLABI(fl_poisson_create(&g, bc, ns->dt / ns->rho, ns->mesh->size > 1 ? &ns->mesh->decomp : NULL, ns->device, &ns->poisson));
+  if (ns->ops->setup) FLCHK(ns->ops->setup(ns));
+  ns->setupcalled = 1;
+  return 0;
+}
+
+FlErrorCode NSStep(NS ns)
+{
+  if (!ns) return E_ARG_NULL;
+  if (!ns->ops->step) return E_SUP;
+  return ns->ops->step(ns);
+}
+FlErrorCode NSGetTimeStep(NS ns, int64_t *step)
+{
+  if (!ns || !step) return E_ARG_NULL;
+  *step = ns->step;
+  return 0;
+}
+FlErrorCode NSGetTime(NS ns, double *t)
+{
+  if (!ns || !t) return E_ARG_NULL;
+  *t = ns->t;
+  return 0;
+}
+
+FlErrorCode NSDestroy(NS *ns)
+{
+  if (!ns || !*ns) return 0;
+  if ((*ns)->ops->destroy) (*ns)->ops->destroy(*ns);
+  if ((*ns)->poisson) fl_poisson_destroy((*ns)->poisson);
+  free((*ns)->bcs);
+  free(*ns);
+  *ns = NULL;
+  return 0;
+}
+
+FlErrorCode NSGetPoisson(NS ns, fl_poisson **poisson)
+{
+  if (!ns || !poisson) return E_ARG_NULL;
+  if (!ns->setupcalled) return E_ARG_WRONGSTATE;
+  *poisson = ns->poisson;
+  return 0;
+}
+FlErrorCode NSGetSchurKSPOptions(NS ns, fl_ksp_opts **opts)
+{
+  if (!ns || !opts) return E_ARG_NULL;
+  *opts = &ns->schur;
+  return 0;
+}
+FlErrorCode NSGetNeedsNullSpace(NS ns, int *needs)
+{
+  if (!ns || !needs) return E_ARG_NULL;
+  if (!ns->setupcalled) return E_ARG_WRONGSTATE;
+  *needs = ns->schur.remove_nullspace;
+  return 0;
+}
+FlErrorCode NSGetLocalSizes(NS ns, int64_t out[4])
+{
+  if (!ns || !out) return E_ARG_NULL;
+  if (!ns->setupcalled) return E_ARG_WRONGSTATE;
+  FLABI(fl_poisson_sizes(ns->poisson, out));
+  return 0;
+}
+
+FlErrorCode NSPressureCorrection(NS ns, double *vstar[3], double *Vstar[3], const double *contrhs, double *dp, fl_ksp_stats *stats)
+{
+  if (!ns || !Vstar || !dp) return E_ARG_NULL;
+  if (!ns->setupcalled) return E_ARG_WRONGSTATE;
+  fl_ksp_stats local;
+  int64_t      sz[4];
+  void        *srhs = NULL;
+  FLABI(fl_poisson_sizes(ns->poisson, sz));
+  FLABI(fl_malloc(ns->device, sizeof(double) * (size_t)sz[0], &srhs));       /* abf->Srhs, abfpc.c:68 */
+  int rc = fl_poisson_rhs(ns->poisson, Vstar[0], Vstar[1], Vstar[2], contrhs, (double *)srhs); /* abfpc.c:75-76 */
+  if (!rc) rc = fl_poisson_solve(ns->poisson, (const double *)srhs, dp, &ns->schur, stats ? stats : &local); /* abfpc.c:77 */
+  if (!rc) rc = fl_poisson_project(ns->poisson, dp, vstar ? vstar[0] : NULL, vstar ? vstar[1] : NULL, vstar ? vstar[2] : NULL, Vstar[0], Vstar[1], Vstar[2]); /* abfpc.c:80-101 */
+  if (!rc) rc = fl_poisson_synchronize(ns->poisson);
+  fl_free(ns->device, srhs);
+  return rc ? -rc : 0;
+}
+
+FlErrorCode NSUpdatePressure(NS ns, const double *dp, const double *p0, double *phalf, double *p)
+{
+  if (!ns) return E_ARG_NULL;
+  if (!ns->setupcalled) return E_ARG_WRONGSTATE;
+  FLABI(fl_pressure_update(ns->poisson, ns->step == 0, dp, p0, phalf, p)); /* cnlinearcart3d.c:2846-2854 */
+  ++ns->step;                                                                /* nsbasic.c:288-291 */
+  ns->t += ns->dt;
+  return 0;
+}
+
+FlErrorCode NSComputeStaggeredPressureGradientBC(NS ns, double t, double *V[3])
+{
+  if (!ns || !V) return E_ARG_NULL;
+  if (!ns->setupcalled) return E_ARG_WRONGSTATE;
+  Mesh_Cart       *cart = (Mesh_Cart *)ns->mesh->data;
+  const fl_decomp *D    = &ns->mesh->decomp;
+  for (int b = 0; b < 6; ++b) {
+    if (ns->bcs[b].type != NS_BC_PRESSURE_OUTLET) continue;
+    const int ax = b / 2, side = b % 2;
+    if (side ? (D->coord[ax] != D->ranks[ax] - 1) : (D->coord[ax] != 0)) continue; /* isFirstRank / isLastRank */
+    if (!ns->bcs[b].pressure) return E_ARG_WRONGSTATE;
+    const int     a1 = ax == 0 ? 1 : 0, a2 = ax == 2 ? 1 : 2; /* the two in-plane axes, a1 fastest */
+    const int64_t n1 = D->len[a1], n2 = D->len[a2];
+    double       *pb = (double *)malloc(sizeof(double) * (size_t)(n1 * n2));
+    if (!pb) return E_MEM;
+    for (int64_t j = 0; j < n2; ++j)
+      for (int64_t i = 0; i < n1; ++i) {
+        double xb[3], val = 0.;
+        xb[ax] = cart->xf[ax][side ? cart->N[ax] : 0];
+        xb[a1] = cart->xc[a1][D->lo[a1] + i];
+        xb[a2] = cart->xc[a2][D->lo[a2] + j];
+        FlErrorCode e = ns->bcs[b].pressure(3, t, xb, &val, ns->bcs[b].ctx_pressure);
+        if (e) {
+          free(pb);
+          return e;
+        }
+        pb[j * n1 + i] = val;
+      }
+    void *pbd = NULL;
+    int   rc  = fl_malloc(ns->device, sizeof(double) * (size_t)(n1 * n2), &pbd);
+    if (!rc) rc = fl_memcpy_h2d(ns->device, pbd, pb, sizeof(double) * (size_t)(n1 * n2));
+    if (!rc) rc = fl_poisson_gst_bc(ns->poisson, b, (const double *)pbd, V[ax]);
+    if (!rc) rc = fl_poisson_synchronize(ns->poisson);
+    fl_free(ns->device, pbd);
+    free(pb);
+    if (rc) return -rc;
+  }
+  return 0;
+}
+
+/* ---- NSCNLINEAR: the shipped type.  Only the pieces on the Poisson path exist; the full step needs the momentum
+ * operator A = I + dt C - (mu dt / 2 rho) L, so `step` reports PETSC_ERR_SUP. */
+static FlErrorCode NSStep_CNLinear(NS ns)
+{
+  (void)ns;
+  return E_SUP;
+}
+static FlErrorCode NSDestroy_CNLinear(NS ns)
+{
+  (void)ns;
+  return 0;
+}
+static FlErrorCode NSCreate_CNLinear(NS ns) /* cnlinear.c:164-187 */
+{
+  ns->ops->setfromoptions = NULL;
+  ns->ops->setup          = NULL;
+  ns->ops->step           = NSStep_CNLinear;
+  ns->ops->destroy        = NSDestroy_CNLinear;
+  return 0;
+}

@@ -1,0 +1,56 @@
+"""ctypes binding of include/fluca_host.h (libfluca_host.so, the C host mirror of Fluca's Mesh / NS surface)."""
+import ctypes as C
+import os
+
+from . import capi  # loads libflucahip.so first (libfluca_host.so links against it)
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libfluca_host.so")
+if not os.path.exists(LIB_PATH):
+    raise ImportError(f"{LIB_PATH} is missing: run `python -m fluca_amd.build`")
+lib = C.CDLL(LIB_PATH)
+
+MESHCART_BOUNDARY_NONE, MESHCART_BOUNDARY_PERIODIC = 0, 1
+MESHCART_LEFT, MESHCART_RIGHT, MESHCART_DOWN, MESHCART_UP, MESHCART_BACK, MESHCART_FRONT = range(6)
+NS_BC_NONE, NS_BC_VELOCITY, NS_BC_PRESSURE_OUTLET, NS_BC_PERIODIC, NS_BC_SYMMETRY = range(5)
+FL_DECIDE = -1
+# positive PETSC_ERR_* values
+ERR_SUP, ERR_ARG_WRONG, ERR_ARG_OUTOFRANGE, ERR_ARG_WRONGSTATE, ERR_ARG_NULL, ERR_ARG_UNKNOWN_TYPE = 56, 62, 63, 73, 85, 86
+
+BCFunc = C.CFUNCTYPE(C.c_int, C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
+
+
+class NSBoundaryCondition(C.Structure):
+    _fields_ = [("type", C.c_int), ("velocity", BCFunc), ("ctx_velocity", C.c_void_p), ("pressure", BCFunc), ("ctx_pressure", C.c_void_p)]
+
+
+_P = C.c_void_p
+_i64p = C.POINTER(C.c_int64)
+_ip = C.POINTER(C.c_int)
+_argv = C.POINTER(C.c_char_p)
+_dp3 = C.POINTER(C.c_void_p)
+PROTOTYPES = {
+    "MeshCreate": [C.POINTER(_P)], "MeshSetType": [_P, C.c_char_p], "MeshSetRank": [_P, C.c_int, C.c_int],
+    "MeshCartCreate3d": [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, _i64p, _i64p, _i64p, C.POINTER(_P)],
+    "MeshSetFromOptions": [_P, C.c_int, _argv], "MeshSetUp": [_P],
+    "MeshCartSetUniformCoordinates": [_P] + [C.c_double] * 6, "MeshCartSetCoordinates": [_P, _P, _P, _P],
+    "MeshCartGetGlobalSizes": [_P, _i64p, _i64p, _i64p], "MeshCartGetNumRanks": [_P, _ip, _ip, _ip],
+    "MeshCartGetCorners": [_P] + [_i64p] * 6, "MeshCartGetIsFirstRank": [_P, _ip, _ip, _ip], "MeshCartGetIsLastRank": [_P, _ip, _ip, _ip],
+    "MeshCartGetBoundaryIndex": [_P, C.c_int, _ip], "MeshGetNumberBoundaries": [_P, _ip], "MeshDestroy": [C.POINTER(_P)],
+    "NSCreate": [C.POINTER(_P)], "NSSetType": [_P, C.c_char_p], "NSGetType": [_P, C.POINTER(C.c_char_p)], "NSSetMesh": [_P, _P],
+    "NSSetDevice": [_P, C.c_int], "NSSetDensity": [_P, C.c_double], "NSSetViscosity": [_P, C.c_double], "NSSetTimeStepSize": [_P, C.c_double],
+    "NSSetMaxSteps": [_P, C.c_int64], "NSSetBoundaryCondition": [_P, C.c_int, NSBoundaryCondition],
+    "NSGetBoundaryCondition": [_P, C.c_int, C.POINTER(NSBoundaryCondition)], "NSSetFromOptions": [_P, C.c_int, _argv], "NSSetUp": [_P],
+    "NSStep": [_P], "NSGetTimeStep": [_P, _i64p], "NSGetTime": [_P, C.POINTER(C.c_double)], "NSDestroy": [C.POINTER(_P)],
+    "NSGetPoisson": [_P, C.POINTER(_P)], "NSGetSchurKSPOptions": [_P, C.POINTER(C.POINTER(capi.fl_ksp_opts))], "NSGetNeedsNullSpace": [_P, _ip],
+    "NSGetLocalSizes": [_P, _i64p], "NSPressureCorrection": [_P, _dp3, _dp3, _P, _P, C.POINTER(capi.fl_ksp_stats)],
+    "NSUpdatePressure": [_P, _P, _P, _P, _P], "NSComputeStaggeredPressureGradientBC": [_P, C.c_double, _dp3],
+}
+for _n, _a in PROTOTYPES.items():
+    _f = getattr(lib, _n)
+    _f.restype = C.c_int
+    _f.argtypes = _a
+
+
+def argv(*opts):
+    a = [b"prog"] + [str(o).encode() for o in opts]
+    return len(a), (C.c_char_p * len(a))(*a)

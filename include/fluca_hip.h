@@ -32,6 +32,7 @@
 #ifndef FLUCA_HIP_H
 #define FLUCA_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -126,6 +127,12 @@ int fl_poisson_synchronize(fl_poisson *h);
 int fl_poisson_sizes(const fl_poisson *h, int64_t out[4]);
 void fl_ksp_opts_default(fl_ksp_opts *o); /* PETSc defaults + cg/jacobi/preconditioned norm */
 const char *fl_version(void);
+
+/* ---- device memory for hosts that have no allocator of their own (the C host mirror, a PETSc host without HIP Vecs) - */
+int fl_malloc(int device, size_t bytes, void **dev_out); /* zero-initialised */
+int fl_free(int device, void *dev);
+int fl_memcpy_h2d(int device, void *dev, const void *host, size_t bytes);
+int fl_memcpy_d2h(int device, void *host, const void *dev, size_t bytes);
 
 /* ---- operator -------------------------------------------------------------------------------- */
 int fl_poisson_apply(fl_poisson *h, const double *x_dev, double *y_dev);  /* y = S x */

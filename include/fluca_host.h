@@ -1,0 +1,126 @@
+/*
+ * fluca_host.h -- host-side C mirror of the part of Fluca's Mesh / NS plugin surface that stands in front of the
+ * pressure-Poisson path.  Same names, argument meaning and error behaviour as the reference; PETSc types replaced by
+ * plain C (no MPI_Comm: the rank/size of the one-process-per-GPU job are set explicitly; no Vec: raw device pointers).
+ * Everything numerical goes through the C-ABI of include/fluca_hip.h.
+ *
+ * Reference interfaces mirrored (file:line relative to thecasterian/fluca):
+ *   MeshCartCreate3d / MeshSetFromOptions / MeshSetUp / MeshCartSetUniformCoordinates / MeshCartGet*   fluca/include/flucameshcart.h:29-56,
+ *                                                                                                       fluca/src/mesh/impl/cart/cart.c:13-151,458-591
+ *   struct _MeshOps, MeshRegister                                                                       fluca/include/fluca/private/meshimpl.h:16-25, flucamesh.h:43-44
+ *   NSCreate / NSSetType / NSRegister / NSSetMesh / NSSet{Density,Viscosity,TimeStepSize} /
+ *   NSSetBoundaryCondition / NSSetFromOptions / NSSetUp / NSDestroy                                     fluca/include/flucans.h:28-60,91-92
+ *   struct _NSOps (setfromoptions, setup, step, destroy)                                                fluca/include/fluca/private/nsimpl.h:21-31
+ *   NSBoundaryCondition, NSBoundaryConditionFunction                                                    fluca/include/flucansbc.h:5-22
+ *   PCApply_ABF without the momentum solve (NSPressureCorrection)                                       fluca/src/ns/utils/abfpc/abfpc.c:73-101
+ *   pressure update of NSStep_CNLinear_Cart3d_Internal (NSUpdatePressure)                               fluca/src/ns/impl/linearcn/cnlinearcart3d.c:2846-2854
+ *   options -cart_grid_x.. -cart_ranks_x.. -cart_boundary_type_x.. -ns_density -ns_viscosity
+ *           -ns_time_step_size -ns_max_steps -ns_abf_schur_ksp_{type,rtol,atol,max_it,norm_type} -ns_abf_schur_pc_type   cart.c:21-43, nsopts.c:177-198, abfpc.c:206,248-249
+ *
+ * Every function returns FlErrorCode: 0 = success, otherwise the positive PETSC_ERR_* value the reference would raise.
+ */
+#ifndef FLUCA_HOST_H
+#define FLUCA_HOST_H
+
+#include "fluca_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int FlErrorCode;
+#define FL_DECIDE (-1) /* PETSC_DECIDE */
+
+typedef struct _p_Mesh *Mesh;
+typedef struct _p_NS   *NS;
+
+typedef const char *MeshType;
+#define MESHCART "cart"
+typedef const char *NSType;
+#define NSCNLINEAR "cnlinear"
+
+typedef enum { MESHCART_BOUNDARY_NONE, MESHCART_BOUNDARY_PERIODIC } MeshCartBoundaryType;
+typedef enum { MESHCART_LEFT, MESHCART_RIGHT, MESHCART_DOWN, MESHCART_UP, MESHCART_BACK, MESHCART_FRONT } MeshCartBoundaryLocation;
+
+/* ---- Mesh ---- */
+struct _MeshOps {
+  FlErrorCode (*setfromoptions)(Mesh, int, char **);
+  FlErrorCode (*setup)(Mesh);
+  FlErrorCode (*destroy)(Mesh);
+  FlErrorCode (*getnumberboundaries)(Mesh, int *);
+};
+FlErrorCode MeshRegister(const char name[], FlErrorCode (*create)(Mesh));
+FlErrorCode MeshCreate(Mesh *mesh);
+FlErrorCode MeshSetType(Mesh mesh, MeshType type);
+FlErrorCode MeshSetRank(Mesh mesh, int rank, int size); /* stands in for the MPI_Comm of MeshCreate(comm, ...) */
+FlErrorCode MeshCartCreate3d(MeshCartBoundaryType bndx, MeshCartBoundaryType bndy, MeshCartBoundaryType bndz, int64_t M, int64_t N, int64_t P, int m, int n, int p, const int64_t *lx, const int64_t *ly, const int64_t *lz, Mesh *mesh);
+FlErrorCode MeshSetFromOptions(Mesh mesh, int argc, char **argv);
+FlErrorCode MeshSetUp(Mesh mesh);
+FlErrorCode MeshCartSetUniformCoordinates(Mesh mesh, double xmin, double xmax, double ymin, double ymax, double zmin, double zmax);
+FlErrorCode MeshCartSetCoordinates(Mesh mesh, const double *xf, const double *yf, const double *zf); /* = the coordLoaded path, cart.c:131-140 */
+FlErrorCode MeshCartGetGlobalSizes(Mesh mesh, int64_t *M, int64_t *N, int64_t *P);
+FlErrorCode MeshCartGetNumRanks(Mesh mesh, int *m, int *n, int *p);
+FlErrorCode MeshCartGetCorners(Mesh mesh, int64_t *x, int64_t *y, int64_t *z, int64_t *m, int64_t *n, int64_t *p);
+FlErrorCode MeshCartGetIsFirstRank(Mesh mesh, int *fx, int *fy, int *fz);
+FlErrorCode MeshCartGetIsLastRank(Mesh mesh, int *lx, int *ly, int *lz);
+FlErrorCode MeshCartGetBoundaryIndex(Mesh mesh, MeshCartBoundaryLocation loc, int *index);
+FlErrorCode MeshGetNumberBoundaries(Mesh mesh, int *nb);
+FlErrorCode MeshDestroy(Mesh *mesh);
+
+/* ---- NS ---- */
+typedef enum { NS_BC_NONE, NS_BC_VELOCITY, NS_BC_PRESSURE_OUTLET, NS_BC_PERIODIC, NS_BC_SYMMETRY } NSBoundaryConditionType;
+typedef FlErrorCode (*NSBoundaryConditionFunction)(int dim, double t, const double x[], double val[], void *ctx);
+typedef struct {
+  NSBoundaryConditionType     type;
+  NSBoundaryConditionFunction velocity;
+  void                       *ctx_velocity;
+  NSBoundaryConditionFunction pressure;
+  void                       *ctx_pressure;
+} NSBoundaryCondition;
+
+struct _NSOps {
+  FlErrorCode (*setfromoptions)(NS, int, char **);
+  FlErrorCode (*setup)(NS);
+  FlErrorCode (*step)(NS); /* the full step needs the momentum operator: the shipped type returns PETSC_ERR_SUP */
+  FlErrorCode (*destroy)(NS);
+};
+FlErrorCode NSRegister(const char name[], FlErrorCode (*create)(NS));
+FlErrorCode NSCreate(NS *ns);
+FlErrorCode NSSetType(NS ns, NSType type);
+FlErrorCode NSGetType(NS ns, NSType *type);
+FlErrorCode NSSetMesh(NS ns, Mesh mesh);
+FlErrorCode NSSetDevice(NS ns, int device);
+FlErrorCode NSSetDensity(NS ns, double rho);
+FlErrorCode NSSetViscosity(NS ns, double mu);
+FlErrorCode NSSetTimeStepSize(NS ns, double dt);
+FlErrorCode NSSetMaxSteps(NS ns, int64_t max_steps);
+FlErrorCode NSSetBoundaryCondition(NS ns, int index, NSBoundaryCondition bc);
+FlErrorCode NSGetBoundaryCondition(NS ns, int index, NSBoundaryCondition *bc);
+FlErrorCode NSSetFromOptions(NS ns, int argc, char **argv);
+FlErrorCode NSSetUp(NS ns);
+FlErrorCode NSStep(NS ns);
+FlErrorCode NSGetTimeStep(NS ns, int64_t *step);
+FlErrorCode NSGetTime(NS ns, double *t);
+FlErrorCode NSDestroy(NS *ns);
+
+/* the Schur-complement half of PCABF: PCABFGetSubKSPs(pc, NULL, &kspS) of the reference */
+FlErrorCode NSGetPoisson(NS ns, fl_poisson **poisson);
+FlErrorCode NSGetSchurKSPOptions(NS ns, fl_ksp_opts **opts);
+/* needs_nullspace = no boundary is a PRESSURE_OUTLET (nsbasic.c:214-231) */
+FlErrorCode NSGetNeedsNullSpace(NS ns, int *needs);
+/* sizes of this rank's arrays: cells, x-, y-, z-faces */
+FlErrorCode NSGetLocalSizes(NS ns, int64_t out[4]);
+
+/* PCApply_ABF minus KSPSolve(kspA): given the intermediate velocities v* (cells, any may be NULL) and V* (faces) on the
+ * device, Srhs = contrhs - D V*, dp = S^-1 Srhs, v = v* - G dp, V = V* - Gst dp  (abfpc.c:73-101, Ainv = ID) */
+FlErrorCode NSPressureCorrection(NS ns, double *vstar_dev[3], double *Vstar_dev[3], const double *contrhs_dev, double *dp_dev, fl_ksp_stats *stats);
+/* p, phalf update of the time step, then ++step, t += dt (cnlinearcart3d.c:2846-2854, nsbasic.c:288-291) */
+FlErrorCode NSUpdatePressure(NS ns, const double *dp_dev, const double *p0_dev, double *phalf_dev, double *p_dev);
+/* Gst boundary vector: evaluates the PRESSURE_OUTLET callbacks at the boundary face centres at time t (host), writes
+ * coeff * p_b into the boundary faces of V_dev[axis] (cnlinearcart3d.c:2602-2805) */
+FlErrorCode NSComputeStaggeredPressureGradientBC(NS ns, double t, double *V_dev[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,221 @@
+"""The C host mirror (include/fluca_host.h) used the way the reference's drivers use Mesh / NS
+(fluca/tests/cavity_flow/cavity_flow_3d.c).  CPU tests cover the host logic; the -m gpu test runs PCApply_ABF's
+pressure half against the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+P = C.c_void_p
+
+
+@pytest.fixture(scope="module")
+def H():
+    from fluca_amd import build
+    build.build()
+    from fluca_amd import hostapi
+    return hostapi
+
+
+def cavity_mesh(H, opts=(), rank=0, size=1):
+    mesh = P()
+    # MeshCartCreate3d(PETSC_COMM_WORLD, NONE, NONE, NONE, 64, 64, 32, PETSC_DECIDE x3, NULL x3, &mesh)  cavity_flow_3d.c:39
+    assert H.lib.MeshCartCreate3d(0, 0, 0, 64, 64, 32, H.FL_DECIDE, H.FL_DECIDE, H.FL_DECIDE, None, None, None, C.byref(mesh)) == 0
+    assert H.lib.MeshSetRank(mesh, rank, size) == 0
+    argc, av = H.argv(*opts)
+    assert H.lib.MeshSetFromOptions(mesh, argc, av) == 0
+    assert H.lib.MeshSetUp(mesh) == 0
+    assert H.lib.MeshCartSetUniformCoordinates(mesh, 0., 1., 0., 1., 0., 0.5) == 0           # cavity_flow_3d.c:42
+    return mesh
+
+
+def set_cavity_bcs(H, ns, mesh):
+    idx = {}
+    for loc in range(6):
+        i = C.c_int()
+        assert H.lib.MeshCartGetBoundaryIndex(mesh, loc, C.byref(i)) == 0
+        idx[loc] = i.value
+    wall = H.NSBoundaryCondition(type=H.NS_BC_VELOCITY)
+    sym = H.NSBoundaryCondition(type=H.NS_BC_SYMMETRY)
+    for loc in (H.MESHCART_LEFT, H.MESHCART_RIGHT, H.MESHCART_DOWN, H.MESHCART_UP, H.MESHCART_FRONT):
+        assert H.lib.NSSetBoundaryCondition(ns, idx[loc], wall) == 0
+    assert H.lib.NSSetBoundaryCondition(ns, idx[H.MESHCART_BACK], sym) == 0               # cavity_flow_3d.c:72-77
+
+
+def test_mesh_options_and_decomposition(H):
+    mesh = cavity_mesh(H, ("-cart_grid_x", 10, "-cart_grid_y", 7, "-cart_grid_z", 5, "-cart_ranks_x", 3, "-cart_ranks_y", 2, "-cart_ranks_z", 1), rank=4, size=6)
+    M, N, Pz = C.c_int64(), C.c_int64(), C.c_int64()
+    assert H.lib.MeshCartGetGlobalSizes(mesh, C.byref(M), C.byref(N), C.byref(Pz)) == 0
+    assert (M.value, N.value, Pz.value) == (10, 7, 5)
+    c = [C.c_int64() for _ in range(6)]
+    assert H.lib.MeshCartGetCorners(mesh, *[C.byref(v) for v in c]) == 0
+    assert [v.value for v in c] == [4, 4, 0, 3, 3, 5]            # rank 4 = coord (1,1,0): x [4,7), y [4,7)
+    f = [C.c_int() for _ in range(3)]
+    l = [C.c_int() for _ in range(3)]
+    H.lib.MeshCartGetIsFirstRank(mesh, *[C.byref(v) for v in f])
+    H.lib.MeshCartGetIsLastRank(mesh, *[C.byref(v) for v in l])
+    assert [v.value for v in f] == [0, 0, 1] and [v.value for v in l] == [0, 1, 1]
+    nb = C.c_int()
+    assert H.lib.MeshGetNumberBoundaries(mesh, C.byref(nb)) == 0 and nb.value == 6
+    assert H.lib.MeshDestroy(C.byref(mesh)) == 0 and not mesh.value
+
+
+def test_mesh_errors_match_reference_behaviour(H):
+    mesh = P()
+    H.lib.MeshCartCreate3d(0, 0, 0, 8, 8, 8, -1, -1, -1, None, None, None, C.byref(mesh))
+    # "This function must be called after MeshSetUp()"  (cart.c:462)
+    assert H.lib.MeshCartSetUniformCoordinates(mesh, 0., 1., 0., 1., 0., 1.) == H.ERR_ARG_WRONGSTATE
+    argc, av = H.argv("-cart_boundary_type_x", "bogus")
+    assert H.lib.MeshSetFromOptions(mesh, argc, av) == H.ERR_ARG_WRONG
+    assert H.lib.MeshSetType(mesh, b"tetra") == H.ERR_ARG_UNKNOWN_TYPE
+    i = C.c_int()
+    assert H.lib.MeshCartGetBoundaryIndex(mesh, 9, C.byref(i)) == H.ERR_ARG_WRONG      # "Invalid boundary location"
+    H.lib.MeshSetRank(mesh, 0, 3)
+    argc, av = H.argv("-cart_ranks_x", 2, "-cart_ranks_y", 2, "-cart_ranks_z", 1)     # 4 ranks requested, job has 3
+    H.lib.MeshSetFromOptions(mesh, argc, av)
+    assert H.lib.MeshSetUp(mesh) == H.ERR_ARG_WRONG
+    H.lib.MeshDestroy(C.byref(mesh))
+
+
+def test_ns_registry_options_and_state_errors(H):
+    ns = P()
+    assert H.lib.NSCreate(C.byref(ns)) == 0
+    assert H.lib.NSSetType(ns, b"fsm") == H.ERR_ARG_UNKNOWN_TYPE      # only "cnlinear" is registered (nsreg.c:17)
+    assert H.lib.NSSetType(ns, b"cnlinear") == 0
+    t = C.c_char_p()
+    H.lib.NSGetType(ns, C.byref(t))
+    assert t.value == b"cnlinear"
+    assert H.lib.NSSetUp(ns) == H.ERR_ARG_WRONGSTATE                   # "Mesh not set"
+    bc = H.NSBoundaryCondition(type=H.NS_BC_VELOCITY)
+    assert H.lib.NSSetBoundaryCondition(ns, 0, bc) == H.ERR_ARG_WRONGSTATE
+    mesh = cavity_mesh(H)
+    assert H.lib.NSSetMesh(ns, mesh) == 0
+    assert H.lib.NSSetBoundaryCondition(ns, 6, bc) == H.ERR_ARG_OUTOFRANGE
+    argc, av = H.argv("-ns_density", 2.0, "-ns_viscosity", 0.01, "-ns_time_step_size", 1e-3, "-ns_max_steps", 5,
+                      "-ns_abf_schur_ksp_type", "bcgs", "-ns_abf_schur_pc_type", "none", "-ns_abf_schur_ksp_rtol", 1e-8,
+                      "-ns_abf_schur_ksp_max_it", 77, "-ns_abf_schur_ksp_norm_type", "preconditioned")
+    assert H.lib.NSSetFromOptions(ns, argc, av) == 0
+    o = C.POINTER(H.capi.fl_ksp_opts)()
+    assert H.lib.NSGetSchurKSPOptions(ns, C.byref(o)) == 0
+    assert (o.contents.type, o.contents.pc, o.contents.rtol, o.contents.maxit) == (1, 0, 1e-8, 77)
+    argc, av = H.argv("-ns_abf_schur_ksp_type", "gmres")
+    assert H.lib.NSSetFromOptions(ns, argc, av) == H.ERR_ARG_UNKNOWN_TYPE
+    argc, av = H.argv("-ns_pc_abf_schur_ainv_type", "DIAG")
+    assert H.lib.NSSetFromOptions(ns, argc, av) == H.ERR_SUP
+    assert H.lib.NSStep(ns) == H.ERR_SUP                               # full step = momentum solve = SURVEY 8f, not built
+    assert H.lib.NSDestroy(C.byref(ns)) == 0
+    H.lib.MeshDestroy(C.byref(mesh))
+
+
+@pytest.mark.gpu
+def test_pressure_half_of_pcapply_abf_matches_oracle(H):
+    """cavity_flow_3d-style set-up at 32x24x16, then PCApply_ABF stage 1 (without kspA) + stage 2 + pressure update."""
+    import torch
+    from oracle import fluca_oracle as fo
+    n = (32, 24, 16)
+    mesh = cavity_mesh(H, ("-cart_grid_x", n[0], "-cart_grid_y", n[1], "-cart_grid_z", n[2]))
+    ns = P()
+    assert H.lib.NSCreate(C.byref(ns)) == 0
+    assert H.lib.NSSetType(ns, b"cnlinear") == 0
+    assert H.lib.NSSetMesh(ns, mesh) == 0
+    assert H.lib.NSSetDensity(ns, 1.0) == 0 and H.lib.NSSetViscosity(ns, 0.01) == 0
+    set_cavity_bcs(H, ns, mesh)
+    argc, av = H.argv("-ns_time_step_size", 1e-3, "-ns_abf_schur_ksp_type", "cg", "-ns_abf_schur_pc_type", "jacobi", "-ns_abf_schur_ksp_rtol", 1e-8)
+    assert H.lib.NSSetFromOptions(ns, argc, av) == 0
+    assert H.lib.NSSetUp(ns) == 0
+    needs = C.c_int()
+    assert H.lib.NSGetNeedsNullSpace(ns, C.byref(needs)) == 0 and needs.value == 1
+    sz = (C.c_int64 * 4)()
+    assert H.lib.NSGetLocalSizes(ns, sz) == 0
+    bc = [fo.BC_VELOCITY] * 4 + [fo.BC_SYMMETRY, fo.BC_VELOCITY]
+    g = fo.Grid.uniform(n, [(0, 1), (0, 1), (0, 0.5)], bc, 1e-3)
+    assert tuple(sz) == (g.ncell,) + tuple(g.nface)
+    rng = np.random.default_rng(8)
+    # a discretely divergence-compatible V*: V* = kappa Gst q  ->  Srhs = -D V* = S q
+    q = rng.standard_normal(g.ncell)
+    q -= q.mean()
+    Vs = g.apply_gst(q)
+    vs = [rng.standard_normal(g.ncell) for _ in range(3)]
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a), device="cuda")
+    Vd, vd = [dev(a) for a in Vs], [dev(a) for a in vs]
+    dp = torch.zeros(g.ncell, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    st = H.capi.fl_ksp_stats()
+    arr = lambda ts: (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
+    assert H.lib.NSPressureCorrection(ns, arr(vd), arr(Vd), None, C.c_void_p(dp.data_ptr()), C.byref(st)) == 0
+    assert st.reason == 2 and st.iters > 3
+    S = g.assemble_S()
+    b = g.rhs(*Vs)
+    xo, io = S.solve(b, rtol=1e-8)
+    assert abs(st.iters - io["iters"]) <= 2
+    dph = dp.cpu().numpy()
+    assert np.linalg.norm((dph - dph.mean()) - (xo - xo.mean())) <= 1e-5 * np.linalg.norm(xo)
+    # stage 2 against the oracle operators applied to the GPU's own dp
+    Gst, Gc = g.apply_gst(dph), g.apply_G(dph)
+    for d in range(3):
+        assert abs(Vd[d].cpu().numpy() - (Vs[d] - Gst[d])).max() <= 1e-11 * max(1.0, abs(Vs[d]).max())
+        assert abs(vd[d].cpu().numpy() - (vs[d] - Gc[d])).max() <= 1e-11 * max(1.0, abs(vs[d]).max())
+    # the projected face velocity is discretely divergence-free to the solver tolerance: || D V || <= 10 rtol ||b||
+    div = g.rhs(*[t.cpu().numpy() for t in Vd])
+    assert np.linalg.norm(div) <= 10 * 1e-8 * np.linalg.norm(b) + 1e-12
+    # pressure update, first step then second (cnlinearcart3d.c:2846-2854)
+    p0 = dev(rng.standard_normal(g.ncell))
+    phalf, p = torch.zeros_like(p0), torch.zeros_like(p0)
+    torch.cuda.synchronize()
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    assert H.lib.NSUpdatePressure(ns, ptr(dp), ptr(p0), ptr(phalf), ptr(p)) == 0
+    torch.cuda.synchronize()
+    assert np.allclose(p.cpu().numpy(), p0.cpu().numpy() + 2 * dph, rtol=1e-15, atol=1e-15)
+    step, t = C.c_int64(), C.c_double()
+    H.lib.NSGetTimeStep(ns, C.byref(step))
+    H.lib.NSGetTime(ns, C.byref(t))
+    assert step.value == 1 and t.value == 1e-3
+    ph1 = phalf.cpu().numpy().copy()
+    assert H.lib.NSUpdatePressure(ns, ptr(dp), None, ptr(phalf), ptr(p)) == 0
+    torch.cuda.synchronize()
+    assert np.allclose(p.cpu().numpy(), ph1 + 1.5 * dph, rtol=1e-15, atol=1e-15)
+    assert H.lib.NSDestroy(C.byref(ns)) == 0
+    H.lib.MeshDestroy(C.byref(mesh))
+
+
+@pytest.mark.gpu
+def test_outlet_bc_vector_from_host_callbacks(H):
+    import torch
+    from oracle import fluca_oracle as fo
+    n = (9, 12, 7)
+    mesh = P()
+    assert H.lib.MeshCartCreate3d(0, 0, 1, n[0], n[1], n[2], -1, -1, -1, None, None, None, C.byref(mesh)) == 0
+    assert H.lib.MeshSetUp(mesh) == 0
+    assert H.lib.MeshCartSetUniformCoordinates(mesh, 0., 2., 0., 1., 0., 1.) == 0
+    ns = P()
+    H.lib.NSCreate(C.byref(ns))
+    H.lib.NSSetMesh(ns, mesh)
+    H.lib.NSSetTimeStepSize(ns, 0.25)
+
+    @H.BCFunc
+    def outlet_pressure(dim, t, x, val, ctx):
+        val[0] = 3.0 + x[1] - 2.0 * x[2] + t
+        return 0
+
+    H.lib.NSSetBoundaryCondition(ns, 0, H.NSBoundaryCondition(type=H.NS_BC_VELOCITY))
+    H.lib.NSSetBoundaryCondition(ns, 1, H.NSBoundaryCondition(type=H.NS_BC_PRESSURE_OUTLET, pressure=outlet_pressure))
+    for b in (2, 3):
+        H.lib.NSSetBoundaryCondition(ns, b, H.NSBoundaryCondition(type=H.NS_BC_VELOCITY))
+    for b in (4, 5):
+        H.lib.NSSetBoundaryCondition(ns, b, H.NSBoundaryCondition(type=H.NS_BC_PERIODIC))
+    assert H.lib.NSSetUp(ns) == 0
+    needs = C.c_int()
+    H.lib.NSGetNeedsNullSpace(ns, C.byref(needs))
+    assert needs.value == 0                                               # an outlet pins the pressure level (nsbasic.c:226-229)
+    g = fo.Grid.uniform(n, [(0, 2), (0, 1), (0, 1)], [1, 2, 1, 1, 3, 3], 0.25)
+    V = [torch.zeros(nf, dtype=torch.float64, device="cuda") for nf in g.nface]
+    torch.cuda.synchronize()
+    assert H.lib.NSComputeStaggeredPressureGradientBC(ns, 0.5, (C.c_void_p * 3)(*[t.data_ptr() for t in V])) == 0
+    Vx = V[0].cpu().numpy().reshape(n[2], n[1], n[0] + 1)
+    yc = (np.arange(n[1]) + 0.5) / n[1]
+    zc = (np.arange(n[2]) + 0.5) / n[2]
+    pb = 3.0 + yc[None, :] - 2.0 * zc[:, None] + 0.5
+    assert np.allclose(Vx[:, :, -1], g.gst_bc_coeff(0, 1) * pb, rtol=1e-14)
+    assert abs(Vx[:, :, :-1]).max() == 0 and float(V[1].abs().max()) == 0 and float(V[2].abs().max()) == 0
+    H.lib.NSDestroy(C.byref(ns))
+    H.lib.MeshDestroy(C.byref(mesh))
