@@ -173,6 +173,8 @@ extern "C" int fl_poisson_create(const fl_grid *grid, const int bc[6], double ka
   FL_HIP(hipMalloc((void **)&h->scal, sizeof(KspScal)));
   FL_HIP(hipHostMalloc((void **)&h->scal_host, sizeof(KspScal)));
   FL_HIP(hipMalloc((void **)&h->sums, sizeof(double) * NSLOT));
+  FL_HIP(hipMalloc((void **)&h->tickets, sizeof(unsigned) * 2));
+  FL_HIP(hipMemset(h->tickets, 0, sizeof(unsigned) * 2));
   *out = h;
   return FL_SUCCESS;
 }
@@ -196,6 +198,7 @@ extern "C" int fl_poisson_destroy(fl_poisson *h)
     if (h->loface_send[d]) (void)hipFree(h->loface_send[d]);
   }
   if (h->scal) (void)hipFree(h->scal);
+  if (h->tickets) (void)hipFree(h->tickets);
   if (h->scal_host) (void)hipHostFree(h->scal_host);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -480,6 +483,9 @@ static int solve_cg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts
   FL_CHK(cg_fin(h, 0, nsb, 5, h->hist, nhist));
   const bool ghosts = fl_any_ghost_exchange(h);
   if (ghosts) FL_CHK(fl_fill_ghosts(h, h->r));
+  // single rank: the last block of k_cg_A / k_cg_B performs the scalar update itself (no k_cg_fin launches)
+  const bool fusedfin = !h->multi && o->variant != 1;
+  if (fusedfin) FL_HIP(hipMemsetAsync(h->tickets, 0, sizeof(unsigned) * 2, s));
 
   std::vector<hipEvent_t> pev;
   if (o->profile) {
@@ -503,13 +509,13 @@ static int solve_cg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts
         if (prof) FL_HIP(hipEventRecord(pev[2 * it + 1], s));
       } else {
         if (prof) FL_HIP(hipEventRecord(pev[2 * it], s));
-        launch_cg_A(s, g, jac, plan, h->r, h->P0, h->P1, h->q, h->xp, h->scal, h->partial);
+        launch_cg_A(s, g, jac, plan, h->r, h->P0, h->P1, h->q, h->xp, h->scal, h->partial, fusedfin ? h->tickets : nullptr, h->hist, nhist);
         if (prof) FL_HIP(hipEventRecord(pev[2 * it + 1], s));
       }
-      FL_CHK(cg_fin(h, 1, nab, 1, h->hist, nhist));
+      if (!fusedfin) FL_CHK(cg_fin(h, 1, nab, 1, h->hist, nhist));
       hostcur ^= 1;
-      launch_cg_B(s, g, jac, planB, h->q, h->r, h->scal, h->partial, h->partial_stride);
-      FL_CHK(cg_fin(h, 2, planB.nblocks, 5, h->hist, nhist));
+      launch_cg_B(s, g, jac, planB, h->q, h->r, h->scal, h->partial, h->partial_stride, fusedfin ? h->tickets + 1 : nullptr, h->hist, nhist);
+      if (!fusedfin) FL_CHK(cg_fin(h, 2, planB.nblocks, 5, h->hist, nhist));
       if (ghosts && o->variant != 1) FL_CHK(fl_fill_ghosts(h, h->r));
     }
     FL_CHK(fl_poll_scal(h));
@@ -680,8 +686,8 @@ extern "C" int fldbg_bench(fl_poisson *h, int kernel, int ry, int pf, int nchunk
   S.beta = 0.5; S.alpha = 1e-3; S.zshift = 1e-4; S.ncell_global = (double)h->ncell; S.maxit = 1 << 30; S.pending_x = 1; S.nullspace = 1; S.rz = 1.;
   FL_HIP(hipMemcpyAsync(h->scal, h->scal_host, sizeof(KspScal), hipMemcpyHostToDevice, s));
   auto once = [&]() {
-    if (kernel == 0) launch_cg_A(s, g, true, plan, h->r, h->P0, h->P1, h->q, h->xp, h->scal, h->partial);
-    else if (kernel == 1) launch_cg_B(s, g, true, plan, h->q, h->r, h->scal, h->partial, h->partial_stride);
+    if (kernel == 0) launch_cg_A(s, g, true, plan, h->r, h->P0, h->P1, h->q, h->xp, h->scal, h->partial, nullptr, nullptr, 0);
+    else if (kernel == 1) launch_cg_B(s, g, true, plan, h->q, h->r, h->scal, h->partial, h->partial_stride, nullptr, nullptr, 0);
     else if (kernel == 2) launch_stream_ref(s, ry, pf, (int64_t)(h->padlen - 256) / 2, h->r, h->P0, h->xp, h->P1, h->q, h->w0);
     else {
       // kernel 3: parametric stream.  ry = 10*NR + NW, pf = 10*U + NT, nchunk = blocks

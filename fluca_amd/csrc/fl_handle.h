@@ -39,8 +39,8 @@ struct PlanA {
 PlanA plan_tiles(const GridP &, int ry, int nw, int nchunk_force, int target_blocks);
 PlanA plan_cg_A(const GridP &, int, int);
 PlanA plan_cg_B(const GridP &);
-void  launch_cg_A(hipStream_t, const GridP &, bool, const PlanA &, const double *, double *, double *, double *, double *, const KspScal *, double *);
-void  launch_cg_B(hipStream_t, const GridP &, bool, const PlanA &, const double *, double *, const KspScal *, double *, int);
+void  launch_cg_A(hipStream_t, const GridP &, bool, const PlanA &, const double *, double *, double *, double *, double *, KspScal *, double *, unsigned *, double *, int);
+void  launch_cg_B(hipStream_t, const GridP &, bool, const PlanA &, const double *, double *, KspScal *, double *, int, unsigned *, double *, int);
 void  launch_stream_ref(hipStream_t, int, int, int64_t, const double *, const double *, const double *, double *, double *, double *);
 void  launch_stream_par(hipStream_t, int, int, int, int, int, int64_t, const double *, const double *, const double *, double *, double *, double *);
 void  launch_cg_pupdate(hipStream_t, const GridP &, bool, const double *, double *, double *, const KspScal *);
@@ -220,6 +220,7 @@ struct fl_poisson {
   double *partial = nullptr;
   int     partial_stride = 0;
   double *sums = nullptr;
+  unsigned *tickets = nullptr;  // [2] device-scope arrival counters of the fused finalisation (k_cg_A, k_cg_B)
   KspScal *scal = nullptr, *scal_host = nullptr;
   double  *hist = nullptr;
   int      hist_cap = 0;

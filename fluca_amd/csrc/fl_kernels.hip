@@ -300,18 +300,9 @@ __device__ __forceinline__ double cg_norms(KspScal *s, const double *sum, double
   }
 }
 
-// mode 0: after k_cg_init.  mode 1: after k_cg_A (alpha).  mode 2: after k_cg_B (beta, convergence).
-// If nblocks > 0 the partials are reduced here (single rank); else `sums` already holds the (all-reduced) sums.
-__global__ void __launch_bounds__(256) k_cg_fin(int mode, const double *__restrict__ partial, int nblocks, int stride, const double *__restrict__ sums, KspScal *__restrict__ s, double *__restrict__ hist, int nhist)
+// mode 0: after k_cg_init.  mode 1: after k_cg_A (alpha).  mode 2: after k_cg_B (beta, convergence).  One thread.
+__device__ __forceinline__ void cg_fin_apply(int mode, const double *out, KspScal *__restrict__ s, double *__restrict__ hist, int nhist)
 {
-  __shared__ double out[NSLOT], red[NSLOT * 4];
-  if (s->reason != 0) return;
-  if (nblocks > 0) reduce_partials(partial, nblocks, stride, mode == 1 ? 1 : 5, out, red);
-  else {
-    if (threadIdx.x < NSLOT) out[threadIdx.x] = sums[threadIdx.x];
-    __syncthreads();
-  }
-  if (threadIdx.x != 0) return;
   if (mode == 1) {
     s->pending_x = 0;
     s->cur ^= 1;
@@ -348,6 +339,69 @@ __global__ void __launch_bounds__(256) k_cg_fin(int mode, const double *__restri
     else if (rz < 0.) reason = FL_DIVERGED_INDEFINITE_PC;
   }
   s->reason = reason;
+}
+
+// If nblocks > 0 the partials are reduced here (single rank, unfused path); else `sums` already holds the (all-reduced) sums.
+__global__ void __launch_bounds__(256) k_cg_fin(int mode, const double *__restrict__ partial, int nblocks, int stride, const double *__restrict__ sums, KspScal *__restrict__ s, double *__restrict__ hist, int nhist)
+{
+  __shared__ double out[NSLOT], red[NSLOT * 4];
+  if (s->reason != 0) return;
+  if (nblocks > 0) reduce_partials(partial, nblocks, stride, mode == 1 ? 1 : 5, out, red);
+  else {
+    if (threadIdx.x < NSLOT) out[threadIdx.x] = sums[threadIdx.x];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) cg_fin_apply(mode, out, s, hist, nhist);
+}
+
+// The same scalar update done by the LAST block of the producing kernel (single rank): saves two launches per CG
+// iteration.  Hand-off = MI355X_MICROARCH "valid forms": every block publishes its partial sums with agent-scope (sc1,
+// write-through) stores, drains them (s_waitcnt vmcnt(0)), then draws a ticket from a device-scope counter; the block
+// that draws the last ticket reads every partial with agent-scope (sc1, L1-bypassing) loads.  The sum order is fixed
+// (thread t takes blocks t, t+T, ...; then a fixed tree), so the result does not depend on which block is last.
+struct FinCtx {
+  unsigned *counter;  // zero between launches (the last block resets it)
+  double   *hist;
+  int       nhist, enabled;
+};
+template <int NV, int NTHR>
+__device__ __forceinline__ void fused_fin(int mode, const double (&v)[NV] /* thread 0 */, double *__restrict__ partial, int stride, const FinCtx &f, KspScal *__restrict__ s, double *red /* shared [NV * NTHR/64] */, int *flag /* shared */)
+{
+  const int nblocks = gridDim.x;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int a = 0; a < NV; ++a) __hip_atomic_store(&partial[(int64_t)a * stride + blockIdx.x], v[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(f.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *flag            = (t == (unsigned)(nblocks - 1));
+  }
+  __syncthreads();
+  if (!*flag) return;
+  double w[NV];
+#pragma unroll
+  for (int a = 0; a < NV; ++a) {
+    w[a] = 0.;
+    for (int b = threadIdx.x; b < nblocks; b += NTHR) w[a] += __hip_atomic_load(&partial[(int64_t)a * stride + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __syncthreads();  // red may still hold the block's own reduction
+#pragma unroll
+  for (int a = 0; a < NV; ++a) {
+    w[a] = wave_sum(w[a]);
+    if (lane == 0) red[a * (NTHR / 64) + wv] = w[a];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double out[NSLOT];
+#pragma unroll
+    for (int a = 0; a < NSLOT; ++a) {
+      out[a] = 0.;
+      if (a < NV)
+        for (int q = 0; q < NTHR / 64; ++q) out[a] += red[a * (NTHR / 64) + q];
+    }
+    cg_fin_apply(mode, out, s, f.hist, f.nhist);
+    __hip_atomic_store(f.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ CG: init / B / flush
@@ -397,9 +451,10 @@ __global__ void __launch_bounds__(256) k_cg_init(GridP g, const double *__restri
 // the loop); loads are unconditional on clamped, always-valid addresses so that the compiler can count them (a load
 // inside a divergent branch costs an s_waitcnt vmcnt(0)); only the stores and the sums are masked.
 template <int RY, bool JAC, int NT>
-__global__ void __launch_bounds__(256) k_cg_B(GridP g, const double *__restrict__ q, double *__restrict__ r, const KspScal *__restrict__ s, double *__restrict__ partial, int stride, int nchunk, int zc, int tiles_x)
+__global__ void __launch_bounds__(256) k_cg_B(GridP g, const double *__restrict__ q, double *__restrict__ r, KspScal *__restrict__ s, double *__restrict__ partial, int stride, int nchunk, int zc, int tiles_x, FinCtx fin)
 {
   __shared__ double red[5 * 4];
+  __shared__ int    flag;
   if (s->reason != 0) return;
   const double alpha = s->alpha;
   const int    b = blockIdx.x, chunk = b % nchunk, tile = b / nchunk;
@@ -470,7 +525,8 @@ __global__ void __launch_bounds__(256) k_cg_B(GridP g, const double *__restrict_
     }
   }
   block_sum<5>(acc, red);
-  if (threadIdx.x == 0)
+  if (fin.enabled) fused_fin<5, 256>(2, acc, partial, stride, fin, s, red, &flag);
+  else if (threadIdx.x == 0)
 #pragma unroll
     for (int a = 0; a < 5; ++a) partial[(int64_t)a * stride + blockIdx.x] = acc[a];
 }
@@ -514,8 +570,8 @@ __device__ __forceinline__ int xcd_remap(int b, int nblocks) { return (nblocks &
 // RY rows per wave, NW waves per block (tile 128 x NW*RY), PF prefetch mode, NT: 0 plain, 1 non-temporal stores,
 // 2 non-temporal stores and tile loads (halo loads stay plain: they are meant to hit in L2)
 template <int RY, int NW, bool JAC, int PF, int NT>
-__global__ void __launch_bounds__(64 * NW, 2) k_cg_A(GridP g, const double *__restrict__ r, double *__restrict__ P0, double *__restrict__ P1, double *__restrict__ q, double *__restrict__ x, const KspScal *__restrict__ s,
-                                                      double *__restrict__ partial, int nchunk, int zc, int tiles_x, int tiles, int remap)
+__global__ void __launch_bounds__(64 * NW, 2) k_cg_A(GridP g, const double *__restrict__ r, double *__restrict__ P0, double *__restrict__ P1, double *__restrict__ q, double *__restrict__ x, KspScal *__restrict__ s,
+                                                      double *__restrict__ partial, int nchunk, int zc, int tiles_x, int tiles, int remap, FinCtx fin)
 {
   using T               = TileA<RY, NW>;
   constexpr int TX = T::TX, TY = T::TY, LX = T::LX, LY = T::LY;
@@ -524,6 +580,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_cg_A(GridP g, const double *__re
   // Keeping the two older planes in LDS instead of registers frees 32 VGPRs for the load prefetch.
   __shared__ __attribute__((aligned(16))) double lds[3][LY][LX];
   __shared__ double                              red[NW];
+  __shared__ int                                 flag;
   if (s->reason != 0) return;
 
   const int     cur        = s->cur;
@@ -536,8 +593,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_cg_A(GridP g, const double *__re
   const int b     = remap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
   const int chunk = b / tiles, tile = b % tiles;  // chunk-major: consecutive logical blocks are neighbouring tiles
   const int i0 = (tile % tiles_x) * TX, j0 = (tile / tiles_x) * TY;
-  const int k0 = chunk * zc, k1 = min(k0 + zc, g.nz);
-  if (k0 >= k1) return;
+  const int k0 = chunk * zc, k1 = min(k0 + zc, g.nz);  // plan_tiles guarantees k0 < k1 for every block
   const int tid = threadIdx.x, lane = tid & 63;
   const int w  = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: rows, row offsets and y-coefficients live in SGPRs
   const int i  = i0 + 2 * lane;  // first of this lane's two cells
@@ -737,12 +793,13 @@ __global__ void __launch_bounds__(64 * NW, 2) k_cg_A(GridP g, const double *__re
   dot = wave_sum(dot);
   if (lane == 0) red[w] = dot;
   __syncthreads();
+  double tot[1] = {0.};
   if (tid == 0) {
-    double t = 0.;
 #pragma unroll
-    for (int a = 0; a < NW; ++a) t += red[a];
-    partial[b] = t;
+    for (int a = 0; a < NW; ++a) tot[0] += red[a];
   }
+  if (fin.enabled) fused_fin<1, 64 * NW>(1, tot, partial, 0, fin, s, red, &flag);
+  else if (tid == 0) partial[blockIdx.x] = tot[0];
 }
 
 // ------------------------------------------------------------------------------------------------ unfused CG pieces (variant 1)
@@ -978,53 +1035,63 @@ PlanA plan_cg_B(const GridP &g)
 }
 
 template <int RY, int NW, int PF, int NT>
-static void launch_cg_A_t(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const double *r, double *P0, double *P1, double *q, double *x, const KspScal *s, double *partial)
+static void launch_cg_A_t(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const double *r, double *P0, double *P1, double *q, double *x, KspScal *s, double *partial, const FinCtx &fin)
 {
   const int tiles = p.tiles_x * p.tiles_y;
-  if (jac) hipLaunchKernelGGL((k_cg_A<RY, NW, true, PF, NT>), dim3(p.nblocks), dim3(64 * NW), 0, st, g, r, P0, P1, q, x, s, partial, p.nchunk, p.zc, p.tiles_x, tiles, p.remap);
-  else hipLaunchKernelGGL((k_cg_A<RY, NW, false, PF, NT>), dim3(p.nblocks), dim3(64 * NW), 0, st, g, r, P0, P1, q, x, s, partial, p.nchunk, p.zc, p.tiles_x, tiles, p.remap);
+  if (jac) hipLaunchKernelGGL((k_cg_A<RY, NW, true, PF, NT>), dim3(p.nblocks), dim3(64 * NW), 0, st, g, r, P0, P1, q, x, s, partial, p.nchunk, p.zc, p.tiles_x, tiles, p.remap, fin);
+  else hipLaunchKernelGGL((k_cg_A<RY, NW, false, PF, NT>), dim3(p.nblocks), dim3(64 * NW), 0, st, g, r, P0, P1, q, x, s, partial, p.nchunk, p.zc, p.tiles_x, tiles, p.remap, fin);
 }
 template <int RY, int NW>
-static void launch_cg_A_v(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const double *r, double *P0, double *P1, double *q, double *x, const KspScal *s, double *partial)
+static void launch_cg_A_v(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const double *r, double *P0, double *P1, double *q, double *x, KspScal *s, double *partial, const FinCtx &fin)
 {
   switch (p.pf * 10 + p.nt) {
-  case 0: launch_cg_A_t<RY, NW, 0, 0>(st, g, jac, p, r, P0, P1, q, x, s, partial); break;
-  case 1: launch_cg_A_t<RY, NW, 0, 1>(st, g, jac, p, r, P0, P1, q, x, s, partial); break;
-  case 2: launch_cg_A_t<RY, NW, 0, 2>(st, g, jac, p, r, P0, P1, q, x, s, partial); break;
-  case 10: launch_cg_A_t<RY, NW, 1, 0>(st, g, jac, p, r, P0, P1, q, x, s, partial); break;
-  case 11: launch_cg_A_t<RY, NW, 1, 1>(st, g, jac, p, r, P0, P1, q, x, s, partial); break;
-  default: launch_cg_A_t<RY, NW, 1, 2>(st, g, jac, p, r, P0, P1, q, x, s, partial); break;
+  case 0: launch_cg_A_t<RY, NW, 0, 0>(st, g, jac, p, r, P0, P1, q, x, s, partial, fin); break;
+  case 1: launch_cg_A_t<RY, NW, 0, 1>(st, g, jac, p, r, P0, P1, q, x, s, partial, fin); break;
+  case 2: launch_cg_A_t<RY, NW, 0, 2>(st, g, jac, p, r, P0, P1, q, x, s, partial, fin); break;
+  case 10: launch_cg_A_t<RY, NW, 1, 0>(st, g, jac, p, r, P0, P1, q, x, s, partial, fin); break;
+  case 11: launch_cg_A_t<RY, NW, 1, 1>(st, g, jac, p, r, P0, P1, q, x, s, partial, fin); break;
+  default: launch_cg_A_t<RY, NW, 1, 2>(st, g, jac, p, r, P0, P1, q, x, s, partial, fin); break;
   }
 }
-void launch_cg_A(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const double *r, double *P0, double *P1, double *q, double *x, const KspScal *s, double *partial)
+void launch_cg_A(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const double *r, double *P0, double *P1, double *q, double *x, KspScal *s, double *partial, unsigned *counter, double *hist, int nhist)
 {
+  FinCtx fin;
+  fin.counter = counter;
+  fin.hist    = hist;
+  fin.nhist   = nhist;
+  fin.enabled = counter != nullptr;
   switch (p.ry * 10 + p.nw) {
-  case 48: launch_cg_A_v<4, 8>(st, g, jac, p, r, P0, P1, q, x, s, partial); break;
-  case 44: launch_cg_A_v<4, 4>(st, g, jac, p, r, P0, P1, q, x, s, partial); break;
-  case 28: launch_cg_A_v<2, 8>(st, g, jac, p, r, P0, P1, q, x, s, partial); break;
-  case 24: launch_cg_A_v<2, 4>(st, g, jac, p, r, P0, P1, q, x, s, partial); break;
-  default: launch_cg_A_v<1, 4>(st, g, jac, p, r, P0, P1, q, x, s, partial); break;
+  case 48: launch_cg_A_v<4, 8>(st, g, jac, p, r, P0, P1, q, x, s, partial, fin); break;
+  case 44: launch_cg_A_v<4, 4>(st, g, jac, p, r, P0, P1, q, x, s, partial, fin); break;
+  case 28: launch_cg_A_v<2, 8>(st, g, jac, p, r, P0, P1, q, x, s, partial, fin); break;
+  case 24: launch_cg_A_v<2, 4>(st, g, jac, p, r, P0, P1, q, x, s, partial, fin); break;
+  default: launch_cg_A_v<1, 4>(st, g, jac, p, r, P0, P1, q, x, s, partial, fin); break;
   }
 }
 
 template <int RY>
-static void launch_cg_B_ry(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const double *q, double *r, const KspScal *s, double *partial, int stride)
+static void launch_cg_B_ry(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const double *q, double *r, KspScal *s, double *partial, int stride, const FinCtx &fin)
 {
   const dim3 gr(p.nblocks), bl(256);
   if (p.nt) {
-    if (jac) hipLaunchKernelGGL((k_cg_B<RY, true, 1>), gr, bl, 0, st, g, q, r, s, partial, stride, p.nchunk, p.zc, p.tiles_x);
-    else hipLaunchKernelGGL((k_cg_B<RY, false, 1>), gr, bl, 0, st, g, q, r, s, partial, stride, p.nchunk, p.zc, p.tiles_x);
+    if (jac) hipLaunchKernelGGL((k_cg_B<RY, true, 1>), gr, bl, 0, st, g, q, r, s, partial, stride, p.nchunk, p.zc, p.tiles_x, fin);
+    else hipLaunchKernelGGL((k_cg_B<RY, false, 1>), gr, bl, 0, st, g, q, r, s, partial, stride, p.nchunk, p.zc, p.tiles_x, fin);
   } else {
-    if (jac) hipLaunchKernelGGL((k_cg_B<RY, true, 0>), gr, bl, 0, st, g, q, r, s, partial, stride, p.nchunk, p.zc, p.tiles_x);
-    else hipLaunchKernelGGL((k_cg_B<RY, false, 0>), gr, bl, 0, st, g, q, r, s, partial, stride, p.nchunk, p.zc, p.tiles_x);
+    if (jac) hipLaunchKernelGGL((k_cg_B<RY, true, 0>), gr, bl, 0, st, g, q, r, s, partial, stride, p.nchunk, p.zc, p.tiles_x, fin);
+    else hipLaunchKernelGGL((k_cg_B<RY, false, 0>), gr, bl, 0, st, g, q, r, s, partial, stride, p.nchunk, p.zc, p.tiles_x, fin);
   }
 }
-void launch_cg_B(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const double *q, double *r, const KspScal *s, double *partial, int stride)
+void launch_cg_B(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const double *q, double *r, KspScal *s, double *partial, int stride, unsigned *counter, double *hist, int nhist)
 {
+  FinCtx fin;
+  fin.counter = counter;
+  fin.hist    = hist;
+  fin.nhist   = nhist;
+  fin.enabled = counter != nullptr;
   switch (p.ry) {
-  case 4: launch_cg_B_ry<4>(st, g, jac, p, q, r, s, partial, stride); break;
-  case 2: launch_cg_B_ry<2>(st, g, jac, p, q, r, s, partial, stride); break;
-  default: launch_cg_B_ry<1>(st, g, jac, p, q, r, s, partial, stride); break;
+  case 4: launch_cg_B_ry<4>(st, g, jac, p, q, r, s, partial, stride, fin); break;
+  case 2: launch_cg_B_ry<2>(st, g, jac, p, q, r, s, partial, stride, fin); break;
+  default: launch_cg_B_ry<1>(st, g, jac, p, q, r, s, partial, stride, fin); break;
   }
 }
 

@@ -41,6 +41,7 @@ def test_bcgs_matches_oracle(n, bc, nonuni, nullspace, pc):
     assert np.allclose(ig["history"][:3], io["history"][:3], rtol=1e-9)
     k = min(m, 10)
     assert np.allclose(ig["history"][:k], io["history"][:k], rtol=1e-5)
+    # later BiCGStab iterations are chaotic w.r.t. summation order: the count may drift, the answer may not
     assert abs(ig["iters"] - io["iters"]) <= max(3, io["iters"] // 10)
     xg = host(xg)
     res = np.linalg.norm(b - S.mult(xg)) / np.linalg.norm(b)
