@@ -239,17 +239,36 @@ extern "C" int fl_poisson_sizes(const fl_poisson *h, int64_t out[4])
 int fl_ensure_vec(fl_poisson *h, double **v)
 {
   if (*v) return 0;
-  static const long skew = []() {
-    const char *e = std::getenv("FLUCA_SKEW");
-    long        s = e ? std::atol(e) : 0;
+  // Placement experiment knobs (profiles/r01_placement.txt): any kernel that streams six 1 GB vectors at once -- k_cg_A, and
+  // equally a plain 3-read/3-write copy kernel -- runs in one of two modes, ~1.11 ms or ~1.27 ms at 512^3, decided by
+  // where the driver puts the vectors physically; a re-allocation inside one process can flip it.  One slab for all
+  // vectors (FLUCA_SLAB=1) is always in the slow mode, whatever the stagger (FLUCA_GAP); separate hipMallocs
+  // (default) are fast in roughly one allocation out of ten.
+  static const long gap = []() {
+    const char *e = std::getenv("FLUCA_GAP");
+    long        s = e ? std::atol(e) : FL_DEFAULT_GAP;
     return (s / 128) * 128;
   }();
-  const int    k     = h->nvec++;
-  const size_t extra = (size_t)skew * 16;
-  void        *base  = nullptr;
-  FL_CHK(fl_dev_alloc(h, &base, sizeof(double) * h->padlen + extra, true));
-  h->vec_bases.push_back(base);
-  *v = (double *)((char *)base + (size_t)skew * (k % 16));
+  constexpr int NSLOTS = 8;
+  const size_t  slot   = ((sizeof(double) * h->padlen + 127) / 128) * 128 + (size_t)gap;
+  static const bool use_slab = []() {
+    const char *e = std::getenv("FLUCA_SLAB");
+    return e ? std::atoi(e) != 0 : false;  // default: one hipMalloc per vector (placement)
+  }();
+  if (!use_slab) {
+    void *base = nullptr;
+    FL_CHK(fl_dev_alloc(h, &base, slot, true));
+    h->vec_bases.push_back(base);
+    h->nvec++;
+    *v = (double *)base;
+    return 0;
+  }
+  if (!h->slab) {
+    FL_CHK(fl_dev_alloc(h, &h->slab, slot * NSLOTS, true));
+    h->vec_bases.push_back(h->slab);
+  }
+  if (h->nvec >= NSLOTS) return FL_ERR_MEM;
+  *v = (double *)((char *)h->slab + slot * (size_t)h->nvec++);
   return 0;
 }
 
@@ -665,6 +684,22 @@ extern "C" int fldbg_bench(fl_poisson *h, int kernel, int ry, int pf, int nchunk
   if (!h || !ms_out) return FL_ERR_ARG_NULL;
   FL_HIP(hipSetDevice(h->device));
   const GridP &g = h->g;
+  if (kernel == 9) {
+    // experiment: drop every padded vector so that the next call gets fresh physical memory (ry extra junk allocations
+    // of pf MiB each are made first and kept, to shift the placement)
+    FL_HIP(hipStreamSynchronize(h->stream));
+    for (void *p : h->vec_bases) (void)hipFree(p);
+    h->vec_bases.clear();
+    h->nvec = 0;
+    h->slab = nullptr;
+    for (double **v : {&h->r, &h->P0, &h->P1, &h->q, &h->xp, &h->w0, &h->w1, &h->w2}) *v = nullptr;
+    for (int a = 0; a < ry; ++a) {
+      void *junk = nullptr;
+      FL_HIP(hipMalloc(&junk, (size_t)pf << 20));
+    }
+    *ms_out = 0.;
+    return FL_SUCCESS;
+  }
   for (double **v : {&h->r, &h->P0, &h->P1, &h->q, &h->xp, &h->w0}) FL_CHK(fl_ensure_vec(h, v));
   hipStream_t s = h->stream;
   if (src_dev) {
@@ -685,6 +720,8 @@ extern "C" int fldbg_bench(fl_poisson *h, int kernel, int ry, int pf, int nchunk
   std::memset(&S, 0, sizeof(S));
   S.beta = 0.5; S.alpha = 1e-3; S.zshift = 1e-4; S.ncell_global = (double)h->ncell; S.maxit = 1 << 30; S.pending_x = 1; S.nullspace = 1; S.rz = 1.;
   FL_HIP(hipMemcpyAsync(h->scal, h->scal_host, sizeof(KspScal), hipMemcpyHostToDevice, s));
+  if (std::getenv("FLUCA_PRINT_PTRS") && kernel == 0)
+    std::fprintf(stderr, "[ptrs] r=%p P0=%p P1=%p q=%p xp=%p w0=%p\n", (void *)h->r, (void *)h->P0, (void *)h->P1, (void *)h->q, (void *)h->xp, (void *)h->w0);
   auto once = [&]() {
     if (kernel == 0) launch_cg_A(s, g, true, plan, h->r, h->P0, h->P1, h->q, h->xp, h->scal, h->partial, nullptr, nullptr, 0);
     else if (kernel == 1) launch_cg_B(s, g, true, plan, h->q, h->r, h->scal, h->partial, h->partial_stride, nullptr, nullptr, 0);

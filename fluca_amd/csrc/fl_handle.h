@@ -12,6 +12,10 @@
 
 #include "fl_internal.h"
 
+#ifndef FL_DEFAULT_GAP
+#define FL_DEFAULT_GAP 0
+#endif
+
 namespace fl {
 
 // launchers defined in fl_kernels.hip
@@ -216,6 +220,7 @@ struct fl_poisson {
   // solver workspace (padded vectors)
   double *r = nullptr, *P0 = nullptr, *P1 = nullptr, *q = nullptr, *xp = nullptr, *w0 = nullptr, *w1 = nullptr, *w2 = nullptr;
   std::vector<void *> vec_bases;
+  void               *slab = nullptr;
   int                 nvec = 0;
   double *partial = nullptr;
   int     partial_stride = 0;

@@ -1,0 +1,20 @@
+import ctypes as C, sys, os
+sys.path.insert(0,'.')
+import torch
+from fluca_amd import capi
+from fluca_amd.poisson import Poisson
+P = Poisson.uniform((512,)*3, [(0,1),(0,1),(0,0.5)], [1,1,1,1,4,1], 1e-3)
+src = torch.rand(P.ncell, dtype=torch.float64, device="cuda") - 0.5
+torch.cuda.synchronize()
+f = capi.lib.fldbg_bench
+f.restype = C.c_int
+f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+def t(kernel, ry, pf, nchunk):
+    ms = C.c_double(); nb = C.c_int()
+    rc = f(P.h, kernel, ry, pf, nchunk, 10, C.c_void_p(src.data_ptr()), C.byref(ms), C.byref(nb)); assert rc == 0, rc
+    return ms.value
+for trial in range(8):
+    a = [t(0, 28, 112, 4) for _ in range(3)]
+    b = [t(1, 44, 1, 8) for _ in range(2)]
+    print(f"trial {trial}: K_A {min(a):.4f} {max(a):.4f}   K_B {min(b):.4f}", flush=True)
+    t(9, trial % 3, 37 + 64 * trial, 0)   # free everything, allocate some junk, re-allocate on the next call
