@@ -89,11 +89,31 @@ def main():
     box = [(0.0, 1.0), (0.0, 1.0), (0.0, 0.5)]
     dec = flp.default_decomp(n, ranks, rank) if world > 1 else None
     P = flp.Poisson.uniform(n, box, bc, 1e-3, decomp=dec, device=local)
-    if world > 1 and args.transport == "rccl":
-        idb = [flp.rccl_unique_id() if rank == 0 else None]
+    transport = args.transport
+    if world > 1 and transport == "rccl":
+        # rank 0 creates the ncclUniqueId, the control plane (gloo) broadcasts it, every rank joins the RCCL communicator.
+        # If RCCL cannot be initialised on this node the run continues on the host-staged transport and SAYS SO in the
+        # JSON line ("halo"): still the GPU kernels, only the wire differs.
+        ok = 1
+        try:
+            idb = [flp.rccl_unique_id() if rank == 0 else None]
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] rank {rank}: RCCL unique id failed: {e}", file=sys.stderr, flush=True)
+            idb, ok = [None], 0
         dist.broadcast_object_list(idb, src=0)
-        P.comm_init_rccl(idb[0], rank, world)
-    elif world > 1:
+        if idb[0] is None:
+            ok = 0
+        if ok:
+            try:
+                P.comm_init_rccl(idb[0], rank, world)
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] rank {rank}: RCCL init failed: {e}", file=sys.stderr, flush=True)
+                ok = 0
+        t_ok = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+        if int(t_ok[0]) == 0:
+            transport = "host"
+    if world > 1 and transport == "host":
         from tests import mp_common as mpc
         P.comm_init_host(mpc.gloo_exchange, mpc.gloo_allreduce, rank, world)
     stream = torch.cuda.Stream()
@@ -147,7 +167,7 @@ def main():
         "config": {"workload": f"{n[0]}x{n[1]}x{n[2]} lid-driven-cavity Schur complement S=-kappa*D*Gst (7-pt, Neumann), "
                                f"matrix-free Jacobi-PCG with constant-null-space removal, b=S*p* seeded, fixed {args.steps} iterations",
                    "cells_per_gpu": int(P.ncell), "rank_grid": list(ranks), "variant": "fused" if args.variant == 0 else "unfused",
-                   "halo": ("RCCL Send/Recv" if args.transport == "rccl" else "host-staged gloo (rehearsal)") if world > 1 else "none"},
+                   "halo": ("RCCL Send/Recv" if transport == "rccl" else "host-staged gloo (NOT the production transport)") if world > 1 else "none"},
         "iteration_algorithmic_GBps_per_gpu": B_ITER_ALGO * P.ncell * args.steps / dt / 1e9,
         "solve_seconds_device": info["seconds"],
         "roofline": {"bound": "hbm", "kernel": "k_cg_A (p-update + S*p + dot + deferred x-update)",

@@ -168,14 +168,14 @@ __global__ void __launch_bounds__(256) k_ibm_interp(IbmP P, const int *__restric
 }
 
 // f[c*ncell + x] += sum_l w_l(x) F[c*L + l] dV_l / (hx hy hz), gather over the tile's bin, markers in ascending id order
-__global__ void __launch_bounds__(256) k_ibm_spread(IbmP P, const int *__restrict__ i0, const double *__restrict__ w, const int *__restrict__ off, const int *__restrict__ list, int ncomp, int64_t ncell, const double *__restrict__ F,
+__global__ void __launch_bounds__(256) k_ibm_spread(IbmP P, const int *__restrict__ i0, const double *__restrict__ w, const int *__restrict__ off, const int *__restrict__ list, const int *__restrict__ active, int ncomp, int64_t ncell, const double *__restrict__ F,
                                                       const double *__restrict__ dV, double *__restrict__ f)
 {
-  __shared__ int    sid[BIN_CHUNK], sraw[BIN_CHUNK];
+  __shared__ int    sraw[BIN_CHUNK];
   __shared__ int    si0[3][BIN_CHUNK];
   __shared__ double sw[3][4][BIN_CHUNK];
   __shared__ double sF[3][BIN_CHUNK];
-  const int tile = blockIdx.x;
+  const int tile = active[blockIdx.x];  // only tiles with a non-empty bin are launched
   const int beg = off[tile], end = off[tile + 1];
   if (beg == end) return;
   const int tx = tile % P.nt[0], ty = (tile / P.nt[0]) % P.nt[1], tz = tile / (P.nt[0] * P.nt[1]);
@@ -194,7 +194,6 @@ __global__ void __launch_bounds__(256) k_ibm_spread(IbmP P, const int *__restric
     __syncthreads();
     if (threadIdx.x < n) {
       const int m = sraw[threadIdx.x];
-      sid[threadIdx.x] = m;
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
         si0[d][threadIdx.x] = i0[d * P.L + m];
@@ -236,10 +235,18 @@ __global__ void __launch_bounds__(256) k_ibm_spread(IbmP P, const int *__restric
     }
 }
 
-// in-place ascending sort of every bin (marker ids are unique within a bin): rank sort, one block per tile
-__global__ void __launch_bounds__(256) k_ibm_sort_bins(const int *__restrict__ off, int *__restrict__ list, int *__restrict__ scratch)
+// compact list of the tiles whose bin is not empty (order irrelevant: every tile owns its cells)
+__global__ void k_ibm_active(const int *__restrict__ off, int ntiles, int *__restrict__ active, int *__restrict__ nactive)
 {
-  const int beg = off[blockIdx.x], end = off[blockIdx.x + 1], n = end - beg;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < ntiles && off[t + 1] > off[t]) active[atomicAdd(nactive, 1)] = t;
+}
+
+// in-place ascending sort of every bin (marker ids are unique within a bin): rank sort, one block per tile
+__global__ void __launch_bounds__(256) k_ibm_sort_bins(const int *__restrict__ off, int *__restrict__ list, int *__restrict__ scratch, const int *__restrict__ active)
+{
+  const int tile = active[blockIdx.x];
+  const int beg = off[tile], end = off[tile + 1], n = end - beg;
   if (n <= 1) return;
   for (int e = threadIdx.x; e < n; e += 256) {
     const int v = list[beg + e];
@@ -259,8 +266,8 @@ struct fl_ibm {
   fl_poisson *gp = nullptr;
   IbmP        P;
   double     *X = nullptr, *Y = nullptr, *Z = nullptr, *w = nullptr;
-  int        *i0 = nullptr, *cnt = nullptr, *off = nullptr, *list = nullptr, *scratch = nullptr;
-  int         ntiles = 0, listcap = 0;
+  int        *i0 = nullptr, *cnt = nullptr, *off = nullptr, *list = nullptr, *scratch = nullptr, *active = nullptr, *nact_dev = nullptr;
+  int         ntiles = 0, listcap = 0, nactive = 0;
 };
 
 static int ibm_rebin(fl_ibm *m)
@@ -275,7 +282,12 @@ static int ibm_rebin(fl_ibm *m)
   hipLaunchKernelGGL(k_ibm_scan, dim3(1), dim3(256), 0, s, m->cnt, m->off, m->ntiles);
   FL_HIP(hipMemsetAsync(m->cnt, 0, sizeof(int) * (m->ntiles + 1), s));
   hipLaunchKernelGGL(k_ibm_bin, dim3(nb), dim3(256), 0, s, P, m->i0, m->cnt, m->off, m->list, 1);
-  hipLaunchKernelGGL(k_ibm_sort_bins, dim3(m->ntiles), dim3(256), 0, s, m->off, m->list, m->scratch);
+  FL_HIP(hipMemsetAsync(m->nact_dev, 0, sizeof(int), s));
+  hipLaunchKernelGGL(k_ibm_active, dim3((m->ntiles + 255) / 256), dim3(256), 0, s, m->off, m->ntiles, m->active, m->nact_dev);
+  FL_HIP(hipMemcpyAsync(&m->nactive, m->nact_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+  FL_HIP(hipStreamSynchronize(s));  // set-up time only (create / marker update), never inside interp / spread
+  // sort only the non-empty bins (ascending marker id -> run-independent accumulation order)
+  if (m->nactive > 0) hipLaunchKernelGGL(k_ibm_sort_bins, dim3(m->nactive), dim3(256), 0, s, m->off, m->list, m->scratch, m->active);
   FL_HIP(hipGetLastError());
   return 0;
 }
@@ -325,6 +337,8 @@ extern "C" int fl_ibm_create(fl_poisson *h, int kind, int64_t L, const double *X
   rc |= fl_dev_alloc(h, (void **)&m->off, sizeof(int) * (m->ntiles + 1), true);
   rc |= fl_dev_alloc(h, (void **)&m->list, sizeof(int) * m->listcap, true);
   rc |= fl_dev_alloc(h, (void **)&m->scratch, sizeof(int) * m->listcap, true);
+  rc |= fl_dev_alloc(h, (void **)&m->active, sizeof(int) * m->ntiles, true);
+  rc |= fl_dev_alloc(h, (void **)&m->nact_dev, sizeof(int), true);
   if (rc) {
     fl_ibm_destroy(m);
     return FL_ERR_MEM;
@@ -361,7 +375,7 @@ extern "C" int fl_ibm_spread(fl_ibm *m, int ncomp, const double *F, const double
   if (ncomp < 1 || ncomp > 3) return FL_ERR_ARG_OUTOFRANGE;
   fl_poisson *h = m->gp;
   FL_HIP(hipSetDevice(h->device));
-  hipLaunchKernelGGL(k_ibm_spread, dim3(m->ntiles), dim3(256), 0, h->stream, m->P, m->i0, m->w, m->off, m->list, ncomp, h->ncell, F, dV, f);
+  if (m->nactive > 0) hipLaunchKernelGGL(k_ibm_spread, dim3(m->nactive), dim3(256), 0, h->stream, m->P, m->i0, m->w, m->off, m->list, m->active, ncomp, h->ncell, F, dV, f);
   FL_HIP(hipGetLastError());
   return FL_SUCCESS;
 }
@@ -370,7 +384,7 @@ extern "C" int fl_ibm_destroy(fl_ibm *m)
 {
   if (!m) return FL_SUCCESS;
   if (m->gp) (void)hipStreamSynchronize(m->gp->stream);
-  for (void *p : {(void *)m->X, (void *)m->Y, (void *)m->Z, (void *)m->w, (void *)m->i0, (void *)m->cnt, (void *)m->off, (void *)m->list, (void *)m->scratch})
+  for (void *p : {(void *)m->X, (void *)m->Y, (void *)m->Z, (void *)m->w, (void *)m->i0, (void *)m->cnt, (void *)m->off, (void *)m->list, (void *)m->scratch, (void *)m->active, (void *)m->nact_dev})
     if (p) (void)hipFree(p);
   delete m;
   return FL_SUCCESS;

@@ -217,3 +217,40 @@ def test_pressure_update_and_outlet_bc_vector():
     P.gst_bc(2, dev(rng.standard_normal(9 * 7)), Vy)             # not an outlet: no-op
     assert float(Vy.abs().max()) == 0.0
     P.close()
+
+
+def test_full_size_properties_512():
+    """BASELINE.json metric size (512^3, 134 M cells): size-independent properties only (the oracle cannot run this in
+    seconds): S 1 = 0, <Sx,y> = <x,Sy>, solve-then-apply round trip, fused and unfused CG agree, Chebyshev damps."""
+    from fluca_amd.poisson import Poisson
+    n = (512, 512, 512)
+    P = Poisson.uniform(n, CAVITY_BOX, CAVITY, 1e-3)
+    N = P.ncell
+    d = P.diagonal()
+    s1 = P.apply(torch.ones(N, dtype=torch.float64, device="cuda"))
+    assert float(s1.abs().max()) <= 1e-12 * float(d.max())
+    g = torch.Generator(device="cuda").manual_seed(2)
+    x = torch.rand(N, generator=g, dtype=torch.float64, device="cuda") - 0.5
+    y = torch.rand(N, generator=g, dtype=torch.float64, device="cuda") - 0.5
+    a, b = float(torch.dot(P.apply(x), y)), float(torch.dot(x, P.apply(y)))
+    assert abs(a - b) <= 1e-10 * max(abs(a), abs(b))
+    # a smooth mean-free field: b = S p, solve, compare (round trip through KSPSolve)
+    i = torch.arange(512, dtype=torch.float64, device="cuda")
+    cx = torch.cos(torch.pi * (i + 0.5) / 512)
+    p = (cx[None, None, :] * cx[None, :, None] * torch.cos(2 * torch.pi * (i + 0.5) / 512)[:, None, None]).reshape(-1).contiguous()
+    p -= p.mean()
+    rhs = P.apply(p)
+    sol, info = P.solve(rhs, rtol=1e-8, maxit=4000)
+    assert info["reason"] == 2
+    res = rhs - P.apply(sol)
+    assert float(res.norm()) <= 1e-5 * float(rhs.norm())
+    assert float(((sol - sol.mean()) - p).abs().max()) <= 1e-4 * float(p.abs().max())
+    sol1, info1 = P.solve(rhs, rtol=1e-8, maxit=4000, variant=1)
+    assert abs(info1["iters"] - info["iters"]) <= 2 and float((sol1 - sol).norm()) <= 1e-6 * float(sol.norm())
+    # 40 Chebyshev-Jacobi steps: residual strictly smaller than after 20
+    r = []
+    for its in (20, 40):
+        xs, _ = P.solve(rhs, type=2, norm_type=3, maxit=its)
+        r.append(float((rhs - P.apply(xs)).norm()))
+    assert r[1] < r[0] < float(rhs.norm())
+    P.close()
