@@ -114,6 +114,7 @@ struct Comm {
   std::vector<double *> hsend, hrecv;
   std::vector<int64_t>  hcap;
   double               *hred = nullptr;
+  int                   hredcap = 0;
 
   int exchange(hipStream_t st, const std::vector<Msg> &m)
   {
@@ -170,7 +171,11 @@ struct Comm {
       return 0;
     }
     if (kind == HOST) {
-      if (!hred) FL_HIP(hipHostMalloc((void **)&hred, sizeof(double) * 64));
+      if (hredcap < n) {
+        if (hred) (void)hipHostFree(hred);
+        FL_HIP(hipHostMalloc((void **)&hred, sizeof(double) * (size_t)std::max(n, 64)));
+        hredcap = std::max(n, 64);
+      }
       FL_HIP(hipMemcpyAsync(hred, dev, sizeof(double) * n, hipMemcpyDeviceToHost, st));
       FL_HIP(hipStreamSynchronize(st));
       if (allred(ctx, hred, n) != 0) return FL_ERR_LIB;
@@ -192,6 +197,7 @@ struct Comm {
     hrecv.clear();
     hcap.clear();
     hred = nullptr;
+    hredcap = 0;
     nccl = nullptr;
     kind = NONE;
   }

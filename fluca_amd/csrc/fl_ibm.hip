@@ -41,12 +41,12 @@ struct IbmP {
   int     n[3];        // local cells
   int     lo[3];       // global index of local cell 0
   int     ng[3];       // global cells
-  int     periodic[3]; // periodic AND held by this rank alone (wrap locally)
+  int     periodic[3]; // periodic axis of the GLOBAL grid (support indices wrap modulo ng, then ownership is tested)
   double  x0[3], h[3]; // global origin, spacing
   int     nt[3];       // tiles
 };
 
-// i0[d*L + l] = first support cell (LOCAL index, may be out of range); w[(d*4 + a)*L + l] = phi weights
+// i0[d*L + l] = first support cell (GLOBAL index, may be out of range); w[(d*4 + a)*L + l] = phi weights
 __global__ void k_ibm_weights(IbmP P, const double *__restrict__ X, const double *__restrict__ Y, const double *__restrict__ Z, int *__restrict__ i0, double *__restrict__ w)
 {
   const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -60,18 +60,21 @@ __global__ void k_ibm_weights(IbmP P, const double *__restrict__ X, const double
       const double r          = s - (double)(i + a);
       w[(d * 4 + a) * P.L + l] = a < P.S ? (P.kind == FL_DELTA_PESKIN4 ? phi_peskin4(r) : phi_roma3(r)) : 0.;
     }
-    i0[d * P.L + l] = i - P.lo[d];
+    i0[d * P.L + l] = i;
   }
 }
 
-// local cell index of support entry a, or -1 when it falls outside this rank's block
+// LOCAL cell index of support entry a, or -1 when that cell is not owned by this rank.  Every rank sees every marker
+// (markers are replicated); a support that straddles a block face is simply shared out between the two owners, and a
+// support that crosses a periodic boundary wraps in GLOBAL index space first.
 __device__ __forceinline__ int support_cell(const IbmP &P, int d, int i0, int a)
 {
   int c = i0 + a;
   if (P.periodic[d]) {
-    if (c < 0) c += P.n[d];
-    else if (c >= P.n[d]) c -= P.n[d];
+    if (c < 0) c += P.ng[d];
+    else if (c >= P.ng[d]) c -= P.ng[d];
   }
+  c -= P.lo[d];
   return (c < 0 || c >= P.n[d]) ? -1 : c;
 }
 
@@ -206,16 +209,16 @@ __global__ void __launch_bounds__(256) k_ibm_spread(IbmP P, const int *__restric
     __syncthreads();
     if (ci < P.n[0] && cj < P.n[1]) {
       for (int e = 0; e < n; ++e) {
-        int a = ci - si0[0][e], b = cj - si0[1][e];
-        if (P.periodic[0]) { if (a < 0) a += P.n[0]; else if (a >= P.n[0]) a -= P.n[0]; }
-        if (P.periodic[1]) { if (b < 0) b += P.n[1]; else if (b >= P.n[1]) b -= P.n[1]; }
+        int a = ci + P.lo[0] - si0[0][e], b = cj + P.lo[1] - si0[1][e];
+        if (P.periodic[0]) { if (a < 0) a += P.ng[0]; else if (a >= P.ng[0]) a -= P.ng[0]; }
+        if (P.periodic[1]) { if (b < 0) b += P.ng[1]; else if (b >= P.ng[1]) b -= P.ng[1]; }
         if (a < 0 || a >= P.S || b < 0 || b >= P.S) continue;
         const double wxy = sw[0][a][e] * sw[1][b][e];
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
           const int ck = tz * TB + lk + 4 * half;
-          int       c3 = ck - si0[2][e];
-          if (P.periodic[2]) { if (c3 < 0) c3 += P.n[2]; else if (c3 >= P.n[2]) c3 -= P.n[2]; }
+          int       c3 = ck + P.lo[2] - si0[2][e];
+          if (P.periodic[2]) { if (c3 < 0) c3 += P.ng[2]; else if (c3 >= P.ng[2]) c3 -= P.ng[2]; }
           if (ck >= P.n[2] || c3 < 0 || c3 >= P.S) continue;
           const double wt = wxy * sw[2][c3][e];
           acc[half][0] += wt * sF[0][e];
@@ -310,7 +313,7 @@ extern "C" int fl_ibm_create(fl_poisson *h, int kind, int64_t L, const double *X
     P.n[d]        = (int)h->dec.len[d];
     P.lo[d]       = (int)h->dec.lo[d];
     P.ng[d]       = (int)A.n;
-    P.periodic[d] = h->wrap_local[d] ? 1 : 0;
+    P.periodic[d] = A.periodic ? 1 : 0;
     P.x0[d]       = A.xf[0];
     P.h[d]        = (A.xf[A.n] - A.xf[0]) / (double)A.n;
     // the delta function is only defined on uniformly spaced grids
@@ -319,7 +322,7 @@ extern "C" int fl_ibm_create(fl_poisson *h, int kind, int64_t L, const double *X
         delete m;
         return FL_ERR_SUP;
       }
-    if (P.periodic[d] && P.n[d] < P.S) {
+    if (P.periodic[d] && P.ng[d] < 2 * P.S) {
       delete m;
       return FL_ERR_ARG_OUTOFRANGE;
     }
@@ -366,6 +369,11 @@ extern "C" int fl_ibm_interp(fl_ibm *m, int ncomp, const double *u, double *U)
   FL_HIP(hipSetDevice(h->device));
   hipLaunchKernelGGL(k_ibm_interp, dim3((unsigned)((m->P.L + 3) / 4)), dim3(256), 0, h->stream, m->P, m->i0, m->w, ncomp, h->ncell, u, U);
   FL_HIP(hipGetLastError());
+  // multi-rank: every rank summed over the support cells it owns; the marker value is the sum over ranks
+  if (h->multi) {
+    if (h->comm.kind == Comm::NONE) return FL_ERR_ARG_WRONGSTATE;
+    FL_CHK(h->comm.allreduce(h->stream, U, (int)(m->P.L * ncomp)));
+  }
   return FL_SUCCESS;
 }
 

@@ -85,6 +85,63 @@ def test_decomposed_solve_matches_single_domain_oracle(world, n, ranks, bc, ksp)
     mpc.run_ranks(world, _worker, n, ranks, bc, ksp)
 
 
+def _ibm_worker(rank, world, n, ranks, bc, kind):
+    """Markers replicated on every rank; interp = all-reduced sum over the owners of the support cells, spread = each rank
+    adds to the cells it owns.  Against the single-domain oracle, including supports that straddle block faces and the
+    periodic seam."""
+    import ctypes as C
+    import torch
+    from fluca_amd import capi
+    from fluca_amd.poisson import Poisson
+    from oracle import fluca_oracle as fo
+    d = mpc.decomp_of(capi, n, ranks, rank)
+    box = [(0.0, 1.0), (0.0, 1.0), (0.0, 1.0)]
+    P = Poisson.uniform(n, box, bc, 1e-3, decomp=d)
+    P.comm_init_host(mpc.gloo_exchange, mpc.gloo_allreduce, rank, world)
+    g = fo.Grid.uniform(n, box, bc, 1e-3)
+    rng = np.random.default_rng(17)
+    L = 257
+    X = [rng.uniform(0.0, 1.0, L) for _ in range(3)]
+    X[0][:4] = [0.499, 0.501, 0.003, 0.998]      # on the block face of a 2-rank split and at the periodic seam / wall
+    X[1][:4] = [0.5, 0.49, 0.51, 0.5]
+    X[2][:4] = [0.5, 0.502, 0.497, 0.001]
+    shp = (n[2], n[1], n[0])
+    blk = mpc.block(d)
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64).ravel(), device="cuda")
+    Xd = [dev(a) for a in X]
+    m = C.c_void_p()
+    P._pre()
+    capi.check(capi.lib.fl_ibm_create(P.h, kind, L, *[C.c_void_p(t.data_ptr()) for t in Xd], C.byref(m)))
+    u = rng.standard_normal((3, g.ncell))
+    ul = dev(np.stack([u[c].reshape(shp)[blk].ravel() for c in range(3)]))
+    U = torch.empty(3 * L, dtype=torch.float64, device="cuda")
+    capi.check(capi.lib.fl_ibm_interp(m, 3, C.c_void_p(ul.data_ptr()), C.c_void_p(U.data_ptr())))
+    P.synchronize()
+    ref = g.ibm_interp(kind, X, u)
+    assert np.allclose(U.cpu().numpy().reshape(3, L), ref, rtol=1e-12, atol=1e-13), ("interp", rank)
+    F = rng.standard_normal((3, L))
+    dV = rng.uniform(0.5, 1.5, L) * 1e-3
+    f0 = rng.standard_normal((3, g.ncell))
+    fl = dev(np.stack([f0[c].reshape(shp)[blk].ravel() for c in range(3)]))
+    Fd, dVd = dev(F), dev(dV)
+    capi.check(capi.lib.fl_ibm_spread(m, 3, C.c_void_p(Fd.data_ptr()), C.c_void_p(dVd.data_ptr()), C.c_void_p(fl.data_ptr())))
+    P.synchronize()
+    reff = g.ibm_spread(kind, X, dV, F, f0.copy())
+    want = np.stack([reff[c].reshape(shp)[blk].ravel() for c in range(3)])
+    got = fl.cpu().numpy().reshape(3, -1)
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-12 * abs(reff).max()), ("spread", rank)
+    capi.lib.fl_ibm_destroy(m)
+    P.close()
+
+
+@pytest.mark.parametrize("world,n,ranks,bc,kind", [
+    (2, (24, 20, 16), (2, 1, 1), [3, 3, 1, 1, 1, 1], 0),      # periodic axis split over two ranks, Peskin 4-point
+    (4, (24, 20, 16), (2, 1, 2), [1, 1, 3, 3, 1, 1], 1),      # walls on the split axes, Roma 3-point
+])
+def test_ibm_multirank_matches_single_domain_oracle(world, n, ranks, bc, kind):
+    mpc.run_ranks(world, _ibm_worker, n, ranks, bc, kind)
+
+
 def _rccl_probe(rank, world):
     """Does RCCL accept two ranks on one device?  Informational: the production transport needs one GPU per rank."""
     import torch
