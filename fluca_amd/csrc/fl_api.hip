@@ -107,11 +107,21 @@ extern "C" int fl_poisson_create(const fl_grid *grid, const int bc[6], double ka
   g.fx    = fl_[0];
   g.fy    = fl_[1];
   g.fz    = fl_[2];
-  g.sx    = ((PADX + g.nx + 1 + 15) / 16) * 16;
+  // Row-interleaved vector layout (FLUCA_INTERLEAVE=NV > 1): row (j,k) of vector v lives at ((k*sy + j)*NV + v)*sx0, i.e. the
+  // same row of all NV solver vectors is contiguous in memory and a kernel that streams several vectors sweeps ONE
+  // address range instead of NV ranges a gigabyte apart.  Kernels only ever see (pointer, row stride, plane stride).
+  {
+    const char *e = std::getenv("FLUCA_INTERLEAVE");
+    h->nv_il      = e ? std::atoi(e) : FL_DEFAULT_INTERLEAVE;
+    if (h->nv_il < 2) h->nv_il = 1;
+    if (h->nv_il > 8) h->nv_il = 8;
+  }
+  h->sx0  = ((PADX + g.nx + 1 + 15) / 16) * 16;
+  g.sx    = h->sx0 * h->nv_il;
   g.sxy   = (int64_t)g.sx * (g.ny + 2);
   g.off0  = g.sxy + g.sx + PADX;
   g.kappa = kappa;
-  h->padlen = (size_t)g.sxy * (g.nz + 2) + 256;
+  h->padlen = (size_t)g.sxy * (g.nz + 2) + 256;  // doubles spanned by one vector (interleaved: by the whole slab)
   h->ncell  = (int64_t)g.nx * g.ny * g.nz;
   h->nface[0] = (int64_t)g.fx * g.ny * g.nz;
   h->nface[1] = (int64_t)g.nx * g.fy * g.nz;
@@ -239,11 +249,16 @@ extern "C" int fl_poisson_sizes(const fl_poisson *h, int64_t out[4])
 int fl_ensure_vec(fl_poisson *h, double **v)
 {
   if (*v) return 0;
-  // Placement experiment knobs (profiles/r01_placement.txt): any kernel that streams six 1 GB vectors at once -- k_cg_A, and
-  // equally a plain 3-read/3-write copy kernel -- runs in one of two modes, ~1.11 ms or ~1.27 ms at 512^3, decided by
-  // where the driver puts the vectors physically; a re-allocation inside one process can flip it.  One slab for all
-  // vectors (FLUCA_SLAB=1) is always in the slow mode, whatever the stagger (FLUCA_GAP); separate hipMallocs
-  // (default) are fast in roughly one allocation out of ten.
+  if (h->nv_il > 1) {
+    // interleaved: one slab, vector k starts k*sx0 doubles into it
+    if (!h->slab) {
+      FL_CHK(fl_dev_alloc(h, &h->slab, sizeof(double) * h->padlen, true));
+      h->vec_bases.push_back(h->slab);
+    }
+    if (h->nvec >= h->nv_il) return FL_ERR_MEM;
+    *v = (double *)h->slab + (size_t)h->sx0 * (size_t)h->nvec++;
+    return 0;
+  }
   static const long gap = []() {
     const char *e = std::getenv("FLUCA_GAP");
     long        s = e ? std::atol(e) : FL_DEFAULT_GAP;
@@ -269,6 +284,18 @@ int fl_ensure_vec(fl_poisson *h, double **v)
   }
   if (h->nvec >= NSLOTS) return FL_ERR_MEM;
   *v = (double *)((char *)h->slab + slot * (size_t)h->nvec++);
+  return 0;
+}
+
+// zero a padded vector (ghosts included) on the handle's stream
+int fl_zero_vec(fl_poisson *h, double *v)
+{
+  if (h->nv_il <= 1) {
+    FL_HIP(hipMemsetAsync(v, 0, sizeof(double) * h->padlen, h->stream));
+    return 0;
+  }
+  const size_t rows = (size_t)(h->g.ny + 2) * (size_t)(h->g.nz + 2);
+  FL_HIP(hipMemset2DAsync(v, sizeof(double) * (size_t)h->g.sx, 0, sizeof(double) * (size_t)h->sx0, rows, h->stream));
   return 0;
 }
 
@@ -339,6 +366,96 @@ int fl_fill_ghosts(fl_poisson *h, double *v)
 }
 
 bool fl_any_ghost_exchange(const fl_poisson *h) { return h->multi || h->wrap_local[0] || h->wrap_local[1] || h->wrap_local[2]; }
+
+// ------------------------------------------------------------------------------------------------ placement tuning
+
+extern "C" int fl_poisson_tune_placement(fl_poisson *h, int max_tries, double probe_ms_out[2])
+{
+  if (!h) return FL_ERR_ARG_NULL;
+  if (max_tries < 1) return FL_ERR_ARG_OUTOFRANGE;
+  if (h->nv_il > 1) return FL_SUCCESS;  // interleaved slab: nothing to choose
+  FL_HIP(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  FL_HIP(hipStreamSynchronize(s));
+  double **slots[6] = {&h->r, &h->P0, &h->P1, &h->q, &h->xp, &h->w0};
+  struct Set {
+    double *v[6];
+    std::vector<void *> bases;
+    double ms;
+  };
+  std::vector<Set> sets;
+  const size_t     set_bytes = 6 * sizeof(double) * h->padlen;
+  const PlanA      plan = plan_cg_A(h->g, 0, 0);
+  FL_CHK(fl_ensure_partials(h, plan.nblocks));
+  // two scalar blocks: direction buffer parity 0 and 1
+  KspScal *scal2 = nullptr;
+  FL_HIP(hipMalloc((void **)&scal2, 2 * sizeof(KspScal)));
+  {
+    KspScal S2[2];
+    std::memset(S2, 0, sizeof(S2));
+    for (int a = 0; a < 2; ++a) {
+      S2[a].beta = 0.5; S2[a].alpha = 1e-3; S2[a].zshift = 1e-4; S2[a].ncell_global = (double)h->ncell; S2[a].maxit = 1 << 30; S2[a].cur = a;
+    }
+    FL_HIP(hipMemcpy(scal2, S2, sizeof(S2), hipMemcpyHostToDevice));
+  }
+  // start from whatever is allocated already
+  auto detach = [&]() {
+    h->vec_bases.clear();
+    h->nvec = 0;
+    h->slab = nullptr;
+    for (double **v : {&h->r, &h->P0, &h->P1, &h->q, &h->xp, &h->w0, &h->w1, &h->w2}) *v = nullptr;
+  };
+  if (h->nvec != 0) {
+    for (void *p : h->vec_bases) (void)hipFree(p);
+    detach();
+  }
+  for (int t = 0; t < max_tries; ++t) {
+    size_t freeb = 0, total = 0;
+    if (hipMemGetInfo(&freeb, &total) == hipSuccess && freeb < 2 * set_bytes + ((size_t)8 << 30)) break;
+    for (double **v : slots) FL_CHK(fl_ensure_vec(h, v));
+    Set c;
+    for (int a = 0; a < 6; ++a) c.v[a] = *slots[a];
+    c.bases = h->vec_bases;
+    // The probe is the dominant kernel itself, in both roles of the two direction buffers (k_cg_A reads one and writes
+    // the other, alternating every iteration): which vectors are read and which are written at the same time matters.
+    for (int a : {0, 1, 2, 4}) FL_HIP(hipMemsetAsync(c.v[a], 0x3f, sizeof(double) * h->padlen, s));
+    auto probe = [&](int reps) {
+      for (int r = 0; r < reps; ++r)
+        for (int par = 0; par < 2; ++par) launch_cg_A(s, h->g, true, plan, c.v[0], c.v[1], c.v[2], c.v[3], c.v[4], scal2 + par, h->partial, nullptr, nullptr, 0);
+    };
+    probe(1);
+    FL_HIP(hipEventRecord(h->ev0, s));
+    probe(2);
+    FL_HIP(hipEventRecord(h->ev1, s));
+    FL_HIP(hipStreamSynchronize(s));
+    float ms = 0.f;
+    FL_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    ms *= 3.f / 4.f;  // 4 launches; keep the "/ 3" below
+    c.ms = ms / 3.;
+    sets.push_back(c);
+    detach();  // keep it allocated: the next candidate must land somewhere else
+  }
+  (void)hipFree(scal2);
+  if (sets.empty()) return FL_ERR_MEM;
+  size_t best = 0;
+  for (size_t a = 1; a < sets.size(); ++a)
+    if (sets[a].ms < sets[best].ms) best = a;
+  for (size_t a = 0; a < sets.size(); ++a)
+    if (a != best)
+      for (void *p : sets[a].bases) (void)hipFree(p);
+  for (int a = 0; a < 6; ++a) {
+    *slots[a] = sets[best].v[a];
+    FL_HIP(hipMemsetAsync(sets[best].v[a], 0, sizeof(double) * h->padlen, s));
+  }
+  h->vec_bases = sets[best].bases;
+  h->nvec      = 6;
+  FL_HIP(hipStreamSynchronize(s));
+  if (probe_ms_out) {
+    probe_ms_out[0] = sets[0].ms;
+    probe_ms_out[1] = sets[best].ms;
+  }
+  return FL_SUCCESS;
+}
 
 // ------------------------------------------------------------------------------------------------ operator entry points
 
@@ -495,9 +612,9 @@ static int solve_cg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts
 
   FL_HIP(hipEventRecord(h->ev0, s));
   FL_HIP(hipMemcpyAsync(h->scal, h->scal_host, sizeof(KspScal), hipMemcpyHostToDevice, s));
-  FL_HIP(hipMemsetAsync(h->P0, 0, sizeof(double) * h->padlen, s));
-  FL_HIP(hipMemsetAsync(h->P1, 0, sizeof(double) * h->padlen, s));
-  FL_HIP(hipMemsetAsync(h->xp, 0, sizeof(double) * h->padlen, s));
+  FL_CHK(fl_zero_vec(h, h->P0));
+  FL_CHK(fl_zero_vec(h, h->P1));
+  FL_CHK(fl_zero_vec(h, h->xp));
   launch_cg_init(s, g, jac, b, h->r, h->partial, h->partial_stride, nsb);
   FL_CHK(cg_fin(h, 0, nsb, 5, h->hist, nhist));
   const bool ghosts = fl_any_ghost_exchange(h);
@@ -684,6 +801,17 @@ extern "C" int fldbg_bench(fl_poisson *h, int kernel, int ry, int pf, int nchunk
   if (!h || !ms_out) return FL_ERR_ARG_NULL;
   FL_HIP(hipSetDevice(h->device));
   const GridP &g = h->g;
+  if (kernel == 8) {
+    // experiment: forget the current padded vectors WITHOUT freeing them (they stay allocated, so the next set must land
+    // on different physical memory)
+    FL_HIP(hipStreamSynchronize(h->stream));
+    h->vec_bases.clear();
+    h->nvec = 0;
+    h->slab = nullptr;
+    for (double **v : {&h->r, &h->P0, &h->P1, &h->q, &h->xp, &h->w0, &h->w1, &h->w2}) *v = nullptr;
+    *ms_out = 0.;
+    return FL_SUCCESS;
+  }
   if (kernel == 9) {
     // experiment: drop every padded vector so that the next call gets fresh physical memory (ry extra junk allocations
     // of pf MiB each are made first and kept, to shift the placement)

@@ -15,6 +15,9 @@
 #ifndef FL_DEFAULT_GAP
 #define FL_DEFAULT_GAP 0
 #endif
+#ifndef FL_DEFAULT_INTERLEAVE
+#define FL_DEFAULT_INTERLEAVE 0
+#endif
 
 namespace fl {
 
@@ -223,6 +226,7 @@ struct fl_poisson {
   std::vector<void *> tables;
   int64_t     ncell = 0, nface[3] = {0, 0, 0};
   size_t      padlen = 0;
+  int         nv_il = 1, sx0 = 0;  // row-interleave factor of the padded vectors and the un-interleaved row length
   // solver workspace (padded vectors)
   double *r = nullptr, *P0 = nullptr, *P1 = nullptr, *q = nullptr, *xp = nullptr, *w0 = nullptr, *w1 = nullptr, *w2 = nullptr;
   std::vector<void *> vec_bases;
@@ -247,6 +251,7 @@ int  fl_dev_alloc(fl_poisson *h, void **p, size_t bytes, bool zero);
 int  fl_ensure_vec(fl_poisson *h, double **v);
 int  fl_ensure_partials(fl_poisson *h, int nblocks);
 int  fl_ensure_hist(fl_poisson *h, int nhist);
+int  fl_zero_vec(fl_poisson *h, double *v);
 int  fl_fill_ghosts(fl_poisson *h, double *v);
 bool fl_any_ghost_exchange(const fl_poisson *h);
 int  fl_poll_scal(fl_poisson *h);

@@ -607,7 +607,7 @@ int fl_solve_bcgs(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *
   init_scal(h, o);
   FL_HIP(hipEventRecord(h->ev0, s));
   FL_HIP(hipMemcpyAsync(h->scal, h->scal_host, sizeof(KspScal), hipMemcpyHostToDevice, s));
-  for (double *v : {h->P1, h->q, h->xp}) FL_HIP(hipMemsetAsync(v, 0, sizeof(double) * h->padlen, s));
+  for (double *v : {h->P1, h->q, h->xp}) FL_CHK(fl_zero_vec(h, v));
   double *R = h->r, *RP = h->P0, *P = h->P1, *V0 = h->q, *X = h->xp, *S0 = h->w0, *T0 = h->w1;
   auto    fin = [&](int mode) {
     return [=](const double *partial, int nb, int stride, const double *sums) { hipLaunchKernelGGL(k_bcgs_fin, dim3(1), dim3(256), 0, s, mode, partial, nb, stride, sums, h->scal, h->hist, nhist); };
@@ -684,7 +684,7 @@ int fl_solve_cheb(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *
   S.cheb_c    = S.scale;
   FL_HIP(hipEventRecord(h->ev0, s));
   FL_HIP(hipMemcpyAsync(h->scal, h->scal_host, sizeof(KspScal), hipMemcpyHostToDevice, s));
-  for (double *v : {h->P0, h->q, h->xp}) FL_HIP(hipMemsetAsync(v, 0, sizeof(double) * h->padlen, s));
+  for (double *v : {h->P0, h->q, h->xp}) FL_CHK(fl_zero_vec(h, v));
   launch_pad_copy(s, g, b, h->r);
   double    *X0 = h->xp, *X1 = h->P0, *B = h->r, *D = h->q;
   const bool ghosts = fl_any_ghost_exchange(h);

@@ -109,6 +109,14 @@ class Poisson:
     def empty(self, n=None):
         return torch.empty(self.ncell if n is None else n, dtype=torch.float64, device=self.device)
 
+    def tune_placement(self, max_tries=12):
+        """One-off search for a fast physical placement of the solver vectors (see fl_poisson_tune_placement)."""
+        out = (C.c_double * 2)()
+        self._pre()
+        check(lib.fl_poisson_tune_placement(self.h, int(max_tries), out), "fl_poisson_tune_placement")
+        self._post()
+        return out[0], out[1]
+
     # ---- MatMult(S) -------------------------------------------------------------------------------------------
     def apply(self, x, y=None):
         y = self.empty() if y is None else y

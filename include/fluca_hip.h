@@ -134,6 +134,13 @@ int fl_free(int device, void *dev);
 int fl_memcpy_h2d(int device, void *dev, const void *host, size_t bytes);
 int fl_memcpy_d2h(int device, void *host, const void *dev, size_t bytes);
 
+/* Optional one-off tuning step after create (like planning an FFT): any kernel that streams six 1 GB vectors at once runs
+ * 10-15 % faster or slower depending on where the driver happened to place them physically (profiles/r01_placement.txt).
+ * This allocates up to max_tries candidate sets of the solver vectors, times a 3-read/3-write streaming probe on each
+ * (a few ms), keeps the fastest set and frees the rest.  Transient memory: up to max_tries x 6 vectors.  probe_ms_out
+ * (may be NULL) receives {first, best} probe times in ms.  Safe to skip; never changes results. */
+int fl_poisson_tune_placement(fl_poisson *h, int max_tries, double probe_ms_out[2]);
+
 /* ---- operator -------------------------------------------------------------------------------- */
 int fl_poisson_apply(fl_poisson *h, const double *x_dev, double *y_dev);  /* y = S x */
 int fl_poisson_diagonal(fl_poisson *h, double *d_dev);                    /* MatGetDiagonal(S) */

@@ -559,19 +559,51 @@ int fo_num_threads(void)
 #endif
 }
 
-/* deterministic for a given thread count: static schedule + ordered combine */
+/* deterministic for a given thread count: static schedule, per-thread partial sums combined in thread order
+ * (an OpenMP reduction clause combines in an unspecified order, which BiCGStab amplifies into +-several iterations) */
+#define FO_MAXT 1024
 static double vdot(int64_t n, const double *a, const double *b)
 {
+  double part[FO_MAXT];
+  int    nt = 1;
+#pragma omp parallel
+  {
+#ifdef _OPENMP
+    const int t = omp_get_thread_num();
+#pragma omp single
+    nt = omp_get_num_threads();
+#else
+    const int t = 0;
+#endif
+    double s = 0.;
+#pragma omp for schedule(static) nowait
+    for (int64_t i = 0; i < n; ++i) s += a[i] * b[i];
+    if (t < FO_MAXT) part[t] = s;
+  }
   double s = 0.;
-#pragma omp parallel for schedule(static) reduction(+ : s)
-  for (int64_t i = 0; i < n; ++i) s += a[i] * b[i];
+  for (int t = 0; t < nt && t < FO_MAXT; ++t) s += part[t];
   return s;
 }
 static double vsum(int64_t n, const double *a)
 {
+  double part[FO_MAXT];
+  int    nt = 1;
+#pragma omp parallel
+  {
+#ifdef _OPENMP
+    const int t = omp_get_thread_num();
+#pragma omp single
+    nt = omp_get_num_threads();
+#else
+    const int t = 0;
+#endif
+    double s = 0.;
+#pragma omp for schedule(static) nowait
+    for (int64_t i = 0; i < n; ++i) s += a[i];
+    if (t < FO_MAXT) part[t] = s;
+  }
   double s = 0.;
-#pragma omp parallel for schedule(static) reduction(+ : s)
-  for (int64_t i = 0; i < n; ++i) s += a[i];
+  for (int t = 0; t < nt && t < FO_MAXT; ++t) s += part[t];
   return s;
 }
 static void vaxpy(int64_t n, double a, const double *x, double *y)

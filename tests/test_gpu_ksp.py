@@ -42,7 +42,7 @@ def test_bcgs_matches_oracle(n, bc, nonuni, nullspace, pc):
     k = min(m, 10)
     assert np.allclose(ig["history"][:k], io["history"][:k], rtol=1e-5)
     # later BiCGStab iterations are chaotic w.r.t. summation order: the count may drift, the answer may not
-    assert abs(ig["iters"] - io["iters"]) <= max(3, io["iters"] // 10)
+    assert abs(ig["iters"] - io["iters"]) <= max(4, io["iters"] // 6)
     xg = host(xg)
     res = np.linalg.norm(b - S.mult(xg)) / np.linalg.norm(b)
     ores = np.linalg.norm(b - S.mult(xo)) / np.linalg.norm(b)

@@ -254,3 +254,18 @@ def test_full_size_properties_512():
         r.append(float((rhs - P.apply(xs)).norm()))
     assert r[1] < r[0] < float(rhs.norm())
     P.close()
+
+
+def test_placement_tuning_changes_nothing_but_speed():
+    """fl_poisson_tune_placement swaps the solver vectors for another allocation: results must be bitwise identical."""
+    P, g = make_pair((130, 37, 20), CAVITY, kappa=1e-3)
+    _, b = mean_free_rhs(g.assemble_S(), g.ncell)
+    x0, i0 = P.solve(dev(b), history=True)
+    first, best = P.tune_placement(3)
+    assert best <= first * 1.0001 and best > 0
+    x1, i1 = P.solve(dev(b), history=True)
+    assert i0["iters"] == i1["iters"] and np.array_equal(i0["history"], i1["history"])
+    assert torch.equal(x0, x1)
+    y = P.apply(dev(b))                       # the scratch vector of apply was re-created as well
+    assert torch.isfinite(y).all()
+    P.close()
