@@ -385,7 +385,8 @@ extern "C" int fl_poisson_tune_placement(fl_poisson *h, int max_tries, double pr
   };
   std::vector<Set> sets;
   const size_t     set_bytes = 6 * sizeof(double) * h->padlen;
-  const PlanA      plan = plan_cg_A(h->g, 0, 0);
+  PlanA            plan = plan_cg_A(h->g, 0, 0);
+  plan.probe            = 1;  // launches k_cg_A_probe: identical code, separate name in profiles
   FL_CHK(fl_ensure_partials(h, plan.nblocks));
   // two scalar blocks: direction buffer parity 0 and 1
   KspScal *scal2 = nullptr;

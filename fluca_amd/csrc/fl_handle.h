@@ -41,7 +41,7 @@ int  stream_blocks(const GridP &);
 void launch_cg_init(hipStream_t, const GridP &, bool, const double *, double *, double *, int, int);
 void launch_cg_flush(hipStream_t, const GridP &, const double *, const double *, double *, const KspScal *, int);
 struct PlanA {
-  int ry, nw, tiles_x, tiles_y, nchunk, zc, nblocks, pf, nt, remap;
+  int ry, nw, tiles_x, tiles_y, nchunk, zc, nblocks, pf, nt, remap, probe;
 };
 PlanA plan_tiles(const GridP &, int ry, int nw, int nchunk_force, int target_blocks);
 PlanA plan_cg_A(const GridP &, int, int);

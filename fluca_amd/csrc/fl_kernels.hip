@@ -570,7 +570,7 @@ __device__ __forceinline__ int xcd_remap(int b, int nblocks) { return (nblocks &
 // RY rows per wave, NW waves per block (tile 128 x NW*RY), PF prefetch mode, NT: 0 plain, 1 non-temporal stores,
 // 2 non-temporal stores and tile loads (halo loads stay plain: they are meant to hit in L2)
 template <int RY, int NW, bool JAC, int PF, int NT>
-__global__ void __launch_bounds__(64 * NW, 2) k_cg_A(GridP g, const double *__restrict__ r, double *__restrict__ P0, double *__restrict__ P1, double *__restrict__ q, double *__restrict__ x, KspScal *__restrict__ s,
+__device__ __forceinline__ void cg_A_body(const GridP &g, const double *__restrict__ r, double *__restrict__ P0, double *__restrict__ P1, double *__restrict__ q, double *__restrict__ x, KspScal *__restrict__ s,
                                                       double *__restrict__ partial, int nchunk, int zc, int tiles_x, int tiles, int remap, FinCtx fin)
 {
   using T               = TileA<RY, NW>;
@@ -802,6 +802,21 @@ __global__ void __launch_bounds__(64 * NW, 2) k_cg_A(GridP g, const double *__re
   else if (tid == 0) partial[blockIdx.x] = tot[0];
 }
 
+#define FL_CG_A_ARGS GridP g, const double *__restrict__ r, double *__restrict__ P0, double *__restrict__ P1, double *__restrict__ q, double *__restrict__ x, KspScal *__restrict__ s, double *__restrict__ partial, int nchunk, int zc, int tiles_x, int tiles, int remap, FinCtx fin
+template <int RY, int NW, bool JAC, int PF, int NT>
+__global__ void __launch_bounds__(64 * NW, 2) k_cg_A(FL_CG_A_ARGS)
+{
+  cg_A_body<RY, NW, JAC, PF, NT>(g, r, P0, P1, q, x, s, partial, nchunk, zc, tiles_x, tiles, remap, fin);
+}
+// The same code under another name: launched only by fl_poisson_tune_placement, so that profiles keep the probe
+// launches (half of them on deliberately rejected placements) apart from the solver's own launches.
+template <int RY, int NW, bool JAC, int PF, int NT>
+__global__ void __launch_bounds__(64 * NW, 2) k_cg_A_probe(FL_CG_A_ARGS)
+{
+  cg_A_body<RY, NW, JAC, PF, NT>(g, r, P0, P1, q, x, s, partial, nchunk, zc, tiles_x, tiles, remap, fin);
+}
+#undef FL_CG_A_ARGS
+
 // ------------------------------------------------------------------------------------------------ unfused CG pieces (variant 1)
 
 // p = (r/diag - mean) + beta p on the owned cells
@@ -992,7 +1007,7 @@ void launch_cg_flush(hipStream_t st, const GridP &g, const double *P0, const dou
 
 // tiling of k_cg_A: returns the number of blocks
 struct PlanA {
-  int ry, nw, tiles_x, tiles_y, nchunk, zc, nblocks, pf, nt, remap;
+  int ry, nw, tiles_x, tiles_y, nchunk, zc, nblocks, pf, nt, remap, probe;
 };
 // tiling of k_cg_A / k_cg_B (K_B always runs 4-wave blocks: it reuses ry, nchunk, zc with nw = 4)
 PlanA plan_tiles(const GridP &g, int ry, int nw, int nchunk_force, int target_blocks)
@@ -1003,6 +1018,7 @@ PlanA plan_tiles(const GridP &g, int ry, int nw, int nchunk_force, int target_bl
   p.pf = 0;
   p.nt = 0;
   p.remap   = 1;
+  p.probe   = 0;
   p.tiles_x = (g.nx + 127) / 128;
   p.tiles_y = (g.ny + nw * ry - 1) / (nw * ry);
   const int tiles = p.tiles_x * p.tiles_y;
@@ -1037,21 +1053,30 @@ PlanA plan_cg_B(const GridP &g)
 template <int RY, int NW, int PF, int NT>
 static void launch_cg_A_t(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const double *r, double *P0, double *P1, double *q, double *x, KspScal *s, double *partial, const FinCtx &fin)
 {
-  const int tiles = p.tiles_x * p.tiles_y;
-  if (jac) hipLaunchKernelGGL((k_cg_A<RY, NW, true, PF, NT>), dim3(p.nblocks), dim3(64 * NW), 0, st, g, r, P0, P1, q, x, s, partial, p.nchunk, p.zc, p.tiles_x, tiles, p.remap, fin);
-  else hipLaunchKernelGGL((k_cg_A<RY, NW, false, PF, NT>), dim3(p.nblocks), dim3(64 * NW), 0, st, g, r, P0, P1, q, x, s, partial, p.nchunk, p.zc, p.tiles_x, tiles, p.remap, fin);
+  const int  tiles = p.tiles_x * p.tiles_y;
+  const dim3 gr(p.nblocks), bl(64 * NW);
+  if (p.probe) {
+    if (jac) hipLaunchKernelGGL((k_cg_A_probe<RY, NW, true, PF, NT>), gr, bl, 0, st, g, r, P0, P1, q, x, s, partial, p.nchunk, p.zc, p.tiles_x, tiles, p.remap, fin);
+    else hipLaunchKernelGGL((k_cg_A_probe<RY, NW, false, PF, NT>), gr, bl, 0, st, g, r, P0, P1, q, x, s, partial, p.nchunk, p.zc, p.tiles_x, tiles, p.remap, fin);
+  } else {
+    if (jac) hipLaunchKernelGGL((k_cg_A<RY, NW, true, PF, NT>), gr, bl, 0, st, g, r, P0, P1, q, x, s, partial, p.nchunk, p.zc, p.tiles_x, tiles, p.remap, fin);
+    else hipLaunchKernelGGL((k_cg_A<RY, NW, false, PF, NT>), gr, bl, 0, st, g, r, P0, P1, q, x, s, partial, p.nchunk, p.zc, p.tiles_x, tiles, p.remap, fin);
+  }
 }
 template <int RY, int NW>
 static void launch_cg_A_v(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const double *r, double *P0, double *P1, double *q, double *x, KspScal *s, double *partial, const FinCtx &fin)
 {
+#ifdef FL_KBENCH_VARIANTS  // the whole sweep space of tools/kbench.py (build with -DFL_KBENCH_VARIANTS)
   switch (p.pf * 10 + p.nt) {
-  case 0: launch_cg_A_t<RY, NW, 0, 0>(st, g, jac, p, r, P0, P1, q, x, s, partial, fin); break;
-  case 1: launch_cg_A_t<RY, NW, 0, 1>(st, g, jac, p, r, P0, P1, q, x, s, partial, fin); break;
-  case 2: launch_cg_A_t<RY, NW, 0, 2>(st, g, jac, p, r, P0, P1, q, x, s, partial, fin); break;
-  case 10: launch_cg_A_t<RY, NW, 1, 0>(st, g, jac, p, r, P0, P1, q, x, s, partial, fin); break;
-  case 11: launch_cg_A_t<RY, NW, 1, 1>(st, g, jac, p, r, P0, P1, q, x, s, partial, fin); break;
-  default: launch_cg_A_t<RY, NW, 1, 2>(st, g, jac, p, r, P0, P1, q, x, s, partial, fin); break;
+  case 0: launch_cg_A_t<RY, NW, 0, 0>(st, g, jac, p, r, P0, P1, q, x, s, partial, fin); return;
+  case 1: launch_cg_A_t<RY, NW, 0, 1>(st, g, jac, p, r, P0, P1, q, x, s, partial, fin); return;
+  case 2: launch_cg_A_t<RY, NW, 0, 2>(st, g, jac, p, r, P0, P1, q, x, s, partial, fin); return;
+  case 10: launch_cg_A_t<RY, NW, 1, 0>(st, g, jac, p, r, P0, P1, q, x, s, partial, fin); return;
+  case 11: launch_cg_A_t<RY, NW, 1, 1>(st, g, jac, p, r, P0, P1, q, x, s, partial, fin); return;
+  default: break;
   }
+#endif
+  launch_cg_A_t<RY, NW, 1, 2>(st, g, jac, p, r, P0, P1, q, x, s, partial, fin);  // the shipped variant
 }
 void launch_cg_A(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const double *r, double *P0, double *P1, double *q, double *x, KspScal *s, double *partial, unsigned *counter, double *hist, int nhist)
 {
@@ -1061,8 +1086,10 @@ void launch_cg_A(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const
   fin.nhist   = nhist;
   fin.enabled = counter != nullptr;
   switch (p.ry * 10 + p.nw) {
+#ifdef FL_KBENCH_VARIANTS
   case 48: launch_cg_A_v<4, 8>(st, g, jac, p, r, P0, P1, q, x, s, partial, fin); break;
   case 44: launch_cg_A_v<4, 4>(st, g, jac, p, r, P0, P1, q, x, s, partial, fin); break;
+#endif
   case 28: launch_cg_A_v<2, 8>(st, g, jac, p, r, P0, P1, q, x, s, partial, fin); break;
   case 24: launch_cg_A_v<2, 4>(st, g, jac, p, r, P0, P1, q, x, s, partial, fin); break;
   default: launch_cg_A_v<1, 4>(st, g, jac, p, r, P0, P1, q, x, s, partial, fin); break;
