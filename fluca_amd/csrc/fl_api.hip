@@ -621,7 +621,11 @@ static int solve_cg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts
   const bool ghosts = fl_any_ghost_exchange(h);
   if (ghosts) FL_CHK(fl_fill_ghosts(h, h->r));
   // single rank: the last block of k_cg_A / k_cg_B performs the scalar update itself (no k_cg_fin launches)
-  const bool fusedfin = !h->multi && o->variant != 1;
+  static const bool fusedfin_env = []() {
+    const char *e = std::getenv("FLUCA_FUSEDFIN");
+    return e ? std::atoi(e) != 0 : true;
+  }();
+  const bool fusedfin = !h->multi && o->variant != 1 && fusedfin_env;
   if (fusedfin) FL_HIP(hipMemsetAsync(h->tickets, 0, sizeof(unsigned) * 2, s));
 
   std::vector<hipEvent_t> pev;
@@ -725,7 +729,10 @@ extern "C" int fl_malloc(int device, size_t bytes, void **dev_out)
   *dev_out = nullptr;
   FL_HIP(hipSetDevice(device));
   if (hipMalloc(dev_out, bytes ? bytes : 8) != hipSuccess) return FL_ERR_MEM;
+  // hipMemset on the null stream is asynchronous and the handles work on non-blocking streams, which do not wait for
+  // the null stream: finish it here, or the zeroes can land on top of the first results written into this buffer.
   FL_HIP(hipMemset(*dev_out, 0, bytes ? bytes : 8));
+  FL_HIP(hipDeviceSynchronize());
   return FL_SUCCESS;
 }
 extern "C" int fl_free(int device, void *dev)
@@ -739,7 +746,9 @@ extern "C" int fl_memcpy_h2d(int device, void *dev, const void *host, size_t byt
 {
   if (!dev || !host) return FL_ERR_ARG_NULL;
   FL_HIP(hipSetDevice(device));
+  FL_HIP(hipDeviceSynchronize());  // whatever still reads or writes `dev` on a handle's stream finishes first
   FL_HIP(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice));
+  FL_HIP(hipDeviceSynchronize());
   return FL_SUCCESS;
 }
 extern "C" int fl_memcpy_d2h(int device, void *host, const void *dev, size_t bytes)

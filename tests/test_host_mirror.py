@@ -219,3 +219,16 @@ def test_outlet_bc_vector_from_host_callbacks(H):
     assert abs(Vx[:, :, :-1]).max() == 0 and float(V[1].abs().max()) == 0 and float(V[2].abs().max()) == 0
     H.lib.NSDestroy(C.byref(ns))
     H.lib.MeshDestroy(C.byref(mesh))
+
+
+@pytest.mark.gpu
+def test_c_driver_runs_without_python(H):
+    """examples/cavity_pressure_step.c = the reference's cavity driver on the C host mirror, as its own process."""
+    import os
+    import subprocess
+    from fluca_amd import build
+    exe = build.build_example()
+    out = subprocess.run([exe, "-cart_grid_x", "48", "-cart_grid_y", "40", "-cart_grid_z", "24", "-ns_abf_schur_ksp_rtol", "1e-9"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "1 NS dt 0.001 time 0.001" in out.stdout and "reason 2" in out.stdout
