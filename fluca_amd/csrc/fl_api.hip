@@ -44,23 +44,15 @@ extern "C" void fl_ksp_opts_default(fl_ksp_opts *o)
   o->check_every      = 16;
 }
 
-extern "C" int fl_poisson_create(const fl_grid *grid, const int bc[6], double kappa, const fl_decomp *decomp, int device, fl_poisson **out)
+// everything that can fail after the handle exists; the caller destroys the handle on any error
+static int poisson_init(fl_poisson *h, const fl_grid *grid, const int bc[6], double kappa, const fl_decomp *decomp, int device)
 {
-  if (!grid || !bc || !out) return FL_ERR_ARG_NULL;
-  *out = nullptr;
-  for (int d = 0; d < 3; ++d)
-    if (grid->n[d] < 1 || grid->n[d] > (int64_t)1 << 30 || !grid->xf[d]) return FL_ERR_ARG_OUTOFRANGE;
-  if (!(kappa > 0.) || !std::isfinite(kappa)) return FL_ERR_ARG_OUTOFRANGE;
-  fl_poisson *h = new fl_poisson();
   h->device     = device;
   h->kappa      = kappa;
   std::memcpy(h->bc, bc, sizeof(int) * 6);
   for (int d = 0; d < 3; ++d) {
     int rc = build_axis(h->ax[d], grid->n[d], grid->xf[d], grid->xc[d], bc[2 * d], bc[2 * d + 1], kappa);
-    if (rc) {
-      delete h;
-      return rc;
-    }
+    if (rc) return rc;
   }
   if (decomp) h->dec = *decomp;
   else
@@ -75,11 +67,9 @@ extern "C" int fl_poisson_create(const fl_grid *grid, const int bc[6], double ka
     const fl_decomp &D = h->dec;
     periodic[d]        = h->ax[d].periodic;
     if (D.ranks[d] < 1 || D.coord[d] < 0 || D.coord[d] >= D.ranks[d] || D.len[d] < 1 || D.lo[d] < 0 || D.lo[d] + D.len[d] > grid->n[d] || D.len[d] > 100000) {
-      delete h;
       return FL_ERR_ARG_OUTOFRANGE;
     }
     if ((D.coord[d] == 0) != (D.lo[d] == 0) || (D.coord[d] == D.ranks[d] - 1) != (D.lo[d] + D.len[d] == grid->n[d])) {
-      delete h;
       return FL_ERR_ARG_WRONG;
     }
     h->wrap_local[d] = periodic[d] && D.ranks[d] == 1;
@@ -159,7 +149,6 @@ extern "C" int fl_poisson_create(const fl_grid *grid, const int bc[6], double ka
       Gv2[i] = A.Gv2[lo + i];
       if (Gs[i] < -1 || Gs[i] + (Gv2[i] != 0. ? 2 : 1) > len) {
         // a one-sided wall row that leaves the block + its single ghost layer
-        fl_poisson_destroy(h);
         return FL_ERR_SUP;
       }
     }
@@ -175,16 +164,29 @@ extern "C" int fl_poisson_create(const fl_grid *grid, const int bc[6], double ka
     rc |= upload_table(h, Gv0, &g.Gv0[d], 0);
     rc |= upload_table(h, Gv1, &g.Gv1[d], 0);
     rc |= upload_table(h, Gv2, &g.Gv2[d], 0);
-    if (rc) {
-      fl_poisson_destroy(h);
-      return FL_ERR_GPU;
-    }
+    if (rc) return FL_ERR_GPU;
   }
   FL_HIP(hipMalloc((void **)&h->scal, sizeof(KspScal)));
   FL_HIP(hipHostMalloc((void **)&h->scal_host, sizeof(KspScal)));
   FL_HIP(hipMalloc((void **)&h->sums, sizeof(double) * NSLOT));
   FL_HIP(hipMalloc((void **)&h->tickets, sizeof(unsigned) * 2));
   FL_HIP(hipMemset(h->tickets, 0, sizeof(unsigned) * 2));
+  return FL_SUCCESS;
+}
+
+extern "C" int fl_poisson_create(const fl_grid *grid, const int bc[6], double kappa, const fl_decomp *decomp, int device, fl_poisson **out)
+{
+  if (!grid || !bc || !out) return FL_ERR_ARG_NULL;
+  *out = nullptr;
+  for (int d = 0; d < 3; ++d)
+    if (grid->n[d] < 1 || grid->n[d] > (int64_t)1 << 30 || !grid->xf[d]) return FL_ERR_ARG_OUTOFRANGE;
+  if (!(kappa > 0.) || !std::isfinite(kappa)) return FL_ERR_ARG_OUTOFRANGE;
+  fl_poisson *h  = new fl_poisson();
+  const int   rc = poisson_init(h, grid, bc, kappa, decomp, device);
+  if (rc) {
+    fl_poisson_destroy(h);  // releases whatever was created before the failure
+    return rc;
+  }
   *out = h;
   return FL_SUCCESS;
 }

@@ -77,3 +77,56 @@ def test_null_arguments_are_rejected_not_dereferenced(capi):
     assert capi.lib.fl_poisson_create(None, None, 1.0, None, 0, None) == -85   # PETSC_ERR_ARG_NULL
     assert capi.lib.fl_poisson_apply(None, None, None) == -85
     assert capi.lib.fl_poisson_destroy(None) == 0
+
+
+def _grid(capi, n, xf=None):
+    import numpy as np
+    g = capi.fl_grid()
+    keep = []
+    for d in range(3):
+        a = np.linspace(0.0, 1.0, n[d] + 1) if xf is None else np.asarray(xf[d], dtype=np.float64)
+        keep.append(a)
+        g.n[d] = n[d]
+        g.xf[d] = a.ctypes.data
+        g.xc[d] = None
+    return g, keep
+
+
+def test_create_validates_before_touching_the_gpu(capi):
+    """argument errors carry the PETSc error class the reference would raise; nothing is leaked or dereferenced"""
+    import numpy as np
+    h = C.c_void_p()
+    bc = lambda *v: (C.c_int * 6)(*v)
+    g, keep = _grid(capi, (4, 4, 4))
+    V, O, PER, SYM = 1, 2, 3, 4
+    # periodic on one side only (the mesh would be inconsistent)
+    assert capi.lib.fl_poisson_create(C.byref(g), bc(PER, V, V, V, V, V), 1.0, None, 0, C.byref(h)) == -62
+    # NS_BC_NONE is "Unsupported boundary condition type" (PETSC_ERR_SUP, cnlinearcart3d.c:2461)
+    assert capi.lib.fl_poisson_create(C.byref(g), bc(0, V, V, V, V, V), 1.0, None, 0, C.byref(h)) == -56
+    # kappa = dt/rho must be positive and finite
+    assert capi.lib.fl_poisson_create(C.byref(g), bc(V, V, V, V, V, V), 0.0, None, 0, C.byref(h)) == -63
+    assert capi.lib.fl_poisson_create(C.byref(g), bc(V, V, V, V, V, V), float("nan"), None, 0, C.byref(h)) == -63
+    # non-monotone coordinates
+    g2, keep2 = _grid(capi, (4, 4, 4), [np.array([0, .2, .1, .5, 1.]), np.linspace(0, 1, 5), np.linspace(0, 1, 5)])
+    assert capi.lib.fl_poisson_create(C.byref(g2), bc(V, V, V, V, V, V), 1.0, None, 0, C.byref(h)) == -62
+    # a decomposition that does not tile the grid
+    d = capi.fl_decomp()
+    for a in range(3):
+        d.ranks[a], d.coord[a], d.lo[a], d.len[a] = 1, 0, 0, 4
+    d.ranks[0], d.len[0] = 2, 3          # first of two ranks but [0,3) + nothing = not the whole axis when coord==last? coord 0 of 2: fine; lo+len != n only allowed if not last
+    d.coord[0] = 1                        # last rank must end at n and not start at 0
+    assert capi.lib.fl_poisson_create(C.byref(g), bc(V, V, V, V, V, V), 1.0, C.byref(d), 0, C.byref(h)) in (-62, -63)
+    assert not h.value
+
+
+def test_ibm_and_solver_entry_points_reject_null_handles(capi):
+    st = capi.fl_ksp_stats()
+    o = capi.fl_ksp_opts()
+    capi.lib.fl_ksp_opts_default(C.byref(o))
+    assert capi.lib.fl_poisson_solve(None, None, None, C.byref(o), C.byref(st)) == -85
+    assert capi.lib.fl_poisson_rhs(None, None, None, None, None, None) == -85
+    assert capi.lib.fl_poisson_project(None, None, None, None, None, None, None, None) == -85
+    assert capi.lib.fl_poisson_tune_placement(None, 3, None) == -85
+    assert capi.lib.fl_ibm_create(None, 0, 1, None, None, None, None) == -85
+    assert capi.lib.fl_ibm_destroy(None) == 0
+    assert capi.lib.fl_halo_plan(None, None, None) == -85
