@@ -97,6 +97,13 @@ PROTOTYPES = {
     "fl_halo_plan": (C.c_int, [C.POINTER(fl_decomp), C.POINTER(C.c_int), C.POINTER(fl_halo_msg)]),
     "fl_decomp_default": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int), C.c_int, C.POINTER(fl_decomp)]),
     "fl_decomp_neighbor": (C.c_int, [C.POINTER(fl_decomp), C.POINTER(C.c_int), C.c_int]),
+    "fl_momentum_create": (C.c_int, [_P, C.POINTER(_P)]),
+    "fl_momentum_destroy": (C.c_int, [_P]),
+    "fl_momentum_set_state": (C.c_int, [_P, C.c_double, C.c_double, C.c_double, _P, _P]),
+    "fl_momentum_set_coefficients": (C.c_int, [_P, C.c_double, C.c_double, C.c_double]),
+    "fl_momentum_apply": (C.c_int, [_P, _P, _P]),
+    "fl_momentum_diagonal": (C.c_int, [_P, _P]),
+    "fl_momentum_solve": (C.c_int, [_P, _P, _P, C.POINTER(fl_ksp_opts), C.POINTER(fl_ksp_stats)]),
     "fl_ibm_create": (C.c_int, [_P, C.c_int, C.c_int64, _P, _P, _P, C.POINTER(_P)]),
     "fl_ibm_update": (C.c_int, [_P, _P, _P, _P]),
     "fl_ibm_interp": (C.c_int, [_P, C.c_int, _P, _P]),

@@ -228,3 +228,107 @@ extern "C" int fl_halo_plan(const fl_decomp *d, const int periodic[3], fl_halo_m
   }
   return n;
 }
+
+namespace fl {
+
+// ------------------------------------------------------------------------------------------------ momentum operator
+// A = I + dt C - (mu dt / 2 rho) L  (NSFormJacobian, cnlinearcart3d.c:2930-2941).  Every row of L
+// (ComputeVelocityLaplacianOperator_Private, cnlinearcart3d.c:425-632) and of C (ComputeConvectionOperator_Private,
+// cnlinearcart3d.c:873-1294) is again a sum of 1-D rows, so each axis is described by MOM_NTAB numbers per cell:
+//   slot  0.. 3  second-derivative row, "tangential" rule : columns i-1, i, i+1, far   (far = i+2 at the low wall, i-2 at
+//   slot  4.. 7  second-derivative row, "normal" rule       the high wall: the one-sided Dirichlet rows)
+//   slot  8..10  convection, low  face, tangential : columns i-1, i, i+1, already times -+0.5/h, to be multiplied by the
+//   slot 11..13  convection, low  face, normal       face value (V0 or v0interp)
+//   slot 14..16  convection, high face, tangential
+//   slot 17..19  convection, high face, normal
+// "normal" = the velocity component along this axis (c == d) and every second-term row; "tangential" = first-term rows
+// of the other two components.  The two differ only on a SYMMETRY boundary (zero normal velocity / zero tangential
+// gradient).  tab is slot-major: tab[slot*n + i].
+int build_axis_momentum(const Axis &a, std::vector<double> &tab)
+{
+  const int64_t n = a.n;
+  tab.assign((size_t)MOM_NTAB * (size_t)n, 0.);
+  auto T = [&](int slot, int64_t i) -> double & { return tab[(size_t)slot * (size_t)n + (size_t)i]; };
+  for (int rule = 0; rule < 2; ++rule)
+    for (int64_t i = 0; i < n; ++i) {
+      // ---- second derivative (cartdiscret.c:167-303)
+      int kind = 0;  // 0 central, 1/3 one-sided Dirichlet (low/high), 2/4 Neumann (low/high)
+      if (i == 0 && !a.periodic) {
+        if (a.bc_lo == FL_BC_VELOCITY) kind = 1;
+        else if (a.bc_lo == FL_BC_PRESSURE_OUTLET) kind = 2;
+        else if (a.bc_lo == FL_BC_SYMMETRY) kind = rule ? 1 : 2;
+        else return FL_ERR_ARG_WRONG;
+      } else if (i == n - 1 && !a.periodic) {
+        if (a.bc_hi == FL_BC_VELOCITY) kind = 3;
+        else if (a.bc_hi == FL_BC_PRESSURE_OUTLET) kind = 4;
+        else if (a.bc_hi == FL_BC_SYMMETRY) kind = rule ? 3 : 4;
+        else return FL_ERR_ARG_WRONG;
+      }
+      if ((kind == 1 || kind == 3) && n < 3) return FL_ERR_SUP;  // the reference reads cell i+-2
+      if ((kind == 2 || kind == 4) && n < 2) return FL_ERR_SUP;
+      const int b = rule * 4;
+      if (kind == 1) {
+        const double h1 = a.xcc(i) - a.xf[i], h2 = a.xcc(i + 1) - a.xcc(i), h3 = a.xcc(i + 2) - a.xcc(i);
+        T(b + 1, i) = 2. * (h1 - h2 - h3) / (h1 * h2 * h3);
+        T(b + 2, i) = 2. * (h1 - h3) / (h2 * (h1 + h2) * (h2 - h3));
+        T(b + 3, i) = 2. * (h2 - h1) / (h3 * (h1 + h3) * (h2 - h3));
+      } else if (kind == 2) {
+        const double h1 = a.xcc(i + 1) - a.xcc(i), h2 = a.xf[i + 1] - a.xf[i];
+        T(b + 1, i) = -1. / (h1 * h2);
+        T(b + 2, i) = 1. / (h1 * h2);
+      } else if (kind == 3) {
+        const double h1 = a.xf[i + 1] - a.xcc(i), h2 = a.xcc(i) - a.xcc(i - 1), h3 = a.xcc(i) - a.xcc(i - 2);
+        T(b + 3, i) = 2. * (h2 - h1) / (h3 * (h1 + h3) * (h2 - h3));
+        T(b + 0, i) = 2. * (h1 - h3) / (h2 * (h1 + h2) * (h2 - h3));
+        T(b + 1, i) = 2. * (h1 - h2 - h3) / (h1 * h2 * h3);
+      } else if (kind == 4) {
+        const double h1 = a.xcc(i) - a.xcc(i - 1), h2 = a.xf[i + 1] - a.xf[i];
+        T(b + 0, i) = 1. / (h1 * h2);
+        T(b + 1, i) = -1. / (h1 * h2);
+      } else {
+        const double h1 = a.xcc(i) - a.xcc(i - 1), h2 = a.xcc(i + 1) - a.xcc(i), h3 = a.xf[i + 1] - a.xf[i];
+        T(b + 0, i) = 1. / (h1 * h3);
+        T(b + 1, i) = -(1. / (h1 * h3) + 1. / (h2 * h3));
+        T(b + 2, i) = 1. / (h2 * h3);
+      }
+      // ---- convection (cartdiscret.c:305-371); vf = 1 here
+      const double h = a.xf[i + 1] - a.xf[i];
+      for (int side = 0; side < 2; ++side) {
+        int ck = 0;  // 0 interpolate, 1 Neumann extrapolation, 2 no entries
+        const int bc = side == 0 ? a.bc_lo : a.bc_hi;
+        if (!a.periodic && ((side == 0 && i == 0) || (side == 1 && i == n - 1))) {
+          if (bc == FL_BC_VELOCITY) ck = 2;
+          else if (bc == FL_BC_PRESSURE_OUTLET) ck = 1;
+          else if (bc == FL_BC_SYMMETRY) ck = rule ? 2 : 1;
+          else return FL_ERR_ARG_WRONG;
+        }
+        if (ck == 1 && n < 2) return FL_ERR_SUP;
+        const int s0 = 8 + (side * 2 + rule) * 3;
+        if (side == 0) {
+          if (ck == 0) {
+            const double xW = a.xcc(i - 1), xw = a.xf[i], xP = a.xcc(i);
+            T(s0 + 0, i) = -0.5 / h * (xP - xw) / (xP - xW);
+            T(s0 + 1, i) = -0.5 / h * (xw - xW) / (xP - xW);
+          } else if (ck == 1) {
+            // the reference's low-side extrapolation row (cartdiscret.c:335-352) as it stands, sign included
+            const double h1 = a.xcc(i) - a.xf[i], h2 = a.xcc(i + 1) - a.xf[i];
+            T(s0 + 1, i) = -0.5 / h * (h2 * h2) / ((h1 + h2) * (h1 - h2));
+            T(s0 + 2, i) = 0.5 / h * (h1 * h1) / ((h1 + h2) * (h1 - h2));
+          }
+        } else {
+          if (ck == 0) {
+            const double xP = a.xcc(i), xe = a.xf[i + 1], xE = a.xcc(i + 1);
+            T(s0 + 1, i) = 0.5 / h * (xE - xe) / (xE - xP);
+            T(s0 + 2, i) = 0.5 / h * (xe - xP) / (xE - xP);
+          } else if (ck == 1) {
+            const double h1 = a.xf[i + 1] - a.xcc(i), h2 = a.xf[i + 1] - a.xcc(i - 1);
+            T(s0 + 0, i) = 0.5 / h * (h1 * h1) / ((h1 + h2) * (h1 - h2));
+            T(s0 + 1, i) = -0.5 / h * (h2 * h2) / ((h1 + h2) * (h1 - h2));
+          }
+        }
+      }
+    }
+  return 0;
+}
+
+}  // namespace fl

@@ -50,6 +50,9 @@ struct Axis {
 
 int build_axis(Axis &a, int64_t n, const double *xf, const double *xc, int bc_lo, int bc_hi, double kappa);
 
+constexpr int MOM_NTAB = 20;  // 1-D numbers per cell and axis of the momentum operator, see build_axis_momentum
+int build_axis_momentum(const Axis &a, std::vector<double> &tab);
+
 // ---- device view shared by every kernel ---------------------------------------------------------------------------
 // 1-D coefficient arrays are LOCAL (this rank's block) and pre-shifted: valid for index -1..len.
 struct GridP {

@@ -3,52 +3,9 @@
 // as the Jacobi smoother of BASELINE.json config 3).  Same conventions as the CG path in fl_kernels.hip: padded vectors,
 // scalars in device memory (KspScal), fixed-order partial sums, lazy constant-null-space removal.
 #include "fl_handle.h"
+#include "fl_device.h"
 
 namespace fl {
-
-__device__ __forceinline__ int64_t pidx(const GridP &g, int i, int j, int k) { return g.off0 + (int64_t)k * g.sxy + (int64_t)j * g.sx + i; }
-__device__ __forceinline__ double  wave_sum(double v)
-{
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  return v;
-}
-template <int NV>
-__device__ __forceinline__ void block_sum(double (&v)[NV], double *red)
-{
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-  for (int a = 0; a < NV; ++a) {
-    v[a] = wave_sum(v[a]);
-    if (lane == 0) red[a * 4 + w] = v[a];
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int a = 0; a < NV; ++a) v[a] = (red[a * 4 + 0] + red[a * 4 + 1]) + (red[a * 4 + 2] + red[a * 4 + 3]);
-  }
-}
-__device__ __forceinline__ void reduce_partials(const double *__restrict__ partial, int nblocks, int stride, int nslot, double *out, double *red)
-{
-  double v[NSLOT];
-#pragma unroll
-  for (int a = 0; a < NSLOT; ++a) {
-    v[a] = 0.;
-    if (a < nslot)
-      for (int b = threadIdx.x; b < nblocks; b += 256) v[a] += partial[(int64_t)a * stride + b];
-  }
-  block_sum<NSLOT>(v, red);
-  if (threadIdx.x == 0)
-    for (int a = 0; a < NSLOT; ++a) out[a] = v[a];
-  __syncthreads();
-}
-__device__ __forceinline__ int converged_default(const KspScal *s, double dp)
-{
-  if (isnan(dp) || isinf(dp)) return FL_DIVERGED_NANORINF;
-  if (dp <= s->ttol) return dp < s->atol ? FL_CONVERGED_ATOL : FL_CONVERGED_RTOL;
-  if (dp >= s->dtol * s->rnorm0) return FL_DIVERGED_DTOL;
-  return 0;
-}
 
 // ------------------------------------------------------------------------------------------------ tile walker
 // 128 x 4*RY x zc tiles like k_cg_B: lane = pair of x-adjacent cells, wave = RY rows, march in z.
@@ -710,3 +667,24 @@ int fl_solve_cheb(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *
   launch_unpad_copy(s, g, R.cur ? X1 : X0, x, R.nullspace ? &h->scal->xshift : nullptr);
   return finish_stats(h, o, st);
 }
+
+// ------------------------------------------------------------------------------------------------ shared with fl_momentum.hip
+// The BiCGStab scalar recurrences do not care which operator produced the inner products: the momentum solve reuses them.
+
+int fl_ksp_begin(fl_poisson *h, const fl_ksp_opts *o)
+{
+  init_scal(h, o);
+  FL_HIP(hipEventRecord(h->ev0, h->stream));
+  FL_HIP(hipMemcpyAsync(h->scal, h->scal_host, sizeof(KspScal), hipMemcpyHostToDevice, h->stream));
+  return 0;
+}
+
+int fl_bcgs_fin_step(fl_poisson *h, int mode, int nblocks, int nslot, int nhist)
+{
+  hipStream_t s = h->stream;
+  return fin_step(h, nblocks, nslot, [=](const double *partial, int nb, int stride, const double *sums) {
+    hipLaunchKernelGGL(k_bcgs_fin, dim3(1), dim3(256), 0, s, mode, partial, nb, stride, sums, h->scal, h->hist, nhist);
+  });
+}
+
+int fl_ksp_finish(fl_poisson *h, const fl_ksp_opts *o, fl_ksp_stats *st) { return finish_stats(h, o, st); }

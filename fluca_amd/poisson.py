@@ -4,6 +4,7 @@
 grid + NS boundary conditions, `.solve` is KSPSolve(kspS), `.rhs` / `.project` are the MatMult chains around it.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 import torch
@@ -63,6 +64,7 @@ class Poisson:
         check(lib.fl_poisson_sizes(self.h, sz))
         self.ncell, self.nface = sz[0], (sz[1], sz[2], sz[3])
         self._cb = None
+        self._children = []   # handles that borrow this one (Momentum): closed first
         # the library works on its own HIP stream; order it against torch's current stream around every call
         self.stream = torch.cuda.Stream(device=self.device)
         self._ext_stream = False
@@ -79,6 +81,11 @@ class Poisson:
         return cls(n, xf, bc, kappa, xc=xc, **kw)
 
     def close(self):
+        for ref in getattr(self, "_children", []):
+            child = ref()
+            if child is not None:
+                child.close()
+        self._children = []
         if getattr(self, "h", None):
             lib.fl_poisson_destroy(self.h)
             self.h = None
@@ -217,3 +224,86 @@ def rccl_unique_id():
     buf = (C.c_char * capi.UNIQUE_ID_BYTES)()
     check(lib.fl_comm_unique_id(buf), "fl_comm_unique_id")
     return bytes(buf)
+
+
+class Momentum:
+    """The momentum block A = I + dt C - (mu dt / 2 rho) L of NSFormJacobian (cnlinearcart3d.c:2930-2941), matrix-free.
+
+    Shares grid / BCs / stream / communicator with a `Poisson`; velocity vectors are component-major (3*ncell).
+    """
+
+    def __init__(self, poisson):
+        self.p = poisson
+        h = C.c_void_p()
+        poisson._pre()
+        check(lib.fl_momentum_create(poisson.h, C.byref(h)), "fl_momentum_create")
+        poisson._post()
+        self.h = h
+        poisson._children.append(weakref.ref(self))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.fl_momentum_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_state(self, dt, rho, mu, V0, W):
+        """V0: 3 face tensors (face-normal velocity of the previous step); W: 9 face tensors, W[c*3+d] = v0interp_c on d-faces."""
+        assert len(V0) == 3 and len(W) == 9
+        for d in range(3):
+            assert V0[d].numel() == self.p.nface[d]
+            for c in range(3):
+                assert W[c * 3 + d].numel() == self.p.nface[d]
+        a = (C.c_void_p * 3)(*[t.data_ptr() for t in V0])
+        b = (C.c_void_p * 9)(*[t.data_ptr() for t in W])
+        for t in list(V0) + list(W):
+            _ptr(t)
+        self.p._pre()
+        check(lib.fl_momentum_set_state(self.h, float(dt), float(rho), float(mu), a, b), "fl_momentum_set_state")
+        self.p._post()
+
+    def set_coefficients(self, cI, cC, cL):
+        self.p._pre()
+        check(lib.fl_momentum_set_coefficients(self.h, float(cI), float(cC), float(cL)), "fl_momentum_set_coefficients")
+        self.p._post()
+
+    def apply(self, v, y=None):
+        y = self.p.empty(3 * self.p.ncell) if y is None else y
+        assert v.numel() == 3 * self.p.ncell
+        self.p._pre()
+        check(lib.fl_momentum_apply(self.h, _ptr(v), _ptr(y)), "fl_momentum_apply")
+        self.p._post()
+        return y
+
+    def diagonal(self):
+        d = self.p.empty(3 * self.p.ncell)
+        self.p._pre()
+        check(lib.fl_momentum_diagonal(self.h, _ptr(d)), "fl_momentum_diagonal")
+        self.p._post()
+        return d
+
+    def solve(self, b, x=None, opts=None, history=False, **kw):
+        kw.setdefault("type", capi.KSP_BCGS)
+        opts = opts or KspOptions(**kw)
+        o = opts.o
+        x = self.p.empty(3 * self.p.ncell) if x is None else x
+        hist = None
+        if history:
+            hist = np.full(o.maxit + 1, np.nan)
+            o.history = hist.ctypes.data_as(C.POINTER(C.c_double))
+            o.nhistory = hist.size
+        st = capi.fl_ksp_stats()
+        self.p._pre()
+        check(lib.fl_momentum_solve(self.h, _ptr(b), _ptr(x), C.byref(o), C.byref(st)), "fl_momentum_solve")
+        self.p._post()
+        info = dict(iters=st.iters, reason=st.reason, rnorm0=st.rnorm0, rnorm=st.rnorm, seconds=st.seconds)
+        if history:
+            info["history"] = hist[:st.iters + 1].copy()
+            o.history = None
+            o.nhistory = 0
+        return x, info

@@ -20,6 +20,7 @@
  *   fl_pressure_update   p = phalf + 1.5 dp ; phalf += dp (first step p0 + 2dp)    cnlinearcart3d.c:2846-2854
  *   fl_ksp_opts          -ns_abf_schur_ksp_* / -ns_abf_schur_pc_type options       abfpc.c:42,206,248-249
  *   fl_bc                NSBoundaryConditionType                                   fluca/include/flucansbc.h:5-11
+ *   fl_momentum_*        A = I + dt C - (mu dt / 2 rho) L and KSPSolve(kspA)                   cnlinearcart3d.c:425-632,873-1294,2930-2941; abfpc.c:72
  *   fl_ibm_*             no reference counterpart (THEORY_GUIDE.md:130-132 is a TODO); specified in DESIGN.md
  *
  * Array layouts (x fastest, block-contiguous per rank, exactly one rank's OWNED part):
@@ -112,8 +113,9 @@ typedef struct fl_ksp_stats {
   int    kernel_launches; /* number of launches averaged in kernel_ms */
 } fl_ksp_stats;
 
-typedef struct fl_poisson fl_poisson;
-typedef struct fl_ibm     fl_ibm;
+typedef struct fl_poisson  fl_poisson;
+typedef struct fl_ibm      fl_ibm;
+typedef struct fl_momentum fl_momentum;
 
 /* ---- life cycle ------------------------------------------------------------------------------ */
 
@@ -181,6 +183,29 @@ int fl_halo_plan(const fl_decomp *d, const int periodic[3], fl_halo_msg out[12])
 int fl_decomp_default(const int64_t n[3], const int ranks[3], int rank, fl_decomp *out);
 /* rank of the neighbour across boundary 0..5 of this block, -1 if physical (non-periodic) boundary */
 int fl_decomp_neighbor(const fl_decomp *d, const int periodic[3], int boundary);
+
+/* ---- momentum block of the Jacobian (first "next" row) --------------- */
+/* Matrix-free A = I + dt C - (mu dt / 2 rho) L on the cell-centred velocity, replacing the AIJ matrix the reference
+ * re-assembles every step (NSFormJacobian_CNLinear_Cart3d_Internal, cnlinearcart3d.c:2930-2941):
+ *   L  ComputeVelocityLaplacianOperator_Private   cnlinearcart3d.c:425-632   (1-D rows: cartdiscret.c:167-303)
+ *   C  ComputeConvectionOperator_Private          cnlinearcart3d.c:873-1294  (1-D rows: cartdiscret.c:305-371)
+ * Velocity vectors are component-major: v[c*cells + cell], c = 0,1,2 (the reference's DMStag vector interleaves the
+ * components per element -- a fixed permutation).  Grid, boundary conditions, decomposition, stream and communicator
+ * are those of `grid_from`, which must outlive the momentum handle; every local block needs >= 2 cells per axis and
+ * a VELOCITY / SYMMETRY wall needs >= 3 cells along its axis (the reference's one-sided rows read cell i+-2). */
+int fl_momentum_create(fl_poisson *grid_from, fl_momentum **out);
+int fl_momentum_destroy(fl_momentum *m);
+/* V0_dev[d]: face-normal velocity of the previous step on the d-faces (sol0's NS_FIELD_FACE_NORMAL_VELOCITY);
+ * v0interp_dev[c*3+d]: component c of cnl->v0interp on the d-faces.  Face layouts as at the top of this file.
+ * Copies the twelve fields (the caller may reuse its buffers) and sets cI = 1, cC = dt, cL = -mu dt / (2 rho). */
+int fl_momentum_set_state(fl_momentum *m, double dt, double rho, double mu, const double *const V0_dev[3], const double *const v0interp_dev[9]);
+/* A = cI I + cC C + cL L with explicit coefficients (other time integrators; L or C alone in the parity tests) */
+int fl_momentum_set_coefficients(fl_momentum *m, double cI, double cC, double cL);
+int fl_momentum_apply(fl_momentum *m, const double *v_dev, double *y_dev); /* y = A v      (MatMult) */
+int fl_momentum_diagonal(fl_momentum *m, double *d_dev);                   /* MatGetDiagonal(A) */
+/* KSPSolve(abf->kspA, momrhs, vstar), abfpc.c:72: opts->type must be FL_KSP_BCGS, pc JACOBI or NONE, preconditioned norm,
+ * zero initial guess; remove_nullspace is ignored (A is non-singular). */
+int fl_momentum_solve(fl_momentum *m, const double *b_dev, double *x_dev, const fl_ksp_opts *opts, fl_ksp_stats *stats);
 
 /* ---- immersed boundary (build-defined; no reference function) -------------------------------- */
 typedef enum { FL_DELTA_PESKIN4 = 0, FL_DELTA_ROMA3 = 1 } fl_delta_kind;

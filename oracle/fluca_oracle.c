@@ -969,3 +969,261 @@ void fo_ibm_spread(const fo_grid *g, int kind, int64_t L, const double *X, const
 }
 
 double fo_ibm_phi(int kind, double r) { return kind == FO_DELTA_PESKIN4 ? phi_peskin4(r) : phi_roma3(r); }
+
+/* ================================================================================================
+ * Momentum operator  A = I + dt*C - (mu*dt/(2 rho)) * L     
+ *
+ *   NSFormJacobian_CNLinear_Cart3d_Internal   cnlinearcart3d.c:2930-2941   (MatScale(A,dt); MatAXPY(L); MatShift(1))
+ *   ComputeVelocityLaplacianOperator_Private  cnlinearcart3d.c:425-632     (L, ADD_VALUES of one 1-D row per axis)
+ *   ComputeConvectionOperator_Private         cnlinearcart3d.c:873-1294    ((Cv)_i = 1/2 d/dx_j (v_i V0_j + v0interp_i v_j))
+ *   1-D rows                                  cartdiscret.c:167-232,262-371
+ *
+ * Unknown ordering here: component-major, row = c*ncell + cell (the reference's DMStag vector interleaves the three
+ * components per element; this is a fixed permutation of it).  V0[d]: face-normal velocity on the d-faces; W[c*3+d]:
+ * component c of v0interp on the d-faces (arrv0interp[..][iv0interp[c][d]]).  Face layouts as at the top of this file.
+ * Restated literally -- including the sign of the low-side Neumann extrapolation row (cartdiscret.c:335-352), which
+ * differs from the high-side one; the product reproduces it, see DESIGN.md.
+ * ================================================================================================ */
+
+typedef struct {
+  int    nc;
+  int    off[4]; /* column offsets along the axis, relative to the row's cell (unwrapped) */
+  double v[4];
+} fo_row1d;
+
+/* One axis' contribution to row (cell i along axis d, component c) of L; cnlinearcart3d.c:466-520 (x), :522-576 (y),
+ * :578-632 (z). */
+void fo_lap_row_1d(const fo_grid *g, int d, int i, int c, fo_row1d *r)
+{
+  const double *xf = g->xf[d], *xc = g->xc[d];
+  int           n = g->n[d];
+  int           kind = 0; /* 0 central, 1 fwd dirichlet, 2 fwd neumann, 3 bwd dirichlet, 4 bwd neumann */
+  double        h1, h2, h3;
+  if (i == 0) {
+    switch (g->bc[2 * d]) {
+    case FO_BC_VELOCITY: kind = 1; break;
+    case FO_BC_PRESSURE_OUTLET: kind = 2; break;
+    case FO_BC_PERIODIC: kind = 0; break;
+    case FO_BC_SYMMETRY: kind = (c == d) ? 1 : 2; break;
+    default: r->nc = -1; return;
+    }
+  } else if (i == n - 1) {
+    switch (g->bc[2 * d + 1]) {
+    case FO_BC_VELOCITY: kind = 3; break;
+    case FO_BC_PRESSURE_OUTLET: kind = 4; break;
+    case FO_BC_PERIODIC: kind = 0; break;
+    case FO_BC_SYMMETRY: kind = (c == d) ? 3 : 4; break;
+    default: r->nc = -1; return;
+    }
+  }
+  switch (kind) {
+  case 1: /* NSComputeSecondDerivForwardDiffDirichletCond_Cart, cartdiscret.c:167-189 */
+    h1 = xc[i] - xf[i];
+    h2 = xc[i + 1] - xc[i];
+    h3 = xc[i + 2] - xc[i];
+    r->v[0] = 2. * (h1 - h2 - h3) / (h1 * h2 * h3);
+    r->v[1] = 2. * (h1 - h3) / (h2 * (h1 + h2) * (h2 - h3));
+    r->v[2] = 2. * (h2 - h1) / (h3 * (h1 + h3) * (h2 - h3));
+    r->off[0] = 0; r->off[1] = 1; r->off[2] = 2;
+    r->nc = 3;
+    break;
+  case 2: /* ...ForwardDiffNeumannCond, :191-208 */
+    h1 = xc[i + 1] - xc[i];
+    h2 = xf[i + 1] - xf[i];
+    r->v[0] = -1. / (h1 * h2);
+    r->v[1] = 1. / (h1 * h2);
+    r->off[0] = 0; r->off[1] = 1;
+    r->nc = 2;
+    break;
+  case 3: /* ...BackwardDiffDirichletCond, :262-284 */
+    h1 = xf[i + 1] - xc[i];
+    h2 = xc[i] - xc[i - 1];
+    h3 = xc[i] - xc[i - 2];
+    r->v[0] = 2. * (h2 - h1) / (h3 * (h1 + h3) * (h2 - h3));
+    r->v[1] = 2. * (h1 - h3) / (h2 * (h1 + h2) * (h2 - h3));
+    r->v[2] = 2. * (h1 - h2 - h3) / (h1 * h2 * h3);
+    r->off[0] = -2; r->off[1] = -1; r->off[2] = 0;
+    r->nc = 3;
+    break;
+  case 4: /* ...BackwardDiffNeumannCond, :286-303 */
+    h1 = xc[i] - xc[i - 1];
+    h2 = xf[i + 1] - xf[i];
+    r->v[0] = 1. / (h1 * h2);
+    r->v[1] = -1. / (h1 * h2);
+    r->off[0] = -1; r->off[1] = 0;
+    r->nc = 2;
+    break;
+  default: /* NSComputeSecondDerivCentralDiff_Cart, :210-232 (interior and periodic) */
+    h1 = xc[i] - xc[i - 1];
+    h2 = xc[i + 1] - xc[i];
+    h3 = xf[i + 1] - xf[i];
+    r->v[0] = 1. / (h1 * h3);
+    r->v[1] = -(1. / (h1 * h3) + 1. / (h2 * h3));
+    r->v[2] = 1. / (h2 * h3);
+    r->off[0] = -1; r->off[1] = 0; r->off[2] = 1;
+    r->nc = 3;
+  }
+}
+
+/* One face's contribution to a row of C: cell i along axis d, side 0 = low face / 1 = high face, face value vf.
+ * normal != 0: the row interpolates the face-normal component (second term, or first term with c == d);
+ * normal == 0: a tangential component (first term, c != d).  They differ only on a SYMMETRY boundary.
+ * cnlinearcart3d.c:931-1040 (x), :1042-1166 (y), :1168-1292 (z). */
+void fo_conv_row_1d(const fo_grid *g, int d, int i, int side, int normal, double vf, fo_row1d *r)
+{
+  const double *xf = g->xf[d], *xc = g->xc[d];
+  int           n = g->n[d];
+  double        h = xf[i + 1] - xf[i];
+  int           kind; /* 0 interpolate, 1 Neumann extrapolation, 2 nothing */
+  double        h1, h2;
+  r->nc = 0;
+  if (side == 0) {
+    kind = 0;
+    if (i == 0) {
+      switch (g->bc[2 * d]) {
+      case FO_BC_VELOCITY: kind = 2; break;
+      case FO_BC_PRESSURE_OUTLET: kind = 1; break;
+      case FO_BC_PERIODIC: kind = 0; break;
+      case FO_BC_SYMMETRY: kind = normal ? 2 : 1; break;
+      default: r->nc = -1; return;
+      }
+    }
+    if (kind == 0) { /* NSComputeConvectionLinearInterpolationPrev_Cart, cartdiscret.c:305-318 */
+      double xW = xc[i - 1], xw = xf[i], xP = xc[i];
+      r->v[0] = -0.5 * vf / h * (xP - xw) / (xP - xW);
+      r->v[1] = -0.5 * vf / h * (xw - xW) / (xP - xW);
+      r->off[0] = -1; r->off[1] = 0;
+      r->nc = 2;
+    } else if (kind == 1) { /* ...LinearForwardExtrapolationNeumannCond_Cart, :335-352 */
+      h1 = xc[i] - xf[i];
+      h2 = xc[i + 1] - xf[i];
+      r->v[0] = -0.5 * vf / h * (h2 * h2) / ((h1 + h2) * (h1 - h2));
+      r->v[1] = 0.5 * vf / h * (h1 * h1) / ((h1 + h2) * (h1 - h2));
+      r->off[0] = 0; r->off[1] = 1;
+      r->nc = 2;
+    }
+  } else {
+    kind = 0;
+    if (i == n - 1) {
+      switch (g->bc[2 * d + 1]) {
+      case FO_BC_VELOCITY: kind = 2; break;
+      case FO_BC_PRESSURE_OUTLET: kind = 1; break;
+      case FO_BC_PERIODIC: kind = 0; break;
+      case FO_BC_SYMMETRY: kind = normal ? 2 : 1; break;
+      default: r->nc = -1; return;
+      }
+    }
+    if (kind == 0) { /* NSComputeConvectionLinearInterpolationNext_Cart, :320-333 */
+      double xP = xc[i], xe = xf[i + 1], xE = xc[i + 1];
+      r->v[0] = 0.5 * vf / h * (xE - xe) / (xE - xP);
+      r->v[1] = 0.5 * vf / h * (xe - xP) / (xE - xP);
+      r->off[0] = 0; r->off[1] = 1;
+      r->nc = 2;
+    } else if (kind == 1) { /* ...LinearBackwardExtrapolationNeumannCond_Cart, :354-371 */
+      h1 = xf[i + 1] - xc[i];
+      h2 = xf[i + 1] - xc[i - 1];
+      r->v[0] = 0.5 * vf / h * (h1 * h1) / ((h1 + h2) * (h1 - h2));
+      r->v[1] = -0.5 * vf / h * (h2 * h2) / ((h1 + h2) * (h1 - h2));
+      r->off[0] = -1; r->off[1] = 0;
+      r->nc = 2;
+    }
+  }
+}
+
+typedef struct {
+  int64_t col;
+  double  c, l; /* accumulated C and L entries (ADD_VALUES order of the reference) */
+} mom_ent;
+
+static void mom_add(mom_ent *e, int *ne, int64_t col, double c, double l)
+{
+  for (int a = 0; a < *ne; ++a)
+    if (e[a].col == col) {
+      e[a].c += c;
+      e[a].l += l;
+      return;
+    }
+  e[*ne].col = col;
+  e[*ne].c   = c;
+  e[*ne].l   = l;
+  ++*ne;
+}
+
+/* A = cI*I + cC*C + cL*L.  The reference's A: cI = 1, cC = dt, cL = -0.5*mu*dt/rho (cnlinearcart3d.c:2937-2940).
+ * V0[3], W[9] may be NULL when cC == 0. */
+fo_csr *fo_assemble_momentum(const fo_grid *g, double cI, double cC, double cL, const double *const *V0, const double *const *W)
+{
+  int64_t N = g->ncell;
+  fo_csr *A = (fo_csr *)calloc(1, sizeof(*A));
+  A->nrow   = 3 * N;
+  A->rowptr = (int64_t *)malloc(sizeof(int64_t) * (A->nrow + 1));
+  int64_t cap = A->nrow * 16 + 16;
+  A->col    = (int32_t *)malloc(sizeof(int32_t) * cap);
+  A->val    = (double *)malloc(sizeof(double) * cap);
+  int64_t nnz = 0;
+  for (int c = 0; c < 3; ++c)
+    for (int k = 0; k < g->n[2]; ++k)
+      for (int j = 0; j < g->n[1]; ++j)
+        for (int i = 0; i < g->n[0]; ++i) {
+          int      idx[3] = {i, j, k};
+          mom_ent  e[48];
+          int      ne  = 0;
+          int64_t  row = (int64_t)c * N + cell_index(g, i, j, k);
+          fo_row1d r;
+          A->rowptr[row] = nnz;
+          mom_add(e, &ne, row, 0., 0.);
+          /* L */
+          for (int d = 0; d < 3; ++d) {
+            fo_lap_row_1d(g, d, idx[d], c, &r);
+            for (int a = 0; a < r.nc; ++a) {
+              int cidx[3] = {i, j, k};
+              cidx[d]     = wrap(idx[d] + r.off[a], g->n[d]);
+              mom_add(e, &ne, (int64_t)c * N + cell_index(g, cidx[0], cidx[1], cidx[2]), 0., r.v[a]);
+            }
+          }
+          /* C */
+          if (cC != 0.)
+            for (int d = 0; d < 3; ++d)
+              for (int side = 0; side < 2; ++side) {
+                int fidx[3] = {i, j, k};
+                fidx[d]     = idx[d] + side;
+                if (g->periodic[d] && fidx[d] == g->n[d]) fidx[d] = 0;
+                int64_t f = face_index(g, d, fidx[0], fidx[1], fidx[2]);
+                for (int term = 0; term < 2; ++term) {
+                  int    cc = term == 0 ? c : d; /* column component */
+                  double vf = term == 0 ? V0[d][f] : W[c * 3 + d][f];
+                  fo_conv_row_1d(g, d, idx[d], side, term == 1 || c == d, vf, &r);
+                  for (int a = 0; a < r.nc; ++a) {
+                    int cidx[3] = {i, j, k};
+                    cidx[d]     = wrap(idx[d] + r.off[a], g->n[d]);
+                    mom_add(e, &ne, (int64_t)cc * N + cell_index(g, cidx[0], cidx[1], cidx[2]), r.v[a], 0.);
+                  }
+                }
+              }
+          /* sort by column */
+          for (int a = 1; a < ne; ++a) {
+            mom_ent t = e[a];
+            int     b = a - 1;
+            while (b >= 0 && e[b].col > t.col) {
+              e[b + 1] = e[b];
+              --b;
+            }
+            e[b + 1] = t;
+          }
+          for (int a = 0; a < ne; ++a) {
+            if (nnz >= cap) {
+              cap    = cap * 2;
+              A->col = (int32_t *)realloc(A->col, sizeof(int32_t) * cap);
+              A->val = (double *)realloc(A->val, sizeof(double) * cap);
+            }
+            double v = cC * e[a].c + cL * e[a].l; /* MatScale(A, dt); MatAXPY(A, cL, L) */
+            if (e[a].col == row) v += cI;        /* MatShift(A, 1) */
+            A->col[nnz] = (int32_t)e[a].col;
+            A->val[nnz] = v;
+            ++nnz;
+          }
+        }
+  A->rowptr[A->nrow] = nnz;
+  A->nnz             = nnz;
+  return A;
+}

@@ -83,10 +83,18 @@ def lib():
         L.fo_set_num_threads.argtypes = [C.c_int]
         L.fo_ibm_interp.argtypes = [C.c_void_p, C.c_int, C.c_int64, _dp, _dp, _dp, C.c_int, _dp, _dp]
         L.fo_ibm_spread.argtypes = [C.c_void_p, C.c_int, C.c_int64, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp]
+        L.fo_lap_row_1d.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(Row1d)]
+        L.fo_conv_row_1d.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(Row1d)]
+        L.fo_assemble_momentum.restype = C.c_void_p
+        L.fo_assemble_momentum.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
         L.fo_ibm_phi.restype = C.c_double
         L.fo_ibm_phi.argtypes = [C.c_int, C.c_double]
         _LIB = L
     return _LIB
+
+
+class Row1d(C.Structure):
+    _fields_ = [("nc", C.c_int), ("off", C.c_int * 4), ("v", C.c_double * 4)]
 
 
 def uniform_coords(n, lo, hi):
@@ -148,7 +156,40 @@ class Grid:
         lib().fo_div_row_1d(self.h, d, i, col, v)
         return [(col[0], v[0]), (col[1], v[1])]
 
+    def lap_row(self, d, i, c):
+        """[(offset, coeff)] of one axis' second-derivative row for component c (cnlinearcart3d.c:466-632)."""
+        r = Row1d()
+        lib().fo_lap_row_1d(self.h, d, i, c, C.byref(r))
+        if r.nc < 0:
+            raise ValueError("unsupported BC")
+        return [(r.off[a], r.v[a]) for a in range(r.nc)]
+
+    def conv_row(self, d, i, side, normal, vf):
+        """[(offset, coeff)] one face's contribution to a convection row (cnlinearcart3d.c:931-1292)."""
+        r = Row1d()
+        lib().fo_conv_row_1d(self.h, d, i, side, int(normal), float(vf), C.byref(r))
+        if r.nc < 0:
+            raise ValueError("unsupported BC")
+        return [(r.off[a], r.v[a]) for a in range(r.nc)]
+
     # operators ----------------------------------------------------------
+    def assemble_momentum(self, cI, cC, cL, V0=None, W=None):
+        """A = cI I + cC C + cL L on the component-major velocity vector; V0: 3 face arrays, W: 9 (c*3+d)."""
+        def pack(arrs, n):
+            if arrs is None:
+                return None, None
+            keep = [np.ascontiguousarray(a, dtype=np.float64) for a in arrs]
+            assert len(keep) == n
+            return keep, (C.c_void_p * n)(*[a.ctypes.data for a in keep])
+        k1, p1 = pack(V0, 3)
+        k2, p2 = pack(W, 9)
+        if cC != 0.0:
+            for d in range(3):
+                assert k1[d].size == self.nface[d]
+                for c in range(3):
+                    assert k2[c * 3 + d].size == self.nface[d]
+        return Csr(lib().fo_assemble_momentum(self.h, cI, cC, cL, p1, p2))
+
     def assemble_S(self):
         return Csr(lib().fo_assemble_S(self.h))
 

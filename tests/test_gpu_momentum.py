@@ -1,0 +1,121 @@
+"""-m gpu: the matrix-free momentum block (fl_momentum_*) through the C-ABI against the oracle's assembled CSR
+(literal restatement of cnlinearcart3d.c:425-632, 873-1294, 2930-2941)."""
+import numpy as np
+import pytest
+
+from oracle import fluca_oracle as fo
+from tests.gpu_common import CAVITY, CAVITY_BOX, O, PER, SYM, V, dev, host, stretched
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    ((17, 9, 11), CAVITY, False),
+    ((12, 10, 9), [PER] * 6, False),
+    ((9, 12, 7), [V, O, V, V, PER, PER], True),
+    ((11, 7, 13), [O, V, SYM, V, V, O], True),
+    ((8, 6, 5), [SYM, SYM, O, O, SYM, SYM], True),
+    ((130, 37, 20), CAVITY, True),          # more than one tile in x, ragged in x and y
+    ((70, 5, 3), [PER, PER, V, V, O, SYM], False),
+]
+
+
+def _pair(n, bc, nonuni):
+    from fluca_amd.poisson import Momentum, Poisson
+    box = CAVITY_BOX
+    if nonuni:
+        xf = [stretched(n[d], box[d][0], box[d][1], 1.1 + 0.2 * d) for d in range(3)]
+        P, g = Poisson(n, xf, bc, 1e-3), fo.Grid(n, xf, bc, 1e-3)
+    else:
+        P, g = Poisson.uniform(n, box, bc, 1e-3), fo.Grid.uniform(n, box, bc, 1e-3)
+    return P, Momentum(P), g
+
+
+def _fields(g, seed=3):
+    rng = np.random.default_rng(seed)
+    V0 = [rng.standard_normal(g.nface[d]) for d in range(3)]
+    W = [rng.standard_normal(g.nface[d]) for c in range(3) for d in range(3)]
+    return V0, W
+
+
+def _close(got, want, tol=2e-13):
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() <= tol * scale, (np.abs(got - want).max(), scale)
+
+
+@pytest.mark.parametrize("n,bc,nonuni", CASES)
+def test_laplacian_convection_and_A_match_assembled_rows(n, bc, nonuni):
+    P, M, g = _pair(n, bc, nonuni)
+    V0, W = _fields(g)
+    dt, rho, mu = 0.013, 1.7, 0.031
+    v = np.random.default_rng(11).standard_normal(3 * g.ncell)
+    vd = dev(v)
+    M.set_state(dt, rho, mu, [dev(a) for a in V0], [dev(a) for a in W])
+    A = g.assemble_momentum(1.0, dt, -0.5 * mu * dt / rho, V0, W)
+    _close(host(M.apply(vd)), A.mult(v))
+    _close(host(M.diagonal()), A.diag())
+    # the two operators on their own
+    M.set_coefficients(0.0, 0.0, 1.0)
+    _close(host(M.apply(vd)), g.assemble_momentum(0.0, 0.0, 1.0).mult(v))
+    M.set_coefficients(0.0, 1.0, 0.0)
+    Cm = g.assemble_momentum(0.0, 1.0, 0.0, V0, W)
+    _close(host(M.apply(vd)), Cm.mult(v))
+    _close(host(M.diagonal()), Cm.diag())
+    M.close()
+    P.close()
+
+
+def test_state_can_be_replaced():
+    """NSFormJacobian re-forms A every step from the new sol0 (cnlinearcart3d.c:2930-2941)."""
+    P, M, g = _pair((20, 9, 6), CAVITY, True)
+    v = np.random.default_rng(1).standard_normal(3 * g.ncell)
+    for seed in (1, 2):
+        V0, W = _fields(g, seed)
+        M.set_state(0.01, 1.0, 0.01, [dev(a) for a in V0], [dev(a) for a in W])
+        _close(host(M.apply(dev(v))), g.assemble_momentum(1.0, 0.01, -0.5 * 0.01 * 0.01, V0, W).mult(v))
+    M.close()
+    P.close()
+
+
+@pytest.mark.parametrize("n,bc,nonuni", [CASES[0], CASES[2], CASES[3], CASES[5]])
+@pytest.mark.parametrize("pc", [fo.PC_JACOBI, fo.PC_NONE])
+def test_momentum_bcgs_matches_oracle(n, bc, nonuni, pc):
+    P, M, g = _pair(n, bc, nonuni)
+    V0, W = _fields(g)
+    # CFL ~ 1 convection and a stiff viscous part so that the solve takes a handful of iterations
+    hmin = min(np.diff(g.xf[d]).min() for d in range(3))
+    dt, rho, mu = 0.5 * hmin, 1.0, 0.5 * hmin
+    M.set_state(dt, rho, mu, [dev(a) for a in V0], [dev(a) for a in W])
+    A = g.assemble_momentum(1.0, dt, -0.5 * mu * dt / rho, V0, W)
+    b = np.random.default_rng(7).standard_normal(3 * g.ncell)
+    rtol = 1e-8
+    xo, io = A.solve(b, ksp=fo.KSP_BCGS, pc=pc, nullspace=False, rtol=rtol, maxit=500)
+    xg, ig = M.solve(dev(b), history=True, pc=pc, rtol=rtol, maxit=500)
+    assert io["reason"] > 0 and ig["reason"] == io["reason"]
+    assert io["iters"] >= 3
+    m = min(len(ig["history"]), len(io["history"]))
+    assert np.allclose(ig["history"][:3], io["history"][:3], rtol=1e-9)
+    assert np.allclose(ig["history"][:min(m, 8)], io["history"][:min(m, 8)], rtol=1e-5)
+    assert abs(ig["iters"] - io["iters"]) <= max(2, io["iters"] // 6)
+    xg = host(xg)
+    assert np.linalg.norm(b - A.mult(xg)) <= 50 * rtol * np.linalg.norm(b)
+    assert np.linalg.norm(xg - xo) <= 1e-5 * np.linalg.norm(xo)
+    M.close()
+    P.close()
+
+
+def test_argument_checks():
+    from fluca_amd import capi
+    from fluca_amd.poisson import Momentum, Poisson
+    P = Poisson.uniform((8, 8, 1), CAVITY_BOX, [V] * 6, 1e-3)
+    with pytest.raises(RuntimeError):
+        Momentum(P)                              # one cell along z: the wall rows of the reference do not exist
+    P.close()
+    P = Poisson.uniform((8, 8, 8), CAVITY_BOX, [V] * 6, 1e-3)
+    M = Momentum(P)
+    b = P.empty(3 * P.ncell).zero_()
+    with pytest.raises(RuntimeError):
+        M.solve(b, type=capi.KSP_CG)             # A is not symmetric
+    x, info = M.solve(b)                          # before set_state: A = I
+    assert info["reason"] == 3 and info["iters"] == 0       # zero rhs: CONVERGED_ATOL at iteration 0 (KSPConvergedDefault)
+    M.close()
+    P.close()

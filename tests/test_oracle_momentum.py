@@ -1,0 +1,168 @@
+"""CPU: the oracle's restatement of the momentum block A = I + dt C - (mu dt / 2 rho) L.
+
+Pins: the second-derivative rows against the reference's FlucaFD golden files (the NS assembly and FlucaFD produce the
+same one-sided Dirichlet and central rows); the convection rows have no golden in the reference -- they are checked by
+the properties the formula (C v)_c = 1/2 d/dx_d (v_c V0_d + v0interp_c v_d) implies.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import fluca_oracle as fo
+from tests.flucafd_golden import fmt_g, parse
+
+V, O, PER, SYM = fo.BC_VELOCITY, fo.BC_PRESSURE_OUTLET, fo.BC_PERIODIC, fo.BC_SYMMETRY
+UNIT = [(0.0, 1.0)] * 3
+
+
+def _golden_rows(golden_dir, name):
+    return parse(os.path.join(golden_dir, "flucafd", name + ".out"))[1]
+
+
+def test_lap_central_row_matches_flucafd(golden_dir):
+    rows = _golden_rows(golden_dir, "ex1_second_deriv")      # stencil at i=4 of an 8-cell unit grid
+    g = fo.Grid.uniform((8, 3, 3), UNIT, [V] * 6)
+    got = {4 + off: fmt_g(v) for off, v in g.lap_row(0, 4, 0)}
+    assert got == {r["i"]: r["v_text"] for r in rows}
+
+
+def test_lap_dirichlet_row_matches_flucafd(golden_dir):
+    rows = _golden_rows(golden_dir, "ex1_second_deriv_left_bc_dirichlet")   # i=0, left Dirichlet
+    g = fo.Grid.uniform((8, 3, 3), UNIT, [V] * 6)
+    elem = {r["i"]: r["v_text"] for r in rows if r["loc"] == "ELEMENT"}
+    for c in range(3):          # VELOCITY: all three components take the Dirichlet row
+        assert {off: fmt_g(v) for off, v in g.lap_row(0, 0, c)} == elem
+    gs = fo.Grid.uniform((8, 3, 3), UNIT, [SYM, V, V, V, V, V])
+    assert {off: fmt_g(v) for off, v in gs.lap_row(0, 0, 0)} == elem        # SYMMETRY: normal component is Dirichlet
+    assert len(gs.lap_row(0, 0, 1)) == 2                                    # tangential: two-point Neumann row
+    # mirror image on the right wall
+    r = g.lap_row(0, 7, 0)
+    assert [fmt_g(v) for _, v in r] == [elem[2], elem[1], elem[0]] and [o for o, _ in r] == [-2, -1, 0]
+
+
+def _coords(n, stretch):
+    if not stretch:
+        return [np.linspace(0.0, 1.0, m + 1) for m in n]
+    return [np.linspace(0.0, 1.0, m + 1) ** (1.0 + 0.3 * (d + 1)) for d, m in enumerate(n)]
+
+
+@pytest.mark.parametrize("stretch", [False, True])
+def test_lap_rows_exact_for_quadratics(stretch):
+    n = (7, 6, 5)
+    xf = _coords(n, stretch)
+    g = fo.Grid(n, xf, [V, O, SYM, V, PER, PER])
+    for d in range(3):
+        xc = 0.5 * (xf[d][1:] + xf[d][:-1])
+        for c in range(3):
+            for i in range(n[d]):
+                row = g.lap_row(d, i, c)
+                if g.periodic[d] and (i == 0 or i == n[d] - 1):
+                    continue
+                lo_wall, hi_wall = i == 0, i == n[d] - 1
+                bc = g.bc[2 * d] if lo_wall else (g.bc[2 * d + 1] if hi_wall else None)
+                dirichlet = bc == V or (bc == SYM and c == d)
+                xw = xf[d][0] if lo_wall else xf[d][-1]
+                if bc is None:
+                    # central row on a non-uniform grid: exact for linears, second-order for quadratics
+                    assert abs(sum(v for _, v in row)) < 1e-9 * max(abs(v) for _, v in row)
+                    assert abs(sum(v * xc[i + o] for o, v in row)) < 1e-8 * max(abs(v) for _, v in row)
+                elif dirichlet:
+                    # one-sided row through the wall value: exact for quadratics that vanish at the wall
+                    f = lambda x: (x - xw) * (1.0 + 2.0 * (x - xw))
+                    assert sum(v * f(xc[i + o]) for o, v in row) == pytest.approx(4.0, rel=1e-9)
+                else:
+                    # two-point zero-gradient row: annihilates constants
+                    assert sum(v for _, v in row) == pytest.approx(0.0, abs=1e-9 * abs(row[0][1]))
+
+
+def test_conv_rows_interior_are_half_face_flux_interpolation():
+    n = (6, 5, 4)
+    xf = _coords(n, True)
+    g = fo.Grid(n, xf, [V] * 6)
+    d, i, vf = 0, 3, 0.7
+    h = xf[d][i + 1] - xf[d][i]
+    xc = 0.5 * (xf[d][1:] + xf[d][:-1])
+    lo, hi = g.conv_row(d, i, 0, False, vf), g.conv_row(d, i, 1, False, vf)
+    assert [o for o, _ in lo] == [-1, 0] and [o for o, _ in hi] == [0, 1]
+    assert sum(v for _, v in lo) == pytest.approx(-0.5 * vf / h)       # weights of a linear interpolation sum to one
+    assert sum(v for _, v in hi) == pytest.approx(+0.5 * vf / h)
+    # interpolation reproduces linear fields at the face
+    assert sum(v * xc[i + o] for o, v in lo) == pytest.approx(-0.5 * vf / h * xf[d][i])
+    assert sum(v * xc[i + o] for o, v in hi) == pytest.approx(+0.5 * vf / h * xf[d][i + 1])
+    # VELOCITY wall faces carry no matrix entries (the boundary value goes to the right-hand side)
+    assert g.conv_row(d, 0, 0, False, vf) == [] and g.conv_row(d, n[d] - 1, 1, True, vf) == []
+
+
+def test_conv_outlet_rows_as_in_reference():
+    """cartdiscret.c:335-371: zero-gradient extrapolation through the two cells next to the outlet.  The high-side row is
+    +0.5 vf/h times extrapolation weights that sum to one; the low-side row, as written in the reference, sums to
+    +0.5 vf/h as well (not -0.5 vf/h as a low face would).  The oracle restates it as it stands."""
+    n = (6, 5, 4)
+    xf = _coords(n, True)
+    g = fo.Grid(n, xf, [O, O, SYM, SYM, V, V])
+    vf = 1.3
+    h0, h1 = xf[0][1] - xf[0][0], xf[0][-1] - xf[0][-2]
+    lo, hi = g.conv_row(0, 0, 0, True, vf), g.conv_row(0, n[0] - 1, 1, True, vf)
+    assert [o for o, _ in lo] == [0, 1] and [o for o, _ in hi] == [-1, 0]
+    assert sum(v for _, v in hi) == pytest.approx(0.5 * vf / h1)
+    assert sum(v for _, v in lo) == pytest.approx(0.5 * vf / h0)
+    # SYMMETRY: no entries for the normal component, extrapolation for a tangential one
+    assert g.conv_row(1, 0, 0, True, vf) == [] and len(g.conv_row(1, 0, 0, False, vf)) == 2
+    assert g.conv_row(1, n[1] - 1, 1, True, vf) == [] and len(g.conv_row(1, n[1] - 1, 1, False, vf)) == 2
+
+
+def _fields(g, seed=3):
+    rng = np.random.default_rng(seed)
+    V0 = [rng.standard_normal(g.nface[d]) for d in range(3)]
+    W = [rng.standard_normal(g.nface[d]) for c in range(3) for d in range(3)]
+    return V0, W
+
+
+def test_periodic_uniform_convection_is_the_skew_form():
+    """Uniform periodic grid, constant advecting fields: (C v)_c = 1/2 (U . grad_h v_c + U_c div_h v) with central
+    differences -- the textbook discretisation of the formula quoted at cnlinearcart3d.c:920."""
+    n = (8, 6, 5)
+    g = fo.Grid.uniform(n, UNIT, [PER] * 6)
+    U = np.array([0.7, -0.4, 1.1])
+    V0 = [np.full(g.nface[d], U[d]) for d in range(3)]
+    W = [np.full(g.nface[d], U[c]) for c in range(3) for d in range(3)]
+    Cm = g.assemble_momentum(0.0, 1.0, 0.0, V0, W)
+    rng = np.random.default_rng(1)
+    v = rng.standard_normal((3, n[2], n[1], n[0]))
+    h = [1.0 / n[0], 1.0 / n[1], 1.0 / n[2]]
+    ax = [3, 2, 1]   # array axis of x, y, z in (c, k, j, i)
+    cd = lambda a, d: (np.roll(a, -1, axis=ax[d] - 1) - np.roll(a, 1, axis=ax[d] - 1)) / (2 * h[d])
+    div = sum(cd(v[d], d) for d in range(3))
+    want = np.stack([0.5 * (sum(U[d] * cd(v[c], d) for d in range(3)) + U[c] * div) for c in range(3)])
+    got = Cm.mult(v.ravel()).reshape(v.shape)
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("bc", [[V] * 6, [V, V, V, V, SYM, V], [PER, PER, V, O, SYM, SYM], [O, V, PER, PER, V, V]])
+def test_assembled_A_is_identity_plus_scaled_parts(bc):
+    n = (6, 5, 4)
+    g = fo.Grid(n, _coords(n, True), bc)
+    V0, W = _fields(g)
+    dt, rho, mu = 0.01, 1.3, 0.02
+    A = g.assemble_momentum(1.0, dt, -0.5 * mu * dt / rho, V0, W)
+    Cm = g.assemble_momentum(0.0, 1.0, 0.0, V0, W)
+    L = g.assemble_momentum(0.0, 0.0, 1.0)
+    v = np.random.default_rng(2).standard_normal(3 * g.ncell)
+    assert np.allclose(A.mult(v), v + dt * Cm.mult(v) - 0.5 * mu * dt / rho * L.mult(v), rtol=1e-12, atol=1e-12)
+    assert A.nrow == 3 * g.ncell
+    # L never couples components; C couples component c only to itself and to the face-normal ones
+    rp, col, val = L.arrays()
+    rows = np.repeat(np.arange(L.nrow), np.diff(rp))
+    assert np.all((rows // g.ncell == col // g.ncell) | (val == 0.0))
+
+
+def test_momentum_bcgs_solve_cpu():
+    n = (8, 7, 6)
+    g = fo.Grid(n, _coords(n, True), [V, V, V, V, SYM, V])
+    V0, W = _fields(g)
+    A = g.assemble_momentum(1.0, 0.02, -0.5 * 0.01 * 0.02, V0, W)
+    b = np.random.default_rng(4).standard_normal(3 * g.ncell)
+    x, info = A.solve(b, ksp=fo.KSP_BCGS, pc=fo.PC_JACOBI, nullspace=False, rtol=1e-10, maxit=200)
+    assert info["reason"] > 0
+    assert np.linalg.norm(b - A.mult(x)) <= 1e-8 * np.linalg.norm(b)

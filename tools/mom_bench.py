@@ -1,0 +1,55 @@
+"""Times the matrix-free momentum block (fl_momentum_apply / fl_momentum_solve) on one GPU.
+
+usage: python tools/mom_bench.py [--cells 512] [--reps 10]
+Algorithmic bytes of one application: 3 reads + 3 writes of the velocity + 12 face fields = 144 B per cell.
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fluca_amd.poisson import Momentum, Poisson  # noqa: E402
+
+V, SYM = 1, 4
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cells", type=int, default=512)
+    ap.add_argument("--reps", type=int, default=10)
+    a = ap.parse_args()
+    n = (a.cells,) * 3
+    P = Poisson.uniform(n, [(0, 1)] * 3, [V, V, V, V, SYM, V], 1e-3)
+    M = Momentum(P)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    rnd = lambda m: torch.rand(m, dtype=torch.float64, device="cuda", generator=g) * 2 - 1
+    V0 = [rnd(P.nface[d]) for d in range(3)]
+    W = [rnd(P.nface[d]) for c in range(3) for d in range(3)]
+    h = 1.0 / a.cells
+    M.set_state(0.5 * h, 1.0, 0.5 * h, V0, W)
+    del V0, W
+    v = rnd(3 * P.ncell)
+    y = torch.empty_like(v)
+    M.apply(v, y)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.reps):
+        M.apply(v, y)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / a.reps
+    out = dict(cells=a.cells, apply_ms_incl_pad=ms)
+    x, info = M.solve(v, rtol=1e-8, maxit=200)
+    x, info = M.solve(v, rtol=1e-8, maxit=200)
+    out.update(solve_iters=info["iters"], solve_reason=info["reason"], solve_ms=info["seconds"] * 1e3,
+               ms_per_iter=info["seconds"] * 1e3 / max(info["iters"], 1))
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
