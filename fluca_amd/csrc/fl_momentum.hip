@@ -16,6 +16,10 @@
 #include "fl_handle.h"
 #include "fl_device.h"
 
+#ifndef FL_MOM_WPE
+#define FL_MOM_WPE 2  // waves per SIMD the register allocator must leave room for (see tools/experiments/mom_wpe.sh)
+#endif
+
 namespace fl {
 
 struct MomP {
@@ -30,6 +34,19 @@ __device__ __forceinline__ double uniform_d(double v)
   const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
   return __hiloint2double(hi, lo);
 }
+
+// 1/d: hardware estimate + two Newton steps (correctly rounded for all but a vanishing fraction of inputs)
+__device__ __forceinline__ double recip(double d)
+{
+  double r = __builtin_amdgcn_rcp(d);
+  r        = fma(r, fma(-d, r, 1.), r);
+  r        = fma(r, fma(-d, r, 1.), r);
+  return r;
+}
+
+// uniform base pointer + per-lane 32-bit byte offset: lets the backend use the scalar-base addressing mode of global_load
+__device__ __forceinline__ double LD(const double *base, unsigned byteoff) { return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + byteoff); }
+__device__ __forceinline__ void   ST(double *base, unsigned byteoff, double v) { *reinterpret_cast<double *>(reinterpret_cast<char *>(base) + byteoff) = v; }
 
 struct MTile {
   int  ic, jc, i, j, k0, k1;
@@ -49,118 +66,315 @@ __device__ __forceinline__ MTile mom_tile(const GridP &g, int tiles_x, int nchun
   return t;
 }
 
+// One axis' share of row (cell, component C) of A.  T(slot) yields the 1-D table number of this cell along axis D
+// (build_axis_momentum).  um/uc/up: component C at the cell and its two neighbours along D; nm/nc/np: the face-normal
+// component D at the same places (the same numbers when C == D).  WALL == false is the fast path for cells that are
+// not next to a wall of this axis: "normal" and "tangential" rules coincide, there is no far column, and the low / high
+// face rows are plain two-point interpolations -- 7 table numbers instead of 20.
+template <int D, int C, bool WALL, bool DG, class TF>
+__device__ __forceinline__ void mom_axis(TF T, double um, double uc, double up, double ufar, double nm, double nc, double np, double vl, double vh, double wl, double wh, double cC, double cL,
+                                         double &yacc, double &dacc)
+{
+  constexpr int r = C == D ? 1 : 0;
+  double        L0, L1, L2, L3 = 0., Tl0 = 0., Tl1 = 0., Tl2 = 0., Th0 = 0., Th1 = 0., Th2 = 0., Nl0, Nl1, Nl2 = 0., Nh0 = 0., Nh1, Nh2;
+  if (WALL) {
+    L0 = T(r * 4 + 0); L1 = T(r * 4 + 1); L2 = T(r * 4 + 2); L3 = T(r * 4 + 3);
+    Nl0 = T(11); Nl1 = T(12); Nl2 = T(13);
+    Nh0 = T(17); Nh1 = T(18); Nh2 = T(19);
+    if (!r) {
+      Tl0 = T(8); Tl1 = T(9); Tl2 = T(10);
+      Th0 = T(14); Th1 = T(15); Th2 = T(16);
+    }
+  } else {
+    L0 = T(0); L1 = T(1); L2 = T(2);
+    Nl0 = T(8); Nl1 = T(9);
+    Nh1 = T(15); Nh2 = T(16);
+    Tl0 = Nl0; Tl1 = Nl1; Th1 = Nh1; Th2 = Nh2;
+  }
+  // face values of the face-normal component ("normal" rule): second term v0interp_C v_D, and the first term when C == D
+  const double Glo = Nl0 * nm + Nl1 * nc + Nl2 * np, Ghi = Nh0 * nm + Nh1 * nc + Nh2 * np;
+  const double Ilo = r ? Glo : Tl0 * um + Tl1 * uc + Tl2 * up, Ihi = r ? Ghi : Th0 * um + Th1 * uc + Th2 * up;
+  const double conv = vl * Ilo + vh * Ihi + wl * Glo + wh * Ghi;
+  double       lap = L0 * um + L1 * uc + L2 * up;
+  if (WALL) lap += L3 * ufar;
+  yacc += cC * conv + cL * lap;
+  if (DG) {
+    double dc = r ? (vl + wl) * Nl1 + (vh + wh) * Nh1 : vl * Tl1 + vh * Th1;
+    dacc += cC * dc + cL * L1;
+  }
+}
+
+constexpr int MOM_RY = 4;            // grid rows per block = waves per block
+constexpr int MOM_NT = 64 * MOM_RY;
+
+// LDS image of one plane of a 64 x MOM_RY tile: what a cell needs from its x/y neighbours.
+struct MomLds {
+  double u[3][MOM_RY + 2][66];   // velocity components incl. a one-cell ring (rows -1..RY, columns -1..64)
+  double fx[4][MOM_RY][66];      // V0x, v0interp_{0,1,2} on x-faces: low face of column 0..64 (64 = high face of the last cell)
+  double fy[4][MOM_RY + 1][64];  // the same on y-faces: low face of row 0..RY
+};
+
 // y = [1/diag] A x   (x padded with valid ghosts; y padded, or unpadded component-major when OUT == 1).
 // OUT == 2 writes diag(A) instead (padded).  DOT: partial slots 0 sum y, 1 y.o (o padded, may be NULL), 2 x.y, 3 y.y.
+//
+// Block = 64 x MOM_RY tile marching through a z chunk, one thread per cell column, all three components.
+//  * Every global address is (wave-uniform base) + (per-lane 32-bit byte offset).
+//  * Every value is fetched from global memory exactly once per tile: the centre column of the 3 velocity components
+//    and the low faces of the 12 face fields (15 streams), plus the one-cell ring of the tile.  x/y neighbours and high
+//    faces are exchanged through LDS (double-buffered, one barrier per plane); z neighbours ride in registers.
+//  * Software pipeline: while plane k is computed, the loads of plane k+1 (faces, ring) and k+2 (velocity, z-faces) are
+//    in flight; they are consumed by the register rotation at the end of the iteration.
 template <bool DOT, bool JAC, int OUT>
-__global__ void __launch_bounds__(256) k_mom_apply(GridP g, MomP m, const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ F, int64_t cs, const double *__restrict__ o,
-                                                   const KspScal *__restrict__ s, double *__restrict__ partial, int pstride, int tiles_x, int nchunk, int zc)
+__global__ void __launch_bounds__(MOM_NT, FL_MOM_WPE) k_mom_apply(GridP g, MomP m, const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ F, int64_t cs, const double *__restrict__ o,
+                                                                const KspScal *__restrict__ s, double *__restrict__ partial, int pstride, int tiles_x, int nchunk, int zc)
 {
-  __shared__ double red[4 * 4];
+  __shared__ MomLds lds[2];
+  __shared__ double ltabx[MOM_NTAB][64];  // the x-axis table numbers of this tile's 64 columns (general rows of wall tiles)
+  __shared__ double red[4 * MOM_RY];
   if (s && s->reason != 0) return;
-  const MTile t = mom_tile(g, tiles_x, nchunk, zc);
-  double      tx[MOM_NTAB], ty[MOM_NTAB];
+  constexpr bool DG = JAC || OUT == 2;
+  const int      b = blockIdx.x, chunk = b % nchunk, tile = b / nchunk;
+  const int      lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int      i0 = (tile % tiles_x) * 64, j0 = (tile / tiles_x) * MOM_RY, j = j0 + w;
+  const int      i = i0 + lane;
+  const bool     own = i < g.nx && j < g.ny;
+  // loads are clamped to the ghost column / row (valid memory holding the right neighbour of the last cell)
+  const int      il = min(i, g.nx), jl = min(j, g.ny), it = min(i, g.nx - 1), jt = min(j, g.ny - 1);
+  const int      k0 = chunk * zc, k1 = min(k0 + zc, g.nz);
+  const unsigned lo0 = (unsigned)(il - i0) * 8u;
+  // ring: lane 0 fetches column -1 of its row, lane 63 column 64 (clamped), the others nothing
+  const bool     ringlane = lane == 0 || lane == 63;
+  const unsigned loring0 = lane == 0 ? 0u : (unsigned)(min(i0 + 64, g.nx) - i0 + 1) * 8u;  // relative to (row base - 1)
+  const bool     toprow = w == MOM_RY - 1, botrow = w == 0;                                   // wave-uniform
+  const int      jr = botrow ? max(j0 - 1, -1) : min(j0 + MOM_RY, g.ny);                      // the ring row this wave fetches
+  const unsigned far0 = it == 0 ? 32u : 0u;          // relative to (base - 2): column i+2 at the low wall, i-2 elsewhere
+  const bool     xwall = i0 == 0 || i0 + 64 >= g.nx;  // block-uniform: this tile touches an x wall
+  const bool     ywall = jt == 0 || jt == g.ny - 1;   // wave-uniform
+  const int      lx = m.len[0], ly = m.len[1], lz = m.len[2];
+  const double  *tabx = m.tab[0] + it, *taby = m.tab[1] + jt;
+  double         txi[7], tyi[7];  // fast-path numbers of the x and y axes: fixed for the whole chunk
+  {
+    const int sl[7] = {0, 1, 2, 8, 9, 15, 16};
 #pragma unroll
-  for (int a = 0; a < MOM_NTAB; ++a) {
-    tx[a] = m.tab[0][(int64_t)a * m.len[0] + t.ic];
-    ty[a] = uniform_d(m.tab[1][(int64_t)a * m.len[1] + t.jc]);
+    for (int a = 0; a < 7; ++a) {
+      txi[a] = tabx[(int64_t)sl[a] * lx];
+      tyi[a] = taby[(int64_t)sl[a] * ly];
+    }
   }
+  if (xwall) {
+    // wall tiles read the general x rows from LDS: a global load in the compute phase would have to wait for every
+    // prefetch issued before it (vmcnt retires in order)
+    for (int q = w; q < MOM_NTAB; q += MOM_RY) ltabx[q][lane] = tabx[(int64_t)q * lx];
+    __syncthreads();
+  }
+  auto          slot7 = [](int q) { return q < 3 ? q : (q < 10 ? q - 5 : q - 10); };  // 0,1,2,8,9,15,16 -> 0..6
   const int64_t sx = g.sx, sxy = g.sxy;
-  const int64_t fox = t.ic == 0 ? 2 : -2, foy = (t.jc == 0 ? 2 : -2) * sx;
+  const int64_t foy = (jt == 0 ? 2 : -2) * sx;
   const int64_t ncell = (int64_t)g.nx * g.ny * g.nz;
+  const int64_t rb0 = g.off0 + (int64_t)jl * sx + i0;  // wave-uniform offset of this row in plane 0
+  const int64_t rr0 = g.off0 + (int64_t)jr * sx + i0;  // ... of the ring row
+  const double  cC = m.cC, cL = m.cL;
   double        acc[4] = {0., 0., 0., 0.};
-  for (int k = t.k0; k < t.k1; ++k) {
-    double tz[MOM_NTAB];
-#pragma unroll
-    for (int a = 0; a < MOM_NTAB; ++a) tz[a] = m.tab[2][(int64_t)a * m.len[2] + k];
-    const int64_t idx = g.off0 + (int64_t)k * sxy + (int64_t)t.jc * sx + t.ic;
-    const int64_t foz = (k == 0 ? 2 : -2) * sxy;
-    double        u[3][3][3], uf[3][3], vl[3], vh[3], wl[3][3], wh[3][3];
+
+  // registers of the pipeline.  Face fields are indexed f = 0: V0, 1..3: v0interp_{0,1,2}.
+  double uzm[3], uc[3], uzp[3], vzl[4], vzh[4], fxl[4], fyl[4], oc[3] = {0., 0., 0.};
+  auto   fld = [&](int f, int d) { return F + (f == 0 ? d : 3 + (f - 1) * 3 + d) * cs; };
+  {
+    const int64_t rb = rb0 + (int64_t)k0 * sxy, rr = rr0 + (int64_t)k0 * sxy;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const double *X = x + c * cs + idx;
-      const double  uc = X[0];
-      u[c][0][0] = X[-1];
-      u[c][0][1] = uc;
-      u[c][0][2] = X[1];
-      u[c][1][0] = X[-sx];
-      u[c][1][1] = uc;
-      u[c][1][2] = X[sx];
-      u[c][2][0] = X[-sxy];
-      u[c][2][1] = uc;
-      u[c][2][2] = X[sxy];
-      uf[c][0]   = X[fox];
-      uf[c][1]   = X[foy];
-      uf[c][2]   = X[foz];
+      const double *X = x + c * cs;
+      uzm[c] = LD(X + rb - sxy, lo0);
+      uc[c]  = LD(X + rb, lo0);
+      uzp[c] = LD(X + rb + sxy, lo0);
+      if (ringlane) lds[k0 & 1].u[c][w + 1][lane == 0 ? 0 : 65] = LD(X + rb - 1, loring0);
+      if (botrow) lds[k0 & 1].u[c][0][lane + 1] = LD(X + rr, lo0);
+      if (toprow) lds[k0 & 1].u[c][MOM_RY + 1][lane + 1] = LD(X + rr, lo0);
+      if (DOT && o) oc[c] = LD(o + c * cs + rb, lo0);
     }
-    const int64_t str[3] = {1, sx, sxy};
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      const double *V = F + d * cs + idx;
-      vl[d] = V[0];
-      vh[d] = V[str[d]];
+    for (int f = 0; f < 4; ++f) {
+      vzl[f] = LD(fld(f, 2) + rb, lo0);
+      vzh[f] = LD(fld(f, 2) + rb + sxy, lo0);
+      fxl[f] = LD(fld(f, 0) + rb, lo0);
+      fyl[f] = LD(fld(f, 1) + rb, lo0);
+      if (lane == 63) lds[k0 & 1].fx[f][w][64] = LD(fld(f, 0) + rb - 1, loring0);
+      if (toprow) lds[k0 & 1].fy[f][MOM_RY][lane] = LD(fld(f, 1) + rr, lo0);
+    }
+  }
+  for (int kl = k0; kl < k1; ++kl) {
+    // Opaque copies of the plane index and the lane offsets: without them the loop optimiser turns every load stream
+    // into its own 64-bit per-lane pointer carried around the loop (dozens of VGPRs, no scalar-base addressing).
+    int      k = kl;
+    unsigned lo = lo0, loring = loring0;
+    asm volatile("" : "+s"(k), "+v"(lo), "+v"(loring));
+    MomLds       &L = lds[k & 1];
+    const int64_t rb = rb0 + (int64_t)k * sxy;
+    const bool    zwall = k == 0 || k == g.nz - 1;
+    // ---- 1: publish this thread's part of plane k (its ring went into this buffer at the end of the previous trip)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) L.u[c][w + 1][lane + 1] = uc[c];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      L.fx[f][w][lane] = fxl[f];
+      L.fy[f][w][lane] = fyl[f];
+    }
+    // far column of the one-sided wall rows (rare: uniform branches; straight from global memory, issued before the prefetches so that waiting for them does not drain those)
+    double ufx[3] = {0., 0., 0.}, ufy[3] = {0., 0., 0.}, ufz[3] = {0., 0., 0.};
+    if (xwall) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) ufx[c] = LD(x + c * cs + rb - 2, lo + far0);
+    }
+    if (ywall) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) ufy[c] = LD(x + c * cs + rb + foy, lo);
+    }
+    if (zwall) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) ufz[c] = LD(x + c * cs + rb + (k == 0 ? 2 : -2) * sxy, lo);
+    }
+    // ---- 2: loads of the next plane(s) (plane k+2 is clamped to the high ghost plane: never read past the array)
+    const int64_t rb1 = rb + sxy, rb2 = rb0 + (int64_t)min(k + 2, g.nz) * sxy, rr1 = rr0 + (int64_t)(k + 1) * sxy;
+    double        n_u[3], n_vz[4], n_fxl[4], n_fyl[4], n_oc[3] = {0., 0., 0.}, n_rcol_u[3], n_rcol_fx[4], n_rrow_u[3], n_rrow_fy[4];  // n_r*: ring of plane k+1
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double *X = x + c * cs;
+      n_u[c] = LD(X + rb2, lo);
+      if (DOT && o) n_oc[c] = LD(o + c * cs + rb1, lo);
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      n_vz[f]  = LD(fld(f, 2) + rb2, lo);
+      n_fxl[f] = LD(fld(f, 0) + rb1, lo);
+      n_fyl[f] = LD(fld(f, 1) + rb1, lo);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double *X = x + c * cs;
+      n_rcol_u[c] = ringlane ? LD(X + rb1 - 1, loring) : 0.;
+      n_rrow_u[c] = (botrow || toprow) ? LD(X + rr1, lo) : 0.;
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      n_rcol_fx[f] = lane == 63 ? LD(fld(f, 0) + rb1 - 1, loring) : 0.;
+      n_rrow_fy[f] = toprow ? LD(fld(f, 1) + rr1, lo) : 0.;
+    }
+    __syncthreads();
+    // ---- 3: the three axes
+    double yacc[3] = {0., 0., 0.}, dacc[3] = {0., 0., 0.};
+    {
+      double um[3], up[3], fh[4];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const double *W = F + (3 + c * 3 + d) * cs + idx;
-        wl[c][d] = W[0];
-        wh[c][d] = W[str[d]];
+        um[c] = L.u[c][w + 1][lane];
+        up[c] = L.u[c][w + 1][lane + 2];
+      }
+#pragma unroll
+      for (int f = 0; f < 4; ++f) fh[f] = L.fx[f][w][lane + 1];
+      if (xwall) {
+        auto T = [&](int q) { return ltabx[q][lane]; };
+        mom_axis<0, 0, true, DG>(T, um[0], uc[0], up[0], ufx[0], um[0], uc[0], up[0], fxl[0], fh[0], fxl[1], fh[1], cC, cL, yacc[0], dacc[0]);
+        mom_axis<0, 1, true, DG>(T, um[1], uc[1], up[1], ufx[1], um[0], uc[0], up[0], fxl[0], fh[0], fxl[2], fh[2], cC, cL, yacc[1], dacc[1]);
+        mom_axis<0, 2, true, DG>(T, um[2], uc[2], up[2], ufx[2], um[0], uc[0], up[0], fxl[0], fh[0], fxl[3], fh[3], cC, cL, yacc[2], dacc[2]);
+      } else {
+        auto T = [&](int q) { return txi[slot7(q)]; };
+        mom_axis<0, 0, false, DG>(T, um[0], uc[0], up[0], 0., um[0], uc[0], up[0], fxl[0], fh[0], fxl[1], fh[1], cC, cL, yacc[0], dacc[0]);
+        mom_axis<0, 1, false, DG>(T, um[1], uc[1], up[1], 0., um[0], uc[0], up[0], fxl[0], fh[0], fxl[2], fh[2], cC, cL, yacc[1], dacc[1]);
+        mom_axis<0, 2, false, DG>(T, um[2], uc[2], up[2], 0., um[0], uc[0], up[0], fxl[0], fh[0], fxl[3], fh[3], cC, cL, yacc[2], dacc[2]);
       }
     }
-    // face interpolants of the face-normal component along each axis ("normal" rule)
-    double Glo[3], Ghi[3];
+    {
+      double um[3], up[3], fh[4];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      const double *tb = d == 0 ? tx : (d == 1 ? ty : tz);
-      Glo[d] = tb[11] * u[d][d][0] + tb[12] * u[d][d][1] + tb[13] * u[d][d][2];
-      Ghi[d] = tb[17] * u[d][d][0] + tb[18] * u[d][d][1] + tb[19] * u[d][d][2];
+      for (int c = 0; c < 3; ++c) {
+        um[c] = L.u[c][w][lane + 1];
+        up[c] = L.u[c][w + 2][lane + 1];
+      }
+#pragma unroll
+      for (int f = 0; f < 4; ++f) fh[f] = L.fy[f][w + 1][lane];
+      if (ywall) {
+        auto T = [&](int q) { return taby[(int64_t)q * ly]; };
+        mom_axis<1, 0, true, DG>(T, um[0], uc[0], up[0], ufy[0], um[1], uc[1], up[1], fyl[0], fh[0], fyl[1], fh[1], cC, cL, yacc[0], dacc[0]);
+        mom_axis<1, 1, true, DG>(T, um[1], uc[1], up[1], ufy[1], um[1], uc[1], up[1], fyl[0], fh[0], fyl[2], fh[2], cC, cL, yacc[1], dacc[1]);
+        mom_axis<1, 2, true, DG>(T, um[2], uc[2], up[2], ufy[2], um[1], uc[1], up[1], fyl[0], fh[0], fyl[3], fh[3], cC, cL, yacc[2], dacc[2]);
+      } else {
+        auto T = [&](int q) { return tyi[slot7(q)]; };
+        mom_axis<1, 0, false, DG>(T, um[0], uc[0], up[0], 0., um[1], uc[1], up[1], fyl[0], fh[0], fyl[1], fh[1], cC, cL, yacc[0], dacc[0]);
+        mom_axis<1, 1, false, DG>(T, um[1], uc[1], up[1], 0., um[1], uc[1], up[1], fyl[0], fh[0], fyl[2], fh[2], cC, cL, yacc[1], dacc[1]);
+        mom_axis<1, 2, false, DG>(T, um[2], uc[2], up[2], 0., um[1], uc[1], up[1], fyl[0], fh[0], fyl[3], fh[3], cC, cL, yacc[2], dacc[2]);
+      }
+    }
+    {
+      const double *tabz = m.tab[2] + k;
+      auto          T = [&](int q) { return tabz[(int64_t)q * lz]; };
+      if (zwall) {
+        mom_axis<2, 0, true, DG>(T, uzm[0], uc[0], uzp[0], ufz[0], uzm[2], uc[2], uzp[2], vzl[0], vzh[0], vzl[1], vzh[1], cC, cL, yacc[0], dacc[0]);
+        mom_axis<2, 1, true, DG>(T, uzm[1], uc[1], uzp[1], ufz[1], uzm[2], uc[2], uzp[2], vzl[0], vzh[0], vzl[2], vzh[2], cC, cL, yacc[1], dacc[1]);
+        mom_axis<2, 2, true, DG>(T, uzm[2], uc[2], uzp[2], ufz[2], uzm[2], uc[2], uzp[2], vzl[0], vzh[0], vzl[3], vzh[3], cC, cL, yacc[2], dacc[2]);
+      } else {
+        mom_axis<2, 0, false, DG>(T, uzm[0], uc[0], uzp[0], 0., uzm[2], uc[2], uzp[2], vzl[0], vzh[0], vzl[1], vzh[1], cC, cL, yacc[0], dacc[0]);
+        mom_axis<2, 1, false, DG>(T, uzm[1], uc[1], uzp[1], 0., uzm[2], uc[2], uzp[2], vzl[0], vzh[0], vzl[2], vzh[2], cC, cL, yacc[1], dacc[1]);
+        mom_axis<2, 2, false, DG>(T, uzm[2], uc[2], uzp[2], 0., uzm[2], uc[2], uzp[2], vzl[0], vzh[0], vzl[3], vzh[3], cC, cL, yacc[2], dacc[2]);
+      }
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      double conv = 0., lap = 0., dgc = 0., dgl = 0.;
-#pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        const double *tb = d == 0 ? tx : (d == 1 ? ty : tz);
-        const int     r = c == d ? 1 : 0;
-        double        Ilo, Ihi;
-        if (r) {
-          Ilo = Glo[d];
-          Ihi = Ghi[d];
-        } else {
-          Ilo = tb[8] * u[c][d][0] + tb[9] * u[c][d][1] + tb[10] * u[c][d][2];
-          Ihi = tb[14] * u[c][d][0] + tb[15] * u[c][d][1] + tb[16] * u[c][d][2];
-        }
-        conv += vl[d] * Ilo + vh[d] * Ihi;              // first term:  v_c V0_d
-        conv += wl[c][d] * Glo[d] + wh[c][d] * Ghi[d];  // second term: v0interp_c v_d
-        lap += tb[r * 4 + 0] * u[c][d][0] + tb[r * 4 + 1] * u[c][d][1] + tb[r * 4 + 2] * u[c][d][2] + tb[r * 4 + 3] * uf[c][d];
-        if (JAC || OUT == 2) {
-          dgc += vl[d] * tb[8 + r * 3 + 1] + vh[d] * tb[14 + r * 3 + 1];
-          if (r) dgc += wl[c][d] * tb[12] + wh[c][d] * tb[18];
-          dgl += tb[r * 4 + 1];
-        }
-      }
-      const double uc = u[c][0][1];
-      double       yv = m.cI * uc + m.cC * conv + m.cL * lap;
-      if (JAC || OUT == 2) {
-        const double dg = m.cI + m.cC * dgc + m.cL * dgl;
+      double yv = m.cI * uc[c] + yacc[c];
+      if (DG) {
+        const double dg = m.cI + dacc[c];
         if (OUT == 2) yv = dg;
-        else yv = yv / dg;
+        else yv = yv * recip(dg);  // PCJacobi: VecReciprocal(diag) once, VecPointwiseMult per apply
       }
-      if (t.own) {
-        if (OUT == 1) y[c * ncell + ((int64_t)k * g.ny + t.j) * g.nx + t.i] = yv;
-        else y[c * cs + idx] = yv;
+      if (own) {
+        if (OUT == 1) y[c * ncell + ((int64_t)k * g.ny + j) * g.nx + i] = yv;
+        else ST(y + c * cs + rb, lo, yv);
         if (DOT) {
           acc[0] += yv;
-          if (o) acc[1] += yv * o[c * cs + idx];
-          acc[2] += uc * yv;
+          acc[1] += yv * oc[c];
+          acc[2] += uc[c] * yv;
           acc[3] += yv * yv;
         }
       }
     }
+    // ---- 4: rotate (this is where the loads of step 2 are waited for)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      uzm[c] = uc[c];
+      uc[c]  = uzp[c];
+      uzp[c] = n_u[c];
+      oc[c]  = n_oc[c];
+    }
+    // the ring of plane k+1 goes straight into the other LDS buffer: nobody reads that one before the next barrier
+    MomLds &Ln = lds[(k + 1) & 1];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      if (ringlane) Ln.u[c][w + 1][lane == 0 ? 0 : 65] = n_rcol_u[c];
+      if (botrow) Ln.u[c][0][lane + 1] = n_rrow_u[c];
+      if (toprow) Ln.u[c][MOM_RY + 1][lane + 1] = n_rrow_u[c];
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      vzl[f] = vzh[f];
+      vzh[f] = n_vz[f];
+      fxl[f] = n_fxl[f];
+      fyl[f] = n_fyl[f];
+      if (lane == 63) Ln.fx[f][w][64] = n_rcol_fx[f];
+      if (toprow) Ln.fy[f][MOM_RY][lane] = n_rrow_fy[f];
+    }
   }
   if (DOT) {
-    block_sum<4>(acc, red);
-    if (threadIdx.x == 0)
 #pragma unroll
-      for (int a = 0; a < 4; ++a) partial[(int64_t)a * pstride + blockIdx.x] = acc[a];
+    for (int a = 0; a < 4; ++a) {
+      const double v = wave_sum(acc[a]);
+      if (lane == 0) red[a * MOM_RY + w] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+      double v = 0.;
+#pragma unroll
+      for (int q = 0; q < MOM_RY; ++q) v += red[threadIdx.x * MOM_RY + q];
+      partial[(int64_t)threadIdx.x * pstride + blockIdx.x] = v;
+    }
   }
 }
 
@@ -241,7 +455,8 @@ struct fl_momentum {
   double     *dg = nullptr;  // diag(A), 3 padded components (valid after set_state)
   double     *vec[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool        have_state = false;
-  int         tiles_x = 1, tiles_y = 1, nchunk = 1, zc = 1, nblocks = 1;
+  int         tiles_x = 1, tiles_y = 1, nchunk = 1, zc = 1, nblocks = 1;  // 64 x 4 x zc tiles of the vector-update kernels
+  int         anchunk = 1, azc = 1, ablocks = 1;                        // 64 x MOM_RY x azc tiles of k_mom_apply
 };
 
 namespace {
@@ -264,7 +479,7 @@ template <bool DOT, bool JAC, int OUT>
 void mom_apply_t(fl_momentum *m, const double *x, double *y, const double *o, const KspScal *s)
 {
   fl_poisson *h = m->p;
-  hipLaunchKernelGGL((k_mom_apply<DOT, JAC, OUT>), dim3(m->nblocks), dim3(256), 0, h->stream, h->g, m->mp, x, y, m->F, (int64_t)h->padlen, o, s, h->partial, h->partial_stride, m->tiles_x, m->nchunk, m->zc);
+  hipLaunchKernelGGL((k_mom_apply<DOT, JAC, OUT>), dim3(m->ablocks), dim3(MOM_NT), 0, h->stream, h->g, m->mp, x, y, m->F, (int64_t)h->padlen, o, s, h->partial, h->partial_stride, m->tiles_x, m->anchunk, m->azc);
 }
 
 template <int OP>
@@ -312,7 +527,17 @@ int mom_init(fl_momentum *m, fl_poisson *h)
     m->nblocks = tiles * m->nchunk;
     if (m->nblocks > MAX_PARTIAL_BLOCKS) return FL_ERR_SUP;
   }
-  FL_CHK(fl_ensure_partials(h, m->nblocks));
+  {
+    const int atiles = m->tiles_x * ((g.ny + MOM_RY - 1) / MOM_RY);
+    int       nc = std::max(1, (2048 + atiles / 2) / atiles);
+    nc         = std::max(1, std::min(std::min(nc, std::max(1, g.nz / 8)), g.nz));
+    if (atiles * nc > MAX_PARTIAL_BLOCKS) nc = std::max(1, MAX_PARTIAL_BLOCKS / atiles);
+    m->azc     = (g.nz + nc - 1) / nc;
+    m->anchunk = (g.nz + m->azc - 1) / m->azc;
+    m->ablocks = atiles * m->anchunk;
+    if (m->ablocks > MAX_PARTIAL_BLOCKS) return FL_ERR_SUP;
+  }
+  FL_CHK(fl_ensure_partials(h, std::max(m->nblocks, m->ablocks)));
   FL_CHK(fl_dev_alloc(h, (void **)&m->F, sizeof(double) * 12 * h->padlen, true));
   FL_CHK(fl_dev_alloc(h, (void **)&m->dg, sizeof(double) * 3 * h->padlen, true));
   return fl_momentum_set_coefficients(m, 1., 0., 0.);  // A = I until the first set_state (also fills diag(A))
@@ -436,7 +661,7 @@ extern "C" int fl_momentum_solve(fl_momentum *m, const double *b_dev, double *x_
   double *R = m->vec[0], *RP = m->vec[1], *P = m->vec[2], *V = m->vec[3], *X = m->vec[4], *S = m->vec[5], *T = m->vec[6];
   const int nhist = opts->maxit + 1;
   FL_CHK(fl_ensure_hist(h, nhist));
-  FL_CHK(fl_ensure_partials(h, m->nblocks));
+  FL_CHK(fl_ensure_partials(h, std::max(m->nblocks, m->ablocks)));
   fl_ksp_opts o = *opts;
   o.remove_nullspace = 0;  // A = I + ... is non-singular
   FL_CHK(fl_ksp_begin(h, &o));
@@ -454,12 +679,12 @@ extern "C" int fl_momentum_solve(fl_momentum *m, const double *b_dev, double *x_
       FL_CHK(mom_ghosts(m, P));
       if (jac) mom_apply_t<true, true, 0>(m, P, V, RP, h->scal);
       else mom_apply_t<true, false, 0>(m, P, V, RP, h->scal);
-      FL_CHK(fl_bcgs_fin_step(h, 1, m->nblocks, 4, nhist));
+      FL_CHK(fl_bcgs_fin_step(h, 1, m->ablocks, 4, nhist));
       mom_pw<1>(m, R, V, nullptr, nullptr, S, nullptr);
       FL_CHK(mom_ghosts(m, S));
       if (jac) mom_apply_t<true, true, 0>(m, S, T, nullptr, h->scal);
       else mom_apply_t<true, false, 0>(m, S, T, nullptr, h->scal);
-      FL_CHK(fl_bcgs_fin_step(h, 3, m->nblocks, 4, nhist));
+      FL_CHK(fl_bcgs_fin_step(h, 3, m->ablocks, 4, nhist));
       mom_pw<2>(m, P, S, T, RP, X, R);
       FL_CHK(fl_bcgs_fin_step(h, 4, m->nblocks, 3, nhist));
     }
@@ -468,4 +693,47 @@ extern "C" int fl_momentum_solve(fl_momentum *m, const double *b_dev, double *x_
   }
   for (int c = 0; c < 3; ++c) launch_unpad_copy(h->stream, h->g, X + (size_t)c * h->padlen, x_dev + (size_t)c * h->ncell, nullptr);
   return fl_ksp_finish(h, &o, stats);
+}
+
+// ------------------------------------------------------------------------------------------------ diagnostics
+// Streaming ceiling of the access mix of k_mom_apply: 15 read streams + 3 write streams, flat, 16 B per lane.
+namespace fl {
+__global__ void __launch_bounds__(256) k_mom_stream(const double *__restrict__ F, const double *__restrict__ x, double *__restrict__ y, int64_t cs, int64_t n2)
+{
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n2; q += (int64_t)gridDim.x * blockDim.x) {
+    double2 a[3] = {{0., 0.}, {0., 0.}, {0., 0.}};
+#pragma unroll
+    for (int f = 0; f < 12; ++f) {
+      const double2 v = reinterpret_cast<const double2 *>(F + f * cs)[q];
+      a[f % 3].x += v.x;
+      a[f % 3].y += v.y;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double2 v = reinterpret_cast<const double2 *>(x + c * cs)[q];
+      a[c].x += v.x;
+      a[c].y += v.y;
+      reinterpret_cast<double2 *>(y + c * cs)[q] = a[c];
+    }
+  }
+}
+}  // namespace fl
+
+extern "C" int fldbg_mom_stream(fl_momentum *m, int reps, int blocks, double *ms_out)
+{
+  fl_poisson *h = m->p;
+  FL_HIP(hipSetDevice(h->device));
+  FL_CHK(mom_vec(m, 6));
+  FL_CHK(mom_vec(m, 7));
+  const int64_t n2 = (int64_t)(h->padlen / 2);
+  auto go = [&]() { hipLaunchKernelGGL(k_mom_stream, dim3(blocks), dim3(256), 0, h->stream, m->F, m->vec[7], m->vec[6], (int64_t)h->padlen, n2); };
+  go();
+  FL_HIP(hipEventRecord(h->ev0, h->stream));
+  for (int r = 0; r < reps; ++r) go();
+  FL_HIP(hipEventRecord(h->ev1, h->stream));
+  FL_HIP(hipStreamSynchronize(h->stream));
+  float ms = 0.f;
+  FL_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  *ms_out = ms / reps;
+  return 0;
 }

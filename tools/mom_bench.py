@@ -48,6 +48,16 @@ def main():
     x, info = M.solve(v, rtol=1e-8, maxit=200)
     out.update(solve_iters=info["iters"], solve_reason=info["reason"], solve_ms=info["seconds"] * 1e3,
                ms_per_iter=info["seconds"] * 1e3 / max(info["iters"], 1))
+    # streaming ceiling of the same access mix (15 reads + 3 writes, flat)
+    import ctypes as C
+    from fluca_amd.capi import lib
+    lib.fldbg_mom_stream.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    for blocks in (2048, 8192):
+        ms = C.c_double()
+        P._pre()
+        lib.fldbg_mom_stream(M.h, 5, blocks, C.byref(ms))
+        P._post()
+        out[f"stream15r3w_ms_{blocks}"] = ms.value
     print(json.dumps(out))
 
 
