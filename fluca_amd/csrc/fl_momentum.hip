@@ -104,7 +104,7 @@ __device__ __forceinline__ void mom_axis(TF T, double um, double uc, double up, 
   }
 }
 
-constexpr int MOM_RY = 4;            // grid rows per block = waves per block
+constexpr int MOM_RY = 8;            // grid rows per block = waves per block
 constexpr int MOM_NT = 64 * MOM_RY;
 
 // LDS image of one plane of a 64 x MOM_RY tile: what a cell needs from its x/y neighbours.
