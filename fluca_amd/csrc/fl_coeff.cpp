@@ -5,6 +5,7 @@
 // On a Cartesian product grid every one of those rows is a sum of three independent 1-D rows, so the
 // whole operator is described by O(M+N+P) numbers per axis.  This file computes them once; the HIP
 // kernels never see a matrix.
+#include <algorithm>
 #include <cmath>
 #include <limits>
 
@@ -328,6 +329,46 @@ int build_axis_momentum(const Axis &a, std::vector<double> &tab)
         }
       }
     }
+  return 0;
+}
+
+// Face-normal velocity interpolation T (ComputeFaceNormalVelocityInterpolationOperator_Private,
+// cnlinearcart3d.c:1934-2140; rows cartdiscret.c:373-423): V_f = w0 v[c0] + w1 v[c0+1] for every face f = 0..n of a
+// grid line (face n of a periodic axis is face 0 and is not stored).  Walls with a VELOCITY / SYMMETRY condition have no
+// row: the value comes from the boundary-condition vector (interprhs) or is zero.
+int build_axis_T(const Axis &a, std::vector<double> &w0, std::vector<double> &w1, std::vector<int> &c0)
+{
+  const int64_t n = a.n;
+  w0.assign((size_t)n + 1, 0.);
+  w1.assign((size_t)n + 1, 0.);
+  c0.assign((size_t)n + 1, 0);
+  for (int64_t f = 0; f <= n; ++f) {
+    if (f == 0 && !a.periodic) {
+      c0[f] = 0;
+      if (a.bc_lo == FL_BC_PRESSURE_OUTLET) {
+        if (n < 2) return FL_ERR_SUP;
+        const double h1 = a.xcc(0) - a.xf[0], h2 = a.xcc(1) - a.xf[0];
+        w0[f] = -(h2 * h2) / ((h1 + h2) * (h1 - h2));
+        w1[f] = (h1 * h1) / ((h1 + h2) * (h1 - h2));
+      } else if (a.bc_lo != FL_BC_VELOCITY && a.bc_lo != FL_BC_SYMMETRY) return FL_ERR_ARG_WRONG;
+    } else if (f == n && !a.periodic) {
+      c0[f] = (int)std::max<int64_t>(n - 2, 0);
+      if (a.bc_hi == FL_BC_PRESSURE_OUTLET) {
+        if (n < 2) return FL_ERR_SUP;
+        // as written in the reference (:1993): the backward extrapolation is handed (centre n-1, face n, centre n) for
+        // (xWW, xW, xw); centre n is the ghost coordinate (face n + h/2 on a uniform grid).  Columns n-2, n-1.
+        const double h1 = a.xcc(n) - a.xf[n], h2 = a.xcc(n) - a.xcc(n - 1);
+        w0[f] = (h1 * h1) / ((h1 + h2) * (h1 - h2));
+        w1[f] = -(h2 * h2) / ((h1 + h2) * (h1 - h2));
+      } else if (a.bc_hi != FL_BC_VELOCITY && a.bc_hi != FL_BC_SYMMETRY) return FL_ERR_ARG_WRONG;
+    } else {
+      const int64_t ff = f == n ? 0 : f;  // periodic: face n == face 0 (its row is never read)
+      const double  xW = a.xcc(ff - 1), xw = a.xf[ff], xP = a.xcc(ff);
+      w0[f] = (xP - xw) / (xP - xW);
+      w1[f] = (xw - xW) / (xP - xW);
+      c0[f] = (int)(f - 1);
+    }
+  }
   return 0;
 }
 

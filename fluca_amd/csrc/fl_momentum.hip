@@ -28,6 +28,12 @@ struct MomP {
   double        cI, cC, cL;
 };
 
+// face-normal interpolation T: per LOCAL face of each axis, V_f = w0 v[c0] + w1 v[c0 + 1] (c0 local, -1 = low ghost)
+struct FaceT {
+  const double *w0[3], *w1[3];
+  const int    *c0[3];
+};
+
 __device__ __forceinline__ double uniform_d(double v)
 {
   // v is wave-uniform: keep it in scalar registers
@@ -441,6 +447,28 @@ __global__ void __launch_bounds__(256) k_pad_copy_ext(GridP g, const double *__r
   }
 }
 
+// V_d = rhs_d + (T v)_d on the owned d-faces (unpadded face array); v: padded component d with valid ghosts
+__global__ void __launch_bounds__(256) k_face_interp(GridP g, FaceT t, int d, const double *__restrict__ vpad, const double *__restrict__ rhs, double *__restrict__ V)
+{
+  const int     ex = d == 0 ? g.fx : g.nx, ey = d == 1 ? g.fy : g.ny, ez = d == 2 ? g.fz : g.nz;
+  const int64_t n = (int64_t)ex * ey * ez;
+  const int64_t str = d == 0 ? 1 : (d == 1 ? (int64_t)g.sx : g.sxy);
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
+    const int     i = (int)(q % ex);
+    const int64_t r = q / ex;
+    const int     j = (int)(r % ey), k = (int)(r / ey);
+    const int     f = d == 0 ? i : (d == 1 ? j : k);
+    const int     c0 = t.c0[d][f];
+    // cell (i,j,k) with the d-th index replaced by c0
+    const int64_t base = g.off0 + (int64_t)k * g.sxy + (int64_t)j * g.sx + i + (int64_t)(c0 - f) * str;
+    const double  w0 = t.w0[d][f], w1 = t.w1[d][f];
+    double        s = rhs ? rhs[q] : 0.;
+    if (w0 != 0.) s += w0 * vpad[base];
+    if (w1 != 0.) s += w1 * vpad[base + str];
+    V[q] = s;
+  }
+}
+
 }  // namespace fl
 
 using namespace fl;
@@ -450,7 +478,10 @@ using namespace fl;
 struct fl_momentum {
   fl_poisson *p = nullptr;
   MomP        mp;
+  FaceT       ft;
   void       *tabs[3] = {nullptr, nullptr, nullptr};
+  void       *ttabs[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  double     *srhs = nullptr;  // Schur right-hand side of fl_abf_apply
   double     *F = nullptr;   // 12 padded face fields: V0[0..2], v0interp[c*3+d] at 3 + c*3 + d
   double     *dg = nullptr;  // diag(A), 3 padded components (valid after set_state)
   double     *vec[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -507,6 +538,27 @@ int mom_init(fl_momentum *m, fl_poisson *h)
     FL_HIP(hipMemcpy(m->tabs[d], loc.data(), sizeof(double) * loc.size(), hipMemcpyHostToDevice));
     m->mp.tab[d] = (const double *)m->tabs[d];
     m->mp.len[d] = len[d];
+    // T rows of the owned faces
+    std::vector<double> w0, w1;
+    std::vector<int>    c0;
+    FL_CHK(build_axis_T(h->ax[d], w0, w1, c0));
+    const int nfl = d == 0 ? g.fx : (d == 1 ? g.fy : g.fz);
+    std::vector<double> l0(nfl), l1(nfl);
+    std::vector<int>    lc(nfl);
+    for (int f = 0; f < nfl; ++f) {
+      l0[f] = w0[(size_t)(lo[d] + f)];
+      l1[f] = w1[(size_t)(lo[d] + f)];
+      lc[f] = (int)(c0[(size_t)(lo[d] + f)] - lo[d]);
+    }
+    const void  *src[3] = {l0.data(), l1.data(), lc.data()};
+    const size_t by[3] = {sizeof(double) * nfl, sizeof(double) * nfl, sizeof(int) * nfl};
+    for (int a = 0; a < 3; ++a) {
+      FL_HIP(hipMalloc(&m->ttabs[d * 3 + a], std::max<size_t>(by[a], 8)));
+      FL_HIP(hipMemcpy(m->ttabs[d * 3 + a], src[a], by[a], hipMemcpyHostToDevice));
+    }
+    m->ft.w0[d] = (const double *)m->ttabs[d * 3 + 0];
+    m->ft.w1[d] = (const double *)m->ttabs[d * 3 + 1];
+    m->ft.c0[d] = (const int *)m->ttabs[d * 3 + 2];
   }
   m->mp.cI = 1.;
   m->mp.cC = 0.;
@@ -570,6 +622,9 @@ extern "C" int fl_momentum_destroy(fl_momentum *m)
   }
   for (void *t : m->tabs)
     if (t) (void)hipFree(t);
+  for (void *t : m->ttabs)
+    if (t) (void)hipFree(t);
+  if (m->srhs) (void)hipFree(m->srhs);
   if (m->F) (void)hipFree(m->F);
   if (m->dg) (void)hipFree(m->dg);
   for (double *v : m->vec)
@@ -693,6 +748,43 @@ extern "C" int fl_momentum_solve(fl_momentum *m, const double *b_dev, double *x_
   }
   for (int c = 0; c < 3; ++c) launch_unpad_copy(h->stream, h->g, X + (size_t)c * h->padlen, x_dev + (size_t)c * h->ncell, nullptr);
   return fl_ksp_finish(h, &o, stats);
+}
+
+// V* = interprhs - (-T) v*   (MatMult(negT) + VecAYPX, abfpc.c:73-74)
+extern "C" int fl_momentum_face_interp(fl_momentum *m, const double *v_dev, const double *const rhs_dev[3], double *const V_dev[3])
+{
+  if (!m || !v_dev || !V_dev) return FL_ERR_ARG_NULL;
+  fl_poisson *h = m->p;
+  FL_HIP(hipSetDevice(h->device));
+  FL_CHK(mom_vec(m, 7));
+  for (int c = 0; c < 3; ++c) launch_pad_copy(h->stream, h->g, v_dev + (size_t)c * h->ncell, m->vec[7] + (size_t)c * h->padlen);
+  FL_CHK(mom_ghosts(m, m->vec[7]));
+  for (int d = 0; d < 3; ++d) {
+    if (!V_dev[d]) return FL_ERR_ARG_NULL;
+    const int64_t n = h->nface[d];
+    const int     nb = (int)std::min<int64_t>((n + 255) / 256, 8192);
+    hipLaunchKernelGGL(k_face_interp, dim3(std::max(nb, 1)), dim3(256), 0, h->stream, h->g, m->ft, d, m->vec[7] + (size_t)d * h->padlen, rhs_dev ? rhs_dev[d] : nullptr, V_dev[d]);
+  }
+  FL_HIP(hipGetLastError());
+  return FL_SUCCESS;
+}
+
+// PCApply_ABF (abfpc.c:48-111) with upperainv = schurainv = ID, start to finish on the device
+extern "C" int fl_abf_apply(fl_momentum *m, const fl_ksp_opts *momentum_opts, const fl_ksp_opts *schur_opts, const double *momrhs_dev, const double *const interprhs_dev[3], const double *contrhs_dev,
+                            double *v_dev, double *const V_dev[3], double *p_dev, fl_ksp_stats stats[2])
+{
+  if (!m || !momentum_opts || !schur_opts || !momrhs_dev || !v_dev || !V_dev || !p_dev || !stats) return FL_ERR_ARG_NULL;
+  fl_poisson *h = m->p;
+  FL_HIP(hipSetDevice(h->device));
+  if (!m->srhs) FL_CHK(fl_dev_alloc(h, (void **)&m->srhs, sizeof(double) * (size_t)h->ncell, true));
+  /* stage 1: the lower-triangular factor */
+  FL_CHK(fl_momentum_solve(m, momrhs_dev, v_dev, momentum_opts, &stats[0]));                        /* :72     v* = A^-1 momrhs */
+  FL_CHK(fl_momentum_face_interp(m, v_dev, interprhs_dev, V_dev));                                  /* :73-74  V* = interprhs + T v* */
+  FL_CHK(fl_poisson_rhs(h, V_dev[0], V_dev[1], V_dev[2], contrhs_dev, m->srhs));                    /* :75-76  Srhs = contrhs - D V* */
+  FL_CHK(fl_poisson_solve(h, m->srhs, p_dev, schur_opts, &stats[1]));                               /* :77     p = S^-1 Srhs */
+  /* stage 2: the upper-triangular factor; (-T)(Gp) - (-R)p == -kappa Gst p, see DESIGN.md section 1 */
+  const size_t N = (size_t)h->ncell;
+  return fl_poisson_project(h, p_dev, v_dev, v_dev + N, v_dev + 2 * N, V_dev[0], V_dev[1], V_dev[2]);   /* :80-101 */
 }
 
 // ------------------------------------------------------------------------------------------------ diagnostics

@@ -412,8 +412,10 @@ struct _p_NS {
   Mesh                 mesh;
   NSBoundaryCondition *bcs;
   int                  nb, device, setupcalled;
-  fl_poisson          *poisson; /* plays PC_ABF's kspS + S */
-  fl_ksp_opts          schur;   /* -ns_abf_schur_* */
+  fl_poisson          *poisson;  /* plays PC_ABF's kspS + S */
+  fl_momentum         *momentum; /* plays PC_ABF's kspA + A (created by the first NSSetPreviousState) */
+  fl_ksp_opts          schur;    /* -ns_abf_schur_* */
+  fl_ksp_opts          mom;      /* -ns_abf_momentum_* */
   void                *data;
 };
 
@@ -436,6 +438,10 @@ FlErrorCode NSCreate(NS *ns)
   n->dt  = 0.;
   n->max_steps = -1;
   fl_ksp_opts_default(&n->schur);
+  fl_ksp_opts_default(&n->mom);
+  n->mom.type = FL_KSP_BCGS; /* PETSc's own default for kspA is gmres + ilu: neither has a matrix-free form here */
+  n->mom.pc   = FL_PC_JACOBI;
+  n->mom.remove_nullspace = 0;
   *ns = n;
   return 0;
 }
@@ -559,6 +565,18 @@ FlErrorCode NSSetFromOptions(NS ns, int argc, char **argv)
   if ((s = opt_find(argc, argv, "-ns_abf_schur_ksp_chebyshev_eigenvalues"))) {
     if (sscanf(s, "%lf,%lf", &ns->schur.emin, &ns->schur.emax) != 2) return E_ARG_WRONG;
   }
+  /* sub-KSP of the momentum block: prefix ns_ + abf_momentum_ (abfpc.c:205) */
+  if ((s = opt_find(argc, argv, "-ns_abf_momentum_ksp_type")))
+    if (strcmp(s, "bcgs")) return !strcmp(s, "gmres") || !strcmp(s, "cg") || !strcmp(s, "fgmres") ? E_SUP : E_ARG_UNKNOWN_TYPE;
+  if ((s = opt_find(argc, argv, "-ns_abf_momentum_pc_type"))) {
+    if (!strcmp(s, "jacobi")) ns->mom.pc = FL_PC_JACOBI;
+    else if (!strcmp(s, "none")) ns->mom.pc = FL_PC_NONE;
+    else return !strcmp(s, "ilu") || !strcmp(s, "bjacobi") ? E_SUP : E_ARG_UNKNOWN_TYPE;
+  }
+  if (opt_real(argc, argv, "-ns_abf_momentum_ksp_rtol", &v)) ns->mom.rtol = v;
+  if (opt_real(argc, argv, "-ns_abf_momentum_ksp_atol", &v)) ns->mom.atol = v;
+  if (opt_real(argc, argv, "-ns_abf_momentum_ksp_divtol", &v)) ns->mom.dtol = v;
+  if (opt_int64(argc, argv, "-ns_abf_momentum_ksp_max_it", &iv)) ns->mom.maxit = (int)iv;
   if ((s = opt_find(argc, argv, "-ns_pc_abf_schur_ainv_type"))) /* abfpc.c:246: only ID is built */
     if (strcmp(s, "ID") && strcmp(s, "id")) return E_SUP;
   return ns->ops->setfromoptions ? ns->ops->setfromoptions(ns, argc, argv) : 0;
@@ -622,6 +640,7 @@ FlErrorCode NSDestroy(NS *ns)
 {
   if (!ns || !*ns) return 0;
   if ((*ns)->ops->destroy) (*ns)->ops->destroy(*ns);
+  if ((*ns)->momentum) fl_momentum_destroy((*ns)->momentum);
   if ((*ns)->poisson) fl_poisson_destroy((*ns)->poisson);
   free((*ns)->bcs);
   free(*ns);
@@ -671,6 +690,42 @@ FlErrorCode NSPressureCorrection(NS ns, double *vstar[3], double *Vstar[3], cons
   if (!rc) rc = fl_poisson_project(ns->poisson, dp, vstar ? vstar[0] : NULL, vstar ? vstar[1] : NULL, vstar ? vstar[2] : NULL, Vstar[0], Vstar[1], Vstar[2]); /* abfpc.c:80-101 */
   if (!rc) rc = fl_poisson_synchronize(ns->poisson);
   fl_free(ns->device, srhs);
+  return rc ? -rc : 0;
+}
+
+FlErrorCode NSGetMomentumKSPOptions(NS ns, fl_ksp_opts **opts)
+{
+  if (!ns || !opts) return E_ARG_NULL;
+  *opts = &ns->mom;
+  return 0;
+}
+
+/* The A block of NSFormJacobian (cnlinearcart3d.c:2930-2941): A = I + dt C(V0, v0interp) - (mu dt / 2 rho) L */
+FlErrorCode NSSetPreviousState(NS ns, const double *const V0[3], const double *const v0interp[9])
+{
+  if (!ns || !V0 || !v0interp) return E_ARG_NULL;
+  if (!ns->setupcalled) return E_ARG_WRONGSTATE;
+  if (!ns->momentum) FLABI(fl_momentum_create(ns->poisson, &ns->momentum));
+  FLABI(fl_momentum_set_state(ns->momentum, ns->dt, ns->rho, ns->mu, V0, v0interp));
+  return 0;
+}
+
+FlErrorCode NSGetMomentum(NS ns, fl_momentum **momentum)
+{
+  if (!ns || !momentum) return E_ARG_NULL;
+  if (!ns->momentum) return E_ARG_WRONGSTATE;
+  *momentum = ns->momentum;
+  return 0;
+}
+
+/* PCApply_ABF, abfpc.c:48-111 */
+FlErrorCode NSApplyPreconditioner(NS ns, const double *momrhs, const double *const interprhs[3], const double *contrhs, double *v, double *const V[3], double *p, fl_ksp_stats stats[2])
+{
+  if (!ns || !momrhs || !v || !V || !p) return E_ARG_NULL;
+  if (!ns->setupcalled || !ns->momentum) return E_ARG_WRONGSTATE; /* "NSSetPreviousState first": A does not exist yet */
+  fl_ksp_stats local[2];
+  int          rc = fl_abf_apply(ns->momentum, &ns->mom, &ns->schur, momrhs, interprhs, contrhs, v, V, p, stats ? stats : local);
+  if (!rc) rc = fl_poisson_synchronize(ns->poisson);
   return rc ? -rc : 0;
 }
 

@@ -3,6 +3,7 @@
 `Poisson` plays the role of PC_ABF's Schur-complement half (fluca/src/ns/utils/abfpc/abfpc.c): set-up builds S from the
 grid + NS boundary conditions, `.solve` is KSPSolve(kspS), `.rhs` / `.project` are the MatMult chains around it.
 """
+import atexit
 import ctypes as C
 import weakref
 
@@ -11,6 +12,19 @@ import torch
 
 from . import capi
 from .capi import check, lib
+
+
+_LIVE = weakref.WeakSet()
+
+
+@atexit.register
+def _close_all():
+    # handles kept alive until interpreter shutdown (e.g. by a traceback) must go before the HIP runtime does
+    for h in list(_LIVE):
+        try:
+            h.close()
+        except Exception:
+            pass
 
 
 def _ptr(t):
@@ -65,6 +79,7 @@ class Poisson:
         self.ncell, self.nface = sz[0], (sz[1], sz[2], sz[3])
         self._cb = None
         self._children = []   # handles that borrow this one (Momentum): closed first
+        _LIVE.add(self)
         # the library works on its own HIP stream; order it against torch's current stream around every call
         self.stream = torch.cuda.Stream(device=self.device)
         self._ext_stream = False
@@ -307,3 +322,29 @@ class Momentum:
             o.history = None
             o.nhistory = 0
         return x, info
+
+    def face_interp(self, v, rhs=(None, None, None)):
+        """V_d = rhs_d + (T v)_d (abfpc.c:73-74)."""
+        V = [self.p.empty(self.p.nface[d]) for d in range(3)]
+        r = (C.c_void_p * 3)(*[None if t is None else t.data_ptr() for t in rhs])
+        o = (C.c_void_p * 3)(*[t.data_ptr() for t in V])
+        self.p._pre()
+        check(lib.fl_momentum_face_interp(self.h, _ptr(v), r, o), "fl_momentum_face_interp")
+        self.p._post()
+        return V
+
+    def abf_apply(self, momrhs, interprhs=(None, None, None), contrhs=None, momentum=None, schur=None):
+        """PCApply_ABF (abfpc.c:48-111): returns v (3*ncell), V (3 face tensors), p, [stats kspA, stats kspS]."""
+        mo = (momentum or KspOptions(type=capi.KSP_BCGS)).o
+        so = (schur or KspOptions()).o
+        v = self.p.empty(3 * self.p.ncell)
+        pr = self.p.empty()
+        V = [self.p.empty(self.p.nface[d]) for d in range(3)]
+        r = (C.c_void_p * 3)(*[None if t is None else t.data_ptr() for t in interprhs])
+        o = (C.c_void_p * 3)(*[t.data_ptr() for t in V])
+        st = (capi.fl_ksp_stats * 2)()
+        self.p._pre()
+        check(lib.fl_abf_apply(self.h, C.byref(mo), C.byref(so), _ptr(momrhs), r, _ptr(contrhs), _ptr(v), o, _ptr(pr), st), "fl_abf_apply")
+        self.p._post()
+        info = [dict(iters=s.iters, reason=s.reason, rnorm0=s.rnorm0, rnorm=s.rnorm, seconds=s.seconds) for s in st]
+        return v, V, pr, info

@@ -20,6 +20,7 @@
  *   fl_pressure_update   p = phalf + 1.5 dp ; phalf += dp (first step p0 + 2dp)    cnlinearcart3d.c:2846-2854
  *   fl_ksp_opts          -ns_abf_schur_ksp_* / -ns_abf_schur_pc_type options       abfpc.c:42,206,248-249
  *   fl_bc                NSBoundaryConditionType                                   fluca/include/flucansbc.h:5-11
+ *   fl_abf_apply         PCApply_ABF, both stages                                          abfpc.c:48-111
  *   fl_momentum_*        A = I + dt C - (mu dt / 2 rho) L and KSPSolve(kspA)                   cnlinearcart3d.c:425-632,873-1294,2930-2941; abfpc.c:72
  *   fl_ibm_*             no reference counterpart (THEORY_GUIDE.md:130-132 is a TODO); specified in DESIGN.md
  *
@@ -206,6 +207,19 @@ int fl_momentum_diagonal(fl_momentum *m, double *d_dev);                   /* Ma
 /* KSPSolve(abf->kspA, momrhs, vstar), abfpc.c:72: opts->type must be FL_KSP_BCGS, pc JACOBI or NONE, preconditioned norm,
  * zero initial guess; remove_nullspace is ignored (A is non-singular). */
 int fl_momentum_solve(fl_momentum *m, const double *b_dev, double *x_dev, const fl_ksp_opts *opts, fl_ksp_stats *stats);
+/* V_d = rhs_d + (T v)_d on the d-faces: MatMult(abf->negT, vstar, Vstar); VecAYPX(Vstar, -1, interprhs), abfpc.c:73-74.
+ * T = ComputeFaceNormalVelocityInterpolationOperator_Private, cnlinearcart3d.c:1934-2140.  rhs_dev (or any entry) may
+ * be NULL = 0.  A VELOCITY / SYMMETRY wall face has no T row: it receives rhs alone (the boundary-condition vector). */
+int fl_momentum_face_interp(fl_momentum *m, const double *v_dev, const double *const rhs_dev[3], double *const V_dev[3]);
+
+/* ---- the whole preconditioner application ---------------------------------------------------- */
+/* PCApply_ABF, abfpc.c:48-111, with the reference's default upperainv = schurainv = ID (abfpc.c:328-329):
+ *   v* = A^-1 momrhs ; V* = interprhs + T v* ; p = S^-1 (contrhs - D V*) ; v = v* - kappa G p ; V = V* - kappa Gst p
+ * v_dev (3*cells, component-major), V_dev[3] (faces) and p_dev (cells) are outputs; interprhs_dev / contrhs_dev may be
+ * NULL = 0.  stats[0] = KSPSolve(kspA), stats[1] = KSPSolve(kspS).  A non-converged inner solve is reported in stats,
+ * not as an error (PETSc's behaviour without -ksp_error_if_not_converged). */
+int fl_abf_apply(fl_momentum *m, const fl_ksp_opts *momentum_opts, const fl_ksp_opts *schur_opts, const double *momrhs_dev, const double *const interprhs_dev[3], const double *contrhs_dev, double *v_dev,
+                 double *const V_dev[3], double *p_dev, fl_ksp_stats stats[2]);
 
 /* ---- immersed boundary (build-defined; no reference function) -------------------------------- */
 typedef enum { FL_DELTA_PESKIN4 = 0, FL_DELTA_ROMA3 = 1 } fl_delta_kind;

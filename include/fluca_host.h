@@ -13,6 +13,7 @@
  *   struct _NSOps (setfromoptions, setup, step, destroy)                                                fluca/include/fluca/private/nsimpl.h:21-31
  *   NSBoundaryCondition, NSBoundaryConditionFunction                                                    fluca/include/flucansbc.h:5-22
  *   PCApply_ABF without the momentum solve (NSPressureCorrection)                                       fluca/src/ns/utils/abfpc/abfpc.c:73-101
+ *   PCApply_ABF in full (NSApplyPreconditioner) and the A block of NSFormJacobian (NSSetPreviousState)  abfpc.c:48-111, cnlinearcart3d.c:2930-2941
  *   pressure update of NSStep_CNLinear_Cart3d_Internal (NSUpdatePressure)                               fluca/src/ns/impl/linearcn/cnlinearcart3d.c:2846-2854
  *   options -cart_grid_x.. -cart_ranks_x.. -cart_boundary_type_x.. -ns_density -ns_viscosity
  *           -ns_time_step_size -ns_max_steps -ns_abf_schur_ksp_{type,rtol,atol,max_it,norm_type} -ns_abf_schur_pc_type   cart.c:21-43, nsopts.c:177-198, abfpc.c:206,248-249
@@ -114,6 +115,17 @@ FlErrorCode NSGetLocalSizes(NS ns, int64_t out[4]);
 /* PCApply_ABF minus KSPSolve(kspA): given the intermediate velocities v* (cells, any may be NULL) and V* (faces) on the
  * device, Srhs = contrhs - D V*, dp = S^-1 Srhs, v = v* - G dp, V = V* - Gst dp  (abfpc.c:73-101, Ainv = ID) */
 FlErrorCode NSPressureCorrection(NS ns, double *vstar_dev[3], double *Vstar_dev[3], const double *contrhs_dev, double *dp_dev, fl_ksp_stats *stats);
+/* The A block of NSFormJacobian (cnlinearcart3d.c:2930-2941): hands over sol0's face-normal velocity V0 (3 face arrays)
+ * and cnl->v0interp (9 face arrays, component c on the faces of axis d at [c*3+d]); A = I + dt C - (mu dt / 2 rho) L is
+ * applied matrix-free from then on.  Call once per time step, before NSApplyPreconditioner. */
+FlErrorCode NSSetPreviousState(NS ns, const double *const V0_dev[3], const double *const v0interp_dev[9]);
+/* the whole PCApply_ABF (abfpc.c:48-111): v* = A^-1 momrhs, V* = interprhs + T v*, p = S^-1(contrhs - D V*),
+ * v = v* - G p, V = V* - Gst p.  v: 3*cells component-major.  stats[0] = kspA, stats[1] = kspS (may be NULL).
+ * Options: -ns_abf_momentum_ksp_type bcgs (gmres, PETSc's default, is not built: PETSC_ERR_SUP),
+ * -ns_abf_momentum_pc_type jacobi|none, -ns_abf_momentum_ksp_{rtol,atol,divtol,max_it}. */
+FlErrorCode NSApplyPreconditioner(NS ns, const double *momrhs_dev, const double *const interprhs_dev[3], const double *contrhs_dev, double *v_dev, double *const V_dev[3], double *p_dev, fl_ksp_stats stats[2]);
+FlErrorCode NSGetMomentumKSPOptions(NS ns, fl_ksp_opts **opts);
+FlErrorCode NSGetMomentum(NS ns, fl_momentum **momentum);
 /* p, phalf update of the time step, then ++step, t += dt (cnlinearcart3d.c:2846-2854, nsbasic.c:288-291) */
 FlErrorCode NSUpdatePressure(NS ns, const double *dp_dev, const double *p0_dev, double *phalf_dev, double *p_dev);
 /* Gst boundary vector: evaluates the PRESSURE_OUTLET callbacks at the boundary face centres at time t (host), writes

@@ -1227,3 +1227,80 @@ fo_csr *fo_assemble_momentum(const fo_grid *g, double cI, double cC, double cL, 
   A->nnz             = nnz;
   return A;
 }
+
+/* ================================================================================================
+ * Face-normal velocity interpolation  T  (cell-centred v_d -> d-faces), the remaining operator of PCApply_ABF:
+ *   V* = interprhs - (-T) v*          abfpc.c:73-74
+ *   ComputeFaceNormalVelocityInterpolationOperator_Private   cnlinearcart3d.c:1934-2140
+ *   rows: NSComputeLinearInterpolation_Cart / ...ForwardExtrapolationNeumannCond / ...BackwardExtrapolationNeumannCond
+ *         cartdiscret.c:373-423
+ * ================================================================================================ */
+
+/* One row of T along axis d at face f (0..n, or 0..n-1 when periodic): columns are UNWRAPPED cell indices.
+ * Returns ncols (0: VELOCITY / SYMMETRY wall, the value comes from the boundary-condition vector or is zero). */
+int fo_T_row_1d(const fo_grid *g, int d, int f, int col[2], double v[2])
+{
+  const double *xf = g->xf[d], *xc = g->xc[d];
+  int           n = g->n[d];
+  double        h1, h2;
+  if (f == 0 && !g->periodic[d]) {
+    if (g->bc[2 * d] != FO_BC_PRESSURE_OUTLET) return (g->bc[2 * d] == FO_BC_VELOCITY || g->bc[2 * d] == FO_BC_SYMMETRY) ? 0 : -1;
+    /* NSComputeLinearForwardExtrapolationNeumannCond_Cart(xw = face 0, xP = centre 0, xE = centre 1), :1974 */
+    h1 = xc[0] - xf[0];
+    h2 = xc[1] - xf[0];
+    v[0] = -(h2 * h2) / ((h1 + h2) * (h1 - h2));
+    v[1] = (h1 * h1) / ((h1 + h2) * (h1 - h2));
+    col[0] = 0; col[1] = 1;
+    return 2;
+  }
+  if (f == n && !g->periodic[d]) {
+    if (g->bc[2 * d + 1] != FO_BC_PRESSURE_OUTLET) return (g->bc[2 * d + 1] == FO_BC_VELOCITY || g->bc[2 * d + 1] == FO_BC_SYMMETRY) ? 0 : -1;
+    /* As written at :1993: NSComputeLinearBackwardExtrapolationNeumannCond_Cart(xWW, xW, xw) is handed
+     * (centre n-1, face n, centre n) -- centre n is the ghost coordinate DMStagSetUniformCoordinatesProduct leaves
+     * there (face n + h/2 on a uniform grid; here g->xc[n]) -- with columns n-2, n-1. */
+    h1 = xc[n] - xf[n];
+    h2 = xc[n] - xc[n - 1];
+    v[0] = (h1 * h1) / ((h1 + h2) * (h1 - h2));
+    v[1] = -(h2 * h2) / ((h1 + h2) * (h1 - h2));
+    col[0] = n - 2; col[1] = n - 1;
+    return 2;
+  }
+  /* NSComputeLinearInterpolation_Cart(xW = centre f-1, xw = face f, xP = centre f), :2005 (interior and periodic) */
+  v[0]   = (xc[f] - xf[f]) / (xc[f] - xc[f - 1]);
+  v[1]   = (xf[f] - xc[f - 1]) / (xc[f] - xc[f - 1]);
+  col[0] = f - 1;
+  col[1] = f;
+  return 2;
+}
+
+/* V_d = rhs_d + T v_d on every face  (v component-major: v[d*ncell + cell]; rhs may be NULL == 0) */
+int fo_apply_T(const fo_grid *g, const double *v, const double *rx, const double *ry, const double *rz, double *Vx, double *Vy, double *Vz)
+{
+  const double *R[3] = {rx, ry, rz};
+  double       *V[3] = {Vx, Vy, Vz};
+  int           err = 0;
+  for (int d = 0; d < 3; ++d) {
+    int nfz = d == 2 ? g->nf[2] : g->n[2], nfy = d == 1 ? g->nf[1] : g->n[1], nfx = d == 0 ? g->nf[0] : g->n[0];
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < nfz; ++k)
+      for (int j = 0; j < nfy; ++j)
+        for (int i = 0; i < nfx; ++i) {
+          int     fi[3] = {i, j, k}, col[2], nc;
+          double  w[2];
+          int64_t q = face_index(g, d, i, j, k);
+          double  s = R[d] ? R[d][q] : 0.;
+          nc = fo_T_row_1d(g, d, fi[d], col, w);
+          if (nc < 0) {
+            err = 1;
+            continue;
+          }
+          for (int c = 0; c < nc; ++c) {
+            int cc[3] = {i, j, k};
+            cc[d]     = wrap(col[c], g->n[d]);
+            s += w[c] * v[(int64_t)d * g->ncell + cell_index(g, cc[0], cc[1], cc[2])];
+          }
+          V[d][q] = s;
+        }
+  }
+  return err;
+}

@@ -87,6 +87,10 @@ def lib():
         L.fo_conv_row_1d.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(Row1d)]
         L.fo_assemble_momentum.restype = C.c_void_p
         L.fo_assemble_momentum.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+        L.fo_T_row_1d.restype = C.c_int
+        L.fo_T_row_1d.argtypes = [C.c_void_p, C.c_int, C.c_int, ip3, C.POINTER(C.c_double)]
+        L.fo_apply_T.restype = C.c_int
+        L.fo_apply_T.argtypes = [C.c_void_p, _dp, C.c_void_p, C.c_void_p, C.c_void_p, _dp, _dp, _dp]
         L.fo_ibm_phi.restype = C.c_double
         L.fo_ibm_phi.argtypes = [C.c_int, C.c_double]
         _LIB = L
@@ -155,6 +159,24 @@ class Grid:
         v = (C.c_double * 2)()
         lib().fo_div_row_1d(self.h, d, i, col, v)
         return [(col[0], v[0]), (col[1], v[1])]
+
+    def T_row(self, d, f):
+        """[(cell, weight)] of the face-normal velocity interpolation at face f of axis d (cnlinearcart3d.c:1934-2140)."""
+        col = (C.c_int * 2)()
+        v = (C.c_double * 2)()
+        nc = lib().fo_T_row_1d(self.h, d, f, col, v)
+        if nc < 0:
+            raise ValueError("unsupported BC")
+        return [(col[i], v[i]) for i in range(nc)]
+
+    def apply_T(self, v, rhs=(None, None, None)):
+        """V_d = rhs_d + T v_d: the face-normal velocity of stage 1 of PCApply_ABF (abfpc.c:73-74)."""
+        V = [np.empty(self.nface[d]) for d in range(3)]
+        keep = [None if r is None else np.ascontiguousarray(r, dtype=np.float64) for r in rhs]
+        ptr = [None if r is None else r.ctypes.data_as(C.c_void_p) for r in keep]
+        if lib().fo_apply_T(self.h, np.ascontiguousarray(v, dtype=np.float64), *ptr, *V):
+            raise ValueError("unsupported BC in T")
+        return V
 
     def lap_row(self, d, i, c):
         """[(offset, coeff)] of one axis' second-derivative row for component c (cnlinearcart3d.c:466-632)."""

@@ -232,3 +232,71 @@ def test_c_driver_runs_without_python(H):
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "1 NS dt 0.001 time 0.001" in out.stdout and "reason 2" in out.stdout
+
+
+def test_momentum_options_and_state_checks(H):
+    """-ns_abf_momentum_* (abfpc.c:205): what is built is accepted, PETSc's own defaults are refused as unsupported."""
+    mesh = cavity_mesh(H, ("-cart_grid_x", 8, "-cart_grid_y", 8, "-cart_grid_z", 8))
+    ns = P()
+    assert H.lib.NSCreate(C.byref(ns)) == 0 and H.lib.NSSetMesh(ns, mesh) == 0
+    argc, av = H.argv("-ns_time_step_size", 1e-3, "-ns_abf_momentum_ksp_type", "bcgs", "-ns_abf_momentum_pc_type", "none", "-ns_abf_momentum_ksp_rtol", 1e-9, "-ns_abf_momentum_ksp_max_it", 77)
+    assert H.lib.NSSetFromOptions(ns, argc, av) == 0
+    o = C.POINTER(H.capi.fl_ksp_opts)()
+    assert H.lib.NSGetMomentumKSPOptions(ns, C.byref(o)) == 0
+    assert (o.contents.type, o.contents.pc, o.contents.rtol, o.contents.maxit) == (H.capi.KSP_BCGS, 0, 1e-9, 77)
+    for bad, rc in (("gmres", 56), ("nonsense", 86)):          # PETSC_ERR_SUP, PETSC_ERR_ARG_UNKNOWN_TYPE
+        argc, av = H.argv("-ns_abf_momentum_ksp_type", bad)
+        assert H.lib.NSSetFromOptions(ns, argc, av) == rc
+    argc, av = H.argv("-ns_abf_momentum_pc_type", "ilu")
+    assert H.lib.NSSetFromOptions(ns, argc, av) == 56
+    # before NSSetUp / NSSetPreviousState there is no A
+    three = (C.c_void_p * 3)()
+    assert H.lib.NSApplyPreconditioner(ns, C.c_void_p(8), three, None, C.c_void_p(8), three, C.c_void_p(8), None) == 73   # PETSC_ERR_ARG_WRONGSTATE
+    assert H.lib.NSDestroy(C.byref(ns)) == 0 and H.lib.MeshDestroy(C.byref(mesh)) == 0
+
+
+@pytest.mark.gpu
+def test_full_pcapply_abf_through_the_mirror(H):
+    """NSSetPreviousState + NSApplyPreconditioner == PCApply_ABF (abfpc.c:48-111) composed from the oracle."""
+    import torch
+    from oracle import fluca_oracle as fo
+    n = (24, 16, 12)
+    mesh = cavity_mesh(H, ("-cart_grid_x", n[0], "-cart_grid_y", n[1], "-cart_grid_z", n[2]))
+    ns = P()
+    assert H.lib.NSCreate(C.byref(ns)) == 0 and H.lib.NSSetType(ns, b"cnlinear") == 0 and H.lib.NSSetMesh(ns, mesh) == 0
+    rho, mu, dt = 1.3, 0.02, 2e-3
+    assert H.lib.NSSetDensity(ns, rho) == 0 and H.lib.NSSetViscosity(ns, mu) == 0
+    set_cavity_bcs(H, ns, mesh)
+    argc, av = H.argv("-ns_time_step_size", dt, "-ns_abf_schur_ksp_rtol", 1e-10, "-ns_abf_momentum_ksp_rtol", 1e-11)
+    assert H.lib.NSSetFromOptions(ns, argc, av) == 0 and H.lib.NSSetUp(ns) == 0
+    bc = [fo.BC_VELOCITY] * 4 + [fo.BC_SYMMETRY, fo.BC_VELOCITY]
+    g = fo.Grid.uniform(n, [(0, 1), (0, 1), (0, 0.5)], bc, dt / rho)
+    rng = np.random.default_rng(12)
+    V0 = [rng.standard_normal(g.nface[d]) for d in range(3)]
+    W = [rng.standard_normal(g.nface[d]) for c in range(3) for d in range(3)]
+    momrhs = rng.standard_normal(3 * g.ncell)
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a), device="cuda")
+    arr = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    V0d, Wd, md = [dev(a) for a in V0], [dev(a) for a in W], dev(momrhs)
+    v = torch.zeros(3 * g.ncell, dtype=torch.float64, device="cuda")
+    p = torch.zeros(g.ncell, dtype=torch.float64, device="cuda")
+    Vd = [torch.zeros(g.nface[d], dtype=torch.float64, device="cuda") for d in range(3)]
+    torch.cuda.synchronize()
+    assert H.lib.NSSetPreviousState(ns, arr(V0d), arr(Wd)) == 0
+    st = (H.capi.fl_ksp_stats * 2)()
+    assert H.lib.NSApplyPreconditioner(ns, C.c_void_p(md.data_ptr()), None, None, C.c_void_p(v.data_ptr()), arr(Vd), C.c_void_p(p.data_ptr()), st) == 0
+    assert st[0].reason == 2 and st[1].reason == 2
+    A = g.assemble_momentum(1.0, dt, -0.5 * mu * dt / rho, V0, W)
+    vs, i0 = A.solve(momrhs, ksp=fo.KSP_BCGS, pc=fo.PC_JACOBI, nullspace=False, rtol=1e-11, maxit=10000)
+    Vs = g.apply_T(vs)
+    S = g.assemble_S()
+    po, i1 = S.solve(g.rhs(*Vs), rtol=1e-10)
+    assert abs(st[0].iters - i0["iters"]) <= 2 and abs(st[1].iters - i1["iters"]) <= max(3, i1["iters"] // 20)
+    pg = p.cpu().numpy()
+    assert np.linalg.norm((pg - pg.mean()) - (po - po.mean())) <= 1e-6 * np.linalg.norm(po - po.mean())
+    v_ref = vs - np.concatenate(g.apply_G(po))
+    assert np.linalg.norm(v.cpu().numpy() - v_ref) <= 1e-7 * np.linalg.norm(v_ref)
+    Gst = g.apply_gst(po)
+    for d in range(3):
+        assert np.linalg.norm(Vd[d].cpu().numpy() - (Vs[d] - Gst[d])) <= 1e-7 * np.linalg.norm(Vs[d])
+    assert H.lib.NSDestroy(C.byref(ns)) == 0 and H.lib.MeshDestroy(C.byref(mesh)) == 0

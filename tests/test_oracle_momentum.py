@@ -166,3 +166,28 @@ def test_momentum_bcgs_solve_cpu():
     x, info = A.solve(b, ksp=fo.KSP_BCGS, pc=fo.PC_JACOBI, nullspace=False, rtol=1e-10, maxit=200)
     assert info["reason"] > 0
     assert np.linalg.norm(b - A.mult(x)) <= 1e-8 * np.linalg.norm(b)
+
+
+def test_T_rows():
+    """Face-normal interpolation (cnlinearcart3d.c:1934-2140): linear interpolation inside, nothing on VELOCITY /
+    SYMMETRY walls, zero-gradient extrapolation at outlets -- the high-side row as the reference writes it."""
+    n = (8, 6, 5)
+    g = fo.Grid.uniform(n, UNIT, [O, O, V, SYM, PER, PER])
+    assert g.T_row(0, 3) == [(2, 0.5), (3, 0.5)]
+    assert g.T_row(1, 0) == [] and g.T_row(1, n[1]) == []
+    lo, hi = g.T_row(0, 0), g.T_row(0, n[0])
+    assert [c for c, _ in lo] == [0, 1] and [c for c, _ in hi] == [n[0] - 2, n[0] - 1]
+    assert lo[0][1] == pytest.approx(9 / 8) and lo[1][1] == pytest.approx(-1 / 8)      # exact extrapolation weights
+    assert hi[0][1] == pytest.approx(-1 / 3) and hi[1][1] == pytest.approx(4 / 3)      # the reference's shifted arguments (:1993)
+    assert sum(w for _, w in lo) == pytest.approx(1.0) and sum(w for _, w in hi) == pytest.approx(1.0)
+    per = g.T_row(2, 0)
+    assert [c for c, _ in per] == [-1, 0] and per[0][1] == pytest.approx(0.5)
+    # stretched grid: interpolation reproduces linear fields at the face
+    xf = _coords(n, True)
+    gs = fo.Grid(n, xf, [V] * 6)
+    xc = 0.5 * (xf[0][1:] + xf[0][:-1])
+    for f in range(1, n[0]):
+        assert sum(w * xc[c] for c, w in gs.T_row(0, f)) == pytest.approx(xf[0][f])
+    v = np.concatenate([np.full(gs.ncell, 2.0), np.full(gs.ncell, -1.0), np.full(gs.ncell, 0.5)])
+    Vf = gs.apply_T(v)
+    assert np.allclose(np.unique(Vf[0]), [0.0, 2.0]) and np.allclose(np.unique(Vf[2]), [0.0, 0.5])
