@@ -435,6 +435,12 @@ __global__ void __launch_bounds__(256) k_mom_pw(GridP g, int64_t cs, const doubl
   }
 }
 
+// y = a x + b z (z may be NULL; y may alias x or z)
+__global__ void __launch_bounds__(256) k_lincomb(int64_t n, double a, const double *x, double b, const double *z, double *y)
+{
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) y[q] = a * x[q] + (z ? b * z[q] : 0.);
+}
+
 // src: x-fastest array of ex*ey*ez entries (ex <= nx+1, ...) -> padded array, entry (i,j,k) at off0 + k sxy + j sx + i
 __global__ void __launch_bounds__(256) k_pad_copy_ext(GridP g, const double *__restrict__ src, double *__restrict__ dst, int ex, int ey, int ez)
 {
@@ -447,8 +453,8 @@ __global__ void __launch_bounds__(256) k_pad_copy_ext(GridP g, const double *__r
   }
 }
 
-// V_d = rhs_d + (T v)_d on the owned d-faces (unpadded face array); v: padded component d with valid ghosts
-__global__ void __launch_bounds__(256) k_face_interp(GridP g, FaceT t, int d, const double *__restrict__ vpad, const double *__restrict__ rhs, double *__restrict__ V)
+// V_d = rhs_d + alpha (T v)_d on the owned d-faces (unpadded face array, rhs may alias V); v: padded component d with valid ghosts
+__global__ void __launch_bounds__(256) k_face_interp(GridP g, FaceT t, int d, double alpha, const double *__restrict__ vpad, const double *rhs, double *V)
 {
   const int     ex = d == 0 ? g.fx : g.nx, ey = d == 1 ? g.fy : g.ny, ez = d == 2 ? g.fz : g.nz;
   const int64_t n = (int64_t)ex * ey * ez;
@@ -461,7 +467,7 @@ __global__ void __launch_bounds__(256) k_face_interp(GridP g, FaceT t, int d, co
     const int     c0 = t.c0[d][f];
     // cell (i,j,k) with the d-th index replaced by c0
     const int64_t base = g.off0 + (int64_t)k * g.sxy + (int64_t)j * g.sx + i + (int64_t)(c0 - f) * str;
-    const double  w0 = t.w0[d][f], w1 = t.w1[d][f];
+    const double  w0 = alpha * t.w0[d][f], w1 = alpha * t.w1[d][f];
     double        s = rhs ? rhs[q] : 0.;
     if (w0 != 0.) s += w0 * vpad[base];
     if (w1 != 0.) s += w1 * vpad[base + str];
@@ -482,6 +488,7 @@ struct fl_momentum {
   void       *tabs[3] = {nullptr, nullptr, nullptr};
   void       *ttabs[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   double     *srhs = nullptr;  // Schur right-hand side of fl_abf_apply
+  double     *tmpv = nullptr;  // 3*cells scratch of fl_abf_jacobian_mult
   double     *F = nullptr;   // 12 padded face fields: V0[0..2], v0interp[c*3+d] at 3 + c*3 + d
   double     *dg = nullptr;  // diag(A), 3 padded components (valid after set_state)
   double     *vec[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -625,6 +632,7 @@ extern "C" int fl_momentum_destroy(fl_momentum *m)
   for (void *t : m->ttabs)
     if (t) (void)hipFree(t);
   if (m->srhs) (void)hipFree(m->srhs);
+  if (m->tmpv) (void)hipFree(m->tmpv);
   if (m->F) (void)hipFree(m->F);
   if (m->dg) (void)hipFree(m->dg);
   for (double *v : m->vec)
@@ -750,12 +758,10 @@ extern "C" int fl_momentum_solve(fl_momentum *m, const double *b_dev, double *x_
   return fl_ksp_finish(h, &o, stats);
 }
 
-// V* = interprhs - (-T) v*   (MatMult(negT) + VecAYPX, abfpc.c:73-74)
-extern "C" int fl_momentum_face_interp(fl_momentum *m, const double *v_dev, const double *const rhs_dev[3], double *const V_dev[3])
+namespace {
+int face_interp(fl_momentum *m, double alpha, const double *v_dev, const double *const rhs_dev[3], double *const V_dev[3])
 {
-  if (!m || !v_dev || !V_dev) return FL_ERR_ARG_NULL;
   fl_poisson *h = m->p;
-  FL_HIP(hipSetDevice(h->device));
   FL_CHK(mom_vec(m, 7));
   for (int c = 0; c < 3; ++c) launch_pad_copy(h->stream, h->g, v_dev + (size_t)c * h->ncell, m->vec[7] + (size_t)c * h->padlen);
   FL_CHK(mom_ghosts(m, m->vec[7]));
@@ -763,8 +769,48 @@ extern "C" int fl_momentum_face_interp(fl_momentum *m, const double *v_dev, cons
     if (!V_dev[d]) return FL_ERR_ARG_NULL;
     const int64_t n = h->nface[d];
     const int     nb = (int)std::min<int64_t>((n + 255) / 256, 8192);
-    hipLaunchKernelGGL(k_face_interp, dim3(std::max(nb, 1)), dim3(256), 0, h->stream, h->g, m->ft, d, m->vec[7] + (size_t)d * h->padlen, rhs_dev ? rhs_dev[d] : nullptr, V_dev[d]);
+    hipLaunchKernelGGL(k_face_interp, dim3(std::max(nb, 1)), dim3(256), 0, h->stream, h->g, m->ft, d, alpha, m->vec[7] + (size_t)d * h->padlen, rhs_dev ? rhs_dev[d] : nullptr, V_dev[d]);
   }
+  FL_HIP(hipGetLastError());
+  return 0;
+}
+void lincomb(fl_poisson *h, int64_t n, double a, const double *x, double b, const double *z, double *y)
+{
+  const int nb = (int)std::min<int64_t>((n + 255) / 256, 8192);
+  hipLaunchKernelGGL(k_lincomb, dim3(std::max(nb, 1)), dim3(256), 0, h->stream, n, a, x, b, z, y);
+}
+}  // namespace
+
+// V* = interprhs - (-T) v*   (MatMult(negT) + VecAYPX, abfpc.c:73-74)
+extern "C" int fl_momentum_face_interp(fl_momentum *m, const double *v_dev, const double *const rhs_dev[3], double *const V_dev[3])
+{
+  if (!m || !v_dev || !V_dev) return FL_ERR_ARG_NULL;
+  FL_HIP(hipSetDevice(m->p->device));
+  return face_interp(m, 1., v_dev, rhs_dev, V_dev);
+}
+
+// MatMult(J) of the 3 x 3 MatNest the preconditioner is built for (NSFormJacobian_CNLinear_Cart3d_Internal,
+// cnlinearcart3d.c:2885-2941):  rows v: [A, 0, kappa G]   V: [-T, I, -R]   p: [0, D, 0],   -R = (-T)(kappa G) + kappa Gst
+extern "C" int fl_abf_jacobian_mult(fl_momentum *m, const double *v_dev, const double *const V_dev[3], const double *p_dev, double *fv_dev, double *const fV_dev[3], double *fp_dev)
+{
+  if (!m || !v_dev || !V_dev || !p_dev || !fv_dev || !fV_dev || !fp_dev) return FL_ERR_ARG_NULL;
+  fl_poisson *h = m->p;
+  FL_HIP(hipSetDevice(h->device));
+  const int64_t N = h->ncell;
+  if (!m->tmpv) FL_CHK(fl_dev_alloc(h, (void **)&m->tmpv, sizeof(double) * 3 * (size_t)N, true));
+  if (!m->srhs) FL_CHK(fl_dev_alloc(h, (void **)&m->srhs, sizeof(double) * (size_t)N, true));
+  for (int d = 0; d < 3; ++d)
+    if (!V_dev[d] || !fV_dev[d]) return FL_ERR_ARG_NULL;
+  FL_CHK(fl_momentum_apply(m, v_dev, fv_dev));                                                        // fv = A v
+  lincomb(h, N, -1., p_dev, 0., nullptr, m->srhs);                                                    // -p
+  lincomb(h, 3 * N, 1., v_dev, 0., nullptr, m->tmpv);                                                 // w = v
+  for (int d = 0; d < 3; ++d) lincomb(h, h->nface[d], 1., V_dev[d], 0., nullptr, fV_dev[d]);          // fV = V
+  FL_CHK(fl_poisson_project(h, m->srhs, m->tmpv, m->tmpv + N, m->tmpv + 2 * N, fV_dev[0], fV_dev[1], fV_dev[2]));  // w = v + kappa G p ; fV = V + kappa Gst p
+  lincomb(h, 3 * N, 1., fv_dev, 1., m->tmpv, fv_dev);                                                 // fv += w
+  lincomb(h, 3 * N, 1., fv_dev, -1., v_dev, fv_dev);                                                  // fv -= v      -> A v + kappa G p
+  FL_CHK(face_interp(m, -1., m->tmpv, fV_dev, fV_dev));                                               // fV -= T w    -> V - T v - T kappa G p + kappa Gst p
+  FL_CHK(fl_poisson_rhs(h, V_dev[0], V_dev[1], V_dev[2], nullptr, fp_dev));                           // -D V
+  lincomb(h, N, -1., fp_dev, 0., nullptr, fp_dev);                                                    // fp = D V
   FL_HIP(hipGetLastError());
   return FL_SUCCESS;
 }

@@ -348,3 +348,15 @@ class Momentum:
         self.p._post()
         info = [dict(iters=s.iters, reason=s.reason, rnorm0=s.rnorm0, rnorm=s.rnorm, seconds=s.seconds) for s in st]
         return v, V, pr, info
+
+    def jacobian_mult(self, v, V, p):
+        """MatMult of the block Jacobian (cnlinearcart3d.c:2885-2941): returns (fv, [fV], fp)."""
+        fv = self.p.empty(3 * self.p.ncell)
+        fp = self.p.empty()
+        fV = [self.p.empty(self.p.nface[d]) for d in range(3)]
+        a = (C.c_void_p * 3)(*[t.data_ptr() for t in V])
+        b = (C.c_void_p * 3)(*[t.data_ptr() for t in fV])
+        self.p._pre()
+        check(lib.fl_abf_jacobian_mult(self.h, _ptr(v), a, _ptr(p), _ptr(fv), b, _ptr(fp)), "fl_abf_jacobian_mult")
+        self.p._post()
+        return fv, fV, fp

@@ -218,6 +218,10 @@ int fl_momentum_face_interp(fl_momentum *m, const double *v_dev, const double *c
  * v_dev (3*cells, component-major), V_dev[3] (faces) and p_dev (cells) are outputs; interprhs_dev / contrhs_dev may be
  * NULL = 0.  stats[0] = KSPSolve(kspA), stats[1] = KSPSolve(kspS).  A non-converged inner solve is reported in stats,
  * not as an error (PETSc's behaviour without -ksp_error_if_not_converged). */
+/* MatMult of the 3 x 3 block Jacobian the preconditioner belongs to (MatNest of cnlinearcart3d.c:2885-2941), for an outer
+ * Krylov method that keeps its vectors on the device:
+ *   fv = A v + kappa G p ;  fV = V - T v - R p,  -R = (-T)(kappa G) + kappa Gst ;  fp = D V */
+int fl_abf_jacobian_mult(fl_momentum *m, const double *v_dev, const double *const V_dev[3], const double *p_dev, double *fv_dev, double *const fV_dev[3], double *fp_dev);
 int fl_abf_apply(fl_momentum *m, const fl_ksp_opts *momentum_opts, const fl_ksp_opts *schur_opts, const double *momrhs_dev, const double *const interprhs_dev[3], const double *contrhs_dev, double *v_dev,
                  double *const V_dev[3], double *p_dev, fl_ksp_stats stats[2]);
 

@@ -195,3 +195,57 @@ def test_pcapply_abf_matches_composed_oracle(n, bc, nonuni):
     assert np.linalg.norm(div) <= 1e-7 * np.linalg.norm(srhs)
     M.close()
     P.close()
+
+
+@pytest.mark.parametrize("n,bc,nonuni", [CASES[0], CASES[1], CASES[3]])
+def test_block_jacobian_mult(n, bc, nonuni):
+    """fl_abf_jacobian_mult == the MatNest product of cnlinearcart3d.c:2885-2941 composed from the oracle's operators."""
+    P, M, g = _pair(n, bc, nonuni)
+    rng = np.random.default_rng(41)
+    V0, W = _fields(g)
+    rho, mu = 1.0, 0.02
+    dt = g.kappa * rho
+    M.set_state(dt, rho, mu, [dev(a) for a in V0], [dev(a) for a in W])
+    A = g.assemble_momentum(1.0, dt, -0.5 * mu * dt / rho, V0, W)
+    v = rng.standard_normal(3 * g.ncell)
+    Vf = [rng.standard_normal(g.nface[d]) for d in range(3)]
+    p = rng.standard_normal(g.ncell)
+    kGp = np.concatenate(g.apply_G(p))
+    w = v + kGp
+    Tw = g.apply_T(w)
+    kGst = g.apply_gst(p)
+    fv_ref = A.mult(v) + kGp
+    fV_ref = [Vf[d] - Tw[d] + kGst[d] for d in range(3)]
+    fp_ref = -g.rhs(*Vf)
+    fv, fV, fp = M.jacobian_mult(dev(v), [dev(a) for a in Vf], dev(p))
+    _close(host(fv), fv_ref)
+    _close(host(fp), fp_ref, 1e-12)
+    for d in range(3):
+        _close(host(fV[d]), fV_ref[d], 1e-12)
+    M.close()
+    P.close()
+
+
+def test_abf_is_an_approximate_inverse_of_the_block_jacobian():
+    """Everything at once, signs and scalings included: with A = I + O(dt) the approximate block factorisation with
+    Ainv = I is an O(dt) perturbation of J^-1, so J (PCApply_ABF f) must come back to f up to a few per cent."""
+    from fluca_amd import capi
+    from fluca_amd.poisson import KspOptions
+    n, bc = (17, 9, 11), CAVITY
+    P, M, g = _pair(n, bc, False)
+    rng = np.random.default_rng(51)
+    V0, W = _fields(g)
+    rho, mu = 1.0, 0.02
+    dt = g.kappa * rho
+    M.set_state(dt, rho, mu, [dev(a) for a in V0], [dev(a) for a in W])
+    momrhs = rng.standard_normal(3 * g.ncell)
+    v, Vf, p, info = M.abf_apply(dev(momrhs), momentum=KspOptions(type=capi.KSP_BCGS, rtol=1e-12, maxit=500), schur=KspOptions(rtol=1e-12, maxit=5000))
+    assert info[0]["reason"] > 0 and info[1]["reason"] > 0
+    fv, fV, fp = M.jacobian_mult(v, Vf, p)
+    r = np.linalg.norm(host(fv) - momrhs) / np.linalg.norm(momrhs)
+    assert r < 0.05, r
+    # interprhs = contrhs = 0: the face row and the continuity row are reproduced to solver accuracy
+    assert max(np.abs(host(fV[d])).max() for d in range(3)) <= 1e-8 * np.abs(host(Vf[0])).max()
+    assert np.abs(host(fp)).max() <= 1e-7 * np.abs(host(Vf[0])).max() / min(np.diff(g.xf[0]).min(), np.diff(g.xf[2]).min())
+    M.close()
+    P.close()
