@@ -332,35 +332,49 @@ int build_axis_momentum(const Axis &a, std::vector<double> &tab)
   return 0;
 }
 
-// Face-normal velocity interpolation T (ComputeFaceNormalVelocityInterpolationOperator_Private,
-// cnlinearcart3d.c:1934-2140; rows cartdiscret.c:373-423): V_f = w0 v[c0] + w1 v[c0+1] for every face f = 0..n of a
-// grid line (face n of a periodic axis is face 0 and is not stored).  Walls with a VELOCITY / SYMMETRY condition have no
-// row: the value comes from the boundary-condition vector (interprhs) or is zero.
-int build_axis_T(const Axis &a, std::vector<double> &w0, std::vector<double> &w1, std::vector<int> &c0)
+// Cell-to-face velocity interpolation rows, V_f = w0 v[c0] + w1 v[c0+1] for every face f = 0..n of a grid line (face n
+// of a periodic axis is face 0 and is not stored).  Linear interpolation inside; at a wall either no row (the value
+// comes from a boundary-condition vector, or is zero) or a zero-gradient extrapolation through the two nearest cells.
+//   kind 0: T, face-normal component, ComputeFaceNormalVelocityInterpolationOperator_Private   cnlinearcart3d.c:1934-2140
+//   kind 1: B, component along the face normal (c == d)                                        cnlinearcart3d.c:1513-1747
+//   kind 2: B, tangential component (c != d): a SYMMETRY wall extrapolates it
+// Rows: cartdiscret.c:373-423.  T's high-side outlet row is restated as written (:1993): the backward extrapolation is
+// handed (centre n-1, face n, centre n) for (xWW, xW, xw); centre n is the ghost coordinate.  B has the intended order.
+int build_axis_faceinterp(const Axis &a, int kind, std::vector<double> &w0, std::vector<double> &w1, std::vector<int> &c0)
 {
   const int64_t n = a.n;
   w0.assign((size_t)n + 1, 0.);
   w1.assign((size_t)n + 1, 0.);
   c0.assign((size_t)n + 1, 0);
+  auto extrapolates = [&](int bc, int &ex) {
+    if (bc == FL_BC_PRESSURE_OUTLET) ex = 1;
+    else if (bc == FL_BC_VELOCITY) ex = 0;
+    else if (bc == FL_BC_SYMMETRY) ex = kind == 2;
+    else return FL_ERR_ARG_WRONG;
+    return 0;
+  };
   for (int64_t f = 0; f <= n; ++f) {
     if (f == 0 && !a.periodic) {
+      int ex = 0;
+      if (int rc = extrapolates(a.bc_lo, ex)) return rc;
       c0[f] = 0;
-      if (a.bc_lo == FL_BC_PRESSURE_OUTLET) {
+      if (ex) {
         if (n < 2) return FL_ERR_SUP;
         const double h1 = a.xcc(0) - a.xf[0], h2 = a.xcc(1) - a.xf[0];
         w0[f] = -(h2 * h2) / ((h1 + h2) * (h1 - h2));
         w1[f] = (h1 * h1) / ((h1 + h2) * (h1 - h2));
-      } else if (a.bc_lo != FL_BC_VELOCITY && a.bc_lo != FL_BC_SYMMETRY) return FL_ERR_ARG_WRONG;
+      }
     } else if (f == n && !a.periodic) {
+      int ex = 0;
+      if (int rc = extrapolates(a.bc_hi, ex)) return rc;
       c0[f] = (int)std::max<int64_t>(n - 2, 0);
-      if (a.bc_hi == FL_BC_PRESSURE_OUTLET) {
+      if (ex) {
         if (n < 2) return FL_ERR_SUP;
-        // as written in the reference (:1993): the backward extrapolation is handed (centre n-1, face n, centre n) for
-        // (xWW, xW, xw); centre n is the ghost coordinate (face n + h/2 on a uniform grid).  Columns n-2, n-1.
-        const double h1 = a.xcc(n) - a.xf[n], h2 = a.xcc(n) - a.xcc(n - 1);
+        const double h1 = kind == 0 ? a.xcc(n) - a.xf[n] : a.xf[n] - a.xcc(n - 1);
+        const double h2 = kind == 0 ? a.xcc(n) - a.xcc(n - 1) : a.xf[n] - a.xcc(n - 2);
         w0[f] = (h1 * h1) / ((h1 + h2) * (h1 - h2));
         w1[f] = -(h2 * h2) / ((h1 + h2) * (h1 - h2));
-      } else if (a.bc_hi != FL_BC_VELOCITY && a.bc_hi != FL_BC_SYMMETRY) return FL_ERR_ARG_WRONG;
+      }
     } else {
       const int64_t ff = f == n ? 0 : f;  // periodic: face n == face 0 (its row is never read)
       const double  xW = a.xcc(ff - 1), xw = a.xf[ff], xP = a.xcc(ff);

@@ -52,7 +52,7 @@ int build_axis(Axis &a, int64_t n, const double *xf, const double *xc, int bc_lo
 
 constexpr int MOM_NTAB = 20;  // 1-D numbers per cell and axis of the momentum operator, see build_axis_momentum
 int build_axis_momentum(const Axis &a, std::vector<double> &tab);
-int build_axis_T(const Axis &a, std::vector<double> &w0, std::vector<double> &w1, std::vector<int> &c0);
+int build_axis_faceinterp(const Axis &a, int kind, std::vector<double> &w0, std::vector<double> &w1, std::vector<int> &c0);
 
 // ---- device view shared by every kernel ---------------------------------------------------------------------------
 // 1-D coefficient arrays are LOCAL (this rank's block) and pre-shifted: valid for index -1..len.

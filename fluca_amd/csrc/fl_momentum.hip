@@ -28,10 +28,11 @@ struct MomP {
   double        cI, cC, cL;
 };
 
-// face-normal interpolation T: per LOCAL face of each axis, V_f = w0 v[c0] + w1 v[c0 + 1] (c0 local, -1 = low ghost)
+// cell-to-face interpolation rows (build_axis_faceinterp): per LOCAL face of each axis, V_f = w0 v[c0] + w1 v[c0 + 1]
+// (c0 local, -1 = low ghost).  kind 0 = T, 1 = B normal component, 2 = B tangential component.
 struct FaceT {
-  const double *w0[3], *w1[3];
-  const int    *c0[3];
+  const double *w0[3][3], *w1[3][3];  // [kind][axis]
+  const int    *c0[3][3];
 };
 
 __device__ __forceinline__ double uniform_d(double v)
@@ -454,7 +455,7 @@ __global__ void __launch_bounds__(256) k_pad_copy_ext(GridP g, const double *__r
 }
 
 // V_d = rhs_d + alpha (T v)_d on the owned d-faces (unpadded face array, rhs may alias V); v: padded component d with valid ghosts
-__global__ void __launch_bounds__(256) k_face_interp(GridP g, FaceT t, int d, double alpha, const double *__restrict__ vpad, const double *rhs, double *V)
+__global__ void __launch_bounds__(256) k_face_interp(GridP g, FaceT t, int kind, int d, double alpha, const double *__restrict__ vpad, const double *rhs, double *V)
 {
   const int     ex = d == 0 ? g.fx : g.nx, ey = d == 1 ? g.fy : g.ny, ez = d == 2 ? g.fz : g.nz;
   const int64_t n = (int64_t)ex * ey * ez;
@@ -464,10 +465,10 @@ __global__ void __launch_bounds__(256) k_face_interp(GridP g, FaceT t, int d, do
     const int64_t r = q / ex;
     const int     j = (int)(r % ey), k = (int)(r / ey);
     const int     f = d == 0 ? i : (d == 1 ? j : k);
-    const int     c0 = t.c0[d][f];
+    const int     c0 = t.c0[kind][d][f];
     // cell (i,j,k) with the d-th index replaced by c0
     const int64_t base = g.off0 + (int64_t)k * g.sxy + (int64_t)j * g.sx + i + (int64_t)(c0 - f) * str;
-    const double  w0 = alpha * t.w0[d][f], w1 = alpha * t.w1[d][f];
+    const double  w0 = alpha * t.w0[kind][d][f], w1 = alpha * t.w1[kind][d][f];
     double        s = rhs ? rhs[q] : 0.;
     if (w0 != 0.) s += w0 * vpad[base];
     if (w1 != 0.) s += w1 * vpad[base + str];
@@ -486,7 +487,7 @@ struct fl_momentum {
   MomP        mp;
   FaceT       ft;
   void       *tabs[3] = {nullptr, nullptr, nullptr};
-  void       *ttabs[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  std::vector<void *> ttabs;
   double     *srhs = nullptr;  // Schur right-hand side of fl_abf_apply
   double     *tmpv = nullptr;  // 3*cells scratch of fl_abf_jacobian_mult
   double     *F = nullptr;   // 12 padded face fields: V0[0..2], v0interp[c*3+d] at 3 + c*3 + d
@@ -545,27 +546,31 @@ int mom_init(fl_momentum *m, fl_poisson *h)
     FL_HIP(hipMemcpy(m->tabs[d], loc.data(), sizeof(double) * loc.size(), hipMemcpyHostToDevice));
     m->mp.tab[d] = (const double *)m->tabs[d];
     m->mp.len[d] = len[d];
-    // T rows of the owned faces
-    std::vector<double> w0, w1;
-    std::vector<int>    c0;
-    FL_CHK(build_axis_T(h->ax[d], w0, w1, c0));
+    // interpolation rows of the owned faces
     const int nfl = d == 0 ? g.fx : (d == 1 ? g.fy : g.fz);
-    std::vector<double> l0(nfl), l1(nfl);
-    std::vector<int>    lc(nfl);
-    for (int f = 0; f < nfl; ++f) {
-      l0[f] = w0[(size_t)(lo[d] + f)];
-      l1[f] = w1[(size_t)(lo[d] + f)];
-      lc[f] = (int)(c0[(size_t)(lo[d] + f)] - lo[d]);
+    for (int kind = 0; kind < 3; ++kind) {
+      std::vector<double> w0, w1;
+      std::vector<int>    c0;
+      FL_CHK(build_axis_faceinterp(h->ax[d], kind, w0, w1, c0));
+      std::vector<double> l0(nfl), l1(nfl);
+      std::vector<int>    lc(nfl);
+      for (int f = 0; f < nfl; ++f) {
+        l0[f] = w0[(size_t)(lo[d] + f)];
+        l1[f] = w1[(size_t)(lo[d] + f)];
+        lc[f] = (int)(c0[(size_t)(lo[d] + f)] - lo[d]);
+      }
+      const void  *src[3] = {l0.data(), l1.data(), lc.data()};
+      const size_t by[3] = {sizeof(double) * nfl, sizeof(double) * nfl, sizeof(int) * nfl};
+      void        *dv[3];
+      for (int a = 0; a < 3; ++a) {
+        FL_HIP(hipMalloc(&dv[a], std::max<size_t>(by[a], 8)));
+        m->ttabs.push_back(dv[a]);
+        FL_HIP(hipMemcpy(dv[a], src[a], by[a], hipMemcpyHostToDevice));
+      }
+      m->ft.w0[kind][d] = (const double *)dv[0];
+      m->ft.w1[kind][d] = (const double *)dv[1];
+      m->ft.c0[kind][d] = (const int *)dv[2];
     }
-    const void  *src[3] = {l0.data(), l1.data(), lc.data()};
-    const size_t by[3] = {sizeof(double) * nfl, sizeof(double) * nfl, sizeof(int) * nfl};
-    for (int a = 0; a < 3; ++a) {
-      FL_HIP(hipMalloc(&m->ttabs[d * 3 + a], std::max<size_t>(by[a], 8)));
-      FL_HIP(hipMemcpy(m->ttabs[d * 3 + a], src[a], by[a], hipMemcpyHostToDevice));
-    }
-    m->ft.w0[d] = (const double *)m->ttabs[d * 3 + 0];
-    m->ft.w1[d] = (const double *)m->ttabs[d * 3 + 1];
-    m->ft.c0[d] = (const int *)m->ttabs[d * 3 + 2];
   }
   m->mp.cI = 1.;
   m->mp.cC = 0.;
@@ -769,7 +774,7 @@ int face_interp(fl_momentum *m, double alpha, const double *v_dev, const double 
     if (!V_dev[d]) return FL_ERR_ARG_NULL;
     const int64_t n = h->nface[d];
     const int     nb = (int)std::min<int64_t>((n + 255) / 256, 8192);
-    hipLaunchKernelGGL(k_face_interp, dim3(std::max(nb, 1)), dim3(256), 0, h->stream, h->g, m->ft, d, alpha, m->vec[7] + (size_t)d * h->padlen, rhs_dev ? rhs_dev[d] : nullptr, V_dev[d]);
+    hipLaunchKernelGGL(k_face_interp, dim3(std::max(nb, 1)), dim3(256), 0, h->stream, h->g, m->ft, 0, d, alpha, m->vec[7] + (size_t)d * h->padlen, rhs_dev ? rhs_dev[d] : nullptr, V_dev[d]);
   }
   FL_HIP(hipGetLastError());
   return 0;
@@ -787,6 +792,27 @@ extern "C" int fl_momentum_face_interp(fl_momentum *m, const double *v_dev, cons
   if (!m || !v_dev || !V_dev) return FL_ERR_ARG_NULL;
   FL_HIP(hipSetDevice(m->p->device));
   return face_interp(m, 1., v_dev, rhs_dev, V_dev);
+}
+
+// v0interp = B v0 (+ vbc): MatMult(cnl->B, v0, cnl->v0interp); VecAXPY(v0interp, 1, vbc), cnlinearcart3d.c:2826-2829
+extern "C" int fl_momentum_interp_faces(fl_momentum *m, const double *v_dev, const double *const vbc_dev[9], double *const out_dev[9])
+{
+  if (!m || !v_dev || !out_dev) return FL_ERR_ARG_NULL;
+  fl_poisson *h = m->p;
+  FL_HIP(hipSetDevice(h->device));
+  FL_CHK(mom_vec(m, 7));
+  for (int c = 0; c < 3; ++c) launch_pad_copy(h->stream, h->g, v_dev + (size_t)c * h->ncell, m->vec[7] + (size_t)c * h->padlen);
+  FL_CHK(mom_ghosts(m, m->vec[7]));
+  for (int c = 0; c < 3; ++c)
+    for (int d = 0; d < 3; ++d) {
+      if (!out_dev[c * 3 + d]) return FL_ERR_ARG_NULL;
+      const int64_t n = h->nface[d];
+      const int     nb = (int)std::min<int64_t>((n + 255) / 256, 8192);
+      hipLaunchKernelGGL(k_face_interp, dim3(std::max(nb, 1)), dim3(256), 0, h->stream, h->g, m->ft, c == d ? 1 : 2, d, 1., m->vec[7] + (size_t)c * h->padlen, vbc_dev ? vbc_dev[c * 3 + d] : nullptr,
+                         out_dev[c * 3 + d]);
+    }
+  FL_HIP(hipGetLastError());
+  return FL_SUCCESS;
 }
 
 // MatMult(J) of the 3 x 3 MatNest the preconditioner is built for (NSFormJacobian_CNLinear_Cart3d_Internal,

@@ -360,3 +360,13 @@ class Momentum:
         check(lib.fl_abf_jacobian_mult(self.h, _ptr(v), a, _ptr(p), _ptr(fv), b, _ptr(fp)), "fl_abf_jacobian_mult")
         self.p._post()
         return fv, fV, fp
+
+    def interp_faces(self, v, vbc=None):
+        """cnl->v0interp = B v (+ vbc): 9 face tensors, [c*3+d] = component c on the d-faces (cnlinearcart3d.c:2826-2829)."""
+        out = [self.p.empty(self.p.nface[d]) for c in range(3) for d in range(3)]
+        o = (C.c_void_p * 9)(*[t.data_ptr() for t in out])
+        r = None if vbc is None else (C.c_void_p * 9)(*[None if t is None else t.data_ptr() for t in vbc])
+        self.p._pre()
+        check(lib.fl_momentum_interp_faces(self.h, _ptr(v), r, o), "fl_momentum_interp_faces")
+        self.p._post()
+        return out

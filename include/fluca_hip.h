@@ -211,6 +211,10 @@ int fl_momentum_solve(fl_momentum *m, const double *b_dev, double *x_dev, const 
  * T = ComputeFaceNormalVelocityInterpolationOperator_Private, cnlinearcart3d.c:1934-2140.  rhs_dev (or any entry) may
  * be NULL = 0.  A VELOCITY / SYMMETRY wall face has no T row: it receives rhs alone (the boundary-condition vector). */
 int fl_momentum_face_interp(fl_momentum *m, const double *v_dev, const double *const rhs_dev[3], double *const V_dev[3]);
+/* out[c*3+d] = vbc[c*3+d] + (B v)_c on the d-faces: cnl->v0interp of NSStep_CNLinear_Cart3d_Internal
+ * (cnlinearcart3d.c:2826-2829), B = ComputeFaceVelocityInterpolationOperator_Private (cnlinearcart3d.c:1513-1747).
+ * vbc_dev (or any entry) may be NULL = 0; out may be handed straight to fl_momentum_set_state. */
+int fl_momentum_interp_faces(fl_momentum *m, const double *v_dev, const double *const vbc_dev[9], double *const out_dev[9]);
 
 /* ---- the whole preconditioner application ---------------------------------------------------- */
 /* PCApply_ABF, abfpc.c:48-111, with the reference's default upperainv = schurainv = ID (abfpc.c:328-329):

@@ -1304,3 +1304,77 @@ int fo_apply_T(const fo_grid *g, const double *v, const double *rx, const double
   }
   return err;
 }
+
+/* ================================================================================================
+ * Face velocity interpolation  B  (every velocity component to every face): v0interp = B v0 + vbc,
+ * NSStep_CNLinear_Cart3d_Internal, cnlinearcart3d.c:2826-2831;
+ * ComputeFaceVelocityInterpolationOperator_Private, cnlinearcart3d.c:1513-1747.
+ * Differs from T (above) in two places: a SYMMETRY wall extrapolates the tangential components (c != d) with zero
+ * gradient, and the high-side outlet row gets the arguments in the intended order (centres n-2, n-1 and face n).
+ * ================================================================================================ */
+int fo_B_row_1d(const fo_grid *g, int d, int f, int c, int col[2], double v[2])
+{
+  const double *xf = g->xf[d], *xc = g->xc[d];
+  int           n = g->n[d];
+  double        h1, h2;
+  if ((f == 0 || f == n) && !g->periodic[d]) {
+    int bc = g->bc[2 * d + (f == n)];
+    int extrap;
+    switch (bc) {
+    case FO_BC_VELOCITY: extrap = 0; break;
+    case FO_BC_PRESSURE_OUTLET: extrap = 1; break;
+    case FO_BC_SYMMETRY: extrap = (c != d); break;
+    default: return -1;
+    }
+    if (!extrap) return 0;
+    if (f == 0) { /* NSComputeLinearForwardExtrapolationNeumannCond_Cart(face 0, centre 0, centre 1), :1551 */
+      h1 = xc[0] - xf[0];
+      h2 = xc[1] - xf[0];
+      v[0] = -(h2 * h2) / ((h1 + h2) * (h1 - h2));
+      v[1] = (h1 * h1) / ((h1 + h2) * (h1 - h2));
+      col[0] = 0; col[1] = 1;
+    } else { /* NSComputeLinearBackwardExtrapolationNeumannCond_Cart(centre n-2, centre n-1, face n), :1577 */
+      h1 = xf[n] - xc[n - 1];
+      h2 = xf[n] - xc[n - 2];
+      v[0] = (h1 * h1) / ((h1 + h2) * (h1 - h2));
+      v[1] = -(h2 * h2) / ((h1 + h2) * (h1 - h2));
+      col[0] = n - 2; col[1] = n - 1;
+    }
+    return 2;
+  }
+  v[0]   = (xc[f] - xf[f]) / (xc[f] - xc[f - 1]); /* NSComputeLinearInterpolation_Cart, :1597 */
+  v[1]   = (xf[f] - xc[f - 1]) / (xc[f] - xc[f - 1]);
+  col[0] = f - 1;
+  col[1] = f;
+  return 2;
+}
+
+/* out[c*3+d] = B v_c on the d-faces (v component-major) */
+int fo_apply_B(const fo_grid *g, const double *v, double *const *out)
+{
+  int err = 0;
+  for (int c = 0; c < 3; ++c)
+    for (int d = 0; d < 3; ++d) {
+      int     nfz = d == 2 ? g->nf[2] : g->n[2], nfy = d == 1 ? g->nf[1] : g->n[1], nfx = d == 0 ? g->nf[0] : g->n[0];
+      double *O = out[c * 3 + d];
+#pragma omp parallel for schedule(static)
+      for (int k = 0; k < nfz; ++k)
+        for (int j = 0; j < nfy; ++j)
+          for (int i = 0; i < nfx; ++i) {
+            int    fi[3] = {i, j, k}, col[2], nc;
+            double w[2], s = 0.;
+            nc = fo_B_row_1d(g, d, fi[d], c, col, w);
+            if (nc < 0) {
+              err = 1;
+              continue;
+            }
+            for (int a = 0; a < nc; ++a) {
+              int cc[3] = {i, j, k};
+              cc[d]     = wrap(col[a], g->n[d]);
+              s += w[a] * v[(int64_t)c * g->ncell + cell_index(g, cc[0], cc[1], cc[2])];
+            }
+            O[face_index(g, d, i, j, k)] = s;
+          }
+    }
+  return err;
+}

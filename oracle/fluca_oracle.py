@@ -91,6 +91,10 @@ def lib():
         L.fo_T_row_1d.argtypes = [C.c_void_p, C.c_int, C.c_int, ip3, C.POINTER(C.c_double)]
         L.fo_apply_T.restype = C.c_int
         L.fo_apply_T.argtypes = [C.c_void_p, _dp, C.c_void_p, C.c_void_p, C.c_void_p, _dp, _dp, _dp]
+        L.fo_B_row_1d.restype = C.c_int
+        L.fo_B_row_1d.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, ip3, C.POINTER(C.c_double)]
+        L.fo_apply_B.restype = C.c_int
+        L.fo_apply_B.argtypes = [C.c_void_p, _dp, C.c_void_p]
         L.fo_ibm_phi.restype = C.c_double
         L.fo_ibm_phi.argtypes = [C.c_int, C.c_double]
         _LIB = L
@@ -177,6 +181,23 @@ class Grid:
         if lib().fo_apply_T(self.h, np.ascontiguousarray(v, dtype=np.float64), *ptr, *V):
             raise ValueError("unsupported BC in T")
         return V
+
+    def B_row(self, d, f, c):
+        """[(cell, weight)] of the face interpolation of component c at face f of axis d (cnlinearcart3d.c:1513-1747)."""
+        col = (C.c_int * 2)()
+        v = (C.c_double * 2)()
+        nc = lib().fo_B_row_1d(self.h, d, f, c, col, v)
+        if nc < 0:
+            raise ValueError("unsupported BC")
+        return [(col[i], v[i]) for i in range(nc)]
+
+    def apply_B(self, v):
+        """v0interp without its boundary-condition vector: 9 face arrays, [c*3+d] = component c on the d-faces."""
+        out = [np.empty(self.nface[d]) for c in range(3) for d in range(3)]
+        ptrs = (C.c_void_p * 9)(*[a.ctypes.data for a in out])
+        if lib().fo_apply_B(self.h, np.ascontiguousarray(v, dtype=np.float64), ptrs):
+            raise ValueError("unsupported BC in B")
+        return out
 
     def lap_row(self, d, i, c):
         """[(offset, coeff)] of one axis' second-derivative row for component c (cnlinearcart3d.c:466-632)."""

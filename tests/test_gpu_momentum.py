@@ -249,3 +249,20 @@ def test_abf_is_an_approximate_inverse_of_the_block_jacobian():
     assert np.abs(host(fp)).max() <= 1e-7 * np.abs(host(Vf[0])).max() / min(np.diff(g.xf[0]).min(), np.diff(g.xf[2]).min())
     M.close()
     P.close()
+
+
+@pytest.mark.parametrize("n,bc,nonuni", [CASES[0], CASES[1], CASES[3], CASES[4], CASES[5]])
+def test_face_velocity_interpolation_B_matches_oracle(n, bc, nonuni):
+    P, M, g = _pair(n, bc, nonuni)
+    rng = np.random.default_rng(61)
+    v = rng.standard_normal(3 * g.ncell)
+    want = g.apply_B(v)
+    got = M.interp_faces(dev(v))
+    for q in range(9):
+        assert np.abs(host(got[q]) - want[q]).max() <= 2e-13 * np.abs(v).max(), q
+    vbc = [rng.standard_normal(g.nface[d]) for c in range(3) for d in range(3)]
+    got = M.interp_faces(dev(v), [dev(a) for a in vbc])
+    for q in range(9):
+        assert np.abs(host(got[q]) - (want[q] + vbc[q])).max() <= 2e-13 * max(np.abs(v).max(), np.abs(vbc[q]).max()), q
+    M.close()
+    P.close()

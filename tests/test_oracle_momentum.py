@@ -191,3 +191,22 @@ def test_T_rows():
     v = np.concatenate([np.full(gs.ncell, 2.0), np.full(gs.ncell, -1.0), np.full(gs.ncell, 0.5)])
     Vf = gs.apply_T(v)
     assert np.allclose(np.unique(Vf[0]), [0.0, 2.0]) and np.allclose(np.unique(Vf[2]), [0.0, 0.5])
+
+
+def test_B_rows():
+    """Face interpolation of every component (cnlinearcart3d.c:1513-1747): like T, except that a SYMMETRY wall
+    extrapolates the tangential components and the high-side outlet row has the intended arguments."""
+    n = (8, 6, 5)
+    g = fo.Grid.uniform(n, UNIT, [O, O, SYM, V, PER, PER])
+    for c in range(3):
+        assert g.B_row(0, 3, c) == [(2, 0.5), (3, 0.5)]
+        lo, hi = g.B_row(0, 0, c), g.B_row(0, n[0], c)
+        assert [w for _, w in lo] == pytest.approx([9 / 8, -1 / 8]) and [w for _, w in hi] == pytest.approx([-1 / 8, 9 / 8])
+        assert [q for q, _ in hi] == [n[0] - 2, n[0] - 1]
+        assert g.B_row(1, n[1], c) == []                                   # VELOCITY wall: boundary-condition vector
+    assert g.B_row(1, 0, 1) == [] and len(g.B_row(1, 0, 0)) == 2 and len(g.B_row(1, 0, 2)) == 2    # SYMMETRY
+    # B and T agree wherever T has a row, except at the high-side outlet
+    for d in range(3):
+        for f in range(g.nf[d]):
+            if not (d == 0 and f == n[0]):
+                assert g.B_row(d, f, d) == g.T_row(d, f)
