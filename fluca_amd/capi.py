@@ -105,6 +105,7 @@ PROTOTYPES = {
     "fl_momentum_diagonal": (C.c_int, [_P, _P]),
     "fl_momentum_solve": (C.c_int, [_P, _P, _P, C.POINTER(fl_ksp_opts), C.POINTER(fl_ksp_stats)]),
     "fl_momentum_face_interp": (C.c_int, [_P, _P, _P, _P]),
+    "fl_momentum_rhs": (C.c_int, [_P, C.c_double, C.c_double, C.c_double, _P, _P, _P, _P]),
     "fl_momentum_interp_faces": (C.c_int, [_P, _P, _P, _P]),
     "fl_abf_jacobian_mult": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "fl_abf_apply": (C.c_int, [_P, C.POINTER(fl_ksp_opts), C.POINTER(fl_ksp_opts), _P, _P, _P, _P, _P, _P, C.POINTER(fl_ksp_stats)]),

@@ -515,10 +515,10 @@ int mom_ghosts(fl_momentum *m, double *v3)
 }
 
 template <bool DOT, bool JAC, int OUT>
-void mom_apply_t(fl_momentum *m, const double *x, double *y, const double *o, const KspScal *s)
+void mom_apply_t(fl_momentum *m, const double *x, double *y, const double *o, const KspScal *s, const MomP *coeffs = nullptr)
 {
   fl_poisson *h = m->p;
-  hipLaunchKernelGGL((k_mom_apply<DOT, JAC, OUT>), dim3(m->ablocks), dim3(MOM_NT), 0, h->stream, h->g, m->mp, x, y, m->F, (int64_t)h->padlen, o, s, h->partial, h->partial_stride, m->tiles_x, m->anchunk, m->azc);
+  hipLaunchKernelGGL((k_mom_apply<DOT, JAC, OUT>), dim3(m->ablocks), dim3(MOM_NT), 0, h->stream, h->g, coeffs ? *coeffs : m->mp, x, y, m->F, (int64_t)h->padlen, o, s, h->partial, h->partial_stride, m->tiles_x, m->anchunk, m->azc);
 }
 
 template <int OP>
@@ -792,6 +792,29 @@ extern "C" int fl_momentum_face_interp(fl_momentum *m, const double *v_dev, cons
   if (!m || !v_dev || !V_dev) return FL_ERR_ARG_NULL;
   FL_HIP(hipSetDevice(m->p->device));
   return face_interp(m, 1., v_dev, rhs_dev, V_dev);
+}
+
+// The part of momrhs (NSFormFunction_CNLinear_Cart3d_Internal, cnlinearcart3d.c:2976-2998) that lives on every cell:
+//   momrhs = v0 + (mu dt / 2 rho) L v0 - kappa G p  (+ vbc: the boundary-condition vectors, combined by the caller)
+extern "C" int fl_momentum_rhs(fl_momentum *m, double dt, double rho, double mu, const double *v0_dev, const double *p_dev, const double *vbc_dev, double *momrhs_dev)
+{
+  if (!m || !v0_dev || !momrhs_dev) return FL_ERR_ARG_NULL;
+  if (!(rho > 0.)) return FL_ERR_ARG_OUTOFRANGE;
+  fl_poisson *h = m->p;
+  FL_HIP(hipSetDevice(h->device));
+  const size_t N = (size_t)h->ncell;
+  FL_CHK(mom_vec(m, 7));
+  for (int c = 0; c < 3; ++c) launch_pad_copy(h->stream, h->g, v0_dev + c * N, m->vec[7] + (size_t)c * h->padlen);
+  FL_CHK(mom_ghosts(m, m->vec[7]));
+  MomP co = m->mp;
+  co.cI   = 1.;
+  co.cC   = 0.;
+  co.cL   = 0.5 * mu * dt / rho;  // VecAXPBYPCZ(momrhs, 1, mu dt / 2 rho, 0, v0, Lv), :2988
+  mom_apply_t<false, false, 1>(m, m->vec[7], momrhs_dev, nullptr, nullptr, &co);
+  if (p_dev) FL_CHK(fl_poisson_project(h, p_dev, momrhs_dev, momrhs_dev + N, momrhs_dev + 2 * N, nullptr, nullptr, nullptr));  // VecAXPY(momrhs, -1, Gp), :2993
+  if (vbc_dev) lincomb(h, (int64_t)(3 * N), 1., momrhs_dev, 1., vbc_dev, momrhs_dev);
+  FL_HIP(hipGetLastError());
+  return FL_SUCCESS;
 }
 
 // v0interp = B v0 (+ vbc): MatMult(cnl->B, v0, cnl->v0interp); VecAXPY(v0interp, 1, vbc), cnlinearcart3d.c:2826-2829

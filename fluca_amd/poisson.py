@@ -370,3 +370,11 @@ class Momentum:
         check(lib.fl_momentum_interp_faces(self.h, _ptr(v), r, o), "fl_momentum_interp_faces")
         self.p._post()
         return out
+
+    def rhs(self, dt, rho, mu, v0, p=None, vbc=None, out=None):
+        """Cell-wise part of momrhs (cnlinearcart3d.c:2976-2998): v0 + (mu dt/2 rho) L v0 - kappa G p (+ vbc)."""
+        out = self.p.empty(3 * self.p.ncell) if out is None else out
+        self.p._pre()
+        check(lib.fl_momentum_rhs(self.h, float(dt), float(rho), float(mu), _ptr(v0), _ptr(p), _ptr(vbc), _ptr(out)), "fl_momentum_rhs")
+        self.p._post()
+        return out

@@ -215,6 +215,12 @@ int fl_momentum_face_interp(fl_momentum *m, const double *v_dev, const double *c
  * (cnlinearcart3d.c:2826-2829), B = ComputeFaceVelocityInterpolationOperator_Private (cnlinearcart3d.c:1513-1747).
  * vbc_dev (or any entry) may be NULL = 0; out may be handed straight to fl_momentum_set_state. */
 int fl_momentum_interp_faces(fl_momentum *m, const double *v_dev, const double *const vbc_dev[9], double *const out_dev[9]);
+/* The cell-wise part of momrhs, NSFormFunction_CNLinear_Cart3d_Internal (cnlinearcart3d.c:2976-2998):
+ *   momrhs = v0 + (mu dt / 2 rho) L v0 - kappa G p + vbc
+ * p_dev: phalf (or p0 on the first step), may be NULL; vbc_dev (3*cells, may be NULL): the boundary-condition vectors of
+ * L, C and G combined by the caller, (mu dt/2 rho)(vbcL(t) + vbcL(t+dt)) - dt vbcC - vbcG -- they are zero for periodic
+ * boundaries and homogeneous walls.  kappa is the handle's dt/rho. */
+int fl_momentum_rhs(fl_momentum *m, double dt, double rho, double mu, const double *v0_dev, const double *p_dev, const double *vbc_dev, double *momrhs_dev);
 
 /* ---- the whole preconditioner application ---------------------------------------------------- */
 /* PCApply_ABF, abfpc.c:48-111, with the reference's default upperainv = schurainv = ID (abfpc.c:328-329):
