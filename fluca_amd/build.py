@@ -60,16 +60,18 @@ def build_host(force=False, verbose=False):
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
     build_example(force, verbose)
+    build_example(force, verbose, name="cavity_flow_3d")
     return HOST_LIB
 
 
 EXAMPLE = os.path.join(LIBDIR, "cavity_pressure_step")
 
 
-def build_example(force=False, verbose=False):
-    """examples/cavity_pressure_step.c: the reference's cavity driver against the C host mirror (no Python at run time)."""
+def build_example(force=False, verbose=False, name="cavity_pressure_step"):
+    """examples/<name>.c: the reference's cavity drivers against the C host mirror (no Python at run time)."""
     root = os.path.normpath(os.path.join(HERE, ".."))
-    src = os.path.join(root, "examples", "cavity_pressure_step.c")
+    src = os.path.join(root, "examples", name + ".c")
+    EXAMPLE = os.path.join(LIBDIR, name)
     if os.path.exists(src) and (force or _stale(EXAMPLE, [src, HOST_LIB, LIB])):
         cmd = [os.environ.get("CC", "gcc"), "-std=gnu99", "-O2", "-Wall", "-o", EXAMPLE, src, "-I" + os.path.join(root, "include"),
                "-L" + LIBDIR, "-lfluca_host", "-lflucahip", "-lm", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]

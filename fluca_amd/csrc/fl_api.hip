@@ -554,6 +554,37 @@ extern "C" int fl_poisson_gst_bc(fl_poisson *h, int boundary, const double *pb_d
   return FL_SUCCESS;
 }
 
+// The two shapes every boundary-condition vector of the reference has: a value per boundary face, written into the boundary
+// faces of a face array (INSERT) or added to the cells next to the boundary (ADD).
+static bool touches_boundary(const fl_poisson *h, int boundary)
+{
+  const int d = boundary / 2, side = boundary % 2;
+  if (h->ax[d].periodic) return false;
+  return side ? (h->dec.coord[d] == h->dec.ranks[d] - 1) : (h->dec.coord[d] == 0);
+}
+
+extern "C" int fl_boundary_set_faces(fl_poisson *h, int boundary, double coeff, const double *plane_dev, double *face_dev)
+{
+  if (!h || !plane_dev || !face_dev) return FL_ERR_ARG_NULL;
+  if (boundary < 0 || boundary > 5) return FL_ERR_ARG_OUTOFRANGE;
+  if (!touches_boundary(h, boundary)) return FL_SUCCESS;
+  FL_HIP(hipSetDevice(h->device));
+  launch_gst_bc(h->stream, h->g, plane_dev, face_dev, boundary / 2, boundary % 2, coeff);
+  FL_HIP(hipGetLastError());
+  return FL_SUCCESS;
+}
+
+extern "C" int fl_boundary_add_cells(fl_poisson *h, int boundary, double coeff, const double *plane_dev, double *cell_dev)
+{
+  if (!h || !plane_dev || !cell_dev) return FL_ERR_ARG_NULL;
+  if (boundary < 0 || boundary > 5) return FL_ERR_ARG_OUTOFRANGE;
+  if (!touches_boundary(h, boundary)) return FL_SUCCESS;
+  FL_HIP(hipSetDevice(h->device));
+  launch_bc_add_cells(h->stream, h->g, plane_dev, cell_dev, boundary / 2, boundary % 2, coeff);
+  FL_HIP(hipGetLastError());
+  return FL_SUCCESS;
+}
+
 extern "C" int fl_pressure_update(fl_poisson *h, int first, const double *dp, const double *p0, double *phalf, double *p)
 {
   if (!h || !dp || !phalf || !p || (first && !p0)) return FL_ERR_ARG_NULL;

@@ -232,6 +232,20 @@ __global__ void k_gst_bc(GridP g, const double *__restrict__ pb, double *__restr
   V[p]        = coeff * pb[(int64_t)b * na + a];
 }
 
+// cell layer next to boundary (axis, side) += coeff * plane   (ADD_VALUES of the boundary-condition vectors)
+__global__ void k_bc_add_cells(GridP g, const double *__restrict__ plane, double *__restrict__ cells, int axis, int side, double coeff)
+{
+  const int a = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y * 4 + threadIdx.y;
+  int       na, nb;
+  if (axis == 0) { na = g.ny; nb = g.nz; }
+  else if (axis == 1) { na = g.nx; nb = g.nz; }
+  else { na = g.nx; nb = g.ny; }
+  if (a >= na || b >= nb) return;
+  const int c = side ? (axis == 0 ? g.nx : (axis == 1 ? g.ny : g.nz)) - 1 : 0;
+  const int64_t p = axis == 0 ? ((int64_t)b * g.ny + a) * g.nx + c : (axis == 1 ? ((int64_t)b * g.ny + c) * g.nx + a : ((int64_t)c * g.ny + b) * g.nx + a);
+  cells[p] += coeff * plane[(int64_t)b * na + a];
+}
+
 // cnlinearcart3d.c:2846-2854
 __global__ void k_pressure_update(int64_t n, int first, const double *__restrict__ dp, const double *__restrict__ p0, double *__restrict__ phalf, double *__restrict__ p)
 {
@@ -980,6 +994,11 @@ void launch_gst_bc(hipStream_t st, const GridP &g, const double *pb, double *V, 
 {
   const int na = axis == 0 ? g.ny : g.nx, nb = axis == 2 ? g.ny : g.nz;
   hipLaunchKernelGGL(k_gst_bc, grid3(na, nb, 1), blk3(), 0, st, g, pb, V, axis, side, coeff);
+}
+void launch_bc_add_cells(hipStream_t st, const GridP &g, const double *plane, double *cells, int axis, int side, double coeff)
+{
+  const int na = axis == 0 ? g.ny : g.nx, nb = axis == 2 ? g.ny : g.nz;
+  hipLaunchKernelGGL(k_bc_add_cells, grid3(na, nb, 1), blk3(), 0, st, g, plane, cells, axis, side, coeff);
 }
 void launch_pressure_update(hipStream_t st, int64_t n, int first, const double *dp, const double *p0, double *phalf, double *p)
 {

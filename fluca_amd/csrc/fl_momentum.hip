@@ -442,6 +442,16 @@ __global__ void __launch_bounds__(256) k_lincomb(int64_t n, double a, const doub
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) y[q] = a * x[q] + (z ? b * z[q] : 0.);
 }
 
+// partial[block] = sum over this block's grid-stride share of x[q] y[q]
+__global__ void __launch_bounds__(256) k_dot(int64_t n, const double *__restrict__ x, const double *__restrict__ y, double *__restrict__ partial)
+{
+  __shared__ double red[4];
+  double            v[1] = {0.};
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) v[0] += x[q] * y[q];
+  block_sum<1>(v, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = v[0];
+}
+
 // src: x-fastest array of ex*ey*ez entries (ex <= nx+1, ...) -> padded array, entry (i,j,k) at off0 + k sxy + j sx + i
 __global__ void __launch_bounds__(256) k_pad_copy_ext(GridP g, const double *__restrict__ src, double *__restrict__ dst, int ex, int ey, int ez)
 {
@@ -880,6 +890,34 @@ extern "C" int fl_abf_apply(fl_momentum *m, const fl_ksp_opts *momentum_opts, co
   /* stage 2: the upper-triangular factor; (-T)(Gp) - (-R)p == -kappa Gst p, see DESIGN.md section 1 */
   const size_t N = (size_t)h->ncell;
   return fl_poisson_project(h, p_dev, v_dev, v_dev + N, v_dev + 2 * N, V_dev[0], V_dev[1], V_dev[2]);   /* :80-101 */
+}
+
+// ------------------------------------------------------------------------------------------------ device BLAS-1 for hosts
+// For hosts that drive an outer iteration over device vectors without a vector library of their own (the C host mirror).
+
+extern "C" int fl_vec_lincomb(fl_poisson *h, int64_t n, double a, const double *x_dev, double b, const double *z_dev, double *y_dev)
+{
+  if (!h || !x_dev || !y_dev) return FL_ERR_ARG_NULL;
+  if (n < 0) return FL_ERR_ARG_OUTOFRANGE;
+  FL_HIP(hipSetDevice(h->device));
+  if (n > 0) lincomb(h, n, a, x_dev, b, z_dev, y_dev);
+  FL_HIP(hipGetLastError());
+  return FL_SUCCESS;
+}
+
+extern "C" int fl_vec_dot(fl_poisson *h, int64_t n, const double *x_dev, const double *y_dev, double *result)
+{
+  if (!h || !x_dev || !y_dev || !result) return FL_ERR_ARG_NULL;
+  if (n < 0) return FL_ERR_ARG_OUTOFRANGE;
+  FL_HIP(hipSetDevice(h->device));
+  FL_CHK(fl_ensure_partials(h, 1024));
+  const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 1024));
+  hipLaunchKernelGGL(k_dot, dim3(nb), dim3(256), 0, h->stream, n, x_dev, y_dev, h->partial);
+  launch_reduce(h->stream, h->partial, nb, h->partial_stride, 1, h->sums);
+  if (h->multi) FL_CHK(h->comm.allreduce(h->stream, h->sums, NSLOT));   // every rank holds its OWNED entries only
+  FL_HIP(hipMemcpyAsync(result, h->sums, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  FL_HIP(hipStreamSynchronize(h->stream));
+  return FL_SUCCESS;
 }
 
 // ------------------------------------------------------------------------------------------------ diagnostics

@@ -416,6 +416,11 @@ struct _p_NS {
   fl_momentum         *momentum; /* plays PC_ABF's kspA + A (created by the first NSSetPreviousState) */
   fl_ksp_opts          schur;    /* -ns_abf_schur_* */
   fl_ksp_opts          mom;      /* -ns_abf_momentum_* */
+  int                  ksp_type;           /* -ns_ksp_type: 0 richardson, 1 preonly (the reference's default, gmres, is not built) */
+  double               ksp_rtol, ksp_atol; /* -ns_ksp_rtol 1e-5 (nssol.c:24), unpreconditioned norm (nssol.c:25) */
+  int                  ksp_max_it;
+  int                  ksp_its, reason;    /* of the last step */
+  double               ksp_rnorm;
   void                *data;
 };
 
@@ -442,6 +447,10 @@ FlErrorCode NSCreate(NS *ns)
   n->mom.type = FL_KSP_BCGS; /* PETSc's own default for kspA is gmres + ilu: neither has a matrix-free form here */
   n->mom.pc   = FL_PC_JACOBI;
   n->mom.remove_nullspace = 0;
+  n->ksp_type   = 0;
+  n->ksp_rtol   = 1e-5; /* nssol.c:24 */
+  n->ksp_atol   = 1e-50;
+  n->ksp_max_it = 10000;
   *ns = n;
   return 0;
 }
@@ -565,6 +574,15 @@ FlErrorCode NSSetFromOptions(NS ns, int argc, char **argv)
   if ((s = opt_find(argc, argv, "-ns_abf_schur_ksp_chebyshev_eigenvalues"))) {
     if (sscanf(s, "%lf,%lf", &ns->schur.emin, &ns->schur.emax) != 2) return E_ARG_WRONG;
   }
+  /* the outer KSP of ns->snes (nssol.c:21-29): prefix ns_ */
+  if ((s = opt_find(argc, argv, "-ns_ksp_type"))) {
+    if (!strcmp(s, "richardson")) ns->ksp_type = 0;
+    else if (!strcmp(s, "preonly")) ns->ksp_type = 1;
+    else return !strcmp(s, "gmres") || !strcmp(s, "fgmres") || !strcmp(s, "bcgs") ? E_SUP : E_ARG_UNKNOWN_TYPE;
+  }
+  if (opt_real(argc, argv, "-ns_ksp_rtol", &v)) ns->ksp_rtol = v;
+  if (opt_real(argc, argv, "-ns_ksp_atol", &v)) ns->ksp_atol = v;
+  if (opt_int64(argc, argv, "-ns_ksp_max_it", &iv)) ns->ksp_max_it = (int)iv;
   /* sub-KSP of the momentum block: prefix ns_ + abf_momentum_ (abfpc.c:205) */
   if ((s = opt_find(argc, argv, "-ns_abf_momentum_ksp_type")))
     if (strcmp(s, "bcgs")) return !strcmp(s, "gmres") || !strcmp(s, "cg") || !strcmp(s, "fgmres") ? E_SUP : E_ARG_UNKNOWN_TYPE;
@@ -617,11 +635,37 @@ FlErrorCode NSSetUp(NS ns) /* nsbasic.c:153-274, restricted to what the Poisson 
   return 0;
 }
 
-FlErrorCode NSStep(NS ns)
+FlErrorCode NSStep(NS ns) /* nsbasic.c:276-299 */
 {
   if (!ns) return E_ARG_NULL;
+  if (!ns->setupcalled) return E_ARG_WRONGSTATE;
   if (!ns->ops->step) return E_SUP;
-  return ns->ops->step(ns);
+  FLCHK(ns->ops->step(ns)); /* VecCopy(sol, sol0) + the type's step */
+  if (ns->reason >= 0) {
+    ++ns->step;
+    ns->t += ns->dt;
+  }
+  return 0;
+}
+
+FlErrorCode NSSolve(NS ns) /* nsbasic.c:325-350: step until -ns_max_steps */
+{
+  if (!ns) return E_ARG_NULL;
+  if (ns->max_steps < 0) return E_ARG_WRONGSTATE; /* "At least one of max time or max steps must be specified" */
+  while (ns->step < ns->max_steps) {
+    FLCHK(NSStep(ns));
+    if (ns->reason < 0) return 91; /* PETSC_ERR_NOT_CONVERGED: "NSStep has failed" */
+  }
+  return 0;
+}
+
+FlErrorCode NSGetLinearSolveInfo(NS ns, int *its, double *rnorm, int *reason)
+{
+  if (!ns) return E_ARG_NULL;
+  if (its) *its = ns->ksp_its;
+  if (rnorm) *rnorm = ns->ksp_rnorm;
+  if (reason) *reason = ns->reason;
+  return 0;
 }
 FlErrorCode NSGetTimeStep(NS ns, int64_t *step)
 {
@@ -779,22 +823,251 @@ FlErrorCode NSComputeStaggeredPressureGradientBC(NS ns, double t, double *V[3])
   return 0;
 }
 
-/* ---- NSCNLINEAR: the shipped type.  Only the pieces on the Poisson path exist; the full step needs the momentum
- * operator A = I + dt C - (mu dt / 2 rho) L, so `step` reports PETSC_ERR_SUP. */
-static FlErrorCode NSStep_CNLinear(NS ns)
+/* ---- NSCNLINEAR: the shipped type (fluca/src/ns/impl/linearcn/) ------------------------------------------------------
+ * The fields and the step of NSStep_CNLinear_Cart3d_Internal / NSFormJacobian / NSFormFunction (cnlinearcart3d.c:2807-3060)
+ * on device arrays.  Built: VELOCITY, PERIODIC and SYMMETRY boundaries; a PRESSURE_OUTLET needs the boundary-condition
+ * vectors of G and the Rhie-Chow terms (:3013-3044), which are not: the step reports PETSC_ERR_SUP then.  Outer solve:
+ * -ns_ksp_type richardson (x += PCApply_ABF(f - J x), unpreconditioned norm, -ns_ksp_rtol) or preonly. */
+typedef struct {
+  int64_t sz[4];                               /* cells, x-, y-, z-faces of this rank */
+  double *sol_v, *sol_V[3], *sol_p;            /* ns->sol  */
+  double *sol0_v, *sol0_V[3], *sol0_p;         /* ns->sol0 */
+  double *phalf;                               /* cnl->phalf */
+  double *x_v, *x_V[3], *x_p;                  /* ns->x: v, V, dp */
+  double *f_v, *f_V[3];                        /* f: momrhs, interprhs; contrhs = 0 (:3046) */
+  double *W[9];                                /* cnl->v0interp */
+  double *r_v, *r_V[3], *r_p, *d_v, *d_V[3], *d_p;
+  double *plane_dev, *plane_host[6];           /* boundary values: 3 components at two times */
+  int64_t plane_cap;
+} NS_CNLinear;
+
+static FlErrorCode cnl_alloc(NS ns, double **p, int64_t n)
 {
-  (void)ns;
-  return E_SUP;
+  void *d = NULL;
+  FLABI(fl_malloc(ns->device, sizeof(double) * (size_t)(n > 0 ? n : 1), &d));
+  *p = (double *)d;
+  return 0;
 }
+
+static FlErrorCode NSSetUp_CNLinear(NS ns)
+{
+  NS_CNLinear *c = (NS_CNLinear *)calloc(1, sizeof(*c));
+  if (!c) return E_MEM;
+  ns->data = c;
+  FLABI(fl_poisson_sizes(ns->poisson, c->sz));
+  const int64_t N = c->sz[0];
+  double      **cellv[] = {&c->sol_v, &c->sol0_v, &c->x_v, &c->f_v, &c->r_v, &c->d_v};
+  double      **cells[] = {&c->sol_p, &c->sol0_p, &c->phalf, &c->x_p, &c->r_p, &c->d_p};
+  for (size_t a = 0; a < sizeof(cellv) / sizeof(cellv[0]); ++a) FLCHK(cnl_alloc(ns, cellv[a], 3 * N));
+  for (size_t a = 0; a < sizeof(cells) / sizeof(cells[0]); ++a) FLCHK(cnl_alloc(ns, cells[a], N));
+  int64_t pmax = 1;
+  for (int d = 0; d < 3; ++d) {
+    double **faces[] = {&c->sol_V[d], &c->sol0_V[d], &c->x_V[d], &c->f_V[d], &c->r_V[d], &c->d_V[d]};
+    for (size_t a = 0; a < sizeof(faces) / sizeof(faces[0]); ++a) FLCHK(cnl_alloc(ns, faces[a], c->sz[1 + d]));
+    for (int q = 0; q < 3; ++q) FLCHK(cnl_alloc(ns, &c->W[q * 3 + d], c->sz[1 + d]));
+    const int     a1 = d == 0 ? 1 : 0, a2 = d == 2 ? 1 : 2;
+    const int64_t pl = ns->mesh->decomp.len[a1] * ns->mesh->decomp.len[a2];
+    if (pl > pmax) pmax = pl;
+  }
+  c->plane_cap = pmax;
+  FLCHK(cnl_alloc(ns, &c->plane_dev, pmax));
+  for (int q = 0; q < 6; ++q)
+    if (!(c->plane_host[q] = (double *)malloc(sizeof(double) * (size_t)pmax))) return E_MEM;
+  return 0;
+}
+
 static FlErrorCode NSDestroy_CNLinear(NS ns)
 {
-  (void)ns;
+  NS_CNLinear *c = (NS_CNLinear *)ns->data;
+  if (!c) return 0;
+  double *cell[] = {c->sol_v, c->sol0_v, c->x_v, c->f_v, c->r_v, c->d_v, c->sol_p, c->sol0_p, c->phalf, c->x_p, c->r_p, c->d_p, c->plane_dev};
+  for (size_t a = 0; a < sizeof(cell) / sizeof(cell[0]); ++a)
+    if (cell[a]) fl_free(ns->device, cell[a]);
+  for (int d = 0; d < 3; ++d) {
+    double *f[] = {c->sol_V[d], c->sol0_V[d], c->x_V[d], c->f_V[d], c->r_V[d], c->d_V[d], c->W[d], c->W[3 + d], c->W[6 + d]};
+    for (size_t a = 0; a < sizeof(f) / sizeof(f[0]); ++a)
+      if (f[a]) fl_free(ns->device, f[a]);
+  }
+  for (int q = 0; q < 6; ++q) free(c->plane_host[q]);
+  free(c);
+  ns->data = NULL;
+  return 0;
+}
+
+FlErrorCode NSGetSolutionArrays(NS ns, double **v, double *V[3], double **p)
+{
+  if (!ns) return E_ARG_NULL;
+  if (!ns->setupcalled || !ns->data) return E_ARG_WRONGSTATE;
+  NS_CNLinear *c = (NS_CNLinear *)ns->data;
+  if (v) *v = c->sol_v;
+  if (p) *p = c->sol_p;
+  if (V)
+    for (int d = 0; d < 3; ++d) V[d] = c->sol_V[d];
+  return 0;
+}
+
+/* boundary b touches this rank and carries a velocity condition: evaluate the callback at the face centres, out[c] =
+ * component c on this rank's part of the boundary (cnlinearcart3d.c:690-698: xb = face coordinate, cell centres in plane) */
+static FlErrorCode cnl_eval_velocity(NS ns, int b, double t, double *out[3])
+{
+  Mesh_Cart       *cart = (Mesh_Cart *)ns->mesh->data;
+  const fl_decomp *D    = &ns->mesh->decomp;
+  const int        ax = b / 2, side = b % 2, a1 = ax == 0 ? 1 : 0, a2 = ax == 2 ? 1 : 2;
+  const int64_t    n1 = D->len[a1], n2 = D->len[a2];
+  if (!ns->bcs[b].velocity) return E_ARG_WRONGSTATE;
+  for (int64_t j = 0; j < n2; ++j)
+    for (int64_t i = 0; i < n1; ++i) {
+      double xb[3], val[3] = {0., 0., 0.};
+      xb[ax] = cart->xf[ax][side ? cart->N[ax] : 0];
+      xb[a1] = cart->xc[a1][D->lo[a1] + i];
+      xb[a2] = cart->xc[a2][D->lo[a2] + j];
+      FLCHK(ns->bcs[b].velocity(3, t, xb, val, ns->bcs[b].ctx_velocity));
+      for (int c = 0; c < 3; ++c) out[c][j * n1 + i] = val[c];
+    }
+  return 0;
+}
+
+static int cnl_touches(NS ns, int b)
+{
+  const fl_decomp *D = &ns->mesh->decomp;
+  return b % 2 ? D->coord[b / 2] == D->ranks[b / 2] - 1 : D->coord[b / 2] == 0;
+}
+
+static FlErrorCode cnl_upload(NS ns, const double *host, int64_t n)
+{
+  NS_CNLinear *c = (NS_CNLinear *)ns->data;
+  FLABI(fl_memcpy_h2d(ns->device, c->plane_dev, host, sizeof(double) * (size_t)n));
+  return 0;
+}
+
+/* r = f - J x  and its 2-norm over (v, V, p) */
+static FlErrorCode cnl_residual(NS ns, double *rnorm)
+{
+  NS_CNLinear *c = (NS_CNLinear *)ns->data;
+  fl_poisson  *h = ns->poisson;
+  const double *xV[3] = {c->x_V[0], c->x_V[1], c->x_V[2]};
+  FLABI(fl_abf_jacobian_mult(ns->momentum, c->x_v, xV, c->x_p, c->r_v, c->r_V, c->r_p));
+  double s = 0., part;
+  FLABI(fl_vec_lincomb(h, 3 * c->sz[0], -1., c->r_v, 1., c->f_v, c->r_v));
+  FLABI(fl_vec_dot(h, 3 * c->sz[0], c->r_v, c->r_v, &part));
+  s += part;
+  for (int d = 0; d < 3; ++d) {
+    FLABI(fl_vec_lincomb(h, c->sz[1 + d], -1., c->r_V[d], 1., c->f_V[d], c->r_V[d]));
+    FLABI(fl_vec_dot(h, c->sz[1 + d], c->r_V[d], c->r_V[d], &part));
+    s += part;
+  }
+  FLABI(fl_vec_lincomb(h, c->sz[0], -1., c->r_p, 0., NULL, c->r_p)); /* contrhs = 0 */
+  FLABI(fl_vec_dot(h, c->sz[0], c->r_p, c->r_p, &part));
+  s += part;
+  *rnorm = sqrt(s);
+  return 0;
+}
+
+static FlErrorCode NSStep_CNLinear(NS ns)
+{
+  NS_CNLinear *c = (NS_CNLinear *)ns->data;
+  if (!c) return E_ARG_WRONGSTATE;
+  Mesh_Cart    *cart = (Mesh_Cart *)ns->mesh->data;
+  fl_poisson   *h = ns->poisson;
+  const int64_t N = c->sz[0];
+  const double  dt = ns->dt, t = ns->t, cv = 0.5 * ns->mu * dt / ns->rho;
+  for (int b = 0; b < 6; ++b)
+    if (ns->bcs[b].type == NS_BC_PRESSURE_OUTLET) return E_SUP;
+  if (!ns->momentum) FLABI(fl_momentum_create(h, &ns->momentum));
+  /* NSStep: VecCopy(sol, sol0), nsbasic.c:281-282 */
+  FLABI(fl_vec_lincomb(h, 3 * N, 1., c->sol_v, 0., NULL, c->sol0_v));
+  FLABI(fl_vec_lincomb(h, N, 1., c->sol_p, 0., NULL, c->sol0_p));
+  for (int d = 0; d < 3; ++d) FLABI(fl_vec_lincomb(h, c->sz[1 + d], 1., c->sol_V[d], 0., NULL, c->sol0_V[d]));
+
+  /* v0interp = B v0 + vbc(t), cnlinearcart3d.c:2826-2829; vbc: :1749-1932 */
+  FLABI(fl_momentum_interp_faces(ns->momentum, c->sol0_v, NULL, c->W));
+  /* momrhs = v0 + cv L v0 - kappa G p, :2976-2993 (p0 on the first step, phalf afterwards) */
+  FLABI(fl_momentum_rhs(ns->momentum, dt, ns->rho, ns->mu, c->sol0_v, ns->step == 0 ? c->sol0_p : c->phalf, NULL, c->f_v));
+  for (int d = 0; d < 3; ++d) FLABI(fl_vec_lincomb(h, c->sz[1 + d], 0., c->f_V[d], 0., NULL, c->f_V[d])); /* interprhs = 0 */
+  for (int b = 0; b < 6; ++b) {
+    if (ns->bcs[b].type != NS_BC_VELOCITY || !cnl_touches(ns, b)) continue;
+    const int        ax = b / 2, side = b % 2, a1 = ax == 0 ? 1 : 0, a2 = ax == 2 ? 1 : 2;
+    const fl_decomp *D = &ns->mesh->decomp;
+    const int64_t    np = D->len[a1] * D->len[a2], n = cart->N[ax];
+    const double    *xf = cart->xf[ax], *xc = cart->xc[ax];
+    double          *vb0[3] = {c->plane_host[0], c->plane_host[1], c->plane_host[2]}, *vb1[3] = {c->plane_host[3], c->plane_host[4], c->plane_host[5]};
+    FLCHK(cnl_eval_velocity(ns, b, t, vb0));
+    FLCHK(cnl_eval_velocity(ns, b, t + dt, vb1));
+    /* coefficient of the wall value in the one-sided second-derivative row, :698-701 / :726-729 */
+    double h1, h2, h3, hcell;
+    if (n < 3) return E_SUP;
+    if (!side) {
+      h1 = xc[0] - xf[0]; h2 = xc[1] - xc[0]; h3 = xc[2] - xc[0]; hcell = xf[1] - xf[0];
+    } else {
+      h1 = xf[n] - xc[n - 1]; h2 = xc[n - 1] - xc[n - 2]; h3 = xc[n - 1] - xc[n - 3]; hcell = xf[n] - xf[n - 1];
+    }
+    const double cl = 2. * (h2 + h3) / (h1 * (h1 + h2) * (h1 + h3)), sgn = side ? 0.5 : -0.5;
+    double      *tmp = (double *)malloc(sizeof(double) * (size_t)np);
+    if (!tmp) return E_MEM;
+    for (int q = 0; q < 3; ++q) {
+      /* v0interp on the wall faces = the wall velocity at t (INSERT), :1788 */
+      FLCHK(cnl_upload(ns, vb0[q], np));
+      FLABI(fl_boundary_set_faces(h, b, 1., c->plane_dev, c->W[q * 3 + ax]));
+      /* momrhs += cv (vbcL(t) + vbcL(t+dt)) - dt vbcC(t, t+dt), :2985-2998 with :698-701 and :1338 */
+      for (int64_t a = 0; a < np; ++a) tmp[a] = cv * cl * (vb0[q][a] + vb1[q][a]) - dt * sgn * (vb1[q][a] * vb0[ax][a] + vb0[q][a] * vb1[ax][a]) / hcell;
+      FLCHK(cnl_upload(ns, tmp, np));
+      FLABI(fl_boundary_add_cells(h, b, 1., c->plane_dev, c->f_v + q * N));
+    }
+    /* interprhs on the wall faces = the wall-normal velocity at t + dt, :3003-3005 with :2178 */
+    FLCHK(cnl_upload(ns, vb1[ax], np));
+    FLABI(fl_boundary_set_faces(h, b, 1., c->plane_dev, c->f_V[ax]));
+    free(tmp);
+  }
+  /* NSFormJacobian: A = I + dt C(V0, v0interp) - cv L, :2930-2941 */
+  {
+    const double *V0[3] = {c->sol0_V[0], c->sol0_V[1], c->sol0_V[2]};
+    const double *W[9];
+    for (int q = 0; q < 9; ++q) W[q] = c->W[q];
+    FLABI(fl_momentum_set_state(ns->momentum, dt, ns->rho, ns->mu, V0, W));
+  }
+  /* KSPSolve(J, f, x) with PC_ABF */
+  fl_ksp_stats  st[2];
+  const double *fV[3] = {c->f_V[0], c->f_V[1], c->f_V[2]};
+  FLABI(fl_abf_apply(ns->momentum, &ns->mom, &ns->schur, c->f_v, fV, NULL, c->x_v, c->x_V, c->x_p, st));
+  ns->ksp_its = 1;
+  ns->reason  = 0;
+  if (st[0].reason < 0 || st[1].reason < 0) ns->reason = -1; /* NS_DIVERGED_LINEAR_SOLVE */
+  if (ns->ksp_type == 0 && ns->reason >= 0) {
+    double fnorm, rnorm = 0., part;
+    FLABI(fl_vec_dot(h, 3 * N, c->f_v, c->f_v, &fnorm));
+    for (int d = 0; d < 3; ++d) {
+      FLABI(fl_vec_dot(h, c->sz[1 + d], c->f_V[d], c->f_V[d], &part));
+      fnorm += part;
+    }
+    fnorm = sqrt(fnorm);
+    const double ttol = ns->ksp_rtol * fnorm > ns->ksp_atol ? ns->ksp_rtol * fnorm : ns->ksp_atol;
+    for (;;) {
+      FLCHK(cnl_residual(ns, &rnorm));
+      ns->ksp_rnorm = rnorm;
+      if (!(rnorm == rnorm)) { ns->reason = -1; break; }
+      if (rnorm <= ttol) break;
+      if (ns->ksp_its >= ns->ksp_max_it) { ns->reason = -1; break; }
+      const double *rV[3] = {c->r_V[0], c->r_V[1], c->r_V[2]};
+      FLABI(fl_abf_apply(ns->momentum, &ns->mom, &ns->schur, c->r_v, rV, c->r_p, c->d_v, c->d_V, c->d_p, st));
+      if (st[0].reason < 0 || st[1].reason < 0) { ns->reason = -1; break; }
+      FLABI(fl_vec_lincomb(h, 3 * N, 1., c->x_v, 1., c->d_v, c->x_v));
+      FLABI(fl_vec_lincomb(h, N, 1., c->x_p, 1., c->d_p, c->x_p));
+      for (int d = 0; d < 3; ++d) FLABI(fl_vec_lincomb(h, c->sz[1 + d], 1., c->x_V[d], 1., c->d_V[d], c->x_V[d]));
+      ++ns->ksp_its;
+    }
+  }
+  if (ns->reason < 0) return 0; /* NSStep reports it; the solution is left untouched (NSCheckDiverged) */
+  /* v, V <- x; pressure update, :2841-2854 */
+  FLABI(fl_vec_lincomb(h, 3 * N, 1., c->x_v, 0., NULL, c->sol_v));
+  for (int d = 0; d < 3; ++d) FLABI(fl_vec_lincomb(h, c->sz[1 + d], 1., c->x_V[d], 0., NULL, c->sol_V[d]));
+  FLABI(fl_pressure_update(h, ns->step == 0, c->x_p, c->sol0_p, c->phalf, c->sol_p));
+  FLABI(fl_poisson_synchronize(h));
   return 0;
 }
 static FlErrorCode NSCreate_CNLinear(NS ns) /* cnlinear.c:164-187 */
 {
   ns->ops->setfromoptions = NULL;
-  ns->ops->setup          = NULL;
+  ns->ops->setup          = NSSetUp_CNLinear;
   ns->ops->step           = NSStep_CNLinear;
   ns->ops->destroy        = NSDestroy_CNLinear;
   return 0;

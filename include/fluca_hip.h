@@ -137,6 +137,11 @@ int fl_free(int device, void *dev);
 int fl_memcpy_h2d(int device, void *dev, const void *host, size_t bytes);
 int fl_memcpy_d2h(int device, void *host, const void *dev, size_t bytes);
 
+/* y = a x + b z (z_dev may be NULL; y may alias x or z) and result = sum x y over all ranks (blocking; every rank passes its
+ * owned entries) -- for hosts that run an outer iteration over device vectors and have no vector library of their own. */
+int fl_vec_lincomb(fl_poisson *h, int64_t n, double a, const double *x_dev, double b, const double *z_dev, double *y_dev);
+int fl_vec_dot(fl_poisson *h, int64_t n, const double *x_dev, const double *y_dev, double *result);
+
 /* Optional one-off tuning step after create (like planning an FFT): any kernel that streams six 1 GB vectors at once runs
  * 10-15 % faster or slower depending on where the driver happened to place them physically (profiles/r01_placement.txt).
  * This allocates up to max_tries candidate sets of the solver vectors, times a 3-read/3-write streaming probe on each
@@ -156,6 +161,13 @@ int fl_poisson_project(fl_poisson *h, const double *p_dev, double *vx_dev, doubl
  * coeff*pb into the boundary faces of V_dev (face array of the boundary's axis), INSERT_VALUES semantics.  No-op (success)
  * unless bc[boundary] is PRESSURE_OUTLET and this rank touches the boundary. */
 int fl_poisson_gst_bc(fl_poisson *h, int boundary, const double *pb_dev, double *V_dev);
+/* Building blocks of the reference's boundary-condition vectors (Compute*BoundaryConditionVector_Private,
+ * cnlinearcart3d.c:219-423, 648-871, 1296-1511, 1749-1932, 2142-2312, 2602-2805): each is "a value per boundary face"
+ * (plane_dev: this rank's part of boundary 0..5, in-plane axes in x,y,z order, the first fastest) either written into the
+ * boundary faces of a face array of the boundary's axis (DMStagVecSetValuesStencil INSERT_VALUES) or added to the cells
+ * next to the boundary (ADD_VALUES).  No-op on ranks that do not touch the boundary and on periodic axes. */
+int fl_boundary_set_faces(fl_poisson *h, int boundary, double coeff, const double *plane_dev, double *face_dev);
+int fl_boundary_add_cells(fl_poisson *h, int boundary, double coeff, const double *plane_dev, double *cell_dev);
 /* first != 0: p = p0 + 2 dp, phalf = p0 + dp ; else p = phalf + 1.5 dp, phalf += dp */
 int fl_pressure_update(fl_poisson *h, int first, const double *dp_dev, const double *p0_dev, double *phalf_dev, double *p_dev);
 

@@ -115,6 +115,15 @@ FlErrorCode NSGetLocalSizes(NS ns, int64_t out[4]);
 /* PCApply_ABF minus KSPSolve(kspA): given the intermediate velocities v* (cells, any may be NULL) and V* (faces) on the
  * device, Srhs = contrhs - D V*, dp = S^-1 Srhs, v = v* - G dp, V = V* - Gst dp  (abfpc.c:73-101, Ainv = ID) */
 FlErrorCode NSPressureCorrection(NS ns, double *vstar_dev[3], double *Vstar_dev[3], const double *contrhs_dev, double *dp_dev, fl_ksp_stats *stats);
+/* NSStep / NSSolve (nsbasic.c:276-350) with the CNLinear step of cnlinearcart3d.c:2807-2863 (+ NSFormJacobian :2930-2941,
+ * NSFormFunction :2945-3060) on device arrays: VELOCITY / PERIODIC / SYMMETRY boundaries (a PRESSURE_OUTLET makes the step
+ * return PETSC_ERR_SUP).  The outer KSP of ns->snes is -ns_ksp_type richardson (default here; x += PCApply_ABF(f - J x) until
+ * the unpreconditioned residual meets -ns_ksp_rtol 1e-5, nssol.c:24-25) or preonly; the reference's own default, gmres,
+ * is not built (PETSC_ERR_SUP).  NSGetSolutionArrays hands out the device arrays of ns->sol (velocity 3*cells
+ * component-major, face-normal velocity per axis, pressure) so that the caller can set the initial condition. */
+FlErrorCode NSSolve(NS ns);
+FlErrorCode NSGetSolutionArrays(NS ns, double **v_dev, double *V_dev[3], double **p_dev);
+FlErrorCode NSGetLinearSolveInfo(NS ns, int *its, double *rnorm, int *reason);
 /* The A block of NSFormJacobian (cnlinearcart3d.c:2930-2941): hands over sol0's face-normal velocity V0 (3 face arrays)
  * and cnl->v0interp (9 face arrays, component c on the faces of axis d at [c*3+d]); A = I + dt C - (mu dt / 2 rho) L is
  * applied matrix-free from then on.  Call once per time step, before NSApplyPreconditioner. */

@@ -300,3 +300,106 @@ def test_full_pcapply_abf_through_the_mirror(H):
     for d in range(3):
         assert np.linalg.norm(Vd[d].cpu().numpy() - (Vs[d] - Gst[d])) <= 1e-7 * np.linalg.norm(Vs[d])
     assert H.lib.NSDestroy(C.byref(ns)) == 0 and H.lib.MeshDestroy(C.byref(mesh)) == 0
+
+
+def _tgv_mirror(H, n, nsteps, walls, t_final=0.4, rho=1.0, mu=0.1, ksp="richardson"):
+    """The reference's own check (fluca/tests/taylor_green_vortex/taylor_green_vortex.c) in 3-D: Taylor-Green vortex in
+    x-y, periodic in z; walls=True puts time-dependent VELOCITY conditions from the exact solution on the four side walls
+    (the boundary-condition vectors of L, C, B and T), walls=False is the fully periodic box."""
+    import torch
+    L = 2 * np.pi
+    nu = mu / rho
+    bt = 0 if walls else 1                      # MESHCART_BOUNDARY_NONE / PERIODIC
+    mesh = P()
+    assert H.lib.MeshCartCreate3d(bt, bt, 1, n, n, 4, -1, -1, -1, None, None, None, C.byref(mesh)) == 0
+    assert H.lib.MeshSetUp(mesh) == 0
+    assert H.lib.MeshCartSetUniformCoordinates(mesh, 0., L, 0., L, 0., L * 4 / n) == 0
+    ns = P()
+    assert H.lib.NSCreate(C.byref(ns)) == 0 and H.lib.NSSetType(ns, b"cnlinear") == 0 and H.lib.NSSetMesh(ns, mesh) == 0
+    assert H.lib.NSSetDensity(ns, rho) == 0 and H.lib.NSSetViscosity(ns, mu) == 0
+
+    @H.BCFunc
+    def velocity(dim, t, x, val, ctx):
+        d = np.exp(-2.0 * nu * t)
+        val[0] = np.sin(x[0]) * np.cos(x[1]) * d
+        val[1] = -np.cos(x[0]) * np.sin(x[1]) * d
+        val[2] = 0.0
+        return 0
+
+    for b in range(4):
+        bc = H.NSBoundaryCondition(type=H.NS_BC_VELOCITY, velocity=velocity) if walls else H.NSBoundaryCondition(type=H.NS_BC_PERIODIC)
+        assert H.lib.NSSetBoundaryCondition(ns, b, bc) == 0
+    for b in (4, 5):
+        assert H.lib.NSSetBoundaryCondition(ns, b, H.NSBoundaryCondition(type=H.NS_BC_PERIODIC)) == 0
+    dt = t_final / nsteps
+    argc, av = H.argv("-ns_time_step_size", dt, "-ns_max_steps", nsteps, "-ns_ksp_type", ksp, "-ns_ksp_rtol", 1e-8,
+                      "-ns_abf_schur_ksp_rtol", 1e-10, "-ns_abf_momentum_ksp_rtol", 1e-10)
+    assert H.lib.NSSetFromOptions(ns, argc, av) == 0 and H.lib.NSSetUp(ns) == 0
+    v, p, V = P(), P(), (C.c_void_p * 3)()
+    assert H.lib.NSGetSolutionArrays(ns, C.byref(v), V, C.byref(p)) == 0
+    h = L / n
+    xc, xf = (np.arange(n) + 0.5) * h, np.arange(n + 1) * h
+    Z = np.ones((4, 1, 1))
+    ex = lambda xs, ys, t: (Z * (np.sin(xs)[None, None, :] * np.cos(ys)[None, :, None]) * np.exp(-2 * nu * t),
+                            Z * (-np.cos(xs)[None, None, :] * np.sin(ys)[None, :, None]) * np.exp(-2 * nu * t))
+    u0, w0 = ex(xc, xc, 0.0)
+    nfx = n + 1 if walls else n
+    put = lambda ptr, a: H.capi.check(H.capi.lib.fl_memcpy_h2d(0, ptr, np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(C.c_void_p), a.size * 8))
+    put(v, np.stack([u0, w0, np.zeros_like(u0)]))
+    put(C.c_void_p(V[0]), ex(xf[:nfx], xc, 0.0)[0])
+    put(C.c_void_p(V[1]), ex(xc, xf[:nfx], 0.0)[1])
+    X, Y = np.meshgrid(xc, xc, indexing="xy")
+    put(p, Z * (rho / 4 * (np.cos(2 * X) + np.cos(2 * Y)))[None, :, :])
+    assert H.lib.NSSolve(ns) == 0
+    its, rn, reason = C.c_int(), C.c_double(), C.c_int()
+    H.lib.NSGetLinearSolveInfo(ns, C.byref(its), C.byref(rn), C.byref(reason))
+    step, t = C.c_int64(), C.c_double()
+    H.lib.NSGetTimeStep(ns, C.byref(step))
+    H.lib.NSGetTime(ns, C.byref(t))
+    assert step.value == nsteps and abs(t.value - t_final) < 1e-12 and reason.value >= 0
+    out = np.empty(3 * 4 * n * n)
+    H.capi.check(H.capi.lib.fl_memcpy_d2h(0, out.ctypes.data_as(C.c_void_p), v, out.size * 8))
+    vh = out.reshape(3, 4, n, n)
+    ue, we = ex(xc, xc, t_final)
+    err = np.sqrt(((vh[0] - ue) ** 2 + (vh[1] - we) ** 2).mean())
+    wmax = np.abs(vh[2]).max()
+    H.lib.NSDestroy(C.byref(ns))
+    H.lib.MeshDestroy(C.byref(mesh))
+    return err, wmax, its.value
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("walls", [False, True])
+def test_nssolve_taylor_green_second_order(H, walls):
+    e1, w1, _ = _tgv_mirror(H, 16, 4, walls)
+    e2, w2, _ = _tgv_mirror(H, 32, 8, walls)
+    assert w1 < 1e-10 and w2 < 1e-10
+    assert e1 < 0.05 and e2 < e1 / 3.0, (e1, e2)
+
+
+@pytest.mark.gpu
+def test_nssolve_preonly_is_the_fractional_step_method(H):
+    """-ns_ksp_type preonly applies PCApply_ABF once per step: still second-order accurate, slightly larger error."""
+    e_r, _, its_r = _tgv_mirror(H, 32, 8, True, ksp="richardson")
+    e_p, _, its_p = _tgv_mirror(H, 32, 8, True, ksp="preonly")
+    assert its_p == 1 and its_r > 1
+    assert e_p < 3 * e_r + 1e-3
+
+
+@pytest.mark.gpu
+def test_c_cavity_driver_full_time_steps(H):
+    """examples/cavity_flow_3d.c: the reference's lid-driven cavity (cavity_flow_3d.c) stepping on the GPU from C."""
+    import re
+    import subprocess
+    from fluca_amd import build
+    exe = build.build_example(name="cavity_flow_3d")
+    out = subprocess.run([exe, "-cart_grid_x", "32", "-cart_grid_y", "32", "-cart_grid_z", "16", "-ns_time_step_size", "1e-2", "-ns_max_steps", "12",
+                          "-ns_ksp_rtol", "1e-6"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [l for l in out.stdout.splitlines() if " NS time " in l]
+    assert len(lines) == 12 and lines[-1].startswith("12 NS time 0.12")
+    ke = [float(re.search(r"kinetic energy (\S+)", l).group(1)) for l in lines]
+    assert all(b > a > 0 for a, b in zip(ke, ke[1:]))                 # the lid keeps feeding the flow at early times
+    prof = [float(x) for x in out.stdout.splitlines()[-1].split(":")[1].split()]
+    assert prof[-1] > 0.2 and min(prof) < 0.0                          # dragged along under the lid, return flow below
+    assert all(abs(x) < 1.0 + 1e-9 for x in prof)
