@@ -102,7 +102,11 @@ def test_ns_registry_options_and_state_errors(H):
     assert H.lib.NSSetFromOptions(ns, argc, av) == H.ERR_ARG_UNKNOWN_TYPE
     argc, av = H.argv("-ns_pc_abf_schur_ainv_type", "DIAG")
     assert H.lib.NSSetFromOptions(ns, argc, av) == H.ERR_SUP
-    assert H.lib.NSStep(ns) == H.ERR_SUP                               # full step = momentum solve = SURVEY 8f, not built
+    assert H.lib.NSStep(ns) == H.ERR_ARG_WRONGSTATE                    # before NSSetUp
+    argc, av = H.argv("-ns_ksp_type", "gmres")                         # the reference's default outer KSP is not built
+    assert H.lib.NSSetFromOptions(ns, argc, av) == H.ERR_SUP
+    argc, av = H.argv("-ns_ksp_type", "preonly", "-ns_ksp_rtol", 1e-7)
+    assert H.lib.NSSetFromOptions(ns, argc, av) == 0
     assert H.lib.NSDestroy(C.byref(ns)) == 0
     H.lib.MeshDestroy(C.byref(mesh))
 
