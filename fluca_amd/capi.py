@@ -53,7 +53,8 @@ class fl_ksp_opts(C.Structure):
     _fields_ = [("type", C.c_int), ("pc", C.c_int), ("norm_type", C.c_int), ("remove_nullspace", C.c_int),
                 ("maxit", C.c_int), ("rtol", C.c_double), ("atol", C.c_double), ("dtol", C.c_double),
                 ("emin", C.c_double), ("emax", C.c_double), ("variant", C.c_int), ("check_every", C.c_int),
-                ("profile", C.c_int), ("history", C.POINTER(C.c_double)), ("nhistory", C.c_int)]
+                ("profile", C.c_int), ("history", C.POINTER(C.c_double)), ("nhistory", C.c_int),
+                ("mg_levels", C.c_int), ("mg_smooth_its", C.c_int)]
 
 
 class fl_ksp_stats(C.Structure):
@@ -105,6 +106,7 @@ PROTOTYPES = {
     "fl_momentum_diagonal": (C.c_int, [_P, _P]),
     "fl_momentum_solve": (C.c_int, [_P, _P, _P, C.POINTER(fl_ksp_opts), C.POINTER(fl_ksp_stats)]),
     "fl_momentum_face_interp": (C.c_int, [_P, _P, _P, _P]),
+    "fl_poisson_gershgorin": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double)]),
     "fl_vec_lincomb": (C.c_int, [_P, C.c_int64, C.c_double, _P, C.c_double, _P, _P]),
     "fl_vec_dot": (C.c_int, [_P, C.c_int64, _P, _P, C.POINTER(C.c_double)]),
     "fl_boundary_set_faces": (C.c_int, [_P, C.c_int, C.c_double, _P, _P]),

@@ -196,6 +196,7 @@ extern "C" int fl_poisson_destroy(fl_poisson *h)
   if (!h) return FL_SUCCESS;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  fl_mg_destroy(h);
   h->comm.destroy();
   for (void *p : h->tables) (void)hipFree(p);
   for (void *p : h->vec_bases) (void)hipFree(p);
@@ -223,6 +224,7 @@ extern "C" int fl_poisson_set_stream(fl_poisson *h, void *hip_stream)
 {
   if (!h) return FL_ERR_ARG_NULL;
   h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+  fl_mg_set_stream(h);
   return FL_SUCCESS;
 }
 
@@ -735,9 +737,13 @@ extern "C" int fl_poisson_solve(fl_poisson *h, const double *b_dev, double *x_de
 {
   if (!h || !b_dev || !x_dev || !opts || !stats) return FL_ERR_ARG_NULL;
   if (opts->maxit < 0 || opts->maxit > 10000000) return FL_ERR_ARG_OUTOFRANGE;
-  if (opts->pc != FL_PC_NONE && opts->pc != FL_PC_JACOBI) return FL_ERR_SUP;
+  if (opts->pc != FL_PC_NONE && opts->pc != FL_PC_JACOBI && opts->pc != FL_PC_MG) return FL_ERR_SUP;
   FL_HIP(hipSetDevice(h->device));
   std::memset(stats, 0, sizeof(*stats));
+  if (opts->pc == FL_PC_MG) {
+    if (opts->type != FL_KSP_CG) return FL_ERR_SUP;
+    return fl_solve_cg_mg(h, b_dev, x_dev, opts, stats);
+  }
   switch (opts->type) {
   case FL_KSP_CG:
     if (opts->norm_type < 0 || opts->norm_type > FL_NORM_NONE) return FL_ERR_ARG_OUTOFRANGE;
@@ -752,6 +758,14 @@ extern "C" int fl_poisson_solve(fl_poisson *h, const double *b_dev, double *x_de
   default:
     return FL_ERR_SUP;
   }
+}
+
+extern "C" int fl_poisson_gershgorin(const fl_poisson *h, int pc, double *bound)
+{
+  if (!h || !bound) return FL_ERR_ARG_NULL;
+  if (pc != FL_PC_NONE && pc != FL_PC_JACOBI) return FL_ERR_ARG_OUTOFRANGE;
+  *bound = fl_gershgorin_bound(h, pc == FL_PC_JACOBI);
+  return FL_SUCCESS;
 }
 
 // ------------------------------------------------------------------------------------------------ plain device memory

@@ -213,6 +213,8 @@ using namespace fl;
 
 // ------------------------------------------------------------------------------------------------ handle
 
+struct fl_mg;
+
 struct fl_poisson {
   int         device = 0;
   hipStream_t stream = nullptr, own_stream = nullptr;
@@ -244,6 +246,7 @@ struct fl_poisson {
   double  *hiface[3] = {nullptr, nullptr, nullptr}, *loface_send[3] = {nullptr, nullptr, nullptr};
   Comm     comm;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  fl_mg     *mg = nullptr;  // multigrid hierarchy, built by the first solve with FL_PC_MG (fl_mg.hip)
 };
 
 
@@ -263,3 +266,8 @@ int fl_ksp_begin(fl_poisson *h, const fl_ksp_opts *o);
 int fl_bcgs_fin_step(fl_poisson *h, int mode, int nblocks, int nslot, int nhist);
 int fl_ksp_finish(fl_poisson *h, const fl_ksp_opts *o, fl_ksp_stats *st);
 int fl_solve_cheb(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *o, fl_ksp_stats *st);
+double fl_gershgorin_bound(const fl_poisson *h, bool jac);
+// fl_mg.hip
+int  fl_solve_cg_mg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *o, fl_ksp_stats *st);
+void fl_mg_destroy(fl_poisson *h);
+void fl_mg_set_stream(fl_poisson *h);

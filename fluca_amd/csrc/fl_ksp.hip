@@ -598,6 +598,25 @@ int fl_solve_bcgs(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *
   return finish_stats(h, o, st);
 }
 
+// Upper bound of the spectrum of M S from the GLOBAL 1-D tables (identical on every rank):
+//   Jacobi: sum_d a_d / sum_d c_d <= max_d max_i a_d(i)/c_d(i)   (mediant inequality), a = |sl|+|sc|+|sh|, c = |sc|
+//   none  : sum_d max_i a_d(i)
+// For the uniform Neumann / periodic Laplacian this is the exact Gershgorin value 2.
+double fl_gershgorin_bound(const fl_poisson *h, bool jac)
+{
+  double lam = 0.;
+  for (int d = 0; d < 3; ++d) {
+    const Axis &A = h->ax[d];
+    double      md = 0.;
+    for (int64_t i = 0; i < A.n; ++i) {
+      const double a = std::fabs(A.sl[i]) + std::fabs(A.sc[i]) + std::fabs(A.sh[i]);
+      md             = std::max(md, jac ? a / std::fabs(A.sc[i]) : a);
+    }
+    lam = jac ? std::max(lam, md) : lam + md;
+  }
+  return lam;
+}
+
 int fl_solve_cheb(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *o, fl_ksp_stats *st)
 {
   const GridP &g   = h->g;
@@ -612,20 +631,7 @@ int fl_solve_cheb(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *
   hipStream_t s = h->stream;
   double emin = o->emin, emax = o->emax;
   if (emin == 0. && emax == 0.) {
-    // Upper bound of the spectrum of M S from the GLOBAL 1-D tables (identical on every rank):
-    //   Jacobi: sum_d a_d / sum_d c_d <= max_d max_i a_d(i)/c_d(i)   (mediant inequality), a = |sl|+|sc|+|sh|, c = |sc|
-    //   none  : sum_d max_i a_d(i)
-    // For the uniform Neumann / periodic Laplacian this is the exact Gershgorin value 2.
-    double lam = 0.;
-    for (int d = 0; d < 3; ++d) {
-      const Axis &A = h->ax[d];
-      double      md = 0.;
-      for (int64_t i = 0; i < A.n; ++i) {
-        const double a = std::fabs(A.sl[i]) + std::fabs(A.sc[i]) + std::fabs(A.sh[i]);
-        md             = std::max(md, jac ? a / std::fabs(A.sc[i]) : a);
-      }
-      lam = jac ? std::max(lam, md) : lam + md;
-    }
+    const double lam = fl_gershgorin_bound(h, jac);
     emin = 0.1 * lam;  // -ksp_chebyshev_esteig 0,0.1,0,1.1 applied to the bound
     emax = 1.1 * lam;
   }

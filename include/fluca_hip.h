@@ -76,7 +76,7 @@ typedef struct fl_decomp {
 } fl_decomp;
 
 typedef enum { FL_KSP_CG = 0, FL_KSP_BCGS = 1, FL_KSP_CHEBYSHEV = 2 } fl_ksp_type;             /* -ksp_type cg|bcgs|chebyshev */
-typedef enum { FL_PC_NONE = 0, FL_PC_JACOBI = 1 } fl_pc_type;                                   /* -pc_type none|jacobi */
+typedef enum { FL_PC_NONE = 0, FL_PC_JACOBI = 1, FL_PC_MG = 2 } fl_pc_type;                     /* -pc_type none|jacobi|mg (mg: fl_ksp_cg only) */
 typedef enum { FL_NORM_PRECONDITIONED = 0, FL_NORM_UNPRECONDITIONED = 1, FL_NORM_NATURAL = 2, FL_NORM_NONE = 3 } fl_norm_type; /* -ksp_norm_type */
 
 /* KSPConvergedReason values */
@@ -103,6 +103,8 @@ typedef struct fl_ksp_opts {
   int     profile;          /* 1: bracket the dominant kernel of every iteration with HIP events -> stats.kernel_ms */
   double *history;          /* optional host array, receives the monitored norm of iterations 0..iters */
   int     nhistory;
+  int     mg_levels;        /* FL_PC_MG: number of grid levels, 0 = coarsen as far as possible (-pc_mg_levels) */
+  int     mg_smooth_its;    /* FL_PC_MG: Chebyshev-Jacobi steps before and after the coarse correction, 0 = 2 (-mg_levels_ksp_max_it) */
 } fl_ksp_opts;
 
 typedef struct fl_ksp_stats {
@@ -153,6 +155,9 @@ int fl_poisson_tune_placement(fl_poisson *h, int max_tries, double probe_ms_out[
 int fl_poisson_apply(fl_poisson *h, const double *x_dev, double *y_dev);  /* y = S x */
 int fl_poisson_diagonal(fl_poisson *h, double *d_dev);                    /* MatGetDiagonal(S) */
 int fl_poisson_solve(fl_poisson *h, const double *b_dev, double *x_dev, const fl_ksp_opts *opts, fl_ksp_stats *stats);
+/* Upper bound of the spectrum of M S (M = 1/diag for pc = FL_PC_JACOBI, identity otherwise) from the 1-D operator tables:
+ * what the Chebyshev solver / smoother multiplies by (0.1, 1.1) when emin = emax = 0.  Host-only, no GPU work. */
+int fl_poisson_gershgorin(const fl_poisson *h, int pc, double *bound);
 /* b = contrhs - D V   (contrhs_dev may be NULL = 0) */
 int fl_poisson_rhs(fl_poisson *h, const double *Vx_dev, const double *Vy_dev, const double *Vz_dev, const double *contrhs_dev, double *b_dev);
 /* v_d -= kappa (G p)_d at cell centres (any v*_dev may be NULL), V_d -= kappa (Gst p)_d on faces (any V*_dev may be NULL) */

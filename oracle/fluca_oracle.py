@@ -332,3 +332,99 @@ def num_threads():
 
 def set_num_threads(n):
     lib().fo_set_num_threads(int(n))
+
+
+class MgOracle:
+    """CPU restatement of the geometric multigrid preconditioner specified in fluca_amd/csrc/fl_mg.hip (no reference
+    function behind it).  Levels: halve every axis with an even cell count >= 8, rediscretise S on
+    the coarse grid; smoother: nu Chebyshev-Jacobi steps from a zero guess over (0.1, 1.1) x bound; restriction: volume-
+    weighted average; prolongation: piecewise constant; coarsest level: Jacobi-PCG to rtol 1e-2; outer: PCG with the
+    V(nu,nu) cycle as left preconditioner.  `bounds[l]` = the eigenvalue bound of D^-1 S the product uses on level l
+    (fl_poisson_gershgorin); None = the row-wise Gershgorin bound of the assembled matrix."""
+
+    def __init__(self, g, max_levels=0, nu=2, nullspace=True, bounds=None):
+        self.nu, self.nullspace = int(nu), bool(nullspace)
+        self.grids, self.S, self.ratio = [g], [g.assemble_S()], []
+        while max_levels <= 0 or len(self.grids) < max_levels:
+            gf = self.grids[-1]
+            r = [2 if (gf.n[d] % 2 == 0 and gf.n[d] >= 8) else 1 for d in range(3)]
+            if max(r) == 1:
+                break
+            try:
+                gc = Grid([gf.n[d] // r[d] for d in range(3)], [gf.xf[d][::r[d]] for d in range(3)], gf.bc, gf.kappa)
+            except ValueError:
+                break
+            self.ratio.append(r)
+            self.grids.append(gc)
+            self.S.append(gc.assemble_S())
+        self.bounds = list(bounds) if bounds is not None else [S.gershgorin(PC_JACOBI) for S in self.S]
+
+    @property
+    def nlevels(self):
+        return len(self.grids)
+
+    def _restrict(self, l, r):
+        gf, gc, rr = self.grids[l], self.grids[l + 1], self.ratio[l]
+        a = r.reshape(gc.n[2], rr[2], gc.n[1], rr[1], gc.n[0], rr[0])
+        w = [np.diff(gf.xf[d]).reshape(gc.n[d], rr[d]) / np.diff(gc.xf[d])[:, None] for d in range(3)]
+        a = a * w[2][:, :, None, None, None, None] * w[1][None, None, :, :, None, None] * w[0][None, None, None, None, :, :]
+        return a.sum(axis=(1, 3, 5)).ravel()
+
+    def _prolong(self, l, e):
+        gc, rr = self.grids[l + 1], self.ratio[l]
+        a = e.reshape(gc.n[2], gc.n[1], gc.n[0])
+        for ax, k in ((0, rr[2]), (1, rr[1]), (2, rr[0])):
+            a = np.repeat(a, k, axis=ax)
+        return a.ravel()
+
+    def _smooth(self, l, b):
+        lam = self.bounds[l]
+        x, _ = self.S[l].solve(b, ksp=KSP_CHEBYSHEV, pc=PC_JACOBI, norm=NORM_NONE, nullspace=self.nullspace, maxit=self.nu,
+                               emin=0.1 * lam, emax=1.1 * lam, history=False)
+        return x
+
+    def vcycle(self, b, l=0):
+        S = self.S[l]
+        if l + 1 == self.nlevels:
+            x, _ = S.solve(b, ksp=KSP_CG, pc=PC_JACOBI, nullspace=self.nullspace, rtol=1e-2, maxit=200, history=False)
+            return x
+        x = self._smooth(l, b)
+        r = b - S.mult(x)
+        x = x + self._prolong(l, self.vcycle(self._restrict(l, r), l + 1))
+        r = b - S.mult(x)
+        return x + self._smooth(l, r)
+
+    def pcg(self, b, rtol=1e-5, atol=1e-50, dtol=1e5, maxit=10000):
+        """KSPCG, left preconditioning, preconditioned norm, zero initial guess (same recurrences as fl_solve_cg_mg)."""
+        S = self.S[0]
+        proj = (lambda v: v - v.mean()) if self.nullspace else (lambda v: v)
+        x = np.zeros_like(b)
+        r = b.copy()
+        z = proj(self.vcycle(r))
+        dp = np.linalg.norm(z)
+        rz = r @ z
+        p = z.copy()
+        hist, it, reason = [dp], 0, 0
+        rn0, ttol = dp, max(rtol * dp, atol)
+        conv = lambda d: (-9 if not np.isfinite(d) else (3 if d < atol else 2) if d <= ttol else (-4 if d >= dtol * rn0 else 0))
+        reason = conv(dp)
+        while not reason:
+            q = S.mult(p)
+            pq = p @ q
+            if not pq > 0:
+                reason = -10
+                break
+            alpha = rz / pq
+            x += alpha * p
+            r -= alpha * q
+            z = proj(self.vcycle(r))
+            rz_old, dp, rz = rz, np.linalg.norm(z), r @ z
+            it += 1
+            hist.append(dp)
+            reason = conv(dp)
+            if not reason and it >= maxit:
+                reason = -3
+            if reason:
+                break
+            p = z + (rz / rz_old) * p
+        return proj(x), dict(iters=it, reason=reason, history=np.array(hist))
