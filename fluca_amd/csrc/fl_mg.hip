@@ -210,7 +210,7 @@ int vcycle(fl_mg *mg, size_t l, const double *b, double *x, const fl_ksp_opts *o
   so.type      = FL_KSP_CHEBYSHEV;
   so.pc        = FL_PC_JACOBI;
   so.norm_type = FL_NORM_NONE;
-  so.maxit     = o->mg_smooth_its > 0 ? o->mg_smooth_its : 2;
+  so.maxit     = o->mg_smooth_its > 0 ? o->mg_smooth_its : 3;
   MgLevel &C   = mg->lv[l + 1];
   FL_CHK(fl_poisson_solve(h, b, x, &so, &st));                                       // x = smooth(b)
   FL_CHK(fl_poisson_apply(h, x, L.res));                                             // S x

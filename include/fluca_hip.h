@@ -104,7 +104,7 @@ typedef struct fl_ksp_opts {
   double *history;          /* optional host array, receives the monitored norm of iterations 0..iters */
   int     nhistory;
   int     mg_levels;        /* FL_PC_MG: number of grid levels, 0 = coarsen as far as possible (-pc_mg_levels) */
-  int     mg_smooth_its;    /* FL_PC_MG: Chebyshev-Jacobi steps before and after the coarse correction, 0 = 2 (-mg_levels_ksp_max_it) */
+  int     mg_smooth_its;    /* FL_PC_MG: Chebyshev-Jacobi steps before and after the coarse correction, 0 = 3 (-mg_levels_ksp_max_it) */
 } fl_ksp_opts;
 
 typedef struct fl_ksp_stats {

@@ -342,7 +342,7 @@ class MgOracle:
     V(nu,nu) cycle as left preconditioner.  `bounds[l]` = the eigenvalue bound of D^-1 S the product uses on level l
     (fl_poisson_gershgorin); None = the row-wise Gershgorin bound of the assembled matrix."""
 
-    def __init__(self, g, max_levels=0, nu=2, nullspace=True, bounds=None):
+    def __init__(self, g, max_levels=0, nu=3, nullspace=True, bounds=None):
         self.nu, self.nullspace = int(nu), bool(nullspace)
         self.grids, self.S, self.ratio = [g], [g.assemble_S()], []
         while max_levels <= 0 or len(self.grids) < max_levels:
