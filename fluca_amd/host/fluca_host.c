@@ -558,8 +558,11 @@ FlErrorCode NSSetFromOptions(NS ns, int argc, char **argv)
   if ((s = opt_find(argc, argv, "-ns_abf_schur_pc_type"))) {
     if (!strcmp(s, "jacobi")) ns->schur.pc = FL_PC_JACOBI;
     else if (!strcmp(s, "none")) ns->schur.pc = FL_PC_NONE;
+    else if (!strcmp(s, "mg")) ns->schur.pc = FL_PC_MG; /* geometric multigrid of fl_mg.hip (KSPCG only) */
     else return E_ARG_UNKNOWN_TYPE;
   }
+  if (opt_int64(argc, argv, "-ns_abf_schur_pc_mg_levels", &iv)) ns->schur.mg_levels = (int)iv;
+  if (opt_int64(argc, argv, "-ns_abf_schur_mg_levels_ksp_max_it", &iv)) ns->schur.mg_smooth_its = (int)iv;
   if ((s = opt_find(argc, argv, "-ns_abf_schur_ksp_norm_type"))) {
     if (!strcmp(s, "preconditioned")) ns->schur.norm_type = FL_NORM_PRECONDITIONED;
     else if (!strcmp(s, "unpreconditioned")) ns->schur.norm_type = FL_NORM_UNPRECONDITIONED;

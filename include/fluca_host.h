@@ -17,6 +17,7 @@
  *   pressure update of NSStep_CNLinear_Cart3d_Internal (NSUpdatePressure)                               fluca/src/ns/impl/linearcn/cnlinearcart3d.c:2846-2854
  *   options -cart_grid_x.. -cart_ranks_x.. -cart_boundary_type_x.. -ns_density -ns_viscosity
  *           -ns_time_step_size -ns_max_steps -ns_abf_schur_ksp_{type,rtol,atol,max_it,norm_type} -ns_abf_schur_pc_type   cart.c:21-43, nsopts.c:177-198, abfpc.c:206,248-249
+ *           (-ns_abf_schur_pc_type mg [-ns_abf_schur_pc_mg_levels N -ns_abf_schur_mg_levels_ksp_max_it NU]: the build's own multigrid)
  *
  * Every function returns FlErrorCode: 0 = success, otherwise the positive PETSC_ERR_* value the reference would raise.
  */
