@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(256) k_ibm_scan(const int *__restrict__ cnt, i
     __syncthreads();
     // Hillis-Steele inclusive scan over the 256 per-thread sums
     for (int o = 1; o < 256; o <<= 1) {
-      const int v = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+      const int v = (int)threadIdx.x >= o ? part[threadIdx.x - o] : 0;
       __syncthreads();
       part[threadIdx.x] += v;
       __syncthreads();
@@ -193,9 +193,9 @@ __global__ void __launch_bounds__(256) k_ibm_spread(IbmP P, const int *__restric
   for (int c0 = beg; c0 < end; c0 += BIN_CHUNK) {
     const int n = min(BIN_CHUNK, end - c0);
     __syncthreads();
-    if (threadIdx.x < n) sraw[threadIdx.x] = list[c0 + threadIdx.x];
+    if ((int)threadIdx.x < n) sraw[threadIdx.x] = list[c0 + threadIdx.x];
     __syncthreads();
-    if (threadIdx.x < n) {
+    if ((int)threadIdx.x < n) {
       const int m = sraw[threadIdx.x];
 #pragma unroll
       for (int d = 0; d < 3; ++d) {

@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(256) k_reduce(const double *__restrict__ parti
 {
   __shared__ double out[NSLOT], red[NSLOT * 4];
   reduce_partials(partial, nblocks, stride, nslot, out, red);
-  if (threadIdx.x < NSLOT) sums[threadIdx.x] = threadIdx.x < nslot ? out[threadIdx.x] : 0.;
+  if (threadIdx.x < NSLOT) sums[threadIdx.x] = (int)threadIdx.x < nslot ? out[threadIdx.x] : 0.;
 }
 
 __device__ __forceinline__ int converged_default(KspScal *s, double dp)

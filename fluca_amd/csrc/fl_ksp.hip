@@ -88,9 +88,13 @@ __global__ void __launch_bounds__(256) k_apply_pc(GridP g, const double *__restr
         if (j < g.ny) {
           const int64_t ro = g.off0 + (int64_t)j * g.sx + t.il + pc;
           double2       ov = make_double2(0., 0.);
-          if (o) ov = *reinterpret_cast<const double2 *>(o + ro);
+          if (o && unpadded_y != 2) ov = *reinterpret_cast<const double2 *>(o + ro);
           if (unpadded_y) {
             const int64_t u = ((int64_t)k * g.ny + j) * g.nx + t.i;
+            if (unpadded_y == 2) {  // residual: y = o - S x with o an UNPADDED right-hand side
+              if (t.own0) v.x = o[u] - v.x;
+              if (t.own1) v.y = o[u + 1] - v.y;
+            }
             if (t.own0) y[u] = v.x;
             if (t.own1) y[u + 1] = v.y;
           } else {
@@ -550,6 +554,17 @@ int fl_apply_tiled(fl_poisson *h, const double *xpad, double *y, int unpadded_y)
   return 0;
 }
 
+// r = b - S x, all three unpadded (x is padded into w0 first)
+int fl_residual(fl_poisson *h, const double *x, const double *b, double *r)
+{
+  FL_CHK(fl_ensure_vec(h, &h->w0));
+  launch_pad_copy(h->stream, h->g, x, h->w0);
+  FL_CHK(fl_fill_ghosts(h, h->w0));
+  const TP tp = tile_plan(h->g);
+  launch_apply_pc(h, tp, false, h->w0, r, b, nullptr, nullptr, 2);
+  return 0;
+}
+
 int fl_solve_bcgs(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *o, fl_ksp_stats *st)
 {
   const GridP &g   = h->g;
@@ -647,7 +662,8 @@ int fl_solve_cheb(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *
   S.cheb_c    = S.scale;
   FL_HIP(hipEventRecord(h->ev0, s));
   FL_HIP(hipMemcpyAsync(h->scal, h->scal_host, sizeof(KspScal), hipMemcpyHostToDevice, s));
-  for (double *v : {h->P0, h->q, h->xp}) FL_CHK(fl_zero_vec(h, v));
+  // X1 (P0) is fully written by the first step before anything reads it; its wall ghosts are zero since allocation
+  for (double *v : {h->q, h->xp}) FL_CHK(fl_zero_vec(h, v));
   launch_pad_copy(s, g, b, h->r);
   double    *X0 = h->xp, *X1 = h->P0, *B = h->r, *D = h->q;
   const bool ghosts = fl_any_ghost_exchange(h);
