@@ -1034,7 +1034,9 @@ static FlErrorCode NSStep_CNLinear(NS ns)
   FLABI(fl_abf_apply(ns->momentum, &ns->mom, &ns->schur, c->f_v, fV, NULL, c->x_v, c->x_V, c->x_p, st));
   ns->ksp_its = 1;
   ns->reason  = 0;
-  if (st[0].reason < 0 || st[1].reason < 0) ns->reason = -1; /* NS_DIVERGED_LINEAR_SOLVE */
+  /* like PETSc without -ksp_error_if_not_converged, an inner solve that stops short is not an error by itself: the outer
+   * residual decides.  NaN / Inf is. */
+  if (st[0].reason == FL_DIVERGED_NANORINF || st[1].reason == FL_DIVERGED_NANORINF) ns->reason = -1; /* NS_DIVERGED_LINEAR_SOLVE */
   if (ns->ksp_type == 0 && ns->reason >= 0) {
     double fnorm, rnorm = 0., part;
     FLABI(fl_vec_dot(h, 3 * N, c->f_v, c->f_v, &fnorm));
@@ -1052,7 +1054,7 @@ static FlErrorCode NSStep_CNLinear(NS ns)
       if (ns->ksp_its >= ns->ksp_max_it) { ns->reason = -1; break; }
       const double *rV[3] = {c->r_V[0], c->r_V[1], c->r_V[2]};
       FLABI(fl_abf_apply(ns->momentum, &ns->mom, &ns->schur, c->r_v, rV, c->r_p, c->d_v, c->d_V, c->d_p, st));
-      if (st[0].reason < 0 || st[1].reason < 0) { ns->reason = -1; break; }
+      if (st[0].reason == FL_DIVERGED_NANORINF || st[1].reason == FL_DIVERGED_NANORINF) { ns->reason = -1; break; }
       FLABI(fl_vec_lincomb(h, 3 * N, 1., c->x_v, 1., c->d_v, c->x_v));
       FLABI(fl_vec_lincomb(h, N, 1., c->x_p, 1., c->d_p, c->x_p));
       for (int d = 0; d < 3; ++d) FLABI(fl_vec_lincomb(h, c->sz[1 + d], 1., c->x_V[d], 1., c->d_V[d], c->x_V[d]));

@@ -428,3 +428,111 @@ class MgOracle:
                 break
             p = z + (rz / rz_old) * p
         return proj(x), dict(iters=it, reason=reason, history=np.array(hist))
+
+
+class StepOracle:
+    """CPU restatement of one CNLinear time step (NSStep_CNLinear_Cart3d_Internal, NSFormJacobian, NSFormFunction:
+    cnlinearcart3d.c:2807-3060) for VELOCITY / PERIODIC / SYMMETRY boundaries, composed from the oracle's operators:
+
+      v0interp = B v0 + vbcB(t)                                   :2826-2829, vbc :1749-1932
+      A = I + dt C(V0, v0interp) - cv L,  cv = mu dt / (2 rho)    :2930-2941
+      momrhs = v0 + cv (L v0 + vbcL(t)) - dt vbcC(t, t+dt) - (kappa G p + 0) + cv vbcL(t+dt)     :2976-2998
+      interprhs = vbcT(t+dt)   (the Rhie-Chow boundary terms :3013-3044 vanish without outlets), contrhs = 0
+      x = J^-1 f by Richardson preconditioned with PCApply_ABF (abfpc.c:48-111), unpreconditioned residual norm
+      v, V <- x ; p = p0 + 2 dp, phalf = p0 + dp on the first step, p = phalf + 1.5 dp, phalf += dp afterwards  :2841-2854
+
+    velocity(b, t, X) -> (3, npoints) array: the wall velocity callback of boundary b at the face centres X (npoints, 3).
+    """
+
+    def __init__(self, g, dt, rho, mu, velocity=None, krylov_rtol=1e-12, outer_rtol=1e-8, outer_maxit=50):
+        assert abs(g.kappa - dt / rho) < 1e-15 * max(1.0, g.kappa)
+        self.g, self.dt, self.rho, self.mu, self.velocity = g, dt, rho, mu, velocity
+        self.S = g.assemble_S()
+        self.L = g.assemble_momentum(0.0, 0.0, 1.0)
+        self.krtol, self.ortol, self.omaxit = krylov_rtol, outer_rtol, outer_maxit
+        self.nullspace = BC_PRESSURE_OUTLET not in g.bc
+        self.step, self.t, self.phalf = 0, 0.0, None
+        n = g.n
+        self.cshape = (n[2], n[1], n[0])
+        self.fshape = [(n[2], n[1], g.nf[0]), (n[2], g.nf[1], n[0]), (g.nf[2], n[1], n[0])]
+
+    # -- boundary data -------------------------------------------------------------------------------------------
+    def _wall(self, b, t):
+        """(3, n2, n1) wall velocity on boundary b (in-plane axes in x,y,z order, the first fastest)"""
+        g, ax, side = self.g, b // 2, b % 2
+        a1, a2 = (1 if ax == 0 else 0), (1 if ax == 2 else 2)
+        xc = [0.5 * (g.xf[d][1:] + g.xf[d][:-1]) if g.xc[d] is None else g.xc[d] for d in range(3)]
+        X = np.empty((g.n[a2], g.n[a1], 3))
+        X[..., ax] = g.xf[ax][-1 if side else 0]
+        X[..., a1] = xc[a1][None, :]
+        X[..., a2] = xc[a2][:, None]
+        return np.asarray(self.velocity(b, t, X.reshape(-1, 3))).reshape(3, g.n[a2], g.n[a1])
+
+    def _layer(self, arr, ax, idx):
+        """view of the layer `idx` along grid axis ax of an array shaped (k, j, i)"""
+        sl = [slice(None)] * 3
+        sl[2 - ax] = idx
+        return arr[tuple(sl)]
+
+    def _walls(self):
+        return [b for b in range(6) if self.g.bc[b] == BC_VELOCITY]
+
+    def step_once(self, v0, V0, p0):
+        g, dt = self.g, self.dt
+        cv = 0.5 * self.mu * dt / self.rho
+        t = self.t
+        N = g.ncell
+        xc = [0.5 * (g.xf[d][1:] + g.xf[d][:-1]) if g.xc[d] is None else g.xc[d] for d in range(3)]
+        W = g.apply_B(v0)
+        momrhs = v0 + cv * self.L.mult(v0) - np.concatenate(g.apply_G(p0 if self.step == 0 else self.phalf))
+        interprhs = [np.zeros(g.nface[d]) for d in range(3)]
+        for b in self._walls():
+            ax, side = b // 2, b % 2
+            n, xf, c = g.n[ax], g.xf[ax], xc[ax]
+            vb0, vb1 = self._wall(b, t), self._wall(b, t + dt)
+            if side == 0:   # cnlinearcart3d.c:698-701
+                h1, h2, h3, hc = c[0] - xf[0], c[1] - c[0], c[2] - c[0], xf[1] - xf[0]
+            else:           # :726-729
+                h1, h2, h3, hc = xf[n] - c[n - 1], c[n - 1] - c[n - 2], c[n - 1] - c[n - 3], xf[n] - xf[n - 1]
+            cl = 2.0 * (h2 + h3) / (h1 * (h1 + h2) * (h1 + h3))
+            sgn = 0.5 if side else -0.5
+            for q in range(3):
+                self._layer(W[q * 3 + ax].reshape(self.fshape[ax]), ax, -1 if side else 0)[...] = vb0[q]          # :1788
+                cells = momrhs[q * N:(q + 1) * N].reshape(self.cshape)
+                self._layer(cells, ax, -1 if side else 0)[...] += (cv * cl * (vb0[q] + vb1[q])                     # L: :701, twice (:2985, :2998)
+                                                                   - dt * sgn * (vb1[q] * vb0[ax] + vb0[q] * vb1[ax]) / hc)   # C: :1338, :2991
+            self._layer(interprhs[ax].reshape(self.fshape[ax]), ax, -1 if side else 0)[...] = vb1[ax]               # :2178, :3003-3005
+        A = g.assemble_momentum(1.0, dt, -cv, V0, W)
+
+        def pcapply(fv, fV, fp):      # abfpc.c:71-101
+            vs, _ = A.solve(fv, ksp=KSP_BCGS, pc=PC_JACOBI, nullspace=False, rtol=self.krtol, maxit=2000, history=False)
+            Vs = g.apply_T(vs, fV)
+            ps, _ = self.S.solve(g.rhs(*Vs, contrhs=fp), nullspace=self.nullspace, rtol=self.krtol, maxit=20000, history=False)
+            Gst = g.apply_gst(ps)
+            return vs - np.concatenate(g.apply_G(ps)), [Vs[d] - Gst[d] for d in range(3)], ps
+
+        def jmult(v, V, p):           # cnlinearcart3d.c:2885-2941
+            kGp = np.concatenate(g.apply_G(p))
+            Tw = g.apply_T(v + kGp)
+            kGst = g.apply_gst(p)
+            return A.mult(v) + kGp, [V[d] - Tw[d] + kGst[d] for d in range(3)], -g.rhs(*V)
+
+        fnorm = np.sqrt(momrhs @ momrhs + sum(a @ a for a in interprhs))
+        xv, xV, xp = pcapply(momrhs, interprhs, None)
+        its = 1
+        while True:
+            jv, jV, jp = jmult(xv, xV, xp)
+            rv, rV, rp = momrhs - jv, [interprhs[d] - jV[d] for d in range(3)], -jp
+            rn = np.sqrt(rv @ rv + sum(a @ a for a in rV) + rp @ rp)
+            if rn <= self.ortol * fnorm or its >= self.omaxit:
+                break
+            dv, dV, dp_ = pcapply(rv, rV, rp)
+            xv, xV, xp = xv + dv, [xV[d] + dV[d] for d in range(3)], xp + dp_
+            its += 1
+        if self.step == 0:
+            p, self.phalf = p0 + 2.0 * xp, p0 + xp
+        else:
+            p, self.phalf = self.phalf + 1.5 * xp, self.phalf + xp
+        self.step += 1
+        self.t += dt
+        return xv, xV, p, dict(outer_its=its, rnorm=rn)

@@ -413,3 +413,72 @@ def test_c_cavity_driver_full_time_steps(H):
     prof = [float(x) for x in out.stdout.splitlines()[-1].split(":")[1].split()]
     assert prof[-1] > 0.2 and min(prof) < 0.0                          # dragged along under the lid, return flow below
     assert all(abs(x) < 1.0 + 1e-9 for x in prof)
+
+
+@pytest.mark.gpu
+def test_nsstep_matches_the_oracle_step(H):
+    """Velocity, face velocity and pressure after two lid-driven-cavity steps: the C mirror on the GPU vs the CPU oracle's
+    composition of the same reference formulas (StepOracle), including the wall terms of L, C, B and T."""
+    from oracle import fluca_oracle as fo
+    n = (16, 12, 10)
+    rho, mu, dt = 1.0, 0.05, 5e-3
+    mesh = cavity_mesh(H, ("-cart_grid_x", n[0], "-cart_grid_y", n[1], "-cart_grid_z", n[2]))
+    ns = P()
+    assert H.lib.NSCreate(C.byref(ns)) == 0 and H.lib.NSSetType(ns, b"cnlinear") == 0 and H.lib.NSSetMesh(ns, mesh) == 0
+    assert H.lib.NSSetDensity(ns, rho) == 0 and H.lib.NSSetViscosity(ns, mu) == 0
+
+    def lid(t, x):
+        return np.array([1.0 + 0.5 * t + 0.1 * x[0], 0.0, 0.2 * x[2]])       # a lid that is neither uniform nor steady
+
+    @H.BCFunc
+    def wall(dim, t, x, val, ctx):
+        val[0] = val[1] = val[2] = 0.0
+        return 0
+
+    @H.BCFunc
+    def moving(dim, t, x, val, ctx):
+        val[0], val[1], val[2] = lid(t, x)
+        return 0
+
+    idx = {}
+    for loc in range(6):
+        i = C.c_int()
+        assert H.lib.MeshCartGetBoundaryIndex(mesh, loc, C.byref(i)) == 0
+        idx[loc] = i.value
+    for loc in (H.MESHCART_LEFT, H.MESHCART_RIGHT, H.MESHCART_DOWN, H.MESHCART_FRONT):
+        assert H.lib.NSSetBoundaryCondition(ns, idx[loc], H.NSBoundaryCondition(type=H.NS_BC_VELOCITY, velocity=wall)) == 0
+    assert H.lib.NSSetBoundaryCondition(ns, idx[H.MESHCART_UP], H.NSBoundaryCondition(type=H.NS_BC_VELOCITY, velocity=moving)) == 0
+    assert H.lib.NSSetBoundaryCondition(ns, idx[H.MESHCART_BACK], H.NSBoundaryCondition(type=H.NS_BC_SYMMETRY)) == 0
+    argc, av = H.argv("-ns_time_step_size", dt, "-ns_max_steps", 2, "-ns_ksp_rtol", 1e-9, "-ns_abf_schur_ksp_rtol", 1e-10,
+                      "-ns_abf_momentum_ksp_rtol", 1e-10, "-ns_abf_schur_ksp_max_it", 20000)
+    assert H.lib.NSSetFromOptions(ns, argc, av) == 0 and H.lib.NSSetUp(ns) == 0
+    assert H.lib.NSSolve(ns) == 0
+    v, p, Vp = P(), P(), (C.c_void_p * 3)()
+    assert H.lib.NSGetSolutionArrays(ns, C.byref(v), Vp, C.byref(p)) == 0
+    bc = [fo.BC_VELOCITY] * 4 + [fo.BC_SYMMETRY, fo.BC_VELOCITY]
+    g = fo.Grid.uniform(n, [(0, 1), (0, 1), (0, 0.5)], bc, dt / rho)
+
+    def get(ptr, m):
+        out = np.empty(m)
+        H.capi.check(H.capi.lib.fl_memcpy_d2h(0, out.ctypes.data_as(C.c_void_p), ptr, m * 8))
+        return out
+
+    vg, pg = get(v, 3 * g.ncell), get(p, g.ncell)
+    Vg = [get(C.c_void_p(Vp[d]), g.nface[d]) for d in range(3)]
+
+    def velocity(b, t, X):
+        if b == 3:
+            return np.stack([lid(t, x) for x in X], axis=1)
+        return np.zeros((3, len(X)))
+
+    so = fo.StepOracle(g, dt, rho, mu, velocity, krylov_rtol=1e-10, outer_rtol=1e-9)
+    vo, Vo, po = np.zeros(3 * g.ncell), [np.zeros(nf) for nf in g.nface], np.zeros(g.ncell)
+    for _ in range(2):
+        vo, Vo, po, info = so.step_once(vo, Vo, po)
+    assert np.abs(vo).max() > 0.05
+    assert np.linalg.norm(vg - vo) <= 1e-6 * np.linalg.norm(vo)
+    for d in range(3):
+        assert np.linalg.norm(Vg[d] - Vo[d]) <= 1e-6 * max(np.linalg.norm(Vo[d]), 1e-12)
+    assert np.linalg.norm((pg - pg.mean()) - (po - po.mean())) <= 1e-5 * np.linalg.norm(po - po.mean())
+    H.lib.NSDestroy(C.byref(ns))
+    H.lib.MeshDestroy(C.byref(mesh))
