@@ -119,6 +119,15 @@ struct Comm {
   std::vector<int64_t>  hcap;
   double               *hred = nullptr;
   int                   hredcap = 0;
+  bool                  owns = true;  // false: the connection belongs to another handle (multigrid levels), never torn down here
+
+  // same wire as `o`, own staging buffers
+  void borrow(const Comm &o)
+  {
+    destroy();
+    kind = o.kind; rank = o.rank; nranks = o.nranks; nccl = o.nccl; xchg = o.xchg; allred = o.allred; ctx = o.ctx;
+    owns = false;
+  }
 
   int exchange(hipStream_t st, const std::vector<Msg> &m)
   {
@@ -191,7 +200,7 @@ struct Comm {
 
   void destroy()
   {
-    if (kind == RCCL && nccl) g_rccl.CommDestroy(nccl);
+    if (kind == RCCL && nccl && owns) g_rccl.CommDestroy(nccl);
     for (double *p : hsend)
       if (p) (void)hipHostFree(p);
     for (double *p : hrecv)
@@ -204,6 +213,7 @@ struct Comm {
     hredcap = 0;
     nccl = nullptr;
     kind = NONE;
+    owns = true;
   }
 };
 

@@ -16,7 +16,10 @@
 //
 // Round-1 shape: every level is a full fl_poisson handle on the fine handle's stream and the cycle is composed from the
 // public entry points (apply, Chebyshev solve) plus three small kernels; scalars of the outer CG live on the host (an
-// iteration is ~10 ms at 512^3, the two round trips per iteration do not matter).  Single rank only.
+// iteration is ~25 ms at 512^3, the round trips per iteration do not matter).
+// Several ranks: every level keeps the fine decomposition (block boundaries coincide with coarse faces), so restriction
+// and prolongation stay local; an axis is coarsened only while every rank's share stays even and >= 8 cells; the levels
+// borrow the fine handle's communicator for their halo exchanges and reductions.
 #include <memory>
 
 #include "fl_handle.h"
@@ -120,6 +123,7 @@ int lincomb_dot(fl_poisson *h, int64_t n, double a, const double *x, double b, c
   hipLaunchKernelGGL(k_mg_lincomb_dot, dim3(nb), dim3(256), 0, h->stream, n, a, x, b, z, y, w, result ? h->partial : nullptr);
   if (result) {
     launch_reduce(h->stream, h->partial, nb, h->partial_stride, 1, h->sums);
+    if (h->multi) FL_CHK(h->comm.allreduce(h->stream, h->sums, NSLOT));
     FL_HIP(hipMemcpyAsync(result, h->sums, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     FL_HIP(hipStreamSynchronize(h->stream));
   }
@@ -142,7 +146,8 @@ int project_constant(fl_poisson *h, int64_t n, double *y)
 {
   double s = 0.;
   FL_CHK(lincomb_dot(h, n, 1., y, 0., nullptr, y, nullptr, &s));
-  hipLaunchKernelGGL(k_mg_shift, dim3(nblk(n)), dim3(256), 0, h->stream, n, s / (double)n, y);
+  const double N = (double)h->ax[0].n * (double)h->ax[1].n * (double)h->ax[2].n;  // global cell count
+  hipLaunchKernelGGL(k_mg_shift, dim3(nblk(n)), dim3(256), 0, h->stream, n, s / N, y);
   return 0;
 }
 
@@ -159,8 +164,9 @@ int mg_build(fl_poisson *h, int max_levels)
     int         r[3];
     bool        any = false;
     for (int d = 0; d < 3; ++d) {
-      const int64_t n = hf->ax[d].n;
-      r[d]            = (n % 2 == 0 && n >= 8) ? 2 : 1;
+      const int64_t n = hf->ax[d].n, m = hf->dec.ranks[d];
+      // every rank's share must stay even and >= 8: with DMStag's default split that means n divisible by 2 m
+      r[d] = (n % (2 * m) == 0 && n / m >= 8 && hf->dec.lo[d] % 2 == 0 && hf->dec.len[d] % 2 == 0) ? 2 : 1;
       any |= r[d] == 2;
     }
     if (!any) break;
@@ -176,7 +182,13 @@ int mg_build(fl_poisson *h, int max_levels)
       cg.xc[d] = nullptr;
     }
     fl_poisson *hc = nullptr;
-    if (fl_poisson_create(&cg, h->bc, h->kappa, nullptr, h->device, &hc) != 0) break;  // cannot be discretised any coarser
+    fl_decomp   cd = hf->dec;
+    for (int d = 0; d < 3; ++d) {
+      cd.lo[d] /= r[d];
+      cd.len[d] /= r[d];
+    }
+    if (fl_poisson_create(&cg, h->bc, h->kappa, h->multi ? &cd : nullptr, h->device, &hc) != 0) break;  // cannot be discretised any coarser
+    if (h->multi) hc->comm.borrow(h->comm);
     MgLevel Lc;
     Lc.h = hc;
     mg->lv.push_back(Lc);
@@ -184,10 +196,10 @@ int mg_build(fl_poisson *h, int max_levels)
     // restriction weights of the fine cells: extent of the cell / extent of its parent
     for (int d = 0; d < 3; ++d) {
       mg->lv[l].r[d] = r[d];
-      std::vector<double> w((size_t)hf->ax[d].n);
-      for (int64_t i = 0; i < hf->ax[d].n; ++i) {
-        const int64_t I = i / r[d];
-        w[(size_t)i]    = (hf->ax[d].xf[(size_t)i + 1] - hf->ax[d].xf[(size_t)i]) / (xf[d][(size_t)I + 1] - xf[d][(size_t)I]);
+      std::vector<double> w((size_t)hf->dec.len[d]);  // this rank's cells
+      for (int64_t il = 0; il < hf->dec.len[d]; ++il) {
+        const int64_t i = hf->dec.lo[d] + il, I = i / r[d];
+        w[(size_t)il]   = (hf->ax[d].xf[(size_t)i + 1] - hf->ax[d].xf[(size_t)i]) / (xf[d][(size_t)I + 1] - xf[d][(size_t)I]);
       }
       FL_HIP(hipMalloc((void **)&mg->lv[l].w[d], sizeof(double) * w.size()));
       FL_HIP(hipMemcpy(mg->lv[l].w[d], w.data(), sizeof(double) * w.size(), hipMemcpyHostToDevice));
@@ -275,7 +287,7 @@ void fl_mg_set_stream(fl_poisson *h)
 // KSPCG with the V-cycle as (left) preconditioner; PETSc's KSPSolve_CG with KSP_NORM_PRECONDITIONED
 int fl_solve_cg_mg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *o, fl_ksp_stats *st)
 {
-  if (h->multi) return FL_ERR_SUP;
+  if (h->multi && h->comm.kind == Comm::NONE) return FL_ERR_ARG_WRONGSTATE;
   if (o->norm_type != FL_NORM_PRECONDITIONED && o->norm_type != FL_NORM_UNPRECONDITIONED) return FL_ERR_SUP;
   if (h->mg && o->mg_levels > 0 && (int)h->mg->lv.size() != std::min<int>(o->mg_levels, (int)h->mg->lv.size()) ) fl_mg_destroy(h);
   if (!h->mg) FL_CHK(mg_build(h, o->mg_levels));

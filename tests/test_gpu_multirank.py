@@ -209,3 +209,58 @@ def _momentum_worker(rank, world, n, ranks, bc):
 ])
 def test_decomposed_momentum_matches_single_domain_oracle(world, n, ranks, bc):
     mpc.run_ranks(world, _momentum_worker, n, ranks, bc)
+
+
+def _mg_worker(rank, world, n, ranks, bc, levels):
+    """Multigrid-preconditioned CG on a decomposed grid (coarse levels keep the fine decomposition and borrow its
+    communicator) vs the single-domain CPU restatement with the same number of levels."""
+    import ctypes as C
+    import torch
+    from fluca_amd import capi
+    from fluca_amd.poisson import Poisson
+    from oracle import fluca_oracle as fo
+    d = mpc.decomp_of(capi, n, ranks, rank)
+    box = [(0.0, 1.0), (0.0, 1.0), (0.0, 0.5)]
+    P = Poisson.uniform(n, box, bc, 1e-3, decomp=d)
+    P.comm_init_host(mpc.gloo_exchange, mpc.gloo_allreduce, rank, world)
+    g = fo.Grid.uniform(n, box, bc, 1e-3)
+    S = g.assemble_S()
+    nullspace = 2 not in bc
+    rng = np.random.default_rng(77)
+    p = rng.standard_normal(g.ncell)
+    if nullspace:
+        p -= p.mean()
+    b = S.mult(p)
+    mg = fo.MgOracle(g, max_levels=levels, nullspace=nullspace)
+    assert mg.nlevels == levels
+    # the product's eigenvalue bounds per level (host-only query on single-domain handles of the same grids)
+    bounds = []
+    for gl in mg.grids:
+        Q = Poisson(gl.n, gl.xf, gl.bc, gl.kappa)
+        lam = C.c_double()
+        capi.check(capi.lib.fl_poisson_gershgorin(Q.h, capi.PC_JACOBI, C.byref(lam)))
+        bounds.append(lam.value)
+        Q.close()
+    mg = fo.MgOracle(g, max_levels=levels, nullspace=nullspace, bounds=bounds)
+    xo, io = mg.pcg(b, rtol=1e-4, maxit=50)
+    shp = (n[2], n[1], n[0])
+    blk = mpc.block(d)
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64).ravel(), device="cuda")
+    # (the host-staged test transport makes every halo exchange a round trip through gloo: keep the solve short)
+    xg, ig = P.solve(dev(b.reshape(shp)[blk]), history=True, type=0, pc=2, remove_nullspace=int(nullspace), rtol=1e-4, maxit=50, mg_levels=levels)
+    assert ig["reason"] == io["reason"] == 2 and abs(ig["iters"] - io["iters"]) <= 1, (ig["iters"], io["iters"])
+    m = min(len(ig["history"]), len(io["history"]))
+    assert np.allclose(ig["history"][:3], io["history"][:3], rtol=1e-6)
+    assert np.allclose(ig["history"][:m], io["history"][:m], rtol=5e-2)
+    diff = np.array([((xg.cpu().numpy() - xo.reshape(shp)[blk].ravel()) ** 2).sum(), (xo ** 2).sum() / world])
+    mpc.gloo_allreduce(diff)
+    assert np.sqrt(diff[0] / diff[1]) <= 1e-5
+    P.close()
+
+
+@pytest.mark.parametrize("world,n,ranks,bc,levels", [
+    (2, (16, 16, 32), (1, 1, 2), [1, 1, 1, 1, 4, 1], 2),       # z split: 16 cells per rank -> one coarsening keeps 8
+    (2, (32, 16, 16), (2, 1, 1), [3, 3, 1, 2, 1, 1], 2),       # periodic axis over two ranks + an outlet (no null space)
+])
+def test_decomposed_multigrid_matches_single_domain_oracle(world, n, ranks, bc, levels):
+    mpc.run_ranks(world, _mg_worker, n, ranks, bc, levels)
