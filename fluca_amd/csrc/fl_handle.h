@@ -176,9 +176,10 @@ struct Comm {
     return FL_ERR_ARG_WRONGSTATE;
   }
 
-  int allreduce(hipStream_t st, double *dev, int n)
+  bool loopback = false;
+  int  allreduce(hipStream_t st, double *dev, int n)
   {
-    if (nranks == 1) return 0;
+    if (nranks == 1 && !loopback) return 0;
     if (kind == RCCL) {
       FL_NCCL(g_rccl.AllReduce(dev, dev, (size_t)n, ncclDouble, ncclSum, nccl, st));
       return 0;
@@ -234,7 +235,9 @@ struct fl_poisson {
   fl_decomp   dec;
   int         nbr[6];        // rank across each boundary, -1 = physical boundary
   bool        wrap_local[3]; // periodic axis held by a single rank: ghosts filled by a local copy
-  bool        multi = false; // more than one rank
+  bool        multi = false; // more than one rank (or loopback)
+  bool        loopback = false;  // FLUCA_COMM_LOOPBACK=1: a single rank sends the ghost layers of its periodic axes to ITSELF through
+                                 // the communicator instead of copying them -- exercises the RCCL path on a one-GPU box
   GridP       g;
   std::vector<void *> tables;
   int64_t     ncell = 0, nface[3] = {0, 0, 0};
