@@ -369,17 +369,16 @@ int fl_fill_ghosts(fl_poisson *h, double *v)
         plan[np++] = {0, 2 * ax, 2 * ax + 1, 2 * ax, 2 * ax};
       }
   std::vector<Msg> msgs;
+  double          *sbuf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, *rbuf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   for (int a = 0; a < np; ++a) {
     const int sb = plan[a].send_boundary, rb = plan[a].recv_boundary;
-    launch_pack(h->stream, g, v, h->fsend[sb], sb / 2, sb % 2);
+    sbuf[sb] = h->fsend[sb];
+    rbuf[rb] = h->frecv[rb];
     msgs.push_back({plan[a].peer, h->fsend[sb], h->frecv[rb], (int64_t)plane_size(h, sb / 2), plan[a].sendtag, plan[a].recvtag});
   }
+  if (np > 0) launch_pack_faces(h->stream, g, v, sbuf);    // all boundary layers in one launch
   FL_CHK(h->comm.exchange(h->stream, msgs));
-  for (int d = 0; d < 3; ++d) {
-    if (h->wrap_local[d]) continue;
-    if (h->nbr[2 * d] >= 0) launch_unpack(h->stream, g, v, h->frecv[2 * d], d, 0);
-    if (h->nbr[2 * d + 1] >= 0) launch_unpack(h->stream, g, v, h->frecv[2 * d + 1], d, 1);
-  }
+  if (np > 0) launch_unpack_faces(h->stream, g, v, rbuf);  // all ghost layers in one launch
   return 0;
 }
 
@@ -675,7 +674,15 @@ static int solve_cg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts
     return e ? std::atoi(e) != 0 : true;
   }();
   const bool fusedfin = !h->multi && o->variant != 1 && fusedfin_env;
-  if (fusedfin) FL_HIP(hipMemsetAsync(h->tickets, 0, sizeof(unsigned) * 2, s));
+  // several ranks: the last block of k_cg_A / k_cg_B still reduces the rank's partial sums (no k_reduce launch); the
+  // all-reduce and the scalar kernel follow
+  const bool fusedsum = h->multi && o->variant != 1 && fusedfin_env;
+  if (fusedfin || fusedsum) FL_HIP(hipMemsetAsync(h->tickets, 0, sizeof(unsigned) * 2, s));
+  auto fin_sums = [&](int mode) -> int {
+    FL_CHK(h->comm.allreduce(s, h->sums, NSLOT));
+    launch_cg_fin(s, mode, nullptr, 0, 0, h->sums, h->scal, h->hist, nhist);
+    return 0;
+  };
 
   std::vector<hipEvent_t> pev;
   if (o->profile) {
@@ -699,13 +706,15 @@ static int solve_cg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts
         if (prof) FL_HIP(hipEventRecord(pev[2 * it + 1], s));
       } else {
         if (prof) FL_HIP(hipEventRecord(pev[2 * it], s));
-        launch_cg_A(s, g, jac, plan, h->r, h->P0, h->P1, h->q, h->xp, h->scal, h->partial, fusedfin ? h->tickets : nullptr, h->hist, nhist);
+        launch_cg_A(s, g, jac, plan, h->r, h->P0, h->P1, h->q, h->xp, h->scal, h->partial, (fusedfin || fusedsum) ? h->tickets : nullptr, h->hist, nhist, fusedsum ? h->sums : nullptr);
         if (prof) FL_HIP(hipEventRecord(pev[2 * it + 1], s));
       }
-      if (!fusedfin) FL_CHK(cg_fin(h, 1, nab, 1, h->hist, nhist));
+      if (fusedsum) FL_CHK(fin_sums(1));
+      else if (!fusedfin) FL_CHK(cg_fin(h, 1, nab, 1, h->hist, nhist));
       hostcur ^= 1;
-      launch_cg_B(s, g, jac, planB, h->q, h->r, h->scal, h->partial, h->partial_stride, fusedfin ? h->tickets + 1 : nullptr, h->hist, nhist);
-      if (!fusedfin) FL_CHK(cg_fin(h, 2, planB.nblocks, 5, h->hist, nhist));
+      launch_cg_B(s, g, jac, planB, h->q, h->r, h->scal, h->partial, h->partial_stride, (fusedfin || fusedsum) ? h->tickets + 1 : nullptr, h->hist, nhist, fusedsum ? h->sums : nullptr);
+      if (fusedsum) FL_CHK(fin_sums(2));
+      else if (!fusedfin) FL_CHK(cg_fin(h, 2, planB.nblocks, 5, h->hist, nhist));
       if (ghosts && o->variant != 1) FL_CHK(fl_fill_ghosts(h, h->r));
     }
     FL_CHK(fl_poll_scal(h));

@@ -27,6 +27,8 @@ void launch_unpad_copy(hipStream_t, const GridP &, const double *, double *, con
 void launch_wrap(hipStream_t, const GridP &, double *, int);
 void launch_pack(hipStream_t, const GridP &, const double *, double *, int, int);
 void launch_unpack(hipStream_t, const GridP &, double *, const double *, int, int);
+void launch_pack_faces(hipStream_t, const GridP &, const double *, double *const bufs[6]);
+void launch_unpack_faces(hipStream_t, const GridP &, double *, double *const bufs[6]);
 void launch_apply(hipStream_t, const GridP &, const double *, double *, int);
 void launch_diagonal(hipStream_t, const GridP &, double *);
 void launch_rhs(hipStream_t, const GridP &, const double *, const double *, const double *, const double *, const double *, const double *, const double *, double *);
@@ -47,8 +49,8 @@ struct PlanA {
 PlanA plan_tiles(const GridP &, int ry, int nw, int nchunk_force, int target_blocks);
 PlanA plan_cg_A(const GridP &, int, int);
 PlanA plan_cg_B(const GridP &);
-void  launch_cg_A(hipStream_t, const GridP &, bool, const PlanA &, const double *, double *, double *, double *, double *, KspScal *, double *, unsigned *, double *, int);
-void  launch_cg_B(hipStream_t, const GridP &, bool, const PlanA &, const double *, double *, KspScal *, double *, int, unsigned *, double *, int);
+void  launch_cg_A(hipStream_t, const GridP &, bool, const PlanA &, const double *, double *, double *, double *, double *, KspScal *, double *, unsigned *, double *, int, double *sums = nullptr);
+void  launch_cg_B(hipStream_t, const GridP &, bool, const PlanA &, const double *, double *, KspScal *, double *, int, unsigned *, double *, int, double *sums = nullptr);
 void  launch_stream_ref(hipStream_t, int, int, int64_t, const double *, const double *, const double *, double *, double *, double *);
 void  launch_stream_par(hipStream_t, int, int, int, int, int, int64_t, const double *, const double *, const double *, double *, double *, double *);
 void  launch_cg_pupdate(hipStream_t, const GridP &, bool, const double *, double *, double *, const KspScal *);

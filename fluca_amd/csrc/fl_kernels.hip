@@ -133,6 +133,35 @@ __global__ void k_unpack_face(GridP g, double *__restrict__ v, const double *__r
   v[p]        = buf[(int64_t)b * na + a];
 }
 
+// all faces of one ghost exchange in ONE launch: blockIdx.z = boundary 0..5; buf[b] == NULL -> that boundary is not exchanged
+struct FaceBufs {
+  double *buf[6];
+};
+__global__ void k_pack_faces(GridP g, const double *__restrict__ v, FaceBufs fb)
+{
+  const int bnd = blockIdx.z, axis = bnd / 2, side = bnd % 2;
+  double   *buf = fb.buf[bnd];
+  if (!buf) return;
+  const int a = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y * 4 + threadIdx.y;
+  const int na = axis == 0 ? g.ny : g.nx, nb = axis == 2 ? g.ny : g.nz;
+  if (a >= na || b >= nb) return;
+  const int     n = axis == 0 ? g.nx : (axis == 1 ? g.ny : g.nz), c = side ? n - 1 : 0;
+  const int64_t p = axis == 0 ? pidx(g, c, a, b) : (axis == 1 ? pidx(g, a, c, b) : pidx(g, a, b, c));
+  buf[(int64_t)b * na + a] = v[p];
+}
+__global__ void k_unpack_faces(GridP g, double *__restrict__ v, FaceBufs fb)
+{
+  const int     bnd = blockIdx.z, axis = bnd / 2, side = bnd % 2;
+  const double *buf = fb.buf[bnd];
+  if (!buf) return;
+  const int a = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y * 4 + threadIdx.y;
+  const int na = axis == 0 ? g.ny : g.nx, nb = axis == 2 ? g.ny : g.nz;
+  if (a >= na || b >= nb) return;
+  const int     n = axis == 0 ? g.nx : (axis == 1 ? g.ny : g.nz), c = side ? n : -1;
+  const int64_t p = axis == 0 ? pidx(g, c, a, b) : (axis == 1 ? pidx(g, a, c, b) : pidx(g, a, b, c));
+  v[p]            = buf[(int64_t)b * na + a];
+}
+
 __device__ __forceinline__ double stencil7(const GridP &g, const double *__restrict__ x, int i, int j, int k)
 {
   const int64_t c = pidx(g, i, j, k);
@@ -377,6 +406,7 @@ struct FinCtx {
   unsigned *counter;  // zero between launches (the last block resets it)
   double   *hist;
   int       nhist, enabled;
+  double   *sums;     // several ranks: the last block only leaves the rank's sums here (all-reduce + k_cg_fin follow)
 };
 template <int NV, int NTHR>
 __device__ __forceinline__ void fused_fin(int mode, const double (&v)[NV] /* thread 0 */, double *__restrict__ partial, int stride, const FinCtx &f, KspScal *__restrict__ s, double *red /* shared [NV * NTHR/64] */, int *flag /* shared */)
@@ -413,7 +443,10 @@ __device__ __forceinline__ void fused_fin(int mode, const double (&v)[NV] /* thr
       if (a < NV)
         for (int q = 0; q < NTHR / 64; ++q) out[a] += red[a * (NTHR / 64) + q];
     }
-    cg_fin_apply(mode, out, s, f.hist, f.nhist);
+    if (f.sums) {
+#pragma unroll
+      for (int a = 0; a < NSLOT; ++a) f.sums[a] = out[a];
+    } else cg_fin_apply(mode, out, s, f.hist, f.nhist);
     __hip_atomic_store(f.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
@@ -973,6 +1006,23 @@ void launch_unpack(hipStream_t st, const GridP &g, double *v, const double *buf,
   const int na = axis == 0 ? g.ny : g.nx, nb = axis == 2 ? g.ny : g.nz;
   hipLaunchKernelGGL(k_unpack_face, grid3(na, nb, 1), blk3(), 0, st, g, v, buf, axis, side);
 }
+// bufs[b] may be NULL; one launch covers the largest plane in x/y and the six boundaries in z
+void launch_pack_faces(hipStream_t st, const GridP &g, const double *v, double *const bufs[6])
+{
+  FaceBufs fb;
+  for (int b = 0; b < 6; ++b) fb.buf[b] = bufs[b];
+  const int na = std::max(g.nx, g.ny), nb = std::max(g.ny, g.nz);
+  dim3      grid((na + 63) / 64, (nb + 3) / 4, 6);
+  hipLaunchKernelGGL(k_pack_faces, grid, dim3(64, 4), 0, st, g, v, fb);
+}
+void launch_unpack_faces(hipStream_t st, const GridP &g, double *v, double *const bufs[6])
+{
+  FaceBufs fb;
+  for (int b = 0; b < 6; ++b) fb.buf[b] = bufs[b];
+  const int na = std::max(g.nx, g.ny), nb = std::max(g.ny, g.nz);
+  dim3      grid((na + 63) / 64, (nb + 3) / 4, 6);
+  hipLaunchKernelGGL(k_unpack_faces, grid, dim3(64, 4), 0, st, g, v, fb);
+}
 void launch_apply(hipStream_t st, const GridP &g, const double *xpad, double *y, int ypad) { hipLaunchKernelGGL(k_apply, grid3(g.nx, g.ny, g.nz), blk3(), 0, st, g, xpad, y, ypad); }
 void launch_diagonal(hipStream_t st, const GridP &g, double *d) { hipLaunchKernelGGL(k_diagonal, grid3(g.nx, g.ny, g.nz), blk3(), 0, st, g, d); }
 void launch_rhs(hipStream_t st, const GridP &g, const double *Vx, const double *Vy, const double *Vz, const double *hix, const double *hiy, const double *hiz, const double *contrhs, double *b)
@@ -1097,9 +1147,10 @@ static void launch_cg_A_v(hipStream_t st, const GridP &g, bool jac, const PlanA 
 #endif
   launch_cg_A_t<RY, NW, 1, 2>(st, g, jac, p, r, P0, P1, q, x, s, partial, fin);  // the shipped variant
 }
-void launch_cg_A(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const double *r, double *P0, double *P1, double *q, double *x, KspScal *s, double *partial, unsigned *counter, double *hist, int nhist)
+void launch_cg_A(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const double *r, double *P0, double *P1, double *q, double *x, KspScal *s, double *partial, unsigned *counter, double *hist, int nhist, double *sums)
 {
   FinCtx fin;
+  fin.sums    = sums;
   fin.counter = counter;
   fin.hist    = hist;
   fin.nhist   = nhist;
@@ -1127,9 +1178,10 @@ static void launch_cg_B_ry(hipStream_t st, const GridP &g, bool jac, const PlanA
     else hipLaunchKernelGGL((k_cg_B<RY, false, 0>), gr, bl, 0, st, g, q, r, s, partial, stride, p.nchunk, p.zc, p.tiles_x, fin);
   }
 }
-void launch_cg_B(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const double *q, double *r, KspScal *s, double *partial, int stride, unsigned *counter, double *hist, int nhist)
+void launch_cg_B(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const double *q, double *r, KspScal *s, double *partial, int stride, unsigned *counter, double *hist, int nhist, double *sums)
 {
   FinCtx fin;
+  fin.sums    = sums;
   fin.counter = counter;
   fin.hist    = hist;
   fin.nhist   = nhist;
