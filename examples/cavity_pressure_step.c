@@ -1,7 +1,8 @@
 /*
  * cavity_pressure_step.c -- the reference's 3-D lid-driven-cavity driver (fluca/tests/cavity_flow/cavity_flow_3d.c)
- * re-written against the C host mirror (include/fluca_host.h): same call sequence, no PETSc, no Python.  Because the
- * momentum solve is not built, the program feeds a synthetic intermediate velocity V* (the staggered gradient
+ * re-written against the C host mirror (include/fluca_host.h): same call sequence, no PETSc, no Python.  This one drives
+ * only the pressure half of PCApply_ABF (examples/cavity_flow_3d.c runs whole time steps): it feeds a synthetic
+ * intermediate velocity V* (the staggered gradient
  * of a smooth field, so that the exact pressure correction is known) through the pressure half of PCApply_ABF and prints
  * what -ns_abf_schur_ksp_monitor-style output would show.
  *

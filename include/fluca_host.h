@@ -83,7 +83,7 @@ typedef struct {
 struct _NSOps {
   FlErrorCode (*setfromoptions)(NS, int, char **);
   FlErrorCode (*setup)(NS);
-  FlErrorCode (*step)(NS); /* the full step needs the momentum operator: the shipped type returns PETSC_ERR_SUP */
+  FlErrorCode (*step)(NS); /* NSStep_CNLinear: VecCopy(sol, sol0) + the CNLinear step on device arrays (see NSStep below) */
   FlErrorCode (*destroy)(NS);
 };
 FlErrorCode NSRegister(const char name[], FlErrorCode (*create)(NS));
