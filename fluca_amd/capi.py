@@ -110,6 +110,8 @@ PROTOTYPES = {
     "fl_vec_lincomb": (C.c_int, [_P, C.c_int64, C.c_double, _P, C.c_double, _P, _P]),
     "fl_vec_dot": (C.c_int, [_P, C.c_int64, _P, _P, C.POINTER(C.c_double)]),
     "fl_boundary_set_faces": (C.c_int, [_P, C.c_int, C.c_double, _P, _P]),
+    "fl_boundary_add_faces": (C.c_int, [_P, C.c_int, C.c_double, _P, _P]),
+    "fl_momentum_face_interp_scaled": (C.c_int, [_P, C.c_double, _P, _P, _P]),
     "fl_boundary_add_cells": (C.c_int, [_P, C.c_int, C.c_double, _P, _P]),
     "fl_momentum_rhs": (C.c_int, [_P, C.c_double, C.c_double, C.c_double, _P, _P, _P, _P]),
     "fl_momentum_interp_faces": (C.c_int, [_P, _P, _P, _P]),

@@ -589,6 +589,17 @@ extern "C" int fl_boundary_set_faces(fl_poisson *h, int boundary, double coeff, 
   return FL_SUCCESS;
 }
 
+extern "C" int fl_boundary_add_faces(fl_poisson *h, int boundary, double coeff, const double *plane_dev, double *face_dev)
+{
+  if (!h || !plane_dev || !face_dev) return FL_ERR_ARG_NULL;
+  if (boundary < 0 || boundary > 5) return FL_ERR_ARG_OUTOFRANGE;
+  if (!touches_boundary(h, boundary)) return FL_SUCCESS;
+  FL_HIP(hipSetDevice(h->device));
+  launch_gst_bc(h->stream, h->g, plane_dev, face_dev, boundary / 2, boundary % 2, coeff, 1);
+  FL_HIP(hipGetLastError());
+  return FL_SUCCESS;
+}
+
 extern "C" int fl_boundary_add_cells(fl_poisson *h, int boundary, double coeff, const double *plane_dev, double *cell_dev)
 {
   if (!h || !plane_dev || !cell_dev) return FL_ERR_ARG_NULL;

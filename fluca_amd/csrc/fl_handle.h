@@ -35,7 +35,7 @@ void launch_rhs(hipStream_t, const GridP &, const double *, const double *, cons
 void launch_face_plane0(hipStream_t, const GridP &, const double *, double *, int);
 void launch_project_faces(hipStream_t, const GridP &, const double *, double *, int);
 void launch_project_cells(hipStream_t, const GridP &, const double *, double *, int);
-void launch_gst_bc(hipStream_t, const GridP &, const double *, double *, int, int, double);
+void launch_gst_bc(hipStream_t, const GridP &, const double *, double *, int, int, double, int add = 0);
 void launch_bc_add_cells(hipStream_t, const GridP &, const double *, double *, int, int, double);
 void launch_pressure_update(hipStream_t, int64_t, int, const double *, const double *, double *, double *);
 void launch_reduce(hipStream_t, const double *, int, int, int, double *);

@@ -248,7 +248,7 @@ __global__ void k_project_cells(GridP g, const double *__restrict__ p, double *_
 }
 
 // boundary face plane of V (axis, side) = coeff * pb     (INSERT_VALUES)
-__global__ void k_gst_bc(GridP g, const double *__restrict__ pb, double *__restrict__ V, int axis, int side, double coeff)
+__global__ void k_gst_bc(GridP g, const double *__restrict__ pb, double *__restrict__ V, int axis, int side, double coeff, int add)
 {
   const int a = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y * 4 + threadIdx.y;
   int       na, nb;
@@ -258,7 +258,8 @@ __global__ void k_gst_bc(GridP g, const double *__restrict__ pb, double *__restr
   if (a >= na || b >= nb) return;
   const int f = side ? (axis == 0 ? g.fx : (axis == 1 ? g.fy : g.fz)) - 1 : 0;
   int64_t   p = axis == 0 ? ((int64_t)b * g.ny + a) * g.fx + f : (axis == 1 ? ((int64_t)b * g.fy + f) * g.nx + a : ((int64_t)f * g.ny + b) * g.nx + a);
-  V[p]        = coeff * pb[(int64_t)b * na + a];
+  const double t = coeff * pb[(int64_t)b * na + a];
+  V[p]           = add ? V[p] + t : t;
 }
 
 // cell layer next to boundary (axis, side) += coeff * plane   (ADD_VALUES of the boundary-condition vectors)
@@ -1040,10 +1041,10 @@ void launch_project_faces(hipStream_t st, const GridP &g, const double *p, doubl
   if (lz > 0) hipLaunchKernelGGL(k_project_faces, grid3(lx, ly, lz), blk3(), 0, st, g, p, V, axis);
 }
 void launch_project_cells(hipStream_t st, const GridP &g, const double *p, double *v, int axis) { hipLaunchKernelGGL(k_project_cells, grid3(g.nx, g.ny, g.nz), blk3(), 0, st, g, p, v, axis); }
-void launch_gst_bc(hipStream_t st, const GridP &g, const double *pb, double *V, int axis, int side, double coeff)
+void launch_gst_bc(hipStream_t st, const GridP &g, const double *pb, double *V, int axis, int side, double coeff, int add)
 {
   const int na = axis == 0 ? g.ny : g.nx, nb = axis == 2 ? g.ny : g.nz;
-  hipLaunchKernelGGL(k_gst_bc, grid3(na, nb, 1), blk3(), 0, st, g, pb, V, axis, side, coeff);
+  hipLaunchKernelGGL(k_gst_bc, grid3(na, nb, 1), blk3(), 0, st, g, pb, V, axis, side, coeff, add);
 }
 void launch_bc_add_cells(hipStream_t st, const GridP &g, const double *plane, double *cells, int axis, int side, double coeff)
 {

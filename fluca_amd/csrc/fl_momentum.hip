@@ -804,6 +804,13 @@ extern "C" int fl_momentum_face_interp(fl_momentum *m, const double *v_dev, cons
   return face_interp(m, 1., v_dev, rhs_dev, V_dev);
 }
 
+extern "C" int fl_momentum_face_interp_scaled(fl_momentum *m, double alpha, const double *v_dev, const double *const rhs_dev[3], double *const V_dev[3])
+{
+  if (!m || !v_dev || !V_dev) return FL_ERR_ARG_NULL;
+  FL_HIP(hipSetDevice(m->p->device));
+  return face_interp(m, alpha, v_dev, rhs_dev, V_dev);
+}
+
 // The part of momrhs (NSFormFunction_CNLinear_Cart3d_Internal, cnlinearcart3d.c:2976-2998) that lives on every cell:
 //   momrhs = v0 + (mu dt / 2 rho) L v0 - kappa G p  (+ vbc: the boundary-condition vectors, combined by the caller)
 extern "C" int fl_momentum_rhs(fl_momentum *m, double dt, double rho, double mu, const double *v0_dev, const double *p_dev, const double *vbc_dev, double *momrhs_dev)

@@ -828,8 +828,7 @@ FlErrorCode NSComputeStaggeredPressureGradientBC(NS ns, double t, double *V[3])
 
 /* ---- NSCNLINEAR: the shipped type (fluca/src/ns/impl/linearcn/) ------------------------------------------------------
  * The fields and the step of NSStep_CNLinear_Cart3d_Internal / NSFormJacobian / NSFormFunction (cnlinearcart3d.c:2807-3060)
- * on device arrays.  Built: VELOCITY, PERIODIC and SYMMETRY boundaries; a PRESSURE_OUTLET needs the boundary-condition
- * vectors of G and the Rhie-Chow terms (:3013-3044), which are not: the step reports PETSC_ERR_SUP then.  Outer solve:
+ * on device arrays, for all four boundary-condition types.  Outer solve:
  * -ns_ksp_type richardson (x += PCApply_ABF(f - J x), unpreconditioned norm, -ns_ksp_rtol) or preonly. */
 typedef struct {
   int64_t sz[4];                               /* cells, x-, y-, z-faces of this rank */
@@ -974,8 +973,6 @@ static FlErrorCode NSStep_CNLinear(NS ns)
   fl_poisson   *h = ns->poisson;
   const int64_t N = c->sz[0];
   const double  dt = ns->dt, t = ns->t, cv = 0.5 * ns->mu * dt / ns->rho;
-  for (int b = 0; b < 6; ++b)
-    if (ns->bcs[b].type == NS_BC_PRESSURE_OUTLET) return E_SUP;
   if (!ns->momentum) FLABI(fl_momentum_create(h, &ns->momentum));
   /* NSStep: VecCopy(sol, sol0), nsbasic.c:281-282 */
   FLABI(fl_vec_lincomb(h, 3 * N, 1., c->sol_v, 0., NULL, c->sol0_v));
@@ -1020,6 +1017,57 @@ static FlErrorCode NSStep_CNLinear(NS ns)
     FLCHK(cnl_upload(ns, vb1[ax], np));
     FLABI(fl_boundary_set_faces(h, b, 1., c->plane_dev, c->f_V[ax]));
     free(tmp);
+  }
+  /* PRESSURE_OUTLET: the boundary-condition vector of G in momrhs (:2976-2984, :219-423) and the Rhie-Chow boundary terms
+   * of interprhs (:3013-3044).  As written in the reference, the G vector is NOT scaled by dt/rho in momrhs. */
+  {
+    int     rhiechow = 0;
+    double *w = c->d_v; /* 3*cells scratch: kappa (vbcG(tq) - vbcG(tp)) */
+    const double tq = ns->step == 0 ? t : t - 0.5 * dt, tp = t + 0.5 * dt, kappa = dt / ns->rho;
+    for (int b = 0; b < 6; ++b) {
+      if (ns->bcs[b].type != NS_BC_PRESSURE_OUTLET || !cnl_touches(ns, b)) continue;
+      const int        ax = b / 2, side = b % 2, a1 = ax == 0 ? 1 : 0, a2 = ax == 2 ? 1 : 2;
+      const fl_decomp *D = &ns->mesh->decomp;
+      const int64_t    n1 = D->len[a1], n2 = D->len[a2], np = n1 * n2, n = cart->N[ax];
+      const double    *xf = cart->xf[ax], *xc = cart->xc[ax];
+      if (!ns->bcs[b].pressure) return E_ARG_WRONGSTATE;
+      if (n < 2) return E_SUP;
+      double *pq = c->plane_host[0], *pp = c->plane_host[1], *tmp = c->plane_host[2];
+      int     differs = 0;
+      for (int64_t j = 0; j < n2; ++j)
+        for (int64_t i = 0; i < n1; ++i) {
+          double xb[3], vq = 0., vp = 0.;
+          xb[ax] = xf[side ? n : 0];
+          xb[a1] = cart->xc[a1][D->lo[a1] + i];
+          xb[a2] = cart->xc[a2][D->lo[a2] + j];
+          FLCHK(ns->bcs[b].pressure(3, tq, xb, &vq, ns->bcs[b].ctx_pressure));
+          FLCHK(ns->bcs[b].pressure(3, tp, xb, &vp, ns->bcs[b].ctx_pressure));
+          pq[j * n1 + i] = vq;
+          pp[j * n1 + i] = vp;
+          differs |= vq != vp;
+        }
+      /* G: one-sided first derivative through the boundary value, :257-259 / :285-287 */
+      const double h1 = side ? xf[n] - xc[n - 1] : xc[0] - xf[0], h2 = side ? xc[n - 1] - xc[n - 2] : xc[1] - xc[0];
+      const double cg = (side ? 1. : -1.) * h2 / (h1 * (h1 + h2));
+      FLCHK(cnl_upload(ns, pq, np));
+      FLABI(fl_boundary_add_cells(h, b, -cg, c->plane_dev, c->f_v + ax * N)); /* VecAXPY(momrhs, -1, Gp), Gp = kappa G p + vbcG(tq) */
+      if (differs) {
+        /* Gst: :2641-2647 / :2669-2675 */
+        const double g1 = side ? xf[n] - xc[n - 1] : xc[0] - xf[0], g2 = side ? xf[n] - xc[n - 2] : xc[1] - xf[0];
+        const double cgst = (side ? 1. : -1.) * (g1 + g2) / (g1 * g2);
+        if (!rhiechow) FLABI(fl_vec_lincomb(h, 3 * N, 0., w, 0., NULL, w));
+        rhiechow = 1;
+        for (int64_t a = 0; a < np; ++a) tmp[a] = pq[a] - pp[a];
+        FLCHK(cnl_upload(ns, tmp, np));
+        FLABI(fl_boundary_add_cells(h, b, kappa * cg, c->plane_dev, w + ax * N));     /* kappa (vbcGq - vbcGp), :3031-3032 */
+        FLABI(fl_boundary_add_faces(h, b, kappa * cgst, c->plane_dev, c->f_V[ax]));   /* + kappa (vbcGstq - vbcGstp), :3034-3035 */
+      }
+    }
+    if (rhiechow) {
+      /* interprhs += (-T) w, :3033 */
+      const double *rhs[3] = {c->f_V[0], c->f_V[1], c->f_V[2]};
+      FLABI(fl_momentum_face_interp_scaled(ns->momentum, -1., w, rhs, c->f_V));
+    }
   }
   /* NSFormJacobian: A = I + dt C(V0, v0interp) - cv L, :2930-2941 */
   {

@@ -173,6 +173,7 @@ int fl_poisson_gst_bc(fl_poisson *h, int boundary, const double *pb_dev, double 
  * next to the boundary (ADD_VALUES).  No-op on ranks that do not touch the boundary and on periodic axes. */
 int fl_boundary_set_faces(fl_poisson *h, int boundary, double coeff, const double *plane_dev, double *face_dev);
 int fl_boundary_add_cells(fl_poisson *h, int boundary, double coeff, const double *plane_dev, double *cell_dev);
+int fl_boundary_add_faces(fl_poisson *h, int boundary, double coeff, const double *plane_dev, double *face_dev); /* ADD_VALUES into the boundary faces */
 /* first != 0: p = p0 + 2 dp, phalf = p0 + dp ; else p = phalf + 1.5 dp, phalf += dp */
 int fl_pressure_update(fl_poisson *h, int first, const double *dp_dev, const double *p0_dev, double *phalf_dev, double *p_dev);
 
@@ -228,6 +229,8 @@ int fl_momentum_solve(fl_momentum *m, const double *b_dev, double *x_dev, const 
  * T = ComputeFaceNormalVelocityInterpolationOperator_Private, cnlinearcart3d.c:1934-2140.  rhs_dev (or any entry) may
  * be NULL = 0.  A VELOCITY / SYMMETRY wall face has no T row: it receives rhs alone (the boundary-condition vector). */
 int fl_momentum_face_interp(fl_momentum *m, const double *v_dev, const double *const rhs_dev[3], double *const V_dev[3]);
+/* V_d = rhs_d + alpha (T v)_d; rhs_dev[d] may alias V_dev[d] (MatMultAdd(negT, ...) of the Rhie-Chow boundary terms, cnlinearcart3d.c:3033: alpha = -1) */
+int fl_momentum_face_interp_scaled(fl_momentum *m, double alpha, const double *v_dev, const double *const rhs_dev[3], double *const V_dev[3]);
 /* out[c*3+d] = vbc[c*3+d] + (B v)_c on the d-faces: cnl->v0interp of NSStep_CNLinear_Cart3d_Internal
  * (cnlinearcart3d.c:2826-2829), B = ComputeFaceVelocityInterpolationOperator_Private (cnlinearcart3d.c:1513-1747).
  * vbc_dev (or any entry) may be NULL = 0; out may be handed straight to fl_momentum_set_state. */

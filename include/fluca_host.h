@@ -117,8 +117,7 @@ FlErrorCode NSGetLocalSizes(NS ns, int64_t out[4]);
  * device, Srhs = contrhs - D V*, dp = S^-1 Srhs, v = v* - G dp, V = V* - Gst dp  (abfpc.c:73-101, Ainv = ID) */
 FlErrorCode NSPressureCorrection(NS ns, double *vstar_dev[3], double *Vstar_dev[3], const double *contrhs_dev, double *dp_dev, fl_ksp_stats *stats);
 /* NSStep / NSSolve (nsbasic.c:276-350) with the CNLinear step of cnlinearcart3d.c:2807-2863 (+ NSFormJacobian :2930-2941,
- * NSFormFunction :2945-3060) on device arrays: VELOCITY / PERIODIC / SYMMETRY boundaries (a PRESSURE_OUTLET makes the step
- * return PETSC_ERR_SUP).  The outer KSP of ns->snes is -ns_ksp_type richardson (default here; x += PCApply_ABF(f - J x) until
+ * NSFormFunction :2945-3060) on device arrays, all four boundary types.  The outer KSP of ns->snes is -ns_ksp_type richardson (default here; x += PCApply_ABF(f - J x) until
  * the unpreconditioned residual meets -ns_ksp_rtol 1e-5, nssol.c:24-25) or preonly; the reference's own default, gmres,
  * is not built (PETSC_ERR_SUP).  NSGetSolutionArrays hands out the device arrays of ns->sol (velocity 3*cells
  * component-major, face-normal velocity per axis, pressure) so that the caller can set the initial condition. */

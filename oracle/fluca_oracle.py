@@ -444,9 +444,9 @@ class StepOracle:
     velocity(b, t, X) -> (3, npoints) array: the wall velocity callback of boundary b at the face centres X (npoints, 3).
     """
 
-    def __init__(self, g, dt, rho, mu, velocity=None, krylov_rtol=1e-12, outer_rtol=1e-8, outer_maxit=50):
+    def __init__(self, g, dt, rho, mu, velocity=None, krylov_rtol=1e-12, outer_rtol=1e-8, outer_maxit=50, pressure=None):
         assert abs(g.kappa - dt / rho) < 1e-15 * max(1.0, g.kappa)
-        self.g, self.dt, self.rho, self.mu, self.velocity = g, dt, rho, mu, velocity
+        self.g, self.dt, self.rho, self.mu, self.velocity, self.pressure = g, dt, rho, mu, velocity, pressure
         self.S = g.assemble_S()
         self.L = g.assemble_momentum(0.0, 0.0, 1.0)
         self.krtol, self.ortol, self.omaxit = krylov_rtol, outer_rtol, outer_maxit
@@ -467,6 +467,17 @@ class StepOracle:
         X[..., a1] = xc[a1][None, :]
         X[..., a2] = xc[a2][:, None]
         return np.asarray(self.velocity(b, t, X.reshape(-1, 3))).reshape(3, g.n[a2], g.n[a1])
+
+    def _outlet(self, b, t):
+        """(n2, n1) outlet pressure on boundary b: pressure(b, t, X) with X the face centres (npoints, 3)"""
+        g, ax, side = self.g, b // 2, b % 2
+        a1, a2 = (1 if ax == 0 else 0), (1 if ax == 2 else 2)
+        xc = [0.5 * (g.xf[d][1:] + g.xf[d][:-1]) if g.xc[d] is None else g.xc[d] for d in range(3)]
+        X = np.empty((g.n[a2], g.n[a1], 3))
+        X[..., ax] = g.xf[ax][-1 if side else 0]
+        X[..., a1] = xc[a1][None, :]
+        X[..., a2] = xc[a2][:, None]
+        return np.asarray(self.pressure(b, t, X.reshape(-1, 3))).reshape(g.n[a2], g.n[a1])
 
     def _layer(self, arr, ax, idx):
         """view of the layer `idx` along grid axis ax of an array shaped (k, j, i)"""
@@ -502,12 +513,30 @@ class StepOracle:
                 self._layer(cells, ax, -1 if side else 0)[...] += (cv * cl * (vb0[q] + vb1[q])                     # L: :701, twice (:2985, :2998)
                                                                    - dt * sgn * (vb1[q] * vb0[ax] + vb0[q] * vb1[ax]) / hc)   # C: :1338, :2991
             self._layer(interprhs[ax].reshape(self.fshape[ax]), ax, -1 if side else 0)[...] = vb1[ax]               # :2178, :3003-3005
+        # PRESSURE_OUTLET: boundary-condition vector of G in momrhs (:2976-2984 with :257-259, :285-287 -- NOT scaled by
+        # dt/rho, as written) and the Rhie-Chow boundary terms of interprhs (:3013-3044)
+        tq, tp = (t if self.step == 0 else t - 0.5 * dt), t + 0.5 * dt
+        wG = np.zeros(3 * N)
+        for b in [b for b in range(6) if g.bc[b] == BC_PRESSURE_OUTLET]:
+            ax, side = b // 2, b % 2
+            n, xf, c = g.n[ax], g.xf[ax], xc[ax]
+            pq, pp = self._outlet(b, tq), self._outlet(b, tp)
+            h1, h2 = (xf[n] - c[n - 1], c[n - 1] - c[n - 2]) if side else (c[0] - xf[0], c[1] - c[0])
+            cg = (1.0 if side else -1.0) * h2 / (h1 * (h1 + h2))
+            cells = momrhs[ax * N:(ax + 1) * N].reshape(self.cshape)
+            self._layer(cells, ax, -1 if side else 0)[...] -= cg * pq
+            wc = wG[ax * N:(ax + 1) * N].reshape(self.cshape)
+            self._layer(wc, ax, -1 if side else 0)[...] += g.kappa * cg * (pq - pp)
+            self._layer(interprhs[ax].reshape(self.fshape[ax]), ax, -1 if side else 0)[...] += g.kappa * g.gst_bc_coeff(ax, side) * (pq - pp)
+        if np.any(wG != 0.0):
+            Tw = g.apply_T(wG)
+            interprhs = [interprhs[d] - Tw[d] for d in range(3)]
         A = g.assemble_momentum(1.0, dt, -cv, V0, W)
 
         def pcapply(fv, fV, fp):      # abfpc.c:71-101
             vs, _ = A.solve(fv, ksp=KSP_BCGS, pc=PC_JACOBI, nullspace=False, rtol=self.krtol, maxit=2000, history=False)
             Vs = g.apply_T(vs, fV)
-            ps, _ = self.S.solve(g.rhs(*Vs, contrhs=fp), nullspace=self.nullspace, rtol=self.krtol, maxit=20000, history=False)
+            ps, _ = self.S.solve(g.rhs(*Vs, contrhs=fp), ksp=getattr(self, "S_ksp", KSP_CG), nullspace=self.nullspace, rtol=self.krtol, maxit=20000, history=False)
             Gst = g.apply_gst(ps)
             return vs - np.concatenate(g.apply_G(ps)), [Vs[d] - Gst[d] for d in range(3)], ps
 

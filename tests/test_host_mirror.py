@@ -482,3 +482,109 @@ def test_nsstep_matches_the_oracle_step(H):
     assert np.linalg.norm((pg - pg.mean()) - (po - po.mean())) <= 1e-5 * np.linalg.norm(po - po.mean())
     H.lib.NSDestroy(C.byref(ns))
     H.lib.MeshDestroy(C.byref(mesh))
+
+
+def _channel(H, n, dt, nsteps, rho, mu, pout, opts=()):
+    """Channel: parabolic VELOCITY inlet at x = 0, PRESSURE_OUTLET at x = Lx, no-slip walls in y, periodic z."""
+    Lx, Ly = 2.0, 1.0
+    mesh = P()
+    assert H.lib.MeshCartCreate3d(0, 0, 1, n[0], n[1], n[2], -1, -1, -1, None, None, None, C.byref(mesh)) == 0
+    assert H.lib.MeshSetUp(mesh) == 0
+    assert H.lib.MeshCartSetUniformCoordinates(mesh, 0., Lx, 0., Ly, 0., Ly * n[2] / n[1]) == 0
+    ns = P()
+    assert H.lib.NSCreate(C.byref(ns)) == 0 and H.lib.NSSetType(ns, b"cnlinear") == 0 and H.lib.NSSetMesh(ns, mesh) == 0
+    assert H.lib.NSSetDensity(ns, rho) == 0 and H.lib.NSSetViscosity(ns, mu) == 0
+
+    @H.BCFunc
+    def inlet(dim, t, x, val, ctx):
+        val[0], val[1], val[2] = 4.0 * x[1] * (Ly - x[1]) / Ly ** 2, 0.0, 0.0
+        return 0
+
+    @H.BCFunc
+    def wall(dim, t, x, val, ctx):
+        val[0] = val[1] = val[2] = 0.0
+        return 0
+
+    @H.BCFunc
+    def outlet(dim, t, x, val, ctx):
+        val[0] = pout(t, x)
+        return 0
+
+    keep = (inlet, wall, outlet)
+    bcs = [H.NSBoundaryCondition(type=H.NS_BC_VELOCITY, velocity=inlet), H.NSBoundaryCondition(type=H.NS_BC_PRESSURE_OUTLET, pressure=outlet),
+           H.NSBoundaryCondition(type=H.NS_BC_VELOCITY, velocity=wall), H.NSBoundaryCondition(type=H.NS_BC_VELOCITY, velocity=wall),
+           H.NSBoundaryCondition(type=H.NS_BC_PERIODIC), H.NSBoundaryCondition(type=H.NS_BC_PERIODIC)]
+    for b in range(6):
+        assert H.lib.NSSetBoundaryCondition(ns, b, bcs[b]) == 0
+    argc, av = H.argv("-ns_time_step_size", dt, "-ns_max_steps", nsteps, "-ns_abf_schur_ksp_type", "bcgs", *opts)
+    assert H.lib.NSSetFromOptions(ns, argc, av) == 0 and H.lib.NSSetUp(ns) == 0
+    return mesh, ns, keep, (Lx, Ly)
+
+
+def _fetch(H, ns, g):
+    v, p, Vp = P(), P(), (C.c_void_p * 3)()
+    assert H.lib.NSGetSolutionArrays(ns, C.byref(v), Vp, C.byref(p)) == 0
+
+    def get(ptr, m):
+        out = np.empty(m)
+        H.capi.check(H.capi.lib.fl_memcpy_d2h(0, out.ctypes.data_as(C.c_void_p), ptr, m * 8))
+        return out
+
+    return get(v, 3 * g.ncell), [get(C.c_void_p(Vp[d]), g.nface[d]) for d in range(3)], get(p, g.ncell)
+
+
+@pytest.mark.gpu
+def test_nsstep_with_an_unsteady_outlet_matches_the_oracle_step(H):
+    """PRESSURE_OUTLET: the G boundary vector in momrhs and the Rhie-Chow boundary terms of interprhs (cnlinearcart3d.c
+    :2976-2984, :3013-3044), exercised with an outlet pressure that varies in space and time."""
+    from oracle import fluca_oracle as fo
+    n, rho, mu, dt = (12, 10, 4), 1.0, 0.05, 5e-3
+    pout = lambda t, x: 0.3 * np.sin(3.0 * t) + 0.1 * x[1]
+    mesh, ns, keep, (Lx, Ly) = _channel(H, n, dt, 2, rho, mu, pout,
+                                        ("-ns_ksp_rtol", 1e-9, "-ns_abf_schur_ksp_rtol", 1e-11, "-ns_abf_momentum_ksp_rtol", 1e-11))
+    assert H.lib.NSSolve(ns) == 0
+    bc = [fo.BC_VELOCITY, fo.BC_PRESSURE_OUTLET, fo.BC_VELOCITY, fo.BC_VELOCITY, fo.BC_PERIODIC, fo.BC_PERIODIC]
+    g = fo.Grid.uniform(n, [(0, Lx), (0, Ly), (0, Ly * n[2] / n[1])], bc, dt / rho)
+    vg, Vg, pg = _fetch(H, ns, g)
+
+    def velocity(b, t, X):
+        if b == 0:
+            return np.stack([4.0 * X[:, 1] * (Ly - X[:, 1]) / Ly ** 2, np.zeros(len(X)), np.zeros(len(X))])
+        return np.zeros((3, len(X)))
+
+    pressure = lambda b, t, X: np.array([pout(t, x) for x in X])
+    so = fo.StepOracle(g, dt, rho, mu, velocity, krylov_rtol=1e-11, outer_rtol=1e-9, pressure=pressure)
+    so.S_ksp = fo.KSP_BCGS
+    vo, Vo, po = np.zeros(3 * g.ncell), [np.zeros(nf) for nf in g.nface], np.zeros(g.ncell)
+    for _ in range(2):
+        vo, Vo, po, info = so.step_once(vo, Vo, po)
+    assert np.linalg.norm(vg - vo) <= 1e-6 * np.linalg.norm(vo)
+    for d in range(2):
+        assert np.linalg.norm(Vg[d] - Vo[d]) <= 1e-6 * np.linalg.norm(Vo[d])
+    assert np.linalg.norm(pg - po) <= 1e-5 * np.linalg.norm(po)
+    H.lib.NSDestroy(C.byref(ns))
+    H.lib.MeshDestroy(C.byref(mesh))
+
+
+@pytest.mark.gpu
+def test_channel_flow_reaches_poiseuille(H):
+    """Inlet / outlet channel (BASELINE config 3's geometry): started from rest, the flow settles on the parabolic profile
+    with a linear pressure drop -- which the second-order scheme reproduces exactly."""
+    from oracle import fluca_oracle as fo
+    n, rho, mu, dt = (16, 12, 4), 1.0, 1.0, 0.05
+    mesh, ns, keep, (Lx, Ly) = _channel(H, n, dt, 40, rho, mu, lambda t, x: 0.0, ("-ns_ksp_rtol", 1e-9, "-ns_abf_schur_ksp_rtol", 1e-10,
+                                                                                  "-ns_abf_momentum_ksp_rtol", 1e-10))
+    assert H.lib.NSSolve(ns) == 0
+    g = fo.Grid.uniform(n, [(0, Lx), (0, Ly), (0, Ly * n[2] / n[1])], [1, 2, 1, 1, 3, 3], dt / rho)
+    vg, Vg, pg = _fetch(H, ns, g)
+    u = vg[:g.ncell].reshape(n[2], n[1], n[0])
+    yc = (np.arange(n[1]) + 0.5) * Ly / n[1]
+    xc = (np.arange(n[0]) + 0.5) * Lx / n[0]
+    want = 4.0 * yc * (Ly - yc)
+    assert np.abs(u - want[None, :, None]).max() < 2e-3
+    assert np.abs(vg[g.ncell:]).max() < 2e-3
+    # dp/dx = -mu u'' = -8 mu / Ly^2, p = 0 at the outlet
+    pc = pg.reshape(n[2], n[1], n[0])
+    assert np.abs(pc - (8.0 * mu / Ly ** 2 * (Lx - xc))[None, None, :]).max() < 0.05 * 8.0 * mu * Lx
+    H.lib.NSDestroy(C.byref(ns))
+    H.lib.MeshDestroy(C.byref(mesh))
