@@ -61,6 +61,7 @@ def build_host(force=False, verbose=False):
         subprocess.check_call(cmd)
     build_example(force, verbose)
     build_example(force, verbose, name="cavity_flow_3d")
+    build_example(force, verbose, name="flow_configs")
     return HOST_LIB
 
 

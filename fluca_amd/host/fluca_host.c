@@ -414,12 +414,17 @@ struct _p_NS {
   int                  nb, device, setupcalled;
   fl_poisson          *poisson;  /* plays PC_ABF's kspS + S */
   fl_momentum         *momentum; /* plays PC_ABF's kspA + A (created by the first NSSetPreviousState) */
+  fl_ibm              *ibm;      /* immersed boundary (build-defined direct forcing, NSSetImmersedBoundary) */
+  int64_t              ibm_L;
+  const double        *ibm_dV, *ibm_Ut;
+  double              *ibm_U;
   fl_ksp_opts          schur;    /* -ns_abf_schur_* */
   fl_ksp_opts          mom;      /* -ns_abf_momentum_* */
   int                  ksp_type;           /* -ns_ksp_type: 0 richardson, 1 preonly (the reference's default, gmres, is not built) */
   double               ksp_rtol, ksp_atol; /* -ns_ksp_rtol 1e-5 (nssol.c:24), unpreconditioned norm (nssol.c:25) */
   int                  ksp_max_it;
   int                  ksp_its, reason;    /* of the last step */
+  int                  mom_its, schur_its; /* inner Krylov iterations summed over the last step's outer iterations */
   double               ksp_rnorm;
   void                *data;
 };
@@ -662,6 +667,14 @@ FlErrorCode NSSolve(NS ns) /* nsbasic.c:325-350: step until -ns_max_steps */
   return 0;
 }
 
+FlErrorCode NSGetInnerIterations(NS ns, int *momentum_its, int *schur_its)
+{
+  if (!ns) return E_ARG_NULL;
+  if (momentum_its) *momentum_its = ns->mom_its;
+  if (schur_its) *schur_its = ns->schur_its;
+  return 0;
+}
+
 FlErrorCode NSGetLinearSolveInfo(NS ns, int *its, double *rnorm, int *reason)
 {
   if (!ns) return E_ARG_NULL;
@@ -687,6 +700,8 @@ FlErrorCode NSDestroy(NS *ns)
 {
   if (!ns || !*ns) return 0;
   if ((*ns)->ops->destroy) (*ns)->ops->destroy(*ns);
+  if ((*ns)->ibm) fl_ibm_destroy((*ns)->ibm);
+  if ((*ns)->ibm_U) fl_free((*ns)->device, (*ns)->ibm_U);
   if ((*ns)->momentum) fl_momentum_destroy((*ns)->momentum);
   if ((*ns)->poisson) fl_poisson_destroy((*ns)->poisson);
   free((*ns)->bcs);
@@ -738,6 +753,39 @@ FlErrorCode NSPressureCorrection(NS ns, double *vstar[3], double *Vstar[3], cons
   if (!rc) rc = fl_poisson_synchronize(ns->poisson);
   fl_free(ns->device, srhs);
   return rc ? -rc : 0;
+}
+
+/* Immersed boundary by explicit direct forcing (build-defined: the reference only promises IBM, THEORY_GUIDE.md:130-132):
+ * every step adds  spread(U_target - interp(v0))  to momrhs, i.e. the force density (U_target - U)/dt that would bring the
+ * interpolated marker velocity to its target within the step, times dt.  Markers / volumes / targets are device arrays
+ * owned by the caller; Utarget_dev may be NULL (body at rest). */
+FlErrorCode NSSetImmersedBoundary(NS ns, int kind, int64_t L, const double *X_dev, const double *Y_dev, const double *Z_dev, const double *dV_dev, const double *Utarget_dev)
+{
+  if (!ns || !X_dev || !Y_dev || !Z_dev || !dV_dev) return E_ARG_NULL;
+  if (!ns->setupcalled) return E_ARG_WRONGSTATE;
+  if (L < 1) return E_ARG_OUTOFRANGE;
+  if (ns->ibm) {
+    fl_ibm_destroy(ns->ibm);
+    ns->ibm = NULL;
+  }
+  if (ns->ibm_U) fl_free(ns->device, ns->ibm_U);
+  ns->ibm_U = NULL;
+  FLABI(fl_ibm_create(ns->poisson, kind, L, X_dev, Y_dev, Z_dev, &ns->ibm));
+  void *u = NULL;
+  FLABI(fl_malloc(ns->device, sizeof(double) * 3 * (size_t)L, &u));
+  ns->ibm_U  = (double *)u;
+  ns->ibm_L  = L;
+  ns->ibm_dV = dV_dev;
+  ns->ibm_Ut = Utarget_dev;
+  return 0;
+}
+
+FlErrorCode NSGetImmersedBoundary(NS ns, fl_ibm **ibm)
+{
+  if (!ns || !ibm) return E_ARG_NULL;
+  if (!ns->ibm) return E_ARG_WRONGSTATE;
+  *ibm = ns->ibm;
+  return 0;
 }
 
 FlErrorCode NSGetMomentumKSPOptions(NS ns, fl_ksp_opts **opts)
@@ -1018,6 +1066,12 @@ static FlErrorCode NSStep_CNLinear(NS ns)
     FLABI(fl_boundary_set_faces(h, b, 1., c->plane_dev, c->f_V[ax]));
     free(tmp);
   }
+  /* immersed boundary: momrhs += spread(U_target - interp(v0)) */
+  if (ns->ibm) {
+    FLABI(fl_ibm_interp(ns->ibm, 3, c->sol0_v, ns->ibm_U));
+    FLABI(fl_vec_lincomb(h, 3 * ns->ibm_L, -1., ns->ibm_U, 1., ns->ibm_Ut, ns->ibm_U)); /* U_target - U (z = NULL: target 0) */
+    FLABI(fl_ibm_spread(ns->ibm, 3, ns->ibm_U, ns->ibm_dV, c->f_v));
+  }
   /* PRESSURE_OUTLET: the boundary-condition vector of G in momrhs (:2976-2984, :219-423) and the Rhie-Chow boundary terms
    * of interprhs (:3013-3044).  As written in the reference, the G vector is NOT scaled by dt/rho in momrhs. */
   {
@@ -1080,8 +1134,10 @@ static FlErrorCode NSStep_CNLinear(NS ns)
   fl_ksp_stats  st[2];
   const double *fV[3] = {c->f_V[0], c->f_V[1], c->f_V[2]};
   FLABI(fl_abf_apply(ns->momentum, &ns->mom, &ns->schur, c->f_v, fV, NULL, c->x_v, c->x_V, c->x_p, st));
-  ns->ksp_its = 1;
-  ns->reason  = 0;
+  ns->ksp_its   = 1;
+  ns->reason    = 0;
+  ns->mom_its   = st[0].iters;
+  ns->schur_its = st[1].iters;
   /* like PETSc without -ksp_error_if_not_converged, an inner solve that stops short is not an error by itself: the outer
    * residual decides.  NaN / Inf is. */
   if (st[0].reason == FL_DIVERGED_NANORINF || st[1].reason == FL_DIVERGED_NANORINF) ns->reason = -1; /* NS_DIVERGED_LINEAR_SOLVE */
@@ -1102,6 +1158,8 @@ static FlErrorCode NSStep_CNLinear(NS ns)
       if (ns->ksp_its >= ns->ksp_max_it) { ns->reason = -1; break; }
       const double *rV[3] = {c->r_V[0], c->r_V[1], c->r_V[2]};
       FLABI(fl_abf_apply(ns->momentum, &ns->mom, &ns->schur, c->r_v, rV, c->r_p, c->d_v, c->d_V, c->d_p, st));
+      ns->mom_its += st[0].iters;
+      ns->schur_its += st[1].iters;
       if (st[0].reason == FL_DIVERGED_NANORINF || st[1].reason == FL_DIVERGED_NANORINF) { ns->reason = -1; break; }
       FLABI(fl_vec_lincomb(h, 3 * N, 1., c->x_v, 1., c->d_v, c->x_v));
       FLABI(fl_vec_lincomb(h, N, 1., c->x_p, 1., c->d_p, c->x_p));

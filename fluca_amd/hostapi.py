@@ -43,8 +43,8 @@ PROTOTYPES = {
     "NSStep": [_P], "NSGetTimeStep": [_P, _i64p], "NSGetTime": [_P, C.POINTER(C.c_double)], "NSDestroy": [C.POINTER(_P)],
     "NSGetPoisson": [_P, C.POINTER(_P)], "NSGetSchurKSPOptions": [_P, C.POINTER(C.POINTER(capi.fl_ksp_opts))], "NSGetNeedsNullSpace": [_P, _ip],
     "NSGetLocalSizes": [_P, _i64p], "NSPressureCorrection": [_P, _dp3, _dp3, _P, _P, C.POINTER(capi.fl_ksp_stats)],
-    "NSSolve": [_P], "NSGetSolutionArrays": [_P, C.POINTER(_P), _dp3, C.POINTER(_P)],
-    "NSGetLinearSolveInfo": [_P, _ip, C.POINTER(C.c_double), _ip],
+    "NSSolve": [_P], "NSSetImmersedBoundary": [_P, C.c_int, C.c_int64, _P, _P, _P, _P, _P], "NSGetSolutionArrays": [_P, C.POINTER(_P), _dp3, C.POINTER(_P)],
+    "NSGetLinearSolveInfo": [_P, _ip, C.POINTER(C.c_double), _ip], "NSGetInnerIterations": [_P, _ip, _ip], "NSGetImmersedBoundary": [_P, C.POINTER(_P)],
     "NSSetPreviousState": [_P, _dp3, _dp3], "NSGetMomentum": [_P, C.POINTER(_P)],
     "NSGetMomentumKSPOptions": [_P, C.POINTER(C.POINTER(capi.fl_ksp_opts))],
     "NSApplyPreconditioner": [_P, _P, _dp3, _P, _P, _dp3, _P, C.POINTER(capi.fl_ksp_stats)],

@@ -122,8 +122,14 @@ FlErrorCode NSPressureCorrection(NS ns, double *vstar_dev[3], double *Vstar_dev[
  * is not built (PETSC_ERR_SUP).  NSGetSolutionArrays hands out the device arrays of ns->sol (velocity 3*cells
  * component-major, face-normal velocity per axis, pressure) so that the caller can set the initial condition. */
 FlErrorCode NSSolve(NS ns);
+/* Immersed boundary by explicit direct forcing -- build-defined, the reference has none (THEORY_GUIDE.md:130-132): every
+ * step adds spread(U_target - interp(v0)) to momrhs.  kind: fl_delta_kind; L markers X,Y,Z with volumes dV (device arrays
+ * owned by the caller, uniform grid spacing required); Utarget_dev: 3*L target velocities or NULL for a body at rest. */
+FlErrorCode NSSetImmersedBoundary(NS ns, int kind, int64_t L, const double *X_dev, const double *Y_dev, const double *Z_dev, const double *dV_dev, const double *Utarget_dev);
 FlErrorCode NSGetSolutionArrays(NS ns, double **v_dev, double *V_dev[3], double **p_dev);
 FlErrorCode NSGetLinearSolveInfo(NS ns, int *its, double *rnorm, int *reason);
+/* kspA / kspS iterations summed over the outer iterations of the last step */
+FlErrorCode NSGetInnerIterations(NS ns, int *momentum_its, int *schur_its);
 /* The A block of NSFormJacobian (cnlinearcart3d.c:2930-2941): hands over sol0's face-normal velocity V0 (3 face arrays)
  * and cnl->v0interp (9 face arrays, component c on the faces of axis d at [c*3+d]); A = I + dt C - (mu dt / 2 rho) L is
  * applied matrix-free from then on.  Call once per time step, before NSApplyPreconditioner. */
@@ -134,6 +140,7 @@ FlErrorCode NSSetPreviousState(NS ns, const double *const V0_dev[3], const doubl
  * -ns_abf_momentum_pc_type jacobi|none, -ns_abf_momentum_ksp_{rtol,atol,divtol,max_it}. */
 FlErrorCode NSApplyPreconditioner(NS ns, const double *momrhs_dev, const double *const interprhs_dev[3], const double *contrhs_dev, double *v_dev, double *const V_dev[3], double *p_dev, fl_ksp_stats stats[2]);
 FlErrorCode NSGetMomentumKSPOptions(NS ns, fl_ksp_opts **opts);
+FlErrorCode NSGetImmersedBoundary(NS ns, fl_ibm **ibm);
 FlErrorCode NSGetMomentum(NS ns, fl_momentum **momentum);
 /* p, phalf update of the time step, then ++step, t += dt (cnlinearcart3d.c:2846-2854, nsbasic.c:288-291) */
 FlErrorCode NSUpdatePressure(NS ns, const double *dp_dev, const double *p0_dev, double *phalf_dev, double *p_dev);

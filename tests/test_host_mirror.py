@@ -588,3 +588,22 @@ def test_channel_flow_reaches_poiseuille(H):
     assert np.abs(pc - (8.0 * mu / Ly ** 2 * (Lx - xc))[None, None, :]).max() < 0.05 * 8.0 * mu * Lx
     H.lib.NSDestroy(C.byref(ns))
     H.lib.MeshDestroy(C.byref(mesh))
+
+
+@pytest.mark.gpu
+def test_flow_config_driver_with_immersed_sphere(H):
+    """examples/flow_configs.c -config sphere: the channel with the direct-forcing IBM active every step."""
+    import re
+    import subprocess
+    from fluca_amd import build
+    exe = build.build_example(name="flow_configs")
+    run = lambda cfg: subprocess.run([exe, "-config", cfg, "-n", "64", "-ns_max_steps", "4", "-ns_ksp_type", "preonly", "-ns_abf_schur_pc_type", "mg"],
+                                     capture_output=True, text=True, timeout=300)
+    out = run("sphere")
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "markers 12868" in out.stdout and out.stdout.count("step ") == 4
+    speed = float(re.search(r"rms fluid speed at the markers (\S+)", out.stdout).group(1))
+    ke_s = float(re.search(r"mean kinetic energy (\S+)", out.stdout).group(1))
+    ke_c = float(re.search(r"mean kinetic energy (\S+)", run("channel").stdout).group(1))
+    assert 0.0 < speed < 0.67          # below the mean speed of the parabolic inflow: the forcing holds the fluid back
+    assert ke_s != ke_c                # and the flow differs from the empty channel
