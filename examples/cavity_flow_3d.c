@@ -6,8 +6,8 @@
  *   gcc -O2 examples/cavity_flow_3d.c -Iinclude -Lfluca_amd/lib -lfluca_host -lflucahip -lm -Wl,-rpath,$PWD/fluca_amd/lib
  *   ./a.out -cart_grid_x 64 -cart_grid_y 64 -cart_grid_z 32 -ns_time_step_size 5e-3 -ns_max_steps 20 -Re 100
  *
- * Differences from the reference run: the outer Krylov method is -ns_ksp_type richardson (default) or preonly instead
- * of GMRES, kspA is BiCGStab + Jacobi instead of GMRES + ILU.
+ * Difference from the reference run: kspA is BiCGStab + Jacobi instead of PETSc's default GMRES + ILU;
+ * the outer solver is GMRES with PC_ABF as in the reference (-ns_ksp_type richardson|preonly are the alternatives).
  */
 #include <math.h>
 #include <stdio.h>

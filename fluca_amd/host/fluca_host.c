@@ -420,7 +420,8 @@ struct _p_NS {
   double              *ibm_U;
   fl_ksp_opts          schur;    /* -ns_abf_schur_* */
   fl_ksp_opts          mom;      /* -ns_abf_momentum_* */
-  int                  ksp_type;           /* -ns_ksp_type: 0 richardson, 1 preonly (the reference's default, gmres, is not built) */
+  int                  ksp_type;           /* -ns_ksp_type: 0 richardson, 1 preonly, 2 gmres (the reference's default, nssol.c:21-29) */
+  int                  gmres_restart;      /* -ns_ksp_gmres_restart (PETSc default 30) */
   double               ksp_rtol, ksp_atol; /* -ns_ksp_rtol 1e-5 (nssol.c:24), unpreconditioned norm (nssol.c:25) */
   int                  ksp_max_it;
   int                  ksp_its, reason;    /* of the last step */
@@ -452,7 +453,8 @@ FlErrorCode NSCreate(NS *ns)
   n->mom.type = FL_KSP_BCGS; /* PETSc's own default for kspA is gmres + ilu: neither has a matrix-free form here */
   n->mom.pc   = FL_PC_JACOBI;
   n->mom.remove_nullspace = 0;
-  n->ksp_type   = 0;
+  n->ksp_type   = 2;
+  n->gmres_restart = 30;
   n->ksp_rtol   = 1e-5; /* nssol.c:24 */
   n->ksp_atol   = 1e-50;
   n->ksp_max_it = 10000;
@@ -586,7 +588,12 @@ FlErrorCode NSSetFromOptions(NS ns, int argc, char **argv)
   if ((s = opt_find(argc, argv, "-ns_ksp_type"))) {
     if (!strcmp(s, "richardson")) ns->ksp_type = 0;
     else if (!strcmp(s, "preonly")) ns->ksp_type = 1;
-    else return !strcmp(s, "gmres") || !strcmp(s, "fgmres") || !strcmp(s, "bcgs") ? E_SUP : E_ARG_UNKNOWN_TYPE;
+    else if (!strcmp(s, "gmres")) ns->ksp_type = 2;
+    else return !strcmp(s, "fgmres") || !strcmp(s, "bcgs") ? E_SUP : E_ARG_UNKNOWN_TYPE;
+  }
+  if (opt_int64(argc, argv, "-ns_ksp_gmres_restart", &iv)) {
+    if (iv < 1 || iv > 200) return E_ARG_OUTOFRANGE;
+    ns->gmres_restart = (int)iv;
   }
   if (opt_real(argc, argv, "-ns_ksp_rtol", &v)) ns->ksp_rtol = v;
   if (opt_real(argc, argv, "-ns_ksp_atol", &v)) ns->ksp_atol = v;
@@ -1013,6 +1020,182 @@ static FlErrorCode cnl_residual(NS ns, double *rnorm)
   return 0;
 }
 
+/* ---- composite vectors (v: 3*cells, V[3]: faces, p: cells) for the outer Krylov method ------------------------------- */
+typedef struct {
+  double *v, *V[3], *p;
+} CVec;
+
+static FlErrorCode cv_alloc(NS ns, CVec *a)
+{
+  NS_CNLinear *c = (NS_CNLinear *)ns->data;
+  FLCHK(cnl_alloc(ns, &a->v, 3 * c->sz[0]));
+  FLCHK(cnl_alloc(ns, &a->p, c->sz[0]));
+  for (int d = 0; d < 3; ++d) FLCHK(cnl_alloc(ns, &a->V[d], c->sz[1 + d]));
+  return 0;
+}
+static void cv_free(NS ns, CVec *a)
+{
+  double *q[5] = {a->v, a->p, a->V[0], a->V[1], a->V[2]};
+  for (int i = 0; i < 5; ++i)
+    if (q[i]) fl_free(ns->device, q[i]);
+  memset(a, 0, sizeof(*a));
+}
+/* y = a x + b z (z may be NULL) */
+static FlErrorCode cv_lincomb(NS ns, double a, const CVec *x, double b, const CVec *z, CVec *y)
+{
+  NS_CNLinear *c = (NS_CNLinear *)ns->data;
+  fl_poisson  *h = ns->poisson;
+  FLABI(fl_vec_lincomb(h, 3 * c->sz[0], a, x->v, b, z ? z->v : NULL, y->v));
+  FLABI(fl_vec_lincomb(h, c->sz[0], a, x->p, b, z ? z->p : NULL, y->p));
+  for (int d = 0; d < 3; ++d) FLABI(fl_vec_lincomb(h, c->sz[1 + d], a, x->V[d], b, z ? z->V[d] : NULL, y->V[d]));
+  return 0;
+}
+static FlErrorCode cv_dot(NS ns, const CVec *x, const CVec *y, double *out)
+{
+  NS_CNLinear *c = (NS_CNLinear *)ns->data;
+  fl_poisson  *h = ns->poisson;
+  double       s = 0., part;
+  FLABI(fl_vec_dot(h, 3 * c->sz[0], x->v, y->v, &part));
+  s += part;
+  FLABI(fl_vec_dot(h, c->sz[0], x->p, y->p, &part));
+  s += part;
+  for (int d = 0; d < 3; ++d) {
+    FLABI(fl_vec_dot(h, c->sz[1 + d], x->V[d], y->V[d], &part));
+    s += part;
+  }
+  *out = s;
+  return 0;
+}
+static FlErrorCode cv_pcapply(NS ns, const CVec *r, CVec *z) /* z = PCApply_ABF(r) */
+{
+  fl_ksp_stats  st[2];
+  const double *rV[3] = {r->V[0], r->V[1], r->V[2]};
+  FLABI(fl_abf_apply(ns->momentum, &ns->mom, &ns->schur, r->v, rV, r->p, z->v, z->V, z->p, st));
+  ns->mom_its += st[0].iters;
+  ns->schur_its += st[1].iters;
+  if (st[0].reason == FL_DIVERGED_NANORINF || st[1].reason == FL_DIVERGED_NANORINF) ns->reason = -1;
+  return 0;
+}
+static FlErrorCode cv_jmult(NS ns, const CVec *x, CVec *y) /* y = J x */
+{
+  const double *xV[3] = {x->V[0], x->V[1], x->V[2]};
+  FLABI(fl_abf_jacobian_mult(ns->momentum, x->v, xV, x->p, y->v, y->V, y->p));
+  return 0;
+}
+
+/* KSPGMRES as the reference's ns->snes uses it (nssol.c:21-29: rtol 1e-5, unpreconditioned norm => right preconditioning,
+ * PETSc defaults: restart 30, classical Gram-Schmidt without refinement -- here modified Gram-Schmidt, the same
+ * numbers up to round-off).  Zero initial guess.  x = P^-1 (V y) at every restart / at the end.  PARITY UNPINNED like the
+ * inner solvers (PETSc absent): restated from the published algorithm. */
+static FlErrorCode cnl_gmres(NS ns, const CVec *f, CVec *x)
+{
+  const int m = ns->gmres_restart;
+  CVec     *Vk = (CVec *)calloc((size_t)m + 1, sizeof(CVec)), w = {0}, t = {0};
+  double   *H = (double *)calloc((size_t)(m + 1) * m, sizeof(double)), *cs = (double *)calloc(m, sizeof(double)), *sn = (double *)calloc(m, sizeof(double)),
+           *g = (double *)calloc((size_t)m + 1, sizeof(double)), *y = (double *)calloc(m, sizeof(double));
+  FlErrorCode rc = 0;
+  int         nalloc = 0;
+#define GM(call)          \
+  do {                    \
+    rc = (call);          \
+    if (rc) goto done;    \
+  } while (0)
+  if (!Vk || !H || !cs || !sn || !g || !y) {
+    rc = E_MEM;
+    goto done;
+  }
+  GM(cv_alloc(ns, &w));
+  GM(cv_alloc(ns, &t));
+  double fnorm, beta;
+  GM(cv_dot(ns, f, f, &fnorm));
+  fnorm = sqrt(fnorm);
+  const double ttol = ns->ksp_rtol * fnorm > ns->ksp_atol ? ns->ksp_rtol * fnorm : ns->ksp_atol;
+  GM(cv_lincomb(ns, 0., f, 0., NULL, x)); /* x = 0 */
+  ns->ksp_its   = 0;
+  ns->ksp_rnorm = fnorm;
+  int first = 1;
+  while (ns->reason >= 0) {
+    /* r = f - J x */
+    if (first) GM(cv_lincomb(ns, 1., f, 0., NULL, &w));
+    else {
+      GM(cv_jmult(ns, x, &w));
+      GM(cv_lincomb(ns, -1., &w, 1., f, &w));
+    }
+    first = 0;
+    GM(cv_dot(ns, &w, &w, &beta));
+    beta          = sqrt(beta);
+    ns->ksp_rnorm = beta;
+    if (!(beta == beta)) { ns->reason = -1; break; }
+    if (beta <= ttol || ns->ksp_its >= ns->ksp_max_it) break;
+    if (nalloc < 1) { GM(cv_alloc(ns, &Vk[0])); nalloc = 1; }
+    GM(cv_lincomb(ns, 1. / beta, &w, 0., NULL, &Vk[0]));
+    memset(g, 0, sizeof(double) * ((size_t)m + 1));
+    g[0] = beta;
+    int j = 0, conv = 0;
+    for (; j < m && ns->ksp_its < ns->ksp_max_it; ++j) {
+      GM(cv_pcapply(ns, &Vk[j], &t)); /* z = P^-1 v_j */
+      if (ns->reason < 0) break;
+      GM(cv_jmult(ns, &t, &w));       /* w = J z */
+      for (int i = 0; i <= j; ++i) {  /* modified Gram-Schmidt */
+        double hij;
+        GM(cv_dot(ns, &w, &Vk[i], &hij));
+        H[i * m + j] = hij;
+        GM(cv_lincomb(ns, 1., &w, -hij, &Vk[i], &w));
+      }
+      double hn;
+      GM(cv_dot(ns, &w, &w, &hn));
+      hn = sqrt(hn);
+      H[(j + 1) * m + j] = hn;
+      for (int i = 0; i < j; ++i) { /* previous Givens rotations on the new column */
+        const double a = H[i * m + j], b = H[(i + 1) * m + j];
+        H[i * m + j]       = cs[i] * a + sn[i] * b;
+        H[(i + 1) * m + j] = -sn[i] * a + cs[i] * b;
+      }
+      {
+        const double a = H[j * m + j], b = H[(j + 1) * m + j], r = hypot(a, b);
+        cs[j] = r > 0. ? a / r : 1.;
+        sn[j] = r > 0. ? b / r : 0.;
+        H[j * m + j]       = r;
+        H[(j + 1) * m + j] = 0.;
+        g[j + 1]           = -sn[j] * g[j];
+        g[j]               = cs[j] * g[j];
+      }
+      ++ns->ksp_its;
+      ns->ksp_rnorm = fabs(g[j + 1]);
+      if (ns->ksp_rnorm <= ttol || hn == 0.) {
+        conv = 1;
+        ++j;
+        break;
+      }
+      if (j + 1 < m || 1) {
+        if (nalloc < j + 2) { GM(cv_alloc(ns, &Vk[j + 1])); nalloc = j + 2; }
+        GM(cv_lincomb(ns, 1. / hn, &w, 0., NULL, &Vk[j + 1]));
+      }
+    }
+    /* y = H^-1 g (back substitution), x += P^-1 (V y) */
+    for (int i = j - 1; i >= 0; --i) {
+      double sacc = g[i];
+      for (int k = i + 1; k < j; ++k) sacc -= H[i * m + k] * y[k];
+      y[i] = sacc / H[i * m + i];
+    }
+    if (j > 0) {
+      GM(cv_lincomb(ns, y[0], &Vk[0], 0., NULL, &w));
+      for (int i = 1; i < j; ++i) GM(cv_lincomb(ns, 1., &w, y[i], &Vk[i], &w));
+      GM(cv_pcapply(ns, &w, &t));
+      GM(cv_lincomb(ns, 1., x, 1., &t, x));
+    }
+    if (conv || ns->reason < 0) break;
+  }
+  if (ns->reason >= 0 && ns->ksp_rnorm > ttol && ns->ksp_its >= ns->ksp_max_it) ns->reason = -1;
+done:
+#undef GM
+  for (int i = 0; i < nalloc; ++i) cv_free(ns, &Vk[i]);
+  cv_free(ns, &w);
+  cv_free(ns, &t);
+  free(Vk); free(H); free(cs); free(sn); free(g); free(y);
+  return rc;
+}
+
 static FlErrorCode NSStep_CNLinear(NS ns)
 {
   NS_CNLinear *c = (NS_CNLinear *)ns->data;
@@ -1133,14 +1316,23 @@ static FlErrorCode NSStep_CNLinear(NS ns)
   /* KSPSolve(J, f, x) with PC_ABF */
   fl_ksp_stats  st[2];
   const double *fV[3] = {c->f_V[0], c->f_V[1], c->f_V[2]};
+  if (ns->ksp_type == 2) {
+    CVec f = {c->f_v, {c->f_V[0], c->f_V[1], c->f_V[2]}, c->r_p}, x = {c->x_v, {c->x_V[0], c->x_V[1], c->x_V[2]}, c->x_p};
+    FLABI(fl_vec_lincomb(h, N, 0., c->r_p, 0., NULL, c->r_p)); /* contrhs = 0 */
+    ns->reason  = 0;
+    ns->mom_its = ns->schur_its = 0;
+    FLCHK(cnl_gmres(ns, &f, &x));
+  } else
   FLABI(fl_abf_apply(ns->momentum, &ns->mom, &ns->schur, c->f_v, fV, NULL, c->x_v, c->x_V, c->x_p, st));
-  ns->ksp_its   = 1;
-  ns->reason    = 0;
-  ns->mom_its   = st[0].iters;
-  ns->schur_its = st[1].iters;
+  if (ns->ksp_type != 2) {
+    ns->ksp_its   = 1;
+    ns->reason    = 0;
+    ns->mom_its   = st[0].iters;
+    ns->schur_its = st[1].iters;
+  }
   /* like PETSc without -ksp_error_if_not_converged, an inner solve that stops short is not an error by itself: the outer
    * residual decides.  NaN / Inf is. */
-  if (st[0].reason == FL_DIVERGED_NANORINF || st[1].reason == FL_DIVERGED_NANORINF) ns->reason = -1; /* NS_DIVERGED_LINEAR_SOLVE */
+  if (ns->ksp_type != 2 && (st[0].reason == FL_DIVERGED_NANORINF || st[1].reason == FL_DIVERGED_NANORINF)) ns->reason = -1; /* NS_DIVERGED_LINEAR_SOLVE */
   if (ns->ksp_type == 0 && ns->reason >= 0) {
     double fnorm, rnorm = 0., part;
     FLABI(fl_vec_dot(h, 3 * N, c->f_v, c->f_v, &fnorm));

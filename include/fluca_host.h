@@ -117,9 +117,9 @@ FlErrorCode NSGetLocalSizes(NS ns, int64_t out[4]);
  * device, Srhs = contrhs - D V*, dp = S^-1 Srhs, v = v* - G dp, V = V* - Gst dp  (abfpc.c:73-101, Ainv = ID) */
 FlErrorCode NSPressureCorrection(NS ns, double *vstar_dev[3], double *Vstar_dev[3], const double *contrhs_dev, double *dp_dev, fl_ksp_stats *stats);
 /* NSStep / NSSolve (nsbasic.c:276-350) with the CNLinear step of cnlinearcart3d.c:2807-2863 (+ NSFormJacobian :2930-2941,
- * NSFormFunction :2945-3060) on device arrays, all four boundary types.  The outer KSP of ns->snes is -ns_ksp_type richardson (default here; x += PCApply_ABF(f - J x) until
- * the unpreconditioned residual meets -ns_ksp_rtol 1e-5, nssol.c:24-25) or preonly; the reference's own default, gmres,
- * is not built (PETSC_ERR_SUP).  NSGetSolutionArrays hands out the device arrays of ns->sol (velocity 3*cells
+ * NSFormFunction :2945-3060) on device arrays, all four boundary types.  The outer KSP of ns->snes is -ns_ksp_type gmres (default as in the reference: right-preconditioned
+ * with PC_ABF, -ns_ksp_rtol 1e-5 on the unpreconditioned norm, nssol.c:24-25, -ns_ksp_gmres_restart 30), richardson
+ * (x += PCApply_ABF(f - J x)) or preonly.  NSGetSolutionArrays hands out the device arrays of ns->sol (velocity 3*cells
  * component-major, face-normal velocity per axis, pressure) so that the caller can set the initial condition. */
 FlErrorCode NSSolve(NS ns);
 /* Immersed boundary by explicit direct forcing -- build-defined, the reference has none (THEORY_GUIDE.md:130-132): every

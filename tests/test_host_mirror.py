@@ -103,8 +103,10 @@ def test_ns_registry_options_and_state_errors(H):
     argc, av = H.argv("-ns_pc_abf_schur_ainv_type", "DIAG")
     assert H.lib.NSSetFromOptions(ns, argc, av) == H.ERR_SUP
     assert H.lib.NSStep(ns) == H.ERR_ARG_WRONGSTATE                    # before NSSetUp
-    argc, av = H.argv("-ns_ksp_type", "gmres")                         # the reference's default outer KSP is not built
+    argc, av = H.argv("-ns_ksp_type", "fgmres")                        # outer KSP: gmres (default), richardson, preonly
     assert H.lib.NSSetFromOptions(ns, argc, av) == H.ERR_SUP
+    argc, av = H.argv("-ns_ksp_type", "gmres", "-ns_ksp_gmres_restart", 12)
+    assert H.lib.NSSetFromOptions(ns, argc, av) == 0
     argc, av = H.argv("-ns_ksp_type", "preonly", "-ns_ksp_rtol", 1e-7)
     assert H.lib.NSSetFromOptions(ns, argc, av) == 0
     assert H.lib.NSDestroy(C.byref(ns)) == 0
@@ -388,6 +390,16 @@ def test_nssolve_preonly_is_the_fractional_step_method(H):
     e_p, _, its_p = _tgv_mirror(H, 32, 8, True, ksp="preonly")
     assert its_p == 1 and its_r > 1
     assert e_p < 3 * e_r + 1e-3
+
+
+@pytest.mark.gpu
+def test_nssolve_gmres_is_the_default_and_beats_richardson(H):
+    """The reference's outer solver (nssol.c:21-29: GMRES, rtol, unpreconditioned norm => right preconditioning with PC_ABF):
+    same answer as the Richardson iteration, in fewer applications of the preconditioner."""
+    e_g, _, its_g = _tgv_mirror(H, 32, 8, True, ksp="gmres")
+    e_r, _, its_r = _tgv_mirror(H, 32, 8, True, ksp="richardson")
+    assert abs(e_g - e_r) < 1e-6
+    assert 1 < its_g < its_r
 
 
 @pytest.mark.gpu
