@@ -17,11 +17,22 @@
  *                                fluca/src/ns/utils/abfpc/abfpc.c:150-171
  *   - PCApply_ABF stage 1/2      abfpc.c:71-101
  *   - constant null space        abfpc.c:173-177, nsbasic.c:214-244
+ *   widened rows, at the end of this file:
+ *   - velocity Laplacian L       cnlinearcart3d.c:425-632      (1-D rows cartdiscret.c:167-303)
+ *   - convection operator C      cnlinearcart3d.c:873-1294     (1-D rows cartdiscret.c:305-371)
+ *   - A = I + dt C - (mu dt/2 rho) L, assembled CSR on 3N unknowns   cnlinearcart3d.c:2930-2941
+ *   - face interpolations T, B   cnlinearcart3d.c:1934-2140, 1513-1747   (rows cartdiscret.c:373-423)
+ *   (fluca_oracle.py composes these into PCApply_ABF, the block Jacobian product and one whole CNLinear time step --
+ *    StepOracle, cnlinearcart3d.c:2807-3060 -- and restates the build's own multigrid cycle, MgOracle.)
  *
  * PARITY PIN STATUS
  *   operator coefficients : pinned by the reference's own FlucaFD golden files
  *                           (fluca/tests/fd/output/<case>.out, copied as data into
- *                           tests/golden/flucafd/), see tests/test_oracle_golden.py
+ *                           tests/golden/flucafd/), see tests/test_oracle_golden.py and, for
+ *                           the second-derivative rows of L, tests/test_oracle_momentum.py.
+ *                           The convection rows and the T / B rows have no golden in the
+ *                           reference; they are checked through the properties they imply
+ *                           (skew form on a periodic uniform grid, exactness on linears).
  *   Krylov solve          : PARITY UNPINNED.  The solve runs inside PETSc
  *                           (>= 3.23, fluca/CMakeLists.txt:9-11) which is not
  *                           vendored, not installed here and cannot be built
