@@ -242,6 +242,7 @@ int vcycle(fl_mg *mg, size_t l, const double *b, double *x, const fl_ksp_opts *o
   so.pc        = FL_PC_JACOBI;
   so.norm_type = FL_NORM_NONE;
   so.maxit     = o->mg_smooth_its > 0 ? o->mg_smooth_its : 3;
+  so.check_every = -1;  // smoother: no convergence test, no host round trip
   MgLevel &C   = mg->lv[l + 1];
   FL_CHK(fl_poisson_solve(h, b, x, &so, &st));                                       // x = smooth(b)
   FL_CHK(fl_residual(h, x, b, L.res));                                               // r = b - S x
