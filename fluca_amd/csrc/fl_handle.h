@@ -46,7 +46,7 @@ void launch_cg_flush(hipStream_t, const GridP &, const double *, const double *,
 struct PlanA {
   int ry, nw, tiles_x, tiles_y, nchunk, zc, nblocks, pf, nt, remap, probe;
 };
-PlanA plan_tiles(const GridP &, int ry, int nw, int nchunk_force, int target_blocks);
+PlanA plan_tiles(const GridP &, int ry, int nw, int nchunk_force, int target_blocks, int min_zc = 8);
 PlanA plan_cg_A(const GridP &, int, int);
 PlanA plan_cg_B(const GridP &);
 void  launch_cg_A(hipStream_t, const GridP &, bool, const PlanA &, const double *, double *, double *, double *, double *, KspScal *, double *, unsigned *, double *, int, double *sums = nullptr);

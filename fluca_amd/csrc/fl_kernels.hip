@@ -1080,7 +1080,7 @@ struct PlanA {
   int ry, nw, tiles_x, tiles_y, nchunk, zc, nblocks, pf, nt, remap, probe;
 };
 // tiling of k_cg_A / k_cg_B (K_B always runs 4-wave blocks: it reuses ry, nchunk, zc with nw = 4)
-PlanA plan_tiles(const GridP &g, int ry, int nw, int nchunk_force, int target_blocks)
+PlanA plan_tiles(const GridP &g, int ry, int nw, int nchunk_force, int target_blocks, int min_zc = 8)
 {
   PlanA p;
   p.ry = ry;
@@ -1093,7 +1093,7 @@ PlanA plan_tiles(const GridP &g, int ry, int nw, int nchunk_force, int target_bl
   p.tiles_y = (g.ny + nw * ry - 1) / (nw * ry);
   const int tiles = p.tiles_x * p.tiles_y;
   int       nchunk = nchunk_force > 0 ? nchunk_force : std::max(1, (target_blocks + tiles / 2) / tiles);
-  if (nchunk_force <= 0) nchunk = std::min(nchunk, std::max(1, g.nz / 8));  // keep the 2-plane chunk prologue <= 25 %
+  if (nchunk_force <= 0) nchunk = std::min(nchunk, std::max(1, g.nz / min_zc));  // min_zc = 8 keeps the 2-plane chunk prologue <= 25 %
   nchunk    = std::max(1, std::min(nchunk, g.nz));
   p.zc      = (g.nz + nchunk - 1) / nchunk;
   p.nchunk  = (g.nz + p.zc - 1) / p.zc;
@@ -1102,20 +1102,32 @@ PlanA plan_tiles(const GridP &g, int ry, int nw, int nchunk_force, int target_bl
 }
 // Defaults from the tools/kbench.py sweeps on MI355X at 512^3 (profiles/r01_kbench*.txt, three different boxes): 128 x 16
 // tiles of 8 waves x 2 rows, two ping-pong prefetch sets, non-temporal tile loads and stores, XCD-contiguous
-// chunk-major block order.  Small grids fall back to 4-wave tiles.
+// chunk-major block order.  Grids too small to give every CU a block with that shape (the reference's own 64 x 64 x 32
+// cavity makes 16) are latency-bound, not bandwidth-bound: they get smaller tiles and short z chunks instead, the chunk
+// prologue no longer matters (tools/experiments/small_grid_plan.py: k_cg_A 23.4 -> 6.9 us, k_cg_B 9.6 -> 4.7 us there).
+constexpr int MIN_BLOCKS = 256;  // one per CU
 PlanA plan_cg_A(const GridP &g, int ry_force, int nchunk_force)
 {
   const int ry = ry_force > 0 ? ry_force : (g.ny >= 8 ? 2 : 1);
   const int nw = (ry == 2 && g.ny >= 32) ? 8 : 4;
   PlanA     p  = plan_tiles(g, ry, nw, nchunk_force, 512);
+  if (ry_force <= 0 && nchunk_force <= 0 && p.nblocks < MIN_BLOCKS) {
+    p = plan_tiles(g, ry, 4, 0, 512, 2);
+    if (p.nblocks < MIN_BLOCKS && ry == 2) p = plan_tiles(g, 1, 4, 0, 512, 2);
+  }
   p.pf         = 1;
   p.nt         = 2;
   return p;
 }
 PlanA plan_cg_B(const GridP &g)
 {
-  const int ry = g.ny >= 32 ? 4 : (g.ny >= 8 ? 2 : 1);
-  PlanA     p  = plan_tiles(g, ry, 4, 0, 1024);
+  int   ry = g.ny >= 32 ? 4 : (g.ny >= 8 ? 2 : 1);
+  PlanA p  = plan_tiles(g, ry, 4, 0, 1024);
+  while (p.nblocks < MIN_BLOCKS) {
+    p = plan_tiles(g, ry, 4, 0, 1024, 2);
+    if (p.nblocks >= MIN_BLOCKS || ry == 1) break;
+    ry /= 2;
+  }
   p.nt         = 1;
   return p;
 }
