@@ -42,9 +42,24 @@ def cpu_baseline(sample_n, iters):
     p = rng.uniform(-1, 1, g.ncell)
     p -= p.mean()
     b = S.mult(p)
-    _, info = S.solve(b, rtol=0.0, atol=0.0, maxit=iters, history=False)
+    xc, info = S.solve(b, rtol=0.0, atol=0.0, maxit=iters, history=False)
     its_per_s = info["iters"] / info["seconds"]
-    return {"value": its_per_s * (sample_n ** 3) / 512.0 ** 3, "unit": "512^3-equivalent PCG iterations/s",
+    # the same sample through the HIP path, checked against what was just timed (after the timed regions of both)
+    parity = None
+    try:
+        import torch
+        from fluca_amd import poisson as flp
+        Pc = flp.Poisson.uniform(n, [(0, 1), (0, 1), (0, 0.5)], bc, 1e-3)
+        xg, ig = Pc.solve(torch.as_tensor(b, device="cuda"), rtol=0.0, atol=0.0, maxit=iters)
+        xg = xg.cpu().numpy()
+        xg -= xg.mean()
+        xc = xc - xc.mean()
+        parity = {"iters_gpu": ig["iters"], "iters_cpu": info["iters"], "rel_max_diff_x": float(np.abs(xg - xc).max() / np.abs(xc).max()),
+                  "rnorm_gpu": ig["rnorm"], "rnorm_cpu": info["rnorm"]}
+        Pc.close()
+    except Exception as e:  # noqa: BLE001  (never lose the bench line over the cross-check)
+        parity = {"error": repr(e)}
+    return {"value": its_per_s * (sample_n ** 3) / 512.0 ** 3, "unit": "512^3-equivalent PCG iterations/s", "parity_on_sample": parity,
             "cores": fo.num_threads(), "kind": "port",
             "sample": f"{sample_n}^3 cavity grid (1/{(512 // sample_n) ** 3} of the cells), {info['iters']} Jacobi-PCG iterations, "
                       f"assembled CSR (AIJ cost model), {info['seconds']:.2f} s, raw {its_per_s:.3f} it/s on the sample",
@@ -59,9 +74,9 @@ def main():
     ap.add_argument("--cells", type=int, default=512, help="cells per axis per GPU")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--cpu-cells", type=int, default=256)
-    ap.add_argument("--cpu-iters", type=int, default=40)
+    ap.add_argument("--cpu-iters", type=int, default=500, help="iterations of the CPU sample (about 10 s on 16 cores at 256^3)")
     ap.add_argument("--skip-cpu", action="store_true")
-    ap.add_argument("--placement-tries", type=int, default=12,
+    ap.add_argument("--placement-tries", type=int, default=24,
                     help="candidate placements of the solver vectors probed before the run (0 = take what the driver gives)")
     ap.add_argument("--transport", choices=["rccl", "host"], default="rccl",
                     help="halo transport for N > 1: RCCL Send/Recv (production) or the host-staged gloo callbacks "
