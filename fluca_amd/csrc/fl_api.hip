@@ -963,3 +963,58 @@ extern "C" int fldbg_bench(fl_poisson *h, int kernel, int ry, int pf, int nchunk
   if (nblocks_out) *nblocks_out = plan.nblocks;
   return FL_SUCCESS;
 }
+
+// Experiment behind fl_poisson_tune_placement (tools/experiments/pool_probe.py): K vectors allocated once, M random
+// assignments of five of them to the roles (r, p0, p1, q, x) of k_cg_A, probe time of each.
+extern "C" int fldbg_pool_probe(fl_poisson *h, int K, int M, unsigned seed, double *ms_out, int *sel_out)
+{
+  if (!h || !ms_out || K < 5 || K > 64) return FL_ERR_ARG_WRONG;
+  FL_HIP(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  PlanA       plan = plan_cg_A(h->g, 0, 0);
+  plan.probe       = 1;
+  FL_CHK(fl_ensure_partials(h, plan.nblocks));
+  std::vector<double *> pool(K, nullptr);
+  for (int k = 0; k < K; ++k) {
+    FL_HIP(hipMalloc((void **)&pool[k], sizeof(double) * h->padlen));
+    FL_HIP(hipMemsetAsync(pool[k], 0x3f, sizeof(double) * h->padlen, s));
+  }
+  KspScal *scal2 = nullptr;
+  FL_HIP(hipMalloc((void **)&scal2, 2 * sizeof(KspScal)));
+  KspScal S2[2];
+  std::memset(S2, 0, sizeof(S2));
+  for (int a = 0; a < 2; ++a) {
+    S2[a].beta = 0.5; S2[a].alpha = 1e-3; S2[a].zshift = 1e-4; S2[a].ncell_global = (double)h->ncell; S2[a].maxit = 1 << 30; S2[a].cur = a;
+  }
+  FL_HIP(hipMemcpy(scal2, S2, sizeof(S2), hipMemcpyHostToDevice));
+  unsigned st = seed * 2654435761u + 12345u;
+  auto     rnd = [&]() { st = st * 1664525u + 1013904223u; return st >> 8; };
+  for (int m = 0; m < M; ++m) {
+    int sel[5];
+    for (int a = 0; a < 5; ++a) {
+      bool ok;
+      do {
+        sel[a] = (int)(rnd() % (unsigned)K);
+        ok     = true;
+        for (int b = 0; b < a; ++b) ok &= sel[b] != sel[a];
+      } while (!ok);
+    }
+    auto probe = [&](int reps) {
+      for (int r = 0; r < reps; ++r)
+        for (int par = 0; par < 2; ++par) launch_cg_A(s, h->g, true, plan, pool[sel[0]], pool[sel[1]], pool[sel[2]], pool[sel[3]], pool[sel[4]], scal2 + par, h->partial, nullptr, nullptr, 0);
+    };
+    probe(1);
+    FL_HIP(hipEventRecord(h->ev0, s));
+    probe(2);
+    FL_HIP(hipEventRecord(h->ev1, s));
+    FL_HIP(hipStreamSynchronize(s));
+    float ms = 0.f;
+    FL_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    ms_out[m] = ms / 4.;
+    if (sel_out)
+      for (int a = 0; a < 5; ++a) sel_out[m * 5 + a] = sel[a];
+  }
+  (void)hipFree(scal2);
+  for (double *p : pool) (void)hipFree(p);
+  return 0;
+}
