@@ -20,7 +20,7 @@
 // Several ranks: every level keeps the fine decomposition (block boundaries coincide with coarse faces), so restriction
 // and prolongation stay local; an axis is coarsened only while every rank's share stays even and >= 8 cells; the levels
 // borrow the fine handle's communicator for their halo exchanges and reductions.
-#include <memory>
+#include <new>
 
 #include "fl_handle.h"
 #include "fl_device.h"
@@ -110,6 +110,8 @@ struct fl_mg {
   double *r = nullptr, *z = nullptr, *p = nullptr, *q = nullptr;  // outer CG, fine level
 };
 
+void fl_mg_destroy(fl_poisson *h);
+
 namespace {
 
 constexpr int MG_DOT_BLOCKS = 4096;
@@ -153,9 +155,20 @@ int project_constant(fl_poisson *h, int64_t n, double *y)
 
 int alloc_cells(fl_poisson *h, double **p) { return fl_dev_alloc(h, (void **)p, sizeof(double) * (size_t)h->ncell, true); }
 
+int mg_build_levels(fl_poisson *h, fl_mg *mg, int max_levels);
+
+// builds h->mg; on any failure everything created so far (coarse handles included) is released again
 int mg_build(fl_poisson *h, int max_levels)
 {
-  auto mg = std::make_unique<fl_mg>();
+  h->mg = new (std::nothrow) fl_mg;
+  if (!h->mg) return FL_ERR_MEM;
+  const int rc = mg_build_levels(h, h->mg, max_levels);
+  if (rc != 0) fl_mg_destroy(h);
+  return rc;
+}
+
+int mg_build_levels(fl_poisson *h, fl_mg *mg, int max_levels)
+{
   MgLevel L0;
   L0.h = h;
   mg->lv.push_back(L0);
@@ -217,7 +230,6 @@ int mg_build(fl_poisson *h, int max_levels)
   }
   for (double **v : {&mg->r, &mg->z, &mg->p, &mg->q}) FL_CHK(alloc_cells(h, v));
   FL_CHK(fl_ensure_partials(h, MG_DOT_BLOCKS));
-  h->mg = mg.release();
   return 0;
 }
 

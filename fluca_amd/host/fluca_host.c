@@ -894,7 +894,7 @@ typedef struct {
   double *f_v, *f_V[3];                        /* f: momrhs, interprhs; contrhs = 0 (:3046) */
   double *W[9];                                /* cnl->v0interp */
   double *r_v, *r_V[3], *r_p, *d_v, *d_V[3], *d_p;
-  double *plane_dev, *plane_host[6];           /* boundary values: 3 components at two times */
+  double *plane_dev, *plane_host[7];           /* boundary values: 3 components at two times + one scratch plane */
   int64_t plane_cap;
 } NS_CNLinear;
 
@@ -928,7 +928,7 @@ static FlErrorCode NSSetUp_CNLinear(NS ns)
   }
   c->plane_cap = pmax;
   FLCHK(cnl_alloc(ns, &c->plane_dev, pmax));
-  for (int q = 0; q < 6; ++q)
+  for (int q = 0; q < 7; ++q)
     if (!(c->plane_host[q] = (double *)malloc(sizeof(double) * (size_t)pmax))) return E_MEM;
   return 0;
 }
@@ -945,7 +945,7 @@ static FlErrorCode NSDestroy_CNLinear(NS ns)
     for (size_t a = 0; a < sizeof(f) / sizeof(f[0]); ++a)
       if (f[a]) fl_free(ns->device, f[a]);
   }
-  for (int q = 0; q < 6; ++q) free(c->plane_host[q]);
+  for (int q = 0; q < 7; ++q) free(c->plane_host[q]);
   free(c);
   ns->data = NULL;
   return 0;
@@ -1233,8 +1233,7 @@ static FlErrorCode NSStep_CNLinear(NS ns)
       h1 = xf[n] - xc[n - 1]; h2 = xc[n - 1] - xc[n - 2]; h3 = xc[n - 1] - xc[n - 3]; hcell = xf[n] - xf[n - 1];
     }
     const double cl = 2. * (h2 + h3) / (h1 * (h1 + h2) * (h1 + h3)), sgn = side ? 0.5 : -0.5;
-    double      *tmp = (double *)malloc(sizeof(double) * (size_t)np);
-    if (!tmp) return E_MEM;
+    double      *tmp = c->plane_host[6];
     for (int q = 0; q < 3; ++q) {
       /* v0interp on the wall faces = the wall velocity at t (INSERT), :1788 */
       FLCHK(cnl_upload(ns, vb0[q], np));
@@ -1247,7 +1246,6 @@ static FlErrorCode NSStep_CNLinear(NS ns)
     /* interprhs on the wall faces = the wall-normal velocity at t + dt, :3003-3005 with :2178 */
     FLCHK(cnl_upload(ns, vb1[ax], np));
     FLABI(fl_boundary_set_faces(h, b, 1., c->plane_dev, c->f_V[ax]));
-    free(tmp);
   }
   /* immersed boundary: momrhs += spread(U_target - interp(v0)) */
   if (ns->ibm) {
