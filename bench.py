@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--cpu-cells", type=int, default=256)
     ap.add_argument("--cpu-iters", type=int, default=500, help="iterations of the CPU sample (about 10 s on 16 cores at 256^3)")
     ap.add_argument("--skip-cpu", action="store_true")
+    ap.add_argument("--skip-extras", action="store_true", help="skip the time-to-solution comparison after the timed region")
     ap.add_argument("--placement-tries", type=int, default=24,
                     help="candidate placements of the solver vectors probed before the run (0 = take what the driver gives)")
     ap.add_argument("--transport", choices=["rccl", "host"], default="rccl",
@@ -196,6 +197,18 @@ def main():
                      "avg_launch_ms": ka_ms, "launches_timed": info["kernel_launches"],
                      "moved_GBps": (B_KERNEL_A_REAL * P.ncell / (ka_ms * 1e-3) / 1e9) if ka_ms > 0 else None},
     }
+    if world == 1 and not args.skip_extras:
+        # not part of the metric: what the iteration rate buys -- time to a converged pressure with the Jacobi preconditioner of
+        # the metric and with the multigrid preconditioner (FL_PC_MG), same right-hand side, outside the timed region
+        try:
+            tts = {"rtol": 1e-8, "norm": "preconditioned (each solver's own)"}
+            for name, kw in (("jacobi_pcg", dict(pc=1, maxit=20000)), ("multigrid_pcg", dict(pc=2, maxit=200))):
+                xs, si = P.solve(b, rtol=1e-8, **kw)
+                err = float(torch.linalg.norm((xs - xs.mean()) - (pstar - pstar.mean())) / torch.linalg.norm(pstar - pstar.mean()))
+                tts[name] = {"iters": si["iters"], "seconds": si["seconds"], "reason": si["reason"], "rel_error_vs_p_star": err}
+            out["time_to_solution"] = tts
+        except Exception as e:  # noqa: BLE001
+            out["time_to_solution"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.skip_cpu:
         out["cpu_baseline"] = cpu_baseline(args.cpu_cells, args.cpu_iters)
     elif rank == 0:
