@@ -207,32 +207,37 @@ class Poisson:
 
     def comm_init_host(self, exchange, allreduce, rank, nranks):
         """exchange(list of (peer, sendtag, recvtag, send_ndarray|None, recv_ndarray|None)); allreduce(ndarray) in place."""
-        def _x(ctx, n, peer, stag, rtag, send, recv, nbytes):
-            try:
-                msgs = []
-                for a in range(n):
-                    cnt = nbytes[a] // 8
-                    s = None if not send[a] else np.ctypeslib.as_array(C.cast(send[a], C.POINTER(C.c_double)), (cnt,))
-                    r = None if not recv[a] else np.ctypeslib.as_array(C.cast(recv[a], C.POINTER(C.c_double)), (cnt,))
-                    msgs.append((peer[a], stag[a], rtag[a], s, r))
-                exchange(msgs)
-                return 0
-            except Exception:  # pragma: no cover
-                import traceback
-                traceback.print_exc()
-                return 1
-
-        def _r(ctx, vals, n):
-            try:
-                allreduce(np.ctypeslib.as_array(vals, (n,)))
-                return 0
-            except Exception:  # pragma: no cover
-                import traceback
-                traceback.print_exc()
-                return 1
-
-        self._cb = (capi.EXCHANGE_FN(_x), capi.ALLREDUCE_FN(_r))
+        self._cb = host_transport_callbacks(exchange, allreduce)
         check(lib.fl_poisson_comm_init_host(self.h, self._cb[0], self._cb[1], None, rank, nranks), "fl_poisson_comm_init_host")
+
+
+def host_transport_callbacks(exchange, allreduce):
+    """The two C callbacks of fl_poisson_comm_init_host around Python functions (keep the returned pair alive)."""
+    def _x(ctx, n, peer, stag, rtag, send, recv, nbytes):
+        try:
+            msgs = []
+            for a in range(n):
+                cnt = nbytes[a] // 8
+                s = None if not send[a] else np.ctypeslib.as_array(C.cast(send[a], C.POINTER(C.c_double)), (cnt,))
+                r = None if not recv[a] else np.ctypeslib.as_array(C.cast(recv[a], C.POINTER(C.c_double)), (cnt,))
+                msgs.append((peer[a], stag[a], rtag[a], s, r))
+            exchange(msgs)
+            return 0
+        except Exception:  # pragma: no cover
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def _r(ctx, vals, n):
+        try:
+            allreduce(np.ctypeslib.as_array(vals, (n,)))
+            return 0
+        except Exception:  # pragma: no cover
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    return capi.EXCHANGE_FN(_x), capi.ALLREDUCE_FN(_r)
 
 
 def rccl_unique_id():

@@ -265,3 +265,82 @@ def _mg_worker(rank, world, n, ranks, bc, levels):
 ])
 def test_decomposed_multigrid_matches_single_domain_oracle(world, n, ranks, bc, levels):
     mpc.run_ranks(world, _mg_worker, n, ranks, bc, levels)
+
+
+def _nsstep_worker(rank, world, n, ranks, opts):
+    """Whole CNLinear time steps through the C host mirror on a decomposed mesh (MeshSetRank + -cart_ranks_*): each rank
+    compares its block with the same run on the undecomposed mesh, made in the same process."""
+    import ctypes as C
+    from fluca_amd import capi, hostapi as H
+    from fluca_amd.poisson import host_transport_callbacks
+    P = C.c_void_p
+    L, nu = 2 * np.pi, 0.1
+
+    @H.BCFunc
+    def velocity(dim, t, x, val, ctx):
+        d = np.exp(-2.0 * nu * t)
+        val[0], val[1], val[2] = np.sin(x[0]) * np.cos(x[1]) * d, -np.cos(x[0]) * np.sin(x[1]) * d, 0.0
+        return 0
+
+    def run(r, size):
+        mesh = P()
+        assert H.lib.MeshCartCreate3d(0, 0, 1, n[0], n[1], n[2], ranks[0] if size > 1 else 1, ranks[1] if size > 1 else 1, ranks[2] if size > 1 else 1,
+                                      None, None, None, C.byref(mesh)) == 0
+        assert H.lib.MeshSetRank(mesh, r, size) == 0
+        assert H.lib.MeshSetUp(mesh) == 0
+        assert H.lib.MeshCartSetUniformCoordinates(mesh, 0., L, 0., L, 0., L * n[2] / n[0]) == 0
+        ns = P()
+        assert H.lib.NSCreate(C.byref(ns)) == 0 and H.lib.NSSetType(ns, b"cnlinear") == 0 and H.lib.NSSetMesh(ns, mesh) == 0
+        assert H.lib.NSSetDensity(ns, 1.0) == 0 and H.lib.NSSetViscosity(ns, nu) == 0
+        for b in range(4):
+            assert H.lib.NSSetBoundaryCondition(ns, b, H.NSBoundaryCondition(type=H.NS_BC_VELOCITY, velocity=velocity)) == 0
+        for b in (4, 5):
+            assert H.lib.NSSetBoundaryCondition(ns, b, H.NSBoundaryCondition(type=H.NS_BC_PERIODIC)) == 0
+        argc, av = H.argv("-ns_time_step_size", 0.05, "-ns_max_steps", 2, "-ns_ksp_rtol", 1e-9, "-ns_abf_schur_ksp_rtol", 1e-11,
+                          "-ns_abf_momentum_ksp_rtol", 1e-11, *opts)
+        assert H.lib.NSSetFromOptions(ns, argc, av) == 0 and H.lib.NSSetUp(ns) == 0
+        cb = None
+        if size > 1:
+            hp = P()
+            assert H.lib.NSGetPoisson(ns, C.byref(hp)) == 0
+            cb = host_transport_callbacks(mpc.gloo_exchange, mpc.gloo_allreduce)
+            capi.check(capi.lib.fl_poisson_comm_init_host(hp, cb[0], cb[1], None, r, size))
+        sz = (C.c_int64 * 4)()
+        assert H.lib.NSGetLocalSizes(ns, sz) == 0
+        cc = [C.c_int64() for _ in range(6)]
+        assert H.lib.MeshCartGetCorners(mesh, *[C.byref(q) for q in cc]) == 0
+        lo, ln = [q.value for q in cc[:3]], [q.value for q in cc[3:]]
+        v, p, V = P(), P(), (C.c_void_p * 3)()
+        assert H.lib.NSGetSolutionArrays(ns, C.byref(v), V, C.byref(p)) == 0
+        h = L / n[0]
+        xs = [(np.arange(lo[d], lo[d] + ln[d]) + 0.5) * h for d in range(3)]
+        Xc, Yc = xs[0][None, None, :], xs[1][None, :, None]
+        Z = np.ones((ln[2], 1, 1))
+        u0, w0 = Z * np.sin(Xc) * np.cos(Yc), Z * (-np.cos(Xc) * np.sin(Yc))
+        put = lambda ptr, a: capi.check(capi.lib.fl_memcpy_h2d(0, ptr, np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(C.c_void_p), a.size * 8))
+        put(v, np.stack([u0, w0, np.zeros_like(u0)]))
+        nfx, nfy = int(sz[1]) // (ln[1] * ln[2]), int(sz[2]) // (ln[0] * ln[2])
+        xf, yf = (lo[0] + np.arange(nfx)) * h, (lo[1] + np.arange(nfy)) * h
+        put(C.c_void_p(V[0]), Z * np.sin(xf)[None, None, :] * np.cos(xs[1])[None, :, None])
+        put(C.c_void_p(V[1]), Z * (-np.cos(xs[0])[None, None, :] * np.sin(yf)[None, :, None]))
+        put(p, Z * 0.25 * (np.cos(2 * Xc) + np.cos(2 * Yc)))
+        assert H.lib.NSSolve(ns) == 0
+        out = np.empty(3 * sz[0])
+        capi.check(capi.lib.fl_memcpy_d2h(0, out.ctypes.data_as(C.c_void_p), v, out.size * 8))
+        res = out.reshape(3, ln[2], ln[1], ln[0]).copy(), tuple(lo), tuple(ln)
+        H.lib.NSDestroy(C.byref(ns))
+        H.lib.MeshDestroy(C.byref(mesh))
+        return res
+
+    part, lo, ln = run(rank, world)
+    full, _, _ = run(0, 1)
+    ref = full[:, lo[2]:lo[2] + ln[2], lo[1]:lo[1] + ln[1], lo[0]:lo[0] + ln[0]]
+    assert np.abs(part - ref).max() <= 1e-7 * np.abs(full).max(), np.abs(part - ref).max()
+
+
+@pytest.mark.parametrize("world,n,ranks,opts", [
+    (2, (16, 16, 8), (2, 1, 1), ()),                                   # walls on the split axis, Jacobi-PCG pressure solve
+    (2, (16, 16, 16), (1, 1, 2), ("-ns_abf_schur_pc_type", "mg")),     # periodic axis split, multigrid pressure solve
+])
+def test_decomposed_time_steps_through_the_mirror(world, n, ranks, opts):
+    mpc.run_ranks(world, _nsstep_worker, n, ranks, opts)
