@@ -318,16 +318,20 @@ __global__ void __launch_bounds__(256) k_cheb(GridP g, const double *X0, const d
     for (int k = t.k0; k < t.k1; ++k) {
       const int64_t pc = (int64_t)k * g.sxy;
       const double  zl = g.sl[2][k], zcc = g.sc[2][k], zh = g.sh[2][k];
-      double2       south, north;
+      double2       south, north, bv[RY], dv[RY];
       double        west[RY], east[RY];
       south = *reinterpret_cast<const double2 *>(x + g.off0 + (int64_t)min(t.j0w - 1, g.ny) * g.sx + t.il + pc);
       north = *reinterpret_cast<const double2 *>(x + g.off0 + (int64_t)min(t.j0w + RY, g.ny) * g.sx + t.il + pc);
+      // every load of the plane is issued here, unconditionally and on clamped (always valid) addresses: a load inside the
+      // divergent ownership branch below would make the compiler drain the whole load queue first
 #pragma unroll
       for (int m = 0; m < RY; ++m) {
         const int64_t ro = g.off0 + (int64_t)min(t.j0w + m, g.ny) * g.sx + t.il;
         nxt[m]  = *reinterpret_cast<const double2 *>(x + ro + pc + g.sxy);
         west[m] = x[ro + pc - 1];
         east[m] = x[ro + pc + 2];
+        bv[m]   = *reinterpret_cast<const double2 *>(b + ro + pc);
+        dv[m]   = *reinterpret_cast<const double2 *>(d + ro + pc);
       }
 #pragma unroll
       for (int m = 0; m < RY; ++m) {
@@ -341,13 +345,11 @@ __global__ void __launch_bounds__(256) k_cheb(GridP g, const double *X0, const d
         if (j < g.ny && t.own0) {
           const int64_t ro = g.off0 + (int64_t)j * g.sx + t.il + pc;
           const bool    two = t.own1;
-          const double2 bv = two ? *reinterpret_cast<const double2 *>(b + ro) : make_double2(b[ro], 0.);
-          const double2 dv = two ? *reinterpret_cast<const double2 *>(d + ro) : make_double2(d[ro], 0.);
-          const double  r0 = bv.x - v.x, r1 = two ? bv.y - v.y : 0.;
+          const double  r0 = bv[m].x - v.x, r1 = two ? bv[m].y - v.y : 0.;
           const double  z0 = JAC ? r0 / (xc0 + dyz) : r0, z1 = two ? (JAC ? r1 / (xc1 + dyz) : r1) : 0.;
           double2       dn, xo;
-          dn.x = rho * dv.x + cc * z0;
-          dn.y = rho * dv.y + cc * z1;
+          dn.x = rho * dv[m].x + cc * z0;
+          dn.y = rho * dv[m].y + cc * z1;
           xo.x = cur[m].x + dn.x;
           xo.y = cur[m].y + dn.y;
           if (two) {
