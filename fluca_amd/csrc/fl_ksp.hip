@@ -7,11 +7,24 @@
 
 namespace fl {
 
+// uniform base (scalar registers) + 32-bit per-lane byte offset: the addressing mode global_load/store ... v_off, s[base:base+1]
+__device__ __forceinline__ double2 LD2(const double *base, unsigned byteoff) { return *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(base) + byteoff); }
+__device__ __forceinline__ void    ST2(double *base, unsigned byteoff, double2 v) { *reinterpret_cast<double2 *>(reinterpret_cast<char *>(base) + byteoff) = v; }
+__device__ __forceinline__ void    ST1(double *base, unsigned byteoff, double v) { *reinterpret_cast<double *>(reinterpret_cast<char *>(base) + byteoff) = v; }
+// a value every lane holds identically (loaded from one address) moved to scalar registers.  (A scalar load of the same
+// address -- constant address space -- measured 15% slower: s_load results return out of order and the wait for them also
+// drains the lane-exchange queue.)
+__device__ __forceinline__ double uniform(double v)
+{
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
 // ------------------------------------------------------------------------------------------------ tile walker
 // 128 x 4*RY x zc tiles like k_cg_B: lane = pair of x-adjacent cells, wave = RY rows, march in z.
 
 struct Tile {
-  int  i, il, k0, k1, lane, w, j0w;
+  int  i, il, k0, k1, lane, w, j0w, i0;
   bool own0, own1;
 };
 template <int RY>
@@ -24,6 +37,7 @@ __device__ __forceinline__ Tile make_tile(const GridP &g, int nchunk, int zc, in
   t.k1   = min(t.k0 + zc, g.nz);
   t.lane = threadIdx.x & 63;
   t.w    = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  t.i0   = i0;
   t.i    = i0 + 2 * t.lane;
   t.il   = min(t.i, g.nx & ~1);
   t.own0 = t.i < g.nx;
@@ -36,6 +50,9 @@ __device__ __forceinline__ Tile make_tile(const GridP &g, int nchunk, int zc, in
 // y = M (S x) with M = 1/diag (JAC) or 1, x padded with valid ghosts, y padded.  Optional second output and dots:
 //   partial slots: 0 sum y   1 y.o (o may be NULL)   2 x.y   3 y.y
 // MODE 0: plain.  MODE 1 (Chebyshev step): see k_cheb below (separate kernel).
+// (k_cheb's plan -- halo one plane ahead, lane exchange, per-plane barrier -- was tried here too: it removes the 2.9 B/cell of
+// excess fetch but the two-stream kernel is latency- rather than bandwidth-limited and BiCGStab got 4-7% slower, so this
+// kernel keeps the plain loads.)
 template <int RY, bool JAC>
 __global__ void __launch_bounds__(256) k_apply_pc(GridP g, const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ o, const KspScal *__restrict__ s, double *__restrict__ partial, int stride, int nchunk,
                                                   int zc, int tiles_x, int unpadded_y)
@@ -308,56 +325,78 @@ __global__ void __launch_bounds__(256) k_cheb(GridP g, const double *X0, const d
   const double  xl1 = g.sl[0][min(t.i + 1, g.nx)], xc1 = g.sc[0][min(t.i + 1, g.nx)], xh1 = g.sh[0][min(t.i + 1, g.nx)];
   double        acc[3] = {0., 0., 0.};
   if (t.k0 < t.k1) {
-    double2 prev[RY], cur[RY], nxt[RY];
+    // Addressing: row and plane offsets are wave-uniform (scalar registers); the only per-lane part of any address in
+    // this kernel is lo = 8 * il, one VGPR for all streams (LD2/ST2: uniform base + 32-bit lane byte offset).
+    // Everything a plane needs from memory is loaded ONE plane ahead, together with the tile's own rows of that plane:
+    // the y-halo rows (south/north) are the rows the neighbouring wave streams at that moment, and the x neighbours
+    // inside the tile come from the adjacent lane (only the two cells outside the 128-wide tile are loaded, from one
+    // uniform address).  Loading them a plane late instead -- after five streams went through -- finds the lines evicted
+    // and fetches them from HBM again: 34.9 B/cell measured against 24 algorithmic + 3 of tile ring; 26.7 with this.
+    double2       prev[RY], cur[RY], nxt[RY], so_c, no_c, so_n, no_n;
+    double        we_c[RY], ee_c[RY], we_n[RY], ee_n[RY];
+    unsigned      lo = 8u * (unsigned)t.il;
+    const int     i0 = t.i0;
+    const int64_t sxy = g.sxy;
+    const int64_t rsou = g.off0 + (int64_t)min(t.j0w - 1, g.ny) * g.sx, rnor = g.off0 + (int64_t)min(t.j0w + RY, g.ny) * g.sx;
+    int64_t       rj[RY];
 #pragma unroll
-    for (int m = 0; m < RY; ++m) {
-      const int64_t ro = g.off0 + (int64_t)min(t.j0w + m, g.ny) * g.sx + t.il;
-      prev[m] = *reinterpret_cast<const double2 *>(x + ro + (int64_t)(t.k0 - 1) * g.sxy);
-      cur[m]  = *reinterpret_cast<const double2 *>(x + ro + (int64_t)t.k0 * g.sxy);
-    }
-    for (int k = t.k0; k < t.k1; ++k) {
-      const int64_t pc = (int64_t)k * g.sxy;
-      const double  zl = g.sl[2][k], zcc = g.sc[2][k], zh = g.sh[2][k];
-      double2       south, north, bv[RY], dv[RY];
-      double        west[RY], east[RY];
-      south = *reinterpret_cast<const double2 *>(x + g.off0 + (int64_t)min(t.j0w - 1, g.ny) * g.sx + t.il + pc);
-      north = *reinterpret_cast<const double2 *>(x + g.off0 + (int64_t)min(t.j0w + RY, g.ny) * g.sx + t.il + pc);
-      // every load of the plane is issued here, unconditionally and on clamped (always valid) addresses: a load inside the
-      // divergent ownership branch below would make the compiler drain the whole load queue first
+    for (int m = 0; m < RY; ++m) rj[m] = g.off0 + (int64_t)min(t.j0w + m, g.ny) * g.sx;
+    const int wofs = i0 - 1, eofs = min(i0 + 128, g.nx);
+    {
+      const int64_t p0 = (int64_t)t.k0 * sxy;
+      so_c = LD2(x + rsou + p0, lo);
+      no_c = LD2(x + rnor + p0, lo);
 #pragma unroll
       for (int m = 0; m < RY; ++m) {
-        const int64_t ro = g.off0 + (int64_t)min(t.j0w + m, g.ny) * g.sx + t.il;
-        nxt[m]  = *reinterpret_cast<const double2 *>(x + ro + pc + g.sxy);
-        west[m] = x[ro + pc - 1];
-        east[m] = x[ro + pc + 2];
-        bv[m]   = *reinterpret_cast<const double2 *>(b + ro + pc);
-        dv[m]   = *reinterpret_cast<const double2 *>(d + ro + pc);
+        prev[m] = LD2(x + rj[m] + p0 - sxy, lo);
+        cur[m]  = LD2(x + rj[m] + p0, lo);
+        we_c[m] = uniform(x[rj[m] + wofs + p0]);
+        ee_c[m] = uniform(x[rj[m] + eofs + p0]);
+      }
+    }
+    for (int k = t.k0; k < t.k1; ++k) {
+      asm volatile("" : "+s"(k), "+v"(lo));  // keep the compiler from strength-reducing every stream into its own 64-bit VGPR pointer
+      const int64_t pc = (int64_t)k * sxy;
+      const double  zl = g.sl[2][k], zcc = g.sc[2][k], zh = g.sh[2][k];
+      double2       bv[RY], dv[RY];
+      // every load of the plane is issued here, unconditionally and on clamped (always valid) addresses: a load inside the
+      // divergent ownership branch below would make the compiler drain the whole load queue first
+      so_n = LD2(x + rsou + pc + sxy, lo);
+      no_n = LD2(x + rnor + pc + sxy, lo);
+#pragma unroll
+      for (int m = 0; m < RY; ++m) {
+        nxt[m]  = LD2(x + rj[m] + pc + sxy, lo);
+        we_n[m] = x[rj[m] + wofs + pc + sxy];
+        ee_n[m] = x[rj[m] + eofs + pc + sxy];
+        bv[m]   = LD2(b + rj[m] + pc, lo);
+        dv[m]   = LD2(d + rj[m] + pc, lo);
       }
 #pragma unroll
       for (int m = 0; m < RY; ++m) {
         const int     j  = t.j0w + m, jc = min(j, g.ny);
         const double  yl = g.sl[1][jc], ycc = g.sc[1][jc], yh = g.sh[1][jc];
-        const double2 so = m > 0 ? cur[m - 1] : south, no = m < RY - 1 ? cur[m + 1] : north;
+        const double2 so = m > 0 ? cur[m - 1] : so_c, no = m < RY - 1 ? cur[m + 1] : no_c;
+        const double  up = __shfl_up(cur[m].y, 1), dn = __shfl_down(cur[m].x, 1);
+        const double  west = t.lane == 0 ? we_c[m] : up, east = t.lane == 63 ? ee_c[m] : dn;
         const double  dyz = ycc + zcc;
         double2       v;
-        v.x = (xc0 + dyz) * cur[m].x + xl0 * west[m] + xh0 * cur[m].y + yl * so.x + yh * no.x + zl * prev[m].x + zh * nxt[m].x;
-        v.y = (xc1 + dyz) * cur[m].y + xl1 * cur[m].x + xh1 * east[m] + yl * so.y + yh * no.y + zl * prev[m].y + zh * nxt[m].y;
+        v.x = (xc0 + dyz) * cur[m].x + xl0 * west + xh0 * cur[m].y + yl * so.x + yh * no.x + zl * prev[m].x + zh * nxt[m].x;
+        v.y = (xc1 + dyz) * cur[m].y + xl1 * cur[m].x + xh1 * east + yl * so.y + yh * no.y + zl * prev[m].y + zh * nxt[m].y;
         if (j < g.ny && t.own0) {
-          const int64_t ro = g.off0 + (int64_t)j * g.sx + t.il + pc;
-          const bool    two = t.own1;
-          const double  r0 = bv[m].x - v.x, r1 = two ? bv[m].y - v.y : 0.;
-          const double  z0 = JAC ? r0 / (xc0 + dyz) : r0, z1 = two ? (JAC ? r1 / (xc1 + dyz) : r1) : 0.;
-          double2       dn, xo;
-          dn.x = rho * dv[m].x + cc * z0;
-          dn.y = rho * dv[m].y + cc * z1;
-          xo.x = cur[m].x + dn.x;
-          xo.y = cur[m].y + dn.y;
+          const bool   two = t.own1;
+          const double r0 = bv[m].x - v.x, r1 = two ? bv[m].y - v.y : 0.;
+          const double z0 = JAC ? r0 / (xc0 + dyz) : r0, z1 = two ? (JAC ? r1 / (xc1 + dyz) : r1) : 0.;
+          double2      dn2, xo;
+          dn2.x = rho * dv[m].x + cc * z0;
+          dn2.y = rho * dv[m].y + cc * z1;
+          xo.x  = cur[m].x + dn2.x;
+          xo.y  = cur[m].y + dn2.y;
           if (two) {
-            *reinterpret_cast<double2 *>(d + ro)  = dn;
-            *reinterpret_cast<double2 *>(xn + ro) = xo;
+            ST2(d + rj[m] + pc, lo, dn2);
+            ST2(xn + rj[m] + pc, lo, xo);
           } else {
-            d[ro]  = dn.x;
-            xn[ro] = xo.x;
+            ST1(d + rj[m] + pc, lo, dn2.x);
+            ST1(xn + rj[m] + pc, lo, xo.x);
           }
           acc[0] += z0 + z1;
           acc[1] += z0 * z0 + z1 * z1;
@@ -368,7 +407,13 @@ __global__ void __launch_bounds__(256) k_cheb(GridP g, const double *X0, const d
       for (int m = 0; m < RY; ++m) {
         prev[m] = cur[m];
         cur[m]  = nxt[m];
+        we_c[m] = uniform(we_n[m]);
+        ee_c[m] = uniform(ee_n[m]);
       }
+      so_c = so_n;
+      no_c = no_n;
+      // keep the four waves of the tile on the same plane, so that a wave's halo rows are in flight with its neighbour's own rows
+      __syncthreads();
     }
   }
   block_sum<3>(acc, red);
