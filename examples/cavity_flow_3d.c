@@ -15,6 +15,9 @@
 #include <string.h>
 
 #include "fluca_host.h"
+#ifdef FLUCA_HAVE_CGNS
+#include "fluca_cgns.h"
+#endif
 
 #define CHK(call)                                                                 \
   do {                                                                            \
@@ -92,8 +95,27 @@ int main(int argc, char **argv)
   CHK(NSGetSolutionArrays(ns, &v_dev, V_dev, &p_dev));
   double *v = (double *)malloc(sizeof(double) * 3 * (size_t)sz[0]);
   if (!v) return 1;
+#ifdef FLUCA_HAVE_CGNS
+  /* -ns_monitor_solution cgns:<template with %d> [-ns_monitor_solution_interval n] [-viewer_cgns_batch_size n] (nsmon.c:47-100)
+   * and -ns_view_solution cgns:<file> after the last step (nsbasic.c:349) */
+  FlucaViewerCGNS  monviewer = NULL, endviewer = NULL;
+  FlucaCGNSMonitor mon = {NULL, 1};
+  int              batch = 1;
+  for (int a = 1; a + 1 < argc; ++a) {
+    if (!strcmp(argv[a], "-ns_monitor_solution") && !strncmp(argv[a + 1], "cgns:", 5)) CHK(FlucaViewerCGNSOpen(argv[a + 1] + 5, 'w', &monviewer));
+    if (!strcmp(argv[a], "-ns_view_solution") && !strncmp(argv[a + 1], "cgns:", 5)) CHK(FlucaViewerCGNSOpen(argv[a + 1] + 5, 'w', &endviewer));
+    if (!strcmp(argv[a], "-ns_monitor_solution_interval")) mon.view_interval = atoi(argv[a + 1]);
+    if (!strcmp(argv[a], "-viewer_cgns_batch_size")) batch = atoi(argv[a + 1]);
+  }
+  if (monviewer) {
+    CHK(FlucaViewerCGNSSetBatchSize(monviewer, batch));
+    mon.viewer = monviewer;
+    CHK(NSMonitorSet(ns, NSMonitorSolutionCGNS, &mon, NULL));
+  }
+#endif
   /* NSSolve, one step at a time so that a monitor line can be printed (-ns_monitor of the reference) */
   while (step < maxsteps) {
+    CHK(NSMonitor(ns));
     int    its, reason;
     double rnorm, t;
     CHK(NSStep(ns));
@@ -118,6 +140,12 @@ int main(int argc, char **argv)
   for (int64_t j = 0; j < N; j += (N >= 16 ? N / 16 : 1)) printf(" %.4f", 0.5 * (v[(0 * N + j) * M + M / 2 - 1] + v[(0 * N + j) * M + M / 2]));
   printf("\n");
   free(v);
+  CHK(NSMonitor(ns));
+#ifdef FLUCA_HAVE_CGNS
+  if (endviewer) CHK(NSViewSolution(ns, endviewer));
+  CHK(FlucaViewerCGNSDestroy(&endviewer));
+  CHK(FlucaViewerCGNSDestroy(&monviewer));
+#endif
   CHK(MeshDestroy(&mesh));
   CHK(NSDestroy(&ns));
   return 0;

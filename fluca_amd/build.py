@@ -59,10 +59,40 @@ def build_host(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    build_cgns(force, verbose)
     build_example(force, verbose)
     build_example(force, verbose, name="cavity_flow_3d")
     build_example(force, verbose, name="flow_configs")
     return HOST_LIB
+
+
+CGNS_LIB = os.path.join(LIBDIR, "libfluca_cgns.so")
+HDF5_ROOT = os.environ.get("HDF5_ROOT", "/opt/conda")
+
+
+def have_hdf5():
+    return os.path.exists(os.path.join(HDF5_ROOT, "include", "hdf5.h")) and os.path.exists(os.path.join(HDF5_ROOT, "lib", "libhdf5.so"))
+
+
+def build_cgns(force=False, verbose=False):
+    """The CGNS-layout field dump (gcc + libhdf5).  Optional: without an HDF5 installation the library is not built and
+    fluca_amd.hostapi.load_cgns() says so; nothing else depends on it."""
+    src = os.path.join(HERE, "host", "fluca_cgns.c")
+    if not have_hdf5():
+        if verbose:
+            print(f"no HDF5 under {HDF5_ROOT}: libfluca_cgns.so not built", flush=True)
+        return None
+    hdrs = [os.path.normpath(os.path.join(HERE, "..", "include", h)) for h in ("fluca_cgns.h", "fluca_host.h", "fluca_hip.h")]
+    if force or _stale(CGNS_LIB, [src, HOST_LIB] + hdrs):
+        # RUNPATH (new dtags), not RPATH: the HDF5 directory is searched for this library's direct dependencies only
+        cmd = [os.environ.get("CC", "gcc"), "-std=gnu99", "-O2", "-fPIC", "-shared", "-Wall", "-o", CGNS_LIB, src,
+               "-I" + os.path.join(HDF5_ROOT, "include"), "-L" + LIBDIR, "-lfluca_host", "-lflucahip",
+               "-L" + os.path.join(HDF5_ROOT, "lib"), "-lhdf5", "-Wl,--enable-new-dtags",
+               "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(HDF5_ROOT, "lib"), "-lm"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return CGNS_LIB
 
 
 EXAMPLE = os.path.join(LIBDIR, "cavity_pressure_step")
@@ -73,9 +103,11 @@ def build_example(force=False, verbose=False, name="cavity_pressure_step"):
     root = os.path.normpath(os.path.join(HERE, ".."))
     src = os.path.join(root, "examples", name + ".c")
     EXAMPLE = os.path.join(LIBDIR, name)
-    if os.path.exists(src) and (force or _stale(EXAMPLE, [src, HOST_LIB, LIB])):
+    cgns = os.path.exists(CGNS_LIB) and name == "cavity_flow_3d"   # the driver with -ns_view_solution / -ns_monitor_solution
+    if os.path.exists(src) and (force or _stale(EXAMPLE, [src, HOST_LIB, LIB] + ([CGNS_LIB] if cgns else []))):
         cmd = [os.environ.get("CC", "gcc"), "-std=gnu99", "-O2", "-Wall", "-o", EXAMPLE, src, "-I" + os.path.join(root, "include"),
-               "-L" + LIBDIR, "-lfluca_host", "-lflucahip", "-lm", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
+               "-L" + LIBDIR] + (["-DFLUCA_HAVE_CGNS", "-lfluca_cgns"] if cgns else []) + ["-lfluca_host", "-lflucahip", "-lm",
+               "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

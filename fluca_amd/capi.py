@@ -77,6 +77,7 @@ PROTOTYPES = {
     "fl_poisson_destroy": (C.c_int, [_P]),
     "fl_poisson_set_stream": (C.c_int, [_P, _P]),
     "fl_poisson_synchronize": (C.c_int, [_P]),
+    "fl_poisson_barrier": (C.c_int, [_P]),
     "fl_poisson_sizes": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "fl_ksp_opts_default": (None, [C.POINTER(fl_ksp_opts)]),
     "fl_version": (C.c_char_p, []),

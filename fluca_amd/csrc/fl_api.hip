@@ -243,6 +243,20 @@ extern "C" int fl_poisson_synchronize(fl_poisson *h)
   return FL_SUCCESS;
 }
 
+// All ranks of the handle's communicator have reached this call (and the handle's stream is idle) when it returns: a
+// one-double sum over the ranks.  The host mirror sequences file output of the ranks with it (MPI_Barrier in the reference).
+extern "C" int fl_poisson_barrier(fl_poisson *h)
+{
+  if (!h) return FL_ERR_ARG_NULL;
+  FL_HIP(hipSetDevice(h->device));
+  if (h->multi) {
+    FL_HIP(hipMemsetAsync(h->sums, 0, sizeof(double) * NSLOT, h->stream));
+    FL_CHK(h->comm.allreduce(h->stream, h->sums, NSLOT));
+  }
+  FL_HIP(hipStreamSynchronize(h->stream));
+  return FL_SUCCESS;
+}
+
 extern "C" int fl_poisson_sizes(const fl_poisson *h, int64_t out[4])
 {
   if (!h || !out) return FL_ERR_ARG_NULL;

@@ -380,6 +380,24 @@ FlErrorCode MeshCartGetIsLastRank(Mesh mesh, int *lx, int *ly, int *lz)
   if (lz) *lz = mesh->decomp.coord[2] == mesh->decomp.ranks[2] - 1;
   return 0;
 }
+/* cart.c:467-510 MeshCartGetCoordinateArraysRead: borrowed GLOBAL face coordinates (n+1 per axis); nothing to restore */
+FlErrorCode MeshCartGetCoordinateArraysRead(Mesh mesh, const double **xf, const double **yf, const double **zf)
+{
+  if (!mesh) return E_ARG_NULL;
+  if (!mesh->setupcalled) return E_ARG_WRONGSTATE;
+  Mesh_Cart *cart = (Mesh_Cart *)mesh->data;
+  if (xf) *xf = cart->xf[0];
+  if (yf) *yf = cart->xf[1];
+  if (zf) *zf = cart->xf[2];
+  return 0;
+}
+FlErrorCode MeshGetRank(Mesh mesh, int *rank, int *size)
+{
+  if (!mesh) return E_ARG_NULL;
+  if (rank) *rank = mesh->rank;
+  if (size) *size = mesh->size;
+  return 0;
+}
 FlErrorCode MeshCartGetBoundaryIndex(Mesh mesh, MeshCartBoundaryLocation loc, int *index)
 {
   if (!mesh || !index) return E_ARG_NULL;
@@ -404,6 +422,7 @@ FlErrorCode MeshDestroy(Mesh *mesh)
 
 /* ------------------------------------------------------------------------------------------------ NS */
 
+#define MAXNSMONITORS 10
 struct _p_NS {
   struct _NSOps        ops[1];
   char                 type_name[32];
@@ -427,6 +446,11 @@ struct _p_NS {
   int                  ksp_its, reason;    /* of the last step */
   int                  mom_its, schur_its; /* inner Krylov iterations summed over the last step's outer iterations */
   double               ksp_rnorm;
+  /* NSMonitorSet list (nsimpl.h: monitor[], monitorctx[], monitordestroy[], MAXNSMONITORS) */
+  int                  nmon;
+  FlErrorCode (*mon[MAXNSMONITORS])(NS, void *);
+  void *monctx[MAXNSMONITORS];
+  FlErrorCode (*mondestroy[MAXNSMONITORS])(void **);
   void                *data;
 };
 
@@ -663,14 +687,42 @@ FlErrorCode NSStep(NS ns) /* nsbasic.c:276-299 */
   return 0;
 }
 
-FlErrorCode NSSolve(NS ns) /* nsbasic.c:325-350: step until -ns_max_steps */
+/* nsmon.c:5-45: NSMonitorSet / NSMonitorCancel / NSMonitor */
+FlErrorCode NSMonitorSet(NS ns, FlErrorCode (*mon)(NS, void *), void *ctx, FlErrorCode (*destroy)(void **))
+{
+  if (!ns || !mon) return E_ARG_NULL;
+  if (ns->nmon >= MAXNSMONITORS) return E_ARG_OUTOFRANGE; /* "Too many monitors set" */
+  ns->mon[ns->nmon]        = mon;
+  ns->monctx[ns->nmon]     = ctx;
+  ns->mondestroy[ns->nmon] = destroy;
+  ++ns->nmon;
+  return 0;
+}
+FlErrorCode NSMonitorCancel(NS ns)
+{
+  if (!ns) return E_ARG_NULL;
+  for (int i = 0; i < ns->nmon; ++i)
+    if (ns->mondestroy[i]) FLCHK(ns->mondestroy[i](&ns->monctx[i]));
+  ns->nmon = 0;
+  return 0;
+}
+FlErrorCode NSMonitor(NS ns)
+{
+  if (!ns) return E_ARG_NULL;
+  for (int i = 0; i < ns->nmon; ++i) FLCHK(ns->mon[i](ns, ns->monctx[i]));
+  return 0;
+}
+
+FlErrorCode NSSolve(NS ns) /* nsbasic.c:325-350: monitor, step, ... until -ns_max_steps, monitor once more */
 {
   if (!ns) return E_ARG_NULL;
   if (ns->max_steps < 0) return E_ARG_WRONGSTATE; /* "At least one of max time or max steps must be specified" */
   while (ns->step < ns->max_steps) {
+    FLCHK(NSMonitor(ns));
     FLCHK(NSStep(ns));
     if (ns->reason < 0) return 91; /* PETSC_ERR_NOT_CONVERGED: "NSStep has failed" */
   }
+  FLCHK(NSMonitor(ns));
   return 0;
 }
 
@@ -706,6 +758,7 @@ FlErrorCode NSGetTime(NS ns, double *t)
 FlErrorCode NSDestroy(NS *ns)
 {
   if (!ns || !*ns) return 0;
+  NSMonitorCancel(*ns);
   if ((*ns)->ops->destroy) (*ns)->ops->destroy(*ns);
   if ((*ns)->ibm) fl_ibm_destroy((*ns)->ibm);
   if ((*ns)->ibm_U) fl_free((*ns)->device, (*ns)->ibm_U);
@@ -951,6 +1004,40 @@ static FlErrorCode NSDestroy_CNLinear(NS ns)
   return 0;
 }
 
+FlErrorCode NSGetPressureHalfStep(NS ns, double **phalf) /* cnl->phalf, "PressureHalfStep" (cnlinear.c:54) */
+{
+  if (!ns || !phalf) return E_ARG_NULL;
+  if (!ns->setupcalled || !ns->data) return E_ARG_WRONGSTATE;
+  *phalf = ((NS_CNLinear *)ns->data)->phalf;
+  return 0;
+}
+FlErrorCode NSGetMesh(NS ns, Mesh *mesh)
+{
+  if (!ns || !mesh) return E_ARG_NULL;
+  *mesh = ns->mesh;
+  return 0;
+}
+FlErrorCode NSGetDevice(NS ns, int *device)
+{
+  if (!ns || !device) return E_ARG_NULL;
+  *device = ns->device;
+  return 0;
+}
+FlErrorCode NSSetTimeStepAndTime(NS ns, int64_t step, double t) /* what NSLoadSolution does last, nssol.c:199-201 */
+{
+  if (!ns) return E_ARG_NULL;
+  if (step < 0) return E_ARG_OUTOFRANGE;
+  ns->step = step;
+  ns->t    = t;
+  return 0;
+}
+FlErrorCode NSBarrier(NS ns) /* MPI_Barrier(PetscObjectComm(ns)) */
+{
+  if (!ns) return E_ARG_NULL;
+  if (!ns->setupcalled) return E_ARG_WRONGSTATE;
+  FLABI(fl_poisson_barrier(ns->poisson));
+  return 0;
+}
 FlErrorCode NSGetSolutionArrays(NS ns, double **v, double *V[3], double **p)
 {
   if (!ns) return E_ARG_NULL;

@@ -49,11 +49,56 @@ PROTOTYPES = {
     "NSGetMomentumKSPOptions": [_P, C.POINTER(C.POINTER(capi.fl_ksp_opts))],
     "NSApplyPreconditioner": [_P, _P, _dp3, _P, _P, _dp3, _P, C.POINTER(capi.fl_ksp_stats)],
     "NSUpdatePressure": [_P, _P, _P, _P, _P], "NSComputeStaggeredPressureGradientBC": [_P, C.c_double, _dp3],
+    "MeshCartGetCoordinateArraysRead": [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)], "MeshGetRank": [_P, _ip, _ip],
+    "NSGetPressureHalfStep": [_P, C.POINTER(_P)], "NSGetMesh": [_P, C.POINTER(_P)], "NSGetDevice": [_P, _ip],
+    "NSSetTimeStepAndTime": [_P, C.c_int64, C.c_double], "NSBarrier": [_P],
+    "NSMonitorSet": [_P, _P, _P, _P], "NSMonitorCancel": [_P], "NSMonitor": [_P],
 }
+MonitorFunc = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
 for _n, _a in PROTOTYPES.items():
     _f = getattr(lib, _n)
     _f.restype = C.c_int
     _f.argtypes = _a
+
+
+class FlucaCGNSLayout(C.Structure):
+    _fields_ = [("N", C.c_int64 * 3), ("periodic", C.c_int * 3), ("rank", C.c_int), ("size", C.c_int), ("first", C.c_int * 3), ("last", C.c_int * 3),
+                ("lo", C.c_int64 * 3), ("len", C.c_int64 * 3)]
+
+
+class FlucaCGNSMonitor(C.Structure):
+    _fields_ = [("viewer", C.c_void_p), ("view_interval", C.c_int)]
+
+
+CGNS_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libfluca_cgns.so")
+_Lp = C.POINTER(FlucaCGNSLayout)
+_names = C.POINTER(C.c_char_p)
+CGNS_PROTOTYPES = {
+    "FlucaViewerCGNSOpen": [C.c_char_p, C.c_char, C.POINTER(_P)], "FlucaViewerCGNSSetBatchSize": [_P, C.c_int], "FlucaViewerCGNSGetBatchSize": [_P, _ip],
+    "FlucaViewerCGNSGetFileName": [_P, C.POINTER(C.c_char_p)], "FlucaViewerCGNSDestroy": [C.POINTER(_P)],
+    "NSViewSolution": [_P, _P], "NSLoadSolution": [_P, _P], "NSMonitorSolutionCGNS": [_P, _P],
+    "FlucaCGNSCreateFile": [C.c_char_p, _Lp, _P, _P, _P], "FlucaCGNSWriteCellInfo": [C.c_char_p, _Lp],
+    "FlucaCGNSCreateSolution": [C.c_char_p, _Lp, C.c_int64, C.c_int, _names, C.c_int, _names],
+    "FlucaCGNSWriteCellField": [C.c_char_p, _Lp, C.c_int64, C.c_char_p, _P], "FlucaCGNSWriteFaceField": [C.c_char_p, _Lp, C.c_int64, C.c_char_p, _dp3],
+    "FlucaCGNSWriteIterativeData": [C.c_char_p, C.c_int, _i64p, C.POINTER(C.c_double)],
+    "FlucaCGNSReadInfo": [C.c_char_p, _i64p, _i64p, C.POINTER(C.c_double), _ip], "FlucaCGNSReadCoordinates": [C.c_char_p, _P, _P, _P],
+    "FlucaCGNSReadCellField": [C.c_char_p, _Lp, C.c_int64, C.c_char_p, _P], "FlucaCGNSReadFaceField": [C.c_char_p, _Lp, C.c_int64, C.c_char_p, _dp3],
+}
+_cgns = None
+
+
+def load_cgns():
+    """libfluca_cgns.so (include/fluca_cgns.h): built only where an HDF5 C library exists (fluca_amd.build.build_cgns)."""
+    global _cgns
+    if _cgns is None:
+        if not os.path.exists(CGNS_LIB_PATH):
+            raise ImportError(f"{CGNS_LIB_PATH} is missing: it needs an HDF5 C library at build time (HDF5_ROOT, default /opt/conda); run `python -m fluca_amd.build`")
+        _cgns = C.CDLL(CGNS_LIB_PATH)
+        for n, a in CGNS_PROTOTYPES.items():
+            f = getattr(_cgns, n)
+            f.restype = C.c_int
+            f.argtypes = a
+    return _cgns
 
 
 def argv(*opts):

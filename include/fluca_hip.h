@@ -129,6 +129,8 @@ int fl_poisson_destroy(fl_poisson *h);
 /* Run on a caller-owned hipStream_t (pass as void*); NULL = the handle's own stream. */
 int fl_poisson_set_stream(fl_poisson *h, void *hip_stream);
 int fl_poisson_synchronize(fl_poisson *h);
+/* every rank of the handle's communicator has reached this call when it returns (MPI_Barrier on the object's comm) */
+int fl_poisson_barrier(fl_poisson *h);
 /* sizes of this rank's arrays: out[0]=cells, out[1..3]=x,y,z faces */
 int fl_poisson_sizes(const fl_poisson *h, int64_t out[4]);
 void fl_ksp_opts_default(fl_ksp_opts *o); /* PETSc defaults + cg/jacobi/preconditioned norm */

@@ -66,6 +66,8 @@ FlErrorCode MeshCartGetCorners(Mesh mesh, int64_t *x, int64_t *y, int64_t *z, in
 FlErrorCode MeshCartGetIsFirstRank(Mesh mesh, int *fx, int *fy, int *fz);
 FlErrorCode MeshCartGetIsLastRank(Mesh mesh, int *lx, int *ly, int *lz);
 FlErrorCode MeshCartGetBoundaryIndex(Mesh mesh, MeshCartBoundaryLocation loc, int *index);
+FlErrorCode MeshCartGetCoordinateArraysRead(Mesh mesh, const double **xf, const double **yf, const double **zf); /* cart.c:467-510; GLOBAL face coordinates, borrowed */
+FlErrorCode MeshGetRank(Mesh mesh, int *rank, int *size);
 FlErrorCode MeshGetNumberBoundaries(Mesh mesh, int *nb);
 FlErrorCode MeshDestroy(Mesh *mesh);
 
@@ -127,6 +129,15 @@ FlErrorCode NSSolve(NS ns);
  * owned by the caller, uniform grid spacing required); Utarget_dev: 3*L target velocities or NULL for a body at rest. */
 FlErrorCode NSSetImmersedBoundary(NS ns, int kind, int64_t L, const double *X_dev, const double *Y_dev, const double *Z_dev, const double *dV_dev, const double *Utarget_dev);
 FlErrorCode NSGetSolutionArrays(NS ns, double **v_dev, double *V_dev[3], double **p_dev);
+FlErrorCode NSGetPressureHalfStep(NS ns, double **phalf_dev); /* cnl->phalf, the vector named "PressureHalfStep" (cnlinear.c:54) */
+FlErrorCode NSGetMesh(NS ns, Mesh *mesh);
+FlErrorCode NSGetDevice(NS ns, int *device);
+FlErrorCode NSSetTimeStepAndTime(NS ns, int64_t step, double t); /* the last thing NSLoadSolution does (nssol.c:199-201) */
+FlErrorCode NSBarrier(NS ns);                                    /* MPI_Barrier on the object's communicator */
+/* nsmon.c:5-45.  NSSolve calls NSMonitor before every step and once after the last (nsbasic.c:337-345); NSDestroy cancels. */
+FlErrorCode NSMonitorSet(NS ns, FlErrorCode (*monitor)(NS, void *), void *ctx, FlErrorCode (*ctxdestroy)(void **));
+FlErrorCode NSMonitorCancel(NS ns);
+FlErrorCode NSMonitor(NS ns);
 FlErrorCode NSGetLinearSolveInfo(NS ns, int *its, double *rnorm, int *reason);
 /* kspA / kspS iterations summed over the outer iterations of the last step */
 FlErrorCode NSGetInnerIterations(NS ns, int *momentum_its, int *schur_its);

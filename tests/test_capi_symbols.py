@@ -32,6 +32,30 @@ def test_every_declared_symbol_is_exported_and_bound(capi):
     assert set(capi.PROTOTYPES) == set(declared_functions())
 
 
+def host_declared(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"struct\s+\w+\s*\{.*?\};", "", src, flags=re.S)          # the ops tables hold function POINTERS, not exports
+    return sorted(set(re.findall(r"^\s*FlErrorCode\s+(\w+)\s*\(", src, flags=re.M)))
+
+
+def test_host_mirror_and_cgns_headers_are_exported_and_bound(capi):
+    from fluca_amd import build, hostapi
+    names = host_declared("fluca_host.h")
+    assert len(names) >= 50
+    for name in names:
+        assert hasattr(hostapi.lib, name), f"{name} declared in fluca_host.h but not exported by libfluca_host.so"
+    assert set(hostapi.PROTOTYPES) <= set(names)
+    if not build.have_hdf5():
+        pytest.skip("no HDF5 C library in this image: libfluca_cgns.so is not built")
+    G = hostapi.load_cgns()
+    cg = host_declared("fluca_cgns.h")
+    assert len(cg) >= 15
+    for name in cg:
+        assert hasattr(G, name), f"{name} declared in fluca_cgns.h but not exported by libfluca_cgns.so"
+    assert set(hostapi.CGNS_PROTOTYPES) == set(cg)
+
+
 def test_version_and_defaults(capi):
     assert b"gfx950" in capi.lib.fl_version()
     o = capi.fl_ksp_opts()

@@ -267,7 +267,7 @@ def test_decomposed_multigrid_matches_single_domain_oracle(world, n, ranks, bc, 
     mpc.run_ranks(world, _mg_worker, n, ranks, bc, levels)
 
 
-def _nsstep_worker(rank, world, n, ranks, opts):
+def _nsstep_worker(rank, world, n, ranks, opts, dump_dir=None):
     """Whole CNLinear time steps through the C host mirror on a decomposed mesh (MeshSetRank + -cart_ranks_*): each rank
     compares its block with the same run on the undecomposed mesh, made in the same process."""
     import ctypes as C
@@ -328,6 +328,12 @@ def _nsstep_worker(rank, world, n, ranks, opts):
         out = np.empty(3 * sz[0])
         capi.check(capi.lib.fl_memcpy_d2h(0, out.ctypes.data_as(C.c_void_p), v, out.size * 8))
         res = out.reshape(3, ln[2], ln[1], ln[0]).copy(), tuple(lo), tuple(ln)
+        if dump_dir and (size > 1 or rank == 0):   # the ranks take turns on ONE file (include/fluca_cgns.h); the serial file comes from rank 0 only
+            G = H.load_cgns()
+            viewer = P()
+            assert G.FlucaViewerCGNSOpen(f"{dump_dir}/ranks{size}.cgns".encode(), b"w", C.byref(viewer)) == 0
+            assert G.NSViewSolution(ns, viewer) == 0
+            assert G.FlucaViewerCGNSDestroy(C.byref(viewer)) == 0
         H.lib.NSDestroy(C.byref(ns))
         H.lib.MeshDestroy(C.byref(mesh))
         return res
@@ -336,6 +342,45 @@ def _nsstep_worker(rank, world, n, ranks, opts):
     full, _, _ = run(0, 1)
     ref = full[:, lo[2]:lo[2] + ln[2], lo[1]:lo[1] + ln[1], lo[0]:lo[0] + ln[0]]
     assert np.abs(part - ref).max() <= 1e-7 * np.abs(full).max(), np.abs(part - ref).max()
+    if dump_dir:
+        import torch.distributed as dist
+        dist.barrier()
+        if rank == 0:
+            G = H.load_cgns()
+            lay = H.FlucaCGNSLayout()
+            for d in range(3):
+                lay.N[d], lay.len[d], lay.lo[d], lay.first[d], lay.last[d], lay.periodic[d] = n[d], n[d], 0, 1, 1, int(d == 2)
+            lay.rank, lay.size = 0, 1
+            info = {}
+            for size in (world, 1):
+                f = f"{dump_dir}/ranks{size}.cgns".encode()
+                step, t, ns_ = C.c_int64(), C.c_double(), C.c_int()
+                assert G.FlucaCGNSReadInfo(f, None, C.byref(step), C.byref(t), C.byref(ns_)) == 0
+                assert (step.value, ns_.value) == (2, 1) and abs(t.value - 0.1) < 1e-14
+                cells = {}
+                for name in ("VelocityX", "VelocityY", "VelocityZ", "Pressure", "PressureHalfStep"):
+                    a = np.full((n[2], n[1], n[0]), np.nan)
+                    assert G.FlucaCGNSReadCellField(f, C.byref(lay), 2, name.encode(), a.ctypes.data) == 0
+                    cells[name] = a
+                faces = [np.full((n[2], n[1], n[0] + 1), np.nan), np.full((n[2], n[1] + 1, n[0]), np.nan), np.full((n[2], n[1], n[0]), np.nan)]
+                ptr = (C.c_void_p * 3)(*[a.ctypes.data for a in faces])
+                assert G.FlucaCGNSReadFaceField(f, C.byref(lay), 2, b"FaceNormalVelocity", ptr) == 0
+                info[size] = (cells, faces)
+            for name, a in info[1][0].items():
+                b = info[world][0][name]
+                assert np.isfinite(b).all() and np.abs(a - b).max() <= 1e-7 * np.abs(full).max(), name   # w is round-off: absolute scale
+            for a, b in zip(info[1][1], info[world][1]):
+                assert np.isfinite(b).all() and np.abs(a - b).max() <= 1e-7 * np.abs(full).max()
+            vx = info[world][0]["VelocityX"]
+            assert np.abs(vx - full[0]).max() == 0.0 or np.abs(vx - full[0]).max() <= 1e-7 * np.abs(full).max()
+
+
+@pytest.mark.parametrize("world,n,ranks", [(2, (16, 16, 8), (2, 1, 1)), (2, (16, 16, 16), (1, 1, 2))])
+def test_decomposed_cgns_dump_is_the_single_domain_file(tmp_path, world, n, ranks):
+    from fluca_amd import build
+    if not build.have_hdf5():
+        pytest.skip("no HDF5 C library in this image")
+    mpc.run_ranks(world, _nsstep_worker, n, ranks, (), str(tmp_path))
 
 
 @pytest.mark.parametrize("world,n,ranks,opts", [

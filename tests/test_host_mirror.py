@@ -428,6 +428,27 @@ def test_c_cavity_driver_full_time_steps(H):
 
 
 @pytest.mark.gpu
+def test_c_cavity_driver_writes_cgns_like_the_reference_options(H, tmp_path):
+    """-ns_monitor_solution cgns:<template> -viewer_cgns_batch_size 2 -ns_view_solution cgns:<file> on the C driver."""
+    import subprocess
+    from fluca_amd import build
+    if not build.have_hdf5():
+        pytest.skip("no HDF5 C library in this image")
+    exe = build.build_example(name="cavity_flow_3d")
+    out = subprocess.run([exe, "-cart_grid_x", "16", "-cart_grid_y", "16", "-cart_grid_z", "8", "-ns_time_step_size", "1e-2", "-ns_max_steps", "4",
+                          "-ns_monitor_solution", f"cgns:{tmp_path}/mon_%d.cgns", "-ns_monitor_solution_interval", "2", "-viewer_cgns_batch_size", "2",
+                          "-ns_view_solution", f"cgns:{tmp_path}/end.cgns"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    G = H.load_cgns()
+    # monitored steps 0, 2, 4 in batches of two: files 0 (steps 0, 2) and 4 (step 4)
+    for name, last, count in (("mon_0.cgns", 2, 2), ("mon_4.cgns", 4, 1), ("end.cgns", 4, 1)):
+        N, step, t, n = (C.c_int64 * 3)(), C.c_int64(), C.c_double(), C.c_int()
+        assert G.FlucaCGNSReadInfo(str(tmp_path / name).encode(), N, C.byref(step), C.byref(t), C.byref(n)) == 0, name
+        assert tuple(N) == (16, 16, 8) and step.value == last and n.value == count and abs(t.value - 0.01 * last) < 1e-15
+    assert sorted(p.name for p in tmp_path.iterdir()) == ["end.cgns", "mon_0.cgns", "mon_4.cgns"]
+
+
+@pytest.mark.gpu
 def test_nsstep_matches_the_oracle_step(H):
     """Velocity, face velocity and pressure after two lid-driven-cavity steps: the C mirror on the GPU vs the CPU oracle's
     composition of the same reference formulas (StepOracle), including the wall terms of L, C, B and T."""
