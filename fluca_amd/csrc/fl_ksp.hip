@@ -49,6 +49,7 @@ __device__ __forceinline__ Tile make_tile(const GridP &g, int nchunk, int zc, in
 // ------------------------------------------------------------------------------------------------ generic fused SpMV
 // y = M (S x) with M = 1/diag (JAC) or 1, x padded with valid ghosts, y padded.  Optional second output and dots:
 //   partial slots: 0 sum y   1 y.o (o may be NULL)   2 x.y   3 y.y
+//   unpadded_y: 0 y padded; 1 y unpadded; 2 y = o - S x with o, y unpadded; 3 y = o - S x with o, y padded
 // MODE 0: plain.  MODE 1 (Chebyshev step): see k_cheb below (separate kernel).
 // (k_cheb's plan -- halo one plane ahead, lane exchange, per-plane barrier -- was tried here too: it removes the 2.9 B/cell of
 // excess fetch but the two-stream kernel is latency- rather than bandwidth-limited and BiCGStab got 4-7% slower, so this
@@ -106,7 +107,8 @@ __global__ void __launch_bounds__(256) k_apply_pc(GridP g, const double *__restr
           const int64_t ro = g.off0 + (int64_t)j * g.sx + t.il + pc;
           double2       ov = make_double2(0., 0.);
           if (o && unpadded_y != 2) ov = *reinterpret_cast<const double2 *>(o + ro);
-          if (unpadded_y) {
+          const bool unpadded_y_is_residual = unpadded_y == 3;
+          if (unpadded_y == 1 || unpadded_y == 2) {
             const int64_t u = ((int64_t)k * g.ny + j) * g.nx + t.i;
             if (unpadded_y == 2) {  // residual: y = o - S x with o an UNPADDED right-hand side
               if (t.own0) v.x = o[u] - v.x;
@@ -115,6 +117,10 @@ __global__ void __launch_bounds__(256) k_apply_pc(GridP g, const double *__restr
             if (t.own0) y[u] = v.x;
             if (t.own1) y[u + 1] = v.y;
           } else {
+            if (unpadded_y_is_residual) {  // y = o - S x, everything padded (multigrid residual)
+              v.x = ov.x - v.x;
+              v.y = ov.y - v.y;
+            }
             if (t.own1) *reinterpret_cast<double2 *>(y + ro) = v;
             else if (t.own0) y[ro] = v.x;
           }
@@ -387,8 +393,8 @@ __global__ void __launch_bounds__(256) k_cheb(GridP g, const double *X0, const d
           const double r0 = bv[m].x - v.x, r1 = two ? bv[m].y - v.y : 0.;
           const double z0 = JAC ? r0 / (xc0 + dyz) : r0, z1 = two ? (JAC ? r1 / (xc1 + dyz) : r1) : 0.;
           double2      dn2, xo;
-          dn2.x = rho * dv[m].x + cc * z0;
-          dn2.y = rho * dv[m].y + cc * z1;
+          dn2.x = (rho != 0. ? rho * dv[m].x : 0.) + cc * z0;  // first step: d is not looked at (it may hold anything)
+          dn2.y = (rho != 0. ? rho * dv[m].y : 0.) + cc * z1;
           xo.x  = cur[m].x + dn2.x;
           xo.y  = cur[m].y + dn2.y;
           if (two) {
@@ -609,6 +615,79 @@ int fl_residual(fl_poisson *h, const double *x, const double *b, double *r)
   FL_CHK(fl_fill_ghosts(h, h->w0));
   const TP tp = tile_plan(h->g);
   launch_apply_pc(h, tp, false, h->w0, r, b, nullptr, nullptr, 2);
+  return 0;
+}
+
+// ---- padded-vector entry points of the multigrid cycle (fl_mg.hip): no pad / unpad copies, no statistics ----------------
+
+// r = b - S x on padded vectors (x's ghosts are filled here)
+int fl_residual_padded(fl_poisson *h, double *xpad, const double *bpad, double *rpad)
+{
+  FL_CHK(fl_fill_ghosts(h, xpad));
+  const TP tp = tile_plan(h->g);
+  launch_apply_pc(h, tp, false, xpad, rpad, bpad, nullptr, nullptr, 3);
+  return 0;
+}
+
+// y = S x on padded vectors (x's ghosts are filled here) and x.y summed over all ranks, on the host
+int fl_apply_padded_dot(fl_poisson *h, double *xpad, double *ypad, double *xy)
+{
+  FL_CHK(fl_fill_ghosts(h, xpad));
+  const TP tp = tile_plan(h->g);
+  FL_CHK(fl_ensure_partials(h, tp.nblocks));
+  launch_apply_pc(h, tp, false, xpad, ypad, nullptr, nullptr, h->partial, 0);
+  launch_reduce(h->stream, h->partial, tp.nblocks, h->partial_stride, 4, h->sums);
+  if (h->multi) FL_CHK(h->comm.allreduce(h->stream, h->sums, NSLOT));
+  FL_HIP(hipMemcpyAsync(xy, h->sums + 2, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  FL_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// nu Chebyshev(-Jacobi) steps on the handle's padded work vectors: right-hand side in h->r, initial guess in h->xp (taken as
+// zero when guess_zero), the result is left in h->xp (the two x buffers h->xp / h->P0 swap roles as needed).  No convergence
+// test, no null-space bookkeeping (a constant in x never reaches a residual: the caller projects once at the end), the host
+// never waits.  Spectrum bounds as in fl_solve_cheb.
+int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero)
+{
+  for (double **v : {&h->r, &h->P0, &h->q, &h->xp}) FL_CHK(fl_ensure_vec(h, v));
+  if (nu <= 0) {
+    if (guess_zero) FL_CHK(fl_zero_vec(h, h->xp));
+    return 0;
+  }
+  const TP tp = tile_plan(h->g);
+  FL_CHK(fl_ensure_partials(h, std::max(tp.nblocks, 1024)));
+  const int nhist = nu + 2;
+  FL_CHK(fl_ensure_hist(h, nhist));
+  hipStream_t  s = h->stream;
+  fl_ksp_opts  o;
+  fl_ksp_opts_default(&o);
+  o.norm_type        = FL_NORM_NONE;
+  o.maxit            = nu;
+  o.remove_nullspace = 0;
+  const double lam = fl_gershgorin_bound(h, jac), emin = 0.1 * lam, emax = 1.1 * lam;
+  init_scal(h, &o);
+  KspScal &S = *h->scal_host;
+  S.scale     = 2. / (emax + emin);
+  const double alpha = 1. - S.scale * emin;
+  S.mu        = 1. / alpha;
+  S.omegaprod = 2. / alpha;
+  S.ckm1      = 1.;
+  S.ck        = S.mu;
+  S.cheb_rho  = 0.;
+  S.cheb_c    = S.scale;
+  FL_HIP(hipMemcpyAsync(h->scal, h->scal_host, sizeof(KspScal), hipMemcpyHostToDevice, s));
+  if (guess_zero) FL_CHK(fl_zero_vec(h, h->xp));
+  double    *X0 = h->xp, *X1 = h->P0, *B = h->r, *D = h->q;
+  const bool ghosts = fl_any_ghost_exchange(h);
+  auto       finl = [=](const double *partial, int nb, int stride, const double *sums) { hipLaunchKernelGGL(k_cheb_fin, dim3(1), dim3(256), 0, s, partial, nb, stride, sums, h->scal, h->hist, nhist); };
+  int        cur = 0;
+  for (int j = 0; j < nu; ++j) {
+    if (ghosts && (j > 0 || !guess_zero)) FL_CHK(fl_fill_ghosts(h, cur ? X1 : X0));
+    launch_cheb(h, tp, jac, X0, X1, B, D);
+    FL_CHK(fin_step(h, tp.nblocks, 3, finl));
+    cur ^= 1;
+  }
+  if (cur) std::swap(h->xp, h->P0);
   return 0;
 }
 

@@ -14,9 +14,13 @@
 //   outer      : KSPCG, left preconditioning, preconditioned norm ||z||, KSPConvergedDefault, constant null space
 //                removed from every preconditioner output
 //
-// Round-1 shape: every level is a full fl_poisson handle on the fine handle's stream and the cycle is composed from the
-// public entry points (apply, Chebyshev solve) plus three small kernels; scalars of the outer CG live on the host (an
-// iteration is ~25 ms at 512^3, the round trips per iteration do not matter).
+// Shape: every level is a full fl_poisson handle on the fine handle's stream, and the cycle works on the PADDED work
+// vectors of those handles (right-hand side h->r, iterate h->xp, scratch h->q) through the padded entry points of
+// fl_ksp.hip -- no pad / unpad copies between the pieces.  Post-smoothing is Chebyshev started from the current iterate
+// (the same polynomial in the residual as "e = smooth(b - S x); x += e", without forming the residual).  The constant null
+// space is handled once per cycle, algebraically: the outer CG needs z' = z - mean(z) only inside inner products and in
+// the direction update, so one pass over (z, r) yields sum z, z.z, r.z, sum r, r.r and the shift is folded into
+// p = (z - m) + beta p.  Scalars of the outer CG live on the host: two waits per iteration (p.q, and the five sums).
 // Several ranks: every level keeps the fine decomposition (block boundaries coincide with coarse faces), so restriction
 // and prolongation stay local; an axis is coarsened only while every rank's share stays even and >= 8 cells; the levels
 // borrow the fine handle's communicator for their halo exchanges and reductions.
@@ -27,70 +31,119 @@
 
 namespace fl {
 
-// coarse(I,J,K) = sum over children of wx wy wz * fine(child); w = child extent / parent extent along each axis
-__global__ void __launch_bounds__(256) k_mg_restrict(int nxc, int nyc, int nzc, int rx, int ry, int rz, int nxf, int nyf, const double *__restrict__ wx, const double *__restrict__ wy,
-                                                     const double *__restrict__ wz, const double *__restrict__ fine, double *__restrict__ coarse)
+// All multigrid vectors are padded (GridP addressing, PADX doubles in front of each row => rows are 128-B aligned and a
+// pair of cells (i even) is one aligned double2).  One thread per pair of owned cells, grid-stride over (pair, row).
+struct Owned {
+  int64_t npair_row, npairs;  // pairs per row (last one may be half), pairs in the block
+};
+__device__ __forceinline__ Owned owned_of(const GridP &g)
 {
-  const int64_t n = (int64_t)nxc * nyc * nzc;
+  Owned o;
+  o.npair_row = (g.nx + 1) / 2;
+  o.npairs    = o.npair_row * (int64_t)g.ny * g.nz;
+  return o;
+}
+// pair q -> offset of its first cell in a padded array, and whether the second cell exists
+__device__ __forceinline__ int64_t pair_off(const GridP &g, const Owned &o, int64_t q, bool &two)
+{
+  const int     ip = (int)(q % o.npair_row);
+  const int64_t row = q / o.npair_row;
+  const int     j = (int)(row % g.ny), k = (int)(row / g.ny);
+  two = 2 * ip + 1 < g.nx;
+  return g.off0 + (int64_t)k * g.sxy + (int64_t)j * g.sx + 2 * ip;
+}
+__device__ __forceinline__ double2 ldp(const double *a, int64_t off, bool two) { return two ? *reinterpret_cast<const double2 *>(a + off) : make_double2(a[off], 0.); }
+__device__ __forceinline__ void    stp(double *a, int64_t off, bool two, double2 v)
+{
+  if (two) *reinterpret_cast<double2 *>(a + off) = v;
+  else a[off] = v.x;
+}
+
+// coarse(I,J,K) = sum over children of wx wy wz * fine(child); w = child extent / parent extent along each axis
+__global__ void __launch_bounds__(256) k_mg_restrict(GridP gc, GridP gf, int rx, int ry, int rz, const double *__restrict__ wx, const double *__restrict__ wy, const double *__restrict__ wz,
+                                                     const double *__restrict__ fine, double *__restrict__ coarse)
+{
+  const int64_t n = (int64_t)gc.nx * gc.ny * gc.nz;
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
-    const int     I = (int)(q % nxc);
-    const int64_t t = q / nxc;
-    const int     J = (int)(t % nyc), K = (int)(t / nyc);
+    const int     I = (int)(q % gc.nx);
+    const int64_t t = q / gc.nx;
+    const int     J = (int)(t % gc.ny), K = (int)(t / gc.ny);
     double        s = 0.;
     for (int c = 0; c < rz; ++c)
-      for (int b = 0; b < ry; ++b)
-        for (int a = 0; a < rx; ++a) {
-          const int i = I * rx + a, j = J * ry + b, k = K * rz + c;
-          s += wx[i] * wy[j] * wz[k] * fine[((int64_t)k * nyf + j) * nxf + i];
-        }
-    coarse[q] = s;
+      for (int b = 0; b < ry; ++b) {
+        const int     j = J * ry + b, k = K * rz + c;
+        const int64_t ro = gf.off0 + (int64_t)k * gf.sxy + (int64_t)j * gf.sx + (int64_t)I * rx;
+        const double  wyz = wy[j] * wz[k];
+        if (rx == 2) {
+          const double2 f = *reinterpret_cast<const double2 *>(fine + ro);
+          s += wyz * (wx[2 * I] * f.x + wx[2 * I + 1] * f.y);
+        } else s += wyz * wx[I] * fine[ro];
+      }
+    coarse[gc.off0 + (int64_t)K * gc.sxy + (int64_t)J * gc.sx + I] = s;
   }
 }
 
 // fine(child) += coarse(parent)
-__global__ void __launch_bounds__(256) k_mg_prolong_add(int nxf, int nyf, int nzf, int rx, int ry, int rz, int nxc, int nyc, const double *__restrict__ coarse, double *__restrict__ fine)
+__global__ void __launch_bounds__(256) k_mg_prolong_add(GridP gf, GridP gc, int rx, int ry, int rz, const double *__restrict__ coarse, double *__restrict__ fine)
 {
-  const int64_t n = (int64_t)nxf * nyf * nzf;
-  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
-    const int     i = (int)(q % nxf);
-    const int64_t t = q / nxf;
-    const int     j = (int)(t % nyf), k = (int)(t / nyf);
-    fine[q] += coarse[((int64_t)(k / rz) * nyc + j / ry) * nxc + i / rx];
+  const Owned o = owned_of(gf);
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < o.npairs; q += (int64_t)gridDim.x * blockDim.x) {
+    const int     ip = (int)(q % o.npair_row);
+    const int64_t row = q / o.npair_row;
+    const int     j = (int)(row % gf.ny), k = (int)(row / gf.ny), i = 2 * ip;
+    const bool    two = i + 1 < gf.nx;
+    const int64_t fo = gf.off0 + (int64_t)k * gf.sxy + (int64_t)j * gf.sx + i;
+    const int64_t co = gc.off0 + (int64_t)(k / rz) * gc.sxy + (int64_t)(j / ry) * gc.sx;
+    double2       f = ldp(fine, fo, two);
+    f.x += coarse[co + i / rx];
+    if (two) f.y += coarse[co + (i + 1) / rx];
+    stp(fine, fo, two, f);
   }
 }
 
-// y = a x + b z (z may be NULL), and optionally partial[block] = sum y*w (w may be NULL -> sum y)
-__global__ void __launch_bounds__(256) k_mg_lincomb_dot(int64_t n, double a, const double *x, double b, const double *z, double *y, const double *w, double *partial)
+// slots: 0 sum z   1 z.z   2 r.z   3 sum r   4 r.r      (owned cells only)
+__global__ void __launch_bounds__(256) k_mg_dots(GridP g, const double *__restrict__ z, const double *__restrict__ r, double *__restrict__ partial, int stride)
 {
-  __shared__ double red[4];
-  double            v[1] = {0.};
-  // 16 B per lane over the even part (hipMalloc'ed arrays are 16-B aligned), the odd tail by thread 0 of block 0
-  const int64_t n2 = n / 2;
-  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n2; q += (int64_t)gridDim.x * blockDim.x) {
-    const double2 xv = reinterpret_cast<const double2 *>(x)[q];
-    double2       t  = make_double2(a * xv.x, a * xv.y);
-    if (z) {
-      const double2 zv = reinterpret_cast<const double2 *>(z)[q];
-      t.x += b * zv.x;
-      t.y += b * zv.y;
-    }
-    reinterpret_cast<double2 *>(y)[q] = t;
-    if (partial) {
-      if (w) {
-        const double2 wv = reinterpret_cast<const double2 *>(w)[q];
-        v[0] += t.x * wv.x + t.y * wv.y;
-      } else v[0] += t.x + t.y;
-    }
+  __shared__ double red[5 * 4];
+  double            v[5] = {0., 0., 0., 0., 0.};
+  const Owned       o = owned_of(g);
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < o.npairs; q += (int64_t)gridDim.x * blockDim.x) {
+    bool          two;
+    const int64_t off = pair_off(g, o, q, two);
+    const double2 zv = ldp(z, off, two), rv = ldp(r, off, two);
+    v[0] += zv.x + zv.y;
+    v[1] += zv.x * zv.x + zv.y * zv.y;
+    v[2] += rv.x * zv.x + rv.y * zv.y;
+    v[3] += rv.x + rv.y;
+    v[4] += rv.x * rv.x + rv.y * rv.y;
   }
-  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-    const int64_t q = n - 1;
-    const double  t = a * x[q] + (z ? b * z[q] : 0.);
-    y[q]            = t;
-    v[0] += w ? t * w[q] : t;
-  }
-  if (partial) {
-    block_sum<1>(v, red);
-    if (threadIdx.x == 0) partial[blockIdx.x] = v[0];
+  block_sum<5>(v, red);
+  if (threadIdx.x == 0)
+#pragma unroll
+    for (int a = 0; a < 5; ++a) partial[(int64_t)a * stride + blockIdx.x] = v[a];
+}
+
+// OP 0:  y0 = a x0 + b (y0 - c)                (p = (z - m) + beta p  as  y0 = p, x0 = z: y0 = 1*(x0 - c) + b y0, see launch)
+// OP 1:  y0 += a x0 ;  y1 -= a x1              (x += alpha p ; r -= alpha q)
+// OP 2:  y0 = x0 - c                           (p = z - m)
+template <int OP>
+__global__ void __launch_bounds__(256) k_mg_pw(GridP g, double a, double b, double c, const double *__restrict__ x0, const double *__restrict__ x1, double *__restrict__ y0, double *__restrict__ y1)
+{
+  const Owned o = owned_of(g);
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < o.npairs; q += (int64_t)gridDim.x * blockDim.x) {
+    bool          two;
+    const int64_t off = pair_off(g, o, q, two);
+    if (OP == 0) {
+      const double2 xv = ldp(x0, off, two), yv = ldp(y0, off, two);
+      stp(y0, off, two, make_double2((xv.x - c) + b * yv.x, (xv.y - c) + b * yv.y));
+    } else if (OP == 1) {
+      const double2 pv = ldp(x0, off, two), qv = ldp(x1, off, two), xv = ldp(y0, off, two), rv = ldp(y1, off, two);
+      stp(y0, off, two, make_double2(xv.x + a * pv.x, xv.y + a * pv.y));
+      stp(y1, off, two, make_double2(rv.x - a * qv.x, rv.y - a * qv.y));
+    } else {
+      const double2 xv = ldp(x0, off, two);
+      stp(y0, off, two, make_double2(xv.x - c, xv.y - c));
+    }
   }
 }
 
@@ -102,54 +155,31 @@ struct MgLevel {
   fl_poisson *h = nullptr;  // level 0: the caller's handle (not owned)
   int         r[3] = {1, 1, 1};  // refinement ratio to the NEXT (coarser) level
   double     *w[3] = {nullptr, nullptr, nullptr};  // restriction weights of this level's cells along each axis
-  double     *x = nullptr, *b = nullptr, *res = nullptr, *e = nullptr;  // unpadded cell arrays
+  double     *x = nullptr, *b = nullptr;  // unpadded cell arrays: the coarsest level's solve goes through the public entry point
 };
 
 struct fl_mg {
   std::vector<MgLevel> lv;
-  double *r = nullptr, *z = nullptr, *p = nullptr, *q = nullptr;  // outer CG, fine level
 };
 
 void fl_mg_destroy(fl_poisson *h);
 
 namespace {
 
-constexpr int MG_DOT_BLOCKS = 4096;
+constexpr int MG_BLOCKS = 4096;
 
-int nblk(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n / 2 + 255) / 256, MG_DOT_BLOCKS)); }
+int nblk(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, MG_BLOCKS)); }
+int nblk_pairs(const GridP &g) { return nblk((int64_t)((g.nx + 1) / 2) * g.ny * g.nz); }
 
-// y = a x + b z ; returns (optionally) sum(y * w) or sum(y) on the host
-int lincomb_dot(fl_poisson *h, int64_t n, double a, const double *x, double b, const double *z, double *y, const double *w, double *result)
+// the five sums of k_mg_dots over all ranks, on the host (one wait)
+int dots(fl_poisson *h, const double *z, const double *r, double out[5])
 {
-  const int nb = nblk(n);
-  hipLaunchKernelGGL(k_mg_lincomb_dot, dim3(nb), dim3(256), 0, h->stream, n, a, x, b, z, y, w, result ? h->partial : nullptr);
-  if (result) {
-    launch_reduce(h->stream, h->partial, nb, h->partial_stride, 1, h->sums);
-    if (h->multi) FL_CHK(h->comm.allreduce(h->stream, h->sums, NSLOT));
-    FL_HIP(hipMemcpyAsync(result, h->sums, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    FL_HIP(hipStreamSynchronize(h->stream));
-  }
-  return 0;
-}
-
-}  // namespace
-
-// constant shift kernel (y -= m)
-namespace fl {
-__global__ void __launch_bounds__(256) k_mg_shift(int64_t n, double m, double *y)
-{
-  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) y[q] -= m;
-}
-}  // namespace fl
-
-namespace {
-
-int project_constant(fl_poisson *h, int64_t n, double *y)
-{
-  double s = 0.;
-  FL_CHK(lincomb_dot(h, n, 1., y, 0., nullptr, y, nullptr, &s));
-  const double N = (double)h->ax[0].n * (double)h->ax[1].n * (double)h->ax[2].n;  // global cell count
-  hipLaunchKernelGGL(k_mg_shift, dim3(nblk(n)), dim3(256), 0, h->stream, n, s / N, y);
+  const int nb = nblk_pairs(h->g);
+  hipLaunchKernelGGL(k_mg_dots, dim3(nb), dim3(256), 0, h->stream, h->g, z, r, h->partial, h->partial_stride);
+  launch_reduce(h->stream, h->partial, nb, h->partial_stride, 5, h->sums);
+  if (h->multi) FL_CHK(h->comm.allreduce(h->stream, h->sums, NSLOT));
+  FL_HIP(hipMemcpyAsync(out, h->sums, sizeof(double) * 5, hipMemcpyDeviceToHost, h->stream));
+  FL_HIP(hipStreamSynchronize(h->stream));
   return 0;
 }
 
@@ -219,57 +249,48 @@ int mg_build_levels(fl_poisson *h, fl_mg *mg, int max_levels)
     }
   }
   for (size_t l = 0; l < mg->lv.size(); ++l) {
-    MgLevel &L = mg->lv[l];
-    if (l > 0) {
-      FL_CHK(alloc_cells(L.h, &L.x));
-      FL_CHK(alloc_cells(L.h, &L.b));
+    MgLevel    &L = mg->lv[l];
+    fl_poisson *hl = L.h;
+    if (hl->nv_il > 1) return FL_ERR_SUP;  // the experimental row-interleaved vector layout is not wired into the cycle
+    for (double **v : {&hl->r, &hl->P0, &hl->q, &hl->xp}) FL_CHK(fl_ensure_vec(hl, v));
+    if (l + 1 == mg->lv.size()) {
+      FL_CHK(alloc_cells(hl, &L.x));
+      FL_CHK(alloc_cells(hl, &L.b));
     }
-    FL_CHK(alloc_cells(L.h, &L.res));
-    FL_CHK(alloc_cells(L.h, &L.e));
-    FL_CHK(fl_ensure_partials(L.h, MG_DOT_BLOCKS));
+    FL_CHK(fl_ensure_partials(hl, MG_BLOCKS));
   }
-  for (double **v : {&mg->r, &mg->z, &mg->p, &mg->q}) FL_CHK(alloc_cells(h, v));
-  FL_CHK(fl_ensure_partials(h, MG_DOT_BLOCKS));
+  for (double **v : {&h->w0, &h->w1, &h->w2}) FL_CHK(fl_ensure_vec(h, v));  // outer CG: x, p, q
   return 0;
 }
 
-// x = V-cycle(b) on level l, zero initial guess
-int vcycle(fl_mg *mg, size_t l, const double *b, double *x, const fl_ksp_opts *o)
+// V-cycle on level l: right-hand side in the level handle's h->r, answer (zero initial guess) in its h->xp -- both padded
+int vcycle(fl_mg *mg, size_t l, const fl_ksp_opts *o)
 {
-  MgLevel      &L = mg->lv[l];
-  fl_poisson   *h = L.h;
-  const int64_t n = h->ncell;
-  fl_ksp_stats  st;
-  fl_ksp_opts   so;
-  fl_ksp_opts_default(&so);
-  so.remove_nullspace = o->remove_nullspace;
+  MgLevel    &L = mg->lv[l];
+  fl_poisson *h = L.h;
   if (l + 1 == mg->lv.size()) {
+    // coarsest level: Jacobi-PCG to rtol 1e-2 through the public entry point (which uses the padded work vectors itself)
+    fl_ksp_stats st;
+    fl_ksp_opts  so;
+    fl_ksp_opts_default(&so);
+    so.remove_nullspace = o->remove_nullspace;
     so.type  = FL_KSP_CG;
     so.pc    = FL_PC_JACOBI;
     so.rtol  = 1e-2;
     so.maxit = 200;
-    return fl_poisson_solve(h, b, x, &so, &st);
+    launch_unpad_copy(h->stream, h->g, h->r, L.b, nullptr);
+    FL_CHK(fl_poisson_solve(h, L.b, L.x, &so, &st));
+    launch_pad_copy(h->stream, h->g, L.x, h->xp);
+    return 0;
   }
-  so.type      = FL_KSP_CHEBYSHEV;
-  so.pc        = FL_PC_JACOBI;
-  so.norm_type = FL_NORM_NONE;
-  so.maxit     = o->mg_smooth_its > 0 ? o->mg_smooth_its : 3;
-  so.check_every = -1;  // smoother: no convergence test, no host round trip
-  MgLevel &C   = mg->lv[l + 1];
-  FL_CHK(fl_poisson_solve(h, b, x, &so, &st));                                       // x = smooth(b)
-  FL_CHK(fl_residual(h, x, b, L.res));                                               // r = b - S x
-  {
-    const GridP &gf = h->g, &gc = C.h->g;
-    hipLaunchKernelGGL(k_mg_restrict, dim3(nblk(C.h->ncell)), dim3(256), 0, h->stream, gc.nx, gc.ny, gc.nz, L.r[0], L.r[1], L.r[2], gf.nx, gf.ny, L.w[0], L.w[1], L.w[2], L.res, C.b);
-  }
-  FL_CHK(vcycle(mg, l + 1, C.b, C.x, o));                                            // e_c = V(R r)
-  {
-    const GridP &gf = h->g, &gc = C.h->g;
-    hipLaunchKernelGGL(k_mg_prolong_add, dim3(nblk(n)), dim3(256), 0, h->stream, gf.nx, gf.ny, gf.nz, L.r[0], L.r[1], L.r[2], gc.nx, gc.ny, C.x, x);  // x += P e_c
-  }
-  FL_CHK(fl_residual(h, x, b, L.res));                                               // r = b - S x
-  FL_CHK(fl_poisson_solve(h, L.res, L.e, &so, &st));                                 // e = smooth(r)
-  FL_CHK(lincomb_dot(h, n, 1., x, 1., L.e, x, nullptr, nullptr));                    // x += e
+  const int nu = o->mg_smooth_its > 0 ? o->mg_smooth_its : 3;
+  MgLevel  &C  = mg->lv[l + 1];
+  FL_CHK(fl_cheb_smooth_padded(h, nu, true, true));                                  // x = smooth(b), zero initial guess
+  FL_CHK(fl_residual_padded(h, h->xp, h->r, h->q));                                  // q = b - S x   (q: the smoother's scratch)
+  hipLaunchKernelGGL(k_mg_restrict, dim3(nblk(C.h->ncell)), dim3(256), 0, h->stream, C.h->g, h->g, L.r[0], L.r[1], L.r[2], L.w[0], L.w[1], L.w[2], h->q, C.h->r);
+  FL_CHK(vcycle(mg, l + 1, o));                                                      // e_c = V(R r)
+  hipLaunchKernelGGL(k_mg_prolong_add, dim3(nblk_pairs(h->g)), dim3(256), 0, h->stream, h->g, C.h->g, L.r[0], L.r[1], L.r[2], C.h->xp, h->xp);  // x += P e_c
+  FL_CHK(fl_cheb_smooth_padded(h, nu, true, false));                                 // nu more steps from x
   return 0;
 }
 
@@ -281,12 +302,10 @@ void fl_mg_destroy(fl_poisson *h)
   if (!mg) return;
   for (size_t l = 0; l < mg->lv.size(); ++l) {
     MgLevel &L = mg->lv[l];
-    for (double *p : {L.x, L.b, L.res, L.e, L.w[0], L.w[1], L.w[2]})
+    for (double *p : {L.x, L.b, L.w[0], L.w[1], L.w[2]})
       if (p) (void)hipFree(p);
     if (l > 0 && L.h) fl_poisson_destroy(L.h);
   }
-  for (double *p : {mg->r, mg->z, mg->p, mg->q})
-    if (p) (void)hipFree(p);
   delete mg;
   h->mg = nullptr;
 }
@@ -304,57 +323,57 @@ int fl_solve_cg_mg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts 
   if (o->norm_type != FL_NORM_PRECONDITIONED && o->norm_type != FL_NORM_UNPRECONDITIONED) return FL_ERR_SUP;
   if (h->mg && o->mg_levels > 0 && (int)h->mg->lv.size() != std::min<int>(o->mg_levels, (int)h->mg->lv.size()) ) fl_mg_destroy(h);
   if (!h->mg) FL_CHK(mg_build(h, o->mg_levels));
-  fl_mg        *mg = h->mg;
-  const int64_t n = h->ncell;
-  const bool    ns = o->remove_nullspace != 0;
-  const bool    pnorm = o->norm_type == FL_NORM_PRECONDITIONED;
-  // the level-0 smoother runs through fl_poisson_solve on this very handle and uses h->ev0 / h->ev1 for its own timing
+  fl_mg       *mg = h->mg;
+  const GridP &g = h->g;
+  const bool   ns = o->remove_nullspace != 0;
+  const bool   pnorm = o->norm_type == FL_NORM_PRECONDITIONED;
+  const double N = (double)h->ax[0].n * (double)h->ax[1].n * (double)h->ax[2].n;  // global cell count
+  const int    nb = nblk_pairs(g);
+  hipStream_t  s = h->stream;
+  // the level-0 smoother runs on this very handle and may use h->ev0 / h->ev1: own events for the timing
   hipEvent_t e0, e1;
   FL_HIP(hipEventCreate(&e0));
   FL_HIP(hipEventCreate(&e1));
-  FL_HIP(hipEventRecord(e0, h->stream));
-  double *r = mg->r, *z = mg->z, *p = mg->p, *q = mg->q;
-  double  rz = 0., rz_old = 1., dp = 0., pq = 0., rr = 0.;
+  FL_HIP(hipEventRecord(e0, s));
+  double *X = h->w0, *P = h->w1, *Q = h->w2;  // padded; r = h->r (the cycle's right-hand side), z = h->xp after the cycle
+  double  d[5], rz = 0., rz_old = 1., dp = 0., pq = 0., m = 0.;
   std::vector<double> hist;
-  FL_CHK(lincomb_dot(h, n, 1., b, 0., nullptr, r, r, &rr));               // r = b (x = 0)
-  FL_CHK(lincomb_dot(h, n, 0., b, 0., nullptr, x, nullptr, nullptr));     // x = 0
-  FL_CHK(vcycle(mg, 0, r, z, o));                                         // z = M^-1 r
-  if (ns) FL_CHK(project_constant(h, n, z));
-  if (pnorm) {
-    FL_CHK(lincomb_dot(h, n, 1., z, 0., nullptr, z, z, &dp));             // ||z||^2
-    dp = std::sqrt(dp);
-  } else dp = std::sqrt(rr);
-  FL_CHK(lincomb_dot(h, n, 1., z, 0., nullptr, p, r, &rz));               // p = z ; rz = r.z
+  // z' = z - m 1 with m = mean(z):  z'.z' = z.z - N m^2,  r.z' = r.z - m sum r
+  auto cycle_and_sums = [&]() -> int {
+    FL_CHK(vcycle(mg, 0, o));                                              // z = M^-1 r
+    FL_CHK(dots(h, h->xp, h->r, d));
+    m = ns ? d[0] / N : 0.;
+    const double zz = d[1] - N * m * m;
+    dp = pnorm ? std::sqrt(zz > 0. ? zz : 0.) : std::sqrt(d[4]);
+    if (std::isnan(d[1])) dp = d[1];
+    rz = d[2] - m * d[3];
+    return 0;
+  };
+  launch_pad_copy(s, g, b, h->r);                                           // r = b (x = 0)
+  FL_CHK(fl_zero_vec(h, X));
+  FL_CHK(cycle_and_sums());
+  hipLaunchKernelGGL(k_mg_pw<2>, dim3(nb), dim3(256), 0, s, g, 0., 0., m, (const double *)h->xp, (const double *)nullptr, P, (double *)nullptr);  // p = z'
   const double rnorm0 = dp, ttol = std::max(o->rtol * dp, o->atol);
   hist.push_back(dp);
   int  it = 0, reason = 0;
-  auto converged = [&](double d) {
-    if (std::isnan(d) || std::isinf(d)) return (int)FL_DIVERGED_NANORINF;
-    if (d <= ttol) return d < o->atol ? (int)FL_CONVERGED_ATOL : (int)FL_CONVERGED_RTOL;
-    if (d >= o->dtol * rnorm0) return (int)FL_DIVERGED_DTOL;
+  auto converged = [&](double v) {
+    if (std::isnan(v) || std::isinf(v)) return (int)FL_DIVERGED_NANORINF;
+    if (v <= ttol) return v < o->atol ? (int)FL_CONVERGED_ATOL : (int)FL_CONVERGED_RTOL;
+    if (v >= o->dtol * rnorm0) return (int)FL_DIVERGED_DTOL;
     return 0;
   };
   reason = converged(dp);
   if (!reason && o->maxit <= 0) reason = FL_DIVERGED_ITS;
   while (!reason) {
-    FL_CHK(fl_poisson_apply(h, p, q));                                     // q = S p
-    FL_CHK(lincomb_dot(h, n, 1., q, 0., nullptr, q, p, &pq));              // p.q
+    FL_CHK(fl_apply_padded_dot(h, P, Q, &pq));                              // q = S p ; p.q
     if (!(pq > 0.)) {
       reason = std::isnan(pq) ? FL_DIVERGED_NANORINF : FL_DIVERGED_INDEFINITE_MAT;
       break;
     }
     const double alpha = rz / pq;
-    FL_CHK(lincomb_dot(h, n, 1., x, alpha, p, x, nullptr, nullptr));       // x += alpha p
-    FL_CHK(lincomb_dot(h, n, 1., r, -alpha, q, r, r, &rr));                // r -= alpha q ; r.r
-    FL_CHK(vcycle(mg, 0, r, z, o));                                        // z = M^-1 r
-    if (ns) FL_CHK(project_constant(h, n, z));
+    hipLaunchKernelGGL(k_mg_pw<1>, dim3(nb), dim3(256), 0, s, g, alpha, 0., 0., (const double *)P, (const double *)Q, X, h->r);  // x += alpha p ; r -= alpha q
     rz_old = rz;
-    if (pnorm) {
-      double zz = 0.;
-      FL_CHK(lincomb_dot(h, n, 1., z, 0., nullptr, z, z, &zz));
-      dp = std::sqrt(zz);
-    } else dp = std::sqrt(rr);
-    FL_CHK(lincomb_dot(h, n, 1., z, 0., nullptr, z, r, &rz));              // r.z
+    FL_CHK(cycle_and_sums());                                               // z = M^-1 r and the five sums
     ++it;
     hist.push_back(dp);
     reason = converged(dp);
@@ -362,11 +381,20 @@ int fl_solve_cg_mg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts 
     if (!reason && !(rz > 0.)) reason = std::isnan(rz) ? FL_DIVERGED_NANORINF : FL_DIVERGED_INDEFINITE_PC;
     if (reason) break;
     const double beta = rz / rz_old;
-    FL_CHK(lincomb_dot(h, n, 1., z, beta, p, p, nullptr, nullptr));        // p = z + beta p
+    hipLaunchKernelGGL(k_mg_pw<0>, dim3(nb), dim3(256), 0, s, g, 1., beta, m, (const double *)h->xp, (const double *)nullptr, P, (double *)nullptr);  // p = z' + beta p
   }
-  if (ns) FL_CHK(project_constant(h, n, x));
-  FL_HIP(hipEventRecord(e1, h->stream));
-  FL_HIP(hipStreamSynchronize(h->stream));
+  // answer, with the constant removed on the way out (the shift is handed over in device memory)
+  double *shift = nullptr;
+  if (ns) {
+    FL_CHK(dots(h, X, X, d));
+    const double mx = d[0] / N;
+    FL_HIP(hipMemcpyAsync(h->sums, &mx, sizeof(double), hipMemcpyHostToDevice, s));
+    FL_HIP(hipStreamSynchronize(s));  // mx lives on this stack frame
+    shift = h->sums;
+  }
+  launch_unpad_copy(s, g, X, x, shift);
+  FL_HIP(hipEventRecord(e1, s));
+  FL_HIP(hipStreamSynchronize(s));
   float ms = 0.f;
   FL_HIP(hipEventElapsedTime(&ms, e0, e1));
   (void)hipEventDestroy(e0);
@@ -377,8 +405,8 @@ int fl_solve_cg_mg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts 
   st->rnorm   = dp;
   st->seconds = ms * 1e-3;
   if (o->history && o->nhistory > 0) {
-    const int m = std::min<int>(o->nhistory, (int)hist.size());
-    std::memcpy(o->history, hist.data(), sizeof(double) * m);
+    const int n = std::min<int>(o->nhistory, (int)hist.size());
+    std::memcpy(o->history, hist.data(), sizeof(double) * n);
   }
   return 0;
 }
