@@ -428,6 +428,38 @@ __global__ void __launch_bounds__(256) k_cheb(GridP g, const double *X0, const d
     for (int a = 0; a < 3; ++a) partial[(int64_t)a * stride + blockIdx.x] = acc[a];
 }
 
+// The first step from a zero initial guess (rho = 0, x = 0): z = M b ; d = c z ; x' = d.  The same numbers k_cheb produces
+// from a zeroed x (S 0 = +0, b - 0 = b, 0 + d = d), without zeroing x, reading it and d, or the stencil: 8 B/cell read and
+// 16 written instead of 8 (memset) + 24 + 16.  No sums: only for the smoother call (KSP_NORM_NONE, no null space).
+template <bool JAC>
+__global__ void __launch_bounds__(256) k_cheb_first(GridP g, double *X0w, double *X1w, const double *__restrict__ b, double *__restrict__ d, const KspScal *__restrict__ s)
+{
+  if (s->reason != 0) return;
+  double       *xn = s->cur ? X0w : X1w;
+  const double  cc = s->cheb_c;
+  const int64_t npr = (g.nx + 1) / 2, total = npr * (int64_t)g.ny * g.nz;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+    const int     i = 2 * (int)(q % npr);
+    const int64_t row = q / npr;
+    const int     j = (int)(row % g.ny), k = (int)(row / g.ny);
+    const bool    two = i + 1 < g.nx;
+    const int64_t off = g.off0 + (int64_t)k * g.sxy + (int64_t)j * g.sx + i;
+    const double  dyz = g.sc[1][j] + g.sc[2][k];
+    double2       bv;
+    if (two) bv = *reinterpret_cast<const double2 *>(b + off);
+    else bv = make_double2(b[off], 0.);
+    const double  z0 = JAC ? bv.x / (g.sc[0][i] + dyz) : bv.x, z1 = two ? (JAC ? bv.y / (g.sc[0][i + 1] + dyz) : bv.y) : 0.;
+    const double2 dn = make_double2(0. + cc * z0, 0. + cc * z1);
+    if (two) {
+      *reinterpret_cast<double2 *>(d + off)  = dn;
+      *reinterpret_cast<double2 *>(xn + off) = dn;
+    } else {
+      d[off]  = dn.x;
+      xn[off] = dn.x;
+    }
+  }
+}
+
 // after launch j of k_cheb: convergence test on the residual of x_j, then either stop (answer = old buffer, x_j) or accept
 // the update (flip) and prepare rho, c of the next step.
 __global__ void __launch_bounds__(256) k_cheb_fin(const double *__restrict__ partial, int nblocks, int stride, const double *__restrict__ sums, KspScal *__restrict__ s, double *__restrict__ hist, int nhist)
@@ -676,14 +708,21 @@ int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero)
   S.cheb_rho  = 0.;
   S.cheb_c    = S.scale;
   FL_HIP(hipMemcpyAsync(h->scal, h->scal_host, sizeof(KspScal), hipMemcpyHostToDevice, s));
-  if (guess_zero) FL_CHK(fl_zero_vec(h, h->xp));
   double    *X0 = h->xp, *X1 = h->P0, *B = h->r, *D = h->q;
   const bool ghosts = fl_any_ghost_exchange(h);
   auto       finl = [=](const double *partial, int nb, int stride, const double *sums) { hipLaunchKernelGGL(k_cheb_fin, dim3(1), dim3(256), 0, s, partial, nb, stride, sums, h->scal, h->hist, nhist); };
   int        cur = 0;
   for (int j = 0; j < nu; ++j) {
-    if (ghosts && (j > 0 || !guess_zero)) FL_CHK(fl_fill_ghosts(h, cur ? X1 : X0));
-    launch_cheb(h, tp, jac, X0, X1, B, D);
+    if (j == 0 && guess_zero) {
+      // the sums k_cheb_fin would look at are not used without a norm and a null space: it only advances the recurrence
+      const int64_t pairs = (int64_t)((h->g.nx + 1) / 2) * h->g.ny * h->g.nz;
+      const int     nb    = (int)std::max<int64_t>(1, std::min<int64_t>((pairs + 255) / 256, 8192));
+      if (jac) hipLaunchKernelGGL((k_cheb_first<true>), dim3(nb), dim3(256), 0, s, h->g, X0, X1, B, D, h->scal);
+      else hipLaunchKernelGGL((k_cheb_first<false>), dim3(nb), dim3(256), 0, s, h->g, X0, X1, B, D, h->scal);
+    } else {
+      if (ghosts) FL_CHK(fl_fill_ghosts(h, cur ? X1 : X0));
+      launch_cheb(h, tp, jac, X0, X1, B, D);
+    }
     FL_CHK(fin_step(h, tp.nblocks, 3, finl));
     cur ^= 1;
   }

@@ -938,6 +938,11 @@ FlErrorCode NSComputeStaggeredPressureGradientBC(NS ns, double t, double *V[3])
  * The fields and the step of NSStep_CNLinear_Cart3d_Internal / NSFormJacobian / NSFormFunction (cnlinearcart3d.c:2807-3060)
  * on device arrays, for all four boundary-condition types.  Outer solve:
  * -ns_ksp_type richardson (x += PCApply_ABF(f - J x), unpreconditioned norm, -ns_ksp_rtol) or preonly. */
+/* composite vector (v: 3*cells, V[3]: faces, p: cells) of the outer Krylov method */
+typedef struct {
+  double *v, *V[3], *p;
+} CVec;
+
 typedef struct {
   int64_t sz[4];                               /* cells, x-, y-, z-faces of this rank */
   double *sol_v, *sol_V[3], *sol_p;            /* ns->sol  */
@@ -949,6 +954,10 @@ typedef struct {
   double *r_v, *r_V[3], *r_p, *d_v, *d_V[3], *d_p;
   double *plane_dev, *plane_host[7];           /* boundary values: 3 components at two times + one scratch plane */
   int64_t plane_cap;
+  /* GMRES work vectors, kept from step to step (allocating and freeing ~70 GB of device memory per step at 512^3 left the
+   * GPU idle for a third of the step): w, t and the Krylov basis, grown lazily up to restart + 1 */
+  CVec  gm_w, gm_t, *gm_V;
+  int   gm_nalloc, gm_cap;
 } NS_CNLinear;
 
 static FlErrorCode cnl_alloc(NS ns, double **p, int64_t n)
@@ -999,6 +1008,13 @@ static FlErrorCode NSDestroy_CNLinear(NS ns)
       if (f[a]) fl_free(ns->device, f[a]);
   }
   for (int q = 0; q < 7; ++q) free(c->plane_host[q]);
+  for (int i = -2; i < c->gm_cap; ++i) { /* every slot of the table: a failed allocation may have left a partly filled one */
+    CVec   *a = i == -2 ? &c->gm_w : i == -1 ? &c->gm_t : &c->gm_V[i];
+    double *q[5] = {a->v, a->p, a->V[0], a->V[1], a->V[2]};
+    for (int k = 0; k < 5; ++k)
+      if (q[k]) fl_free(ns->device, q[k]);
+  }
+  free(c->gm_V);
   free(c);
   ns->data = NULL;
   return 0;
@@ -1108,10 +1124,6 @@ static FlErrorCode cnl_residual(NS ns, double *rnorm)
 }
 
 /* ---- composite vectors (v: 3*cells, V[3]: faces, p: cells) for the outer Krylov method ------------------------------- */
-typedef struct {
-  double *v, *V[3], *p;
-} CVec;
-
 static FlErrorCode cv_alloc(NS ns, CVec *a)
 {
   NS_CNLinear *c = (NS_CNLinear *)ns->data;
@@ -1119,13 +1131,6 @@ static FlErrorCode cv_alloc(NS ns, CVec *a)
   FLCHK(cnl_alloc(ns, &a->p, c->sz[0]));
   for (int d = 0; d < 3; ++d) FLCHK(cnl_alloc(ns, &a->V[d], c->sz[1 + d]));
   return 0;
-}
-static void cv_free(NS ns, CVec *a)
-{
-  double *q[5] = {a->v, a->p, a->V[0], a->V[1], a->V[2]};
-  for (int i = 0; i < 5; ++i)
-    if (q[i]) fl_free(ns->device, q[i]);
-  memset(a, 0, sizeof(*a));
 }
 /* y = a x + b z (z may be NULL) */
 static FlErrorCode cv_lincomb(NS ns, double a, const CVec *x, double b, const CVec *z, CVec *y)
@@ -1176,23 +1181,32 @@ static FlErrorCode cv_jmult(NS ns, const CVec *x, CVec *y) /* y = J x */
  * inner solvers (PETSc absent): restated from the published algorithm. */
 static FlErrorCode cnl_gmres(NS ns, const CVec *f, CVec *x)
 {
-  const int m = ns->gmres_restart;
-  CVec     *Vk = (CVec *)calloc((size_t)m + 1, sizeof(CVec)), w = {0}, t = {0};
+  const int    m = ns->gmres_restart;
+  NS_CNLinear *c = (NS_CNLinear *)ns->data;
+  if (c->gm_cap < m + 1) { /* the restart length grew: the basis table follows (the vectors in it stay) */
+    CVec *nv = (CVec *)calloc((size_t)m + 1, sizeof(CVec));
+    if (!nv) return E_MEM;
+    if (c->gm_V) memcpy(nv, c->gm_V, sizeof(CVec) * (size_t)c->gm_nalloc);
+    free(c->gm_V);
+    c->gm_V   = nv;
+    c->gm_cap = m + 1;
+  }
+  CVec     *Vk = c->gm_V;
+  CVec     *w = &c->gm_w, *t = &c->gm_t; /* persistent work vectors */
   double   *H = (double *)calloc((size_t)(m + 1) * m, sizeof(double)), *cs = (double *)calloc(m, sizeof(double)), *sn = (double *)calloc(m, sizeof(double)),
            *g = (double *)calloc((size_t)m + 1, sizeof(double)), *y = (double *)calloc(m, sizeof(double));
   FlErrorCode rc = 0;
-  int         nalloc = 0;
 #define GM(call)          \
   do {                    \
     rc = (call);          \
     if (rc) goto done;    \
   } while (0)
-  if (!Vk || !H || !cs || !sn || !g || !y) {
+  if (!H || !cs || !sn || !g || !y) {
     rc = E_MEM;
     goto done;
   }
-  GM(cv_alloc(ns, &w));
-  GM(cv_alloc(ns, &t));
+  if (!w->v) GM(cv_alloc(ns, w));
+  if (!t->v) GM(cv_alloc(ns, t));
   double fnorm, beta;
   GM(cv_dot(ns, f, f, &fnorm));
   fnorm = sqrt(fnorm);
@@ -1203,34 +1217,34 @@ static FlErrorCode cnl_gmres(NS ns, const CVec *f, CVec *x)
   int first = 1;
   while (ns->reason >= 0) {
     /* r = f - J x */
-    if (first) GM(cv_lincomb(ns, 1., f, 0., NULL, &w));
+    if (first) GM(cv_lincomb(ns, 1., f, 0., NULL, w));
     else {
-      GM(cv_jmult(ns, x, &w));
-      GM(cv_lincomb(ns, -1., &w, 1., f, &w));
+      GM(cv_jmult(ns, x, w));
+      GM(cv_lincomb(ns, -1., w, 1., f, w));
     }
     first = 0;
-    GM(cv_dot(ns, &w, &w, &beta));
+    GM(cv_dot(ns, w, w, &beta));
     beta          = sqrt(beta);
     ns->ksp_rnorm = beta;
     if (!(beta == beta)) { ns->reason = -1; break; }
     if (beta <= ttol || ns->ksp_its >= ns->ksp_max_it) break;
-    if (nalloc < 1) { GM(cv_alloc(ns, &Vk[0])); nalloc = 1; }
-    GM(cv_lincomb(ns, 1. / beta, &w, 0., NULL, &Vk[0]));
+    if (c->gm_nalloc < 1) { GM(cv_alloc(ns, &Vk[0])); c->gm_nalloc = 1; }
+    GM(cv_lincomb(ns, 1. / beta, w, 0., NULL, &Vk[0]));
     memset(g, 0, sizeof(double) * ((size_t)m + 1));
     g[0] = beta;
     int j = 0, conv = 0;
     for (; j < m && ns->ksp_its < ns->ksp_max_it; ++j) {
-      GM(cv_pcapply(ns, &Vk[j], &t)); /* z = P^-1 v_j */
+      GM(cv_pcapply(ns, &Vk[j], t)); /* z = P^-1 v_j */
       if (ns->reason < 0) break;
-      GM(cv_jmult(ns, &t, &w));       /* w = J z */
+      GM(cv_jmult(ns, t, w));       /* w = J z */
       for (int i = 0; i <= j; ++i) {  /* modified Gram-Schmidt */
         double hij;
-        GM(cv_dot(ns, &w, &Vk[i], &hij));
+        GM(cv_dot(ns, w, &Vk[i], &hij));
         H[i * m + j] = hij;
-        GM(cv_lincomb(ns, 1., &w, -hij, &Vk[i], &w));
+        GM(cv_lincomb(ns, 1., w, -hij, &Vk[i], w));
       }
       double hn;
-      GM(cv_dot(ns, &w, &w, &hn));
+      GM(cv_dot(ns, w, w, &hn));
       hn = sqrt(hn);
       H[(j + 1) * m + j] = hn;
       for (int i = 0; i < j; ++i) { /* previous Givens rotations on the new column */
@@ -1255,8 +1269,8 @@ static FlErrorCode cnl_gmres(NS ns, const CVec *f, CVec *x)
         break;
       }
       if (j + 1 < m || 1) {
-        if (nalloc < j + 2) { GM(cv_alloc(ns, &Vk[j + 1])); nalloc = j + 2; }
-        GM(cv_lincomb(ns, 1. / hn, &w, 0., NULL, &Vk[j + 1]));
+        if (c->gm_nalloc < j + 2) { GM(cv_alloc(ns, &Vk[j + 1])); c->gm_nalloc = j + 2; }
+        GM(cv_lincomb(ns, 1. / hn, w, 0., NULL, &Vk[j + 1]));
       }
     }
     /* y = H^-1 g (back substitution), x += P^-1 (V y) */
@@ -1266,20 +1280,17 @@ static FlErrorCode cnl_gmres(NS ns, const CVec *f, CVec *x)
       y[i] = sacc / H[i * m + i];
     }
     if (j > 0) {
-      GM(cv_lincomb(ns, y[0], &Vk[0], 0., NULL, &w));
-      for (int i = 1; i < j; ++i) GM(cv_lincomb(ns, 1., &w, y[i], &Vk[i], &w));
-      GM(cv_pcapply(ns, &w, &t));
-      GM(cv_lincomb(ns, 1., x, 1., &t, x));
+      GM(cv_lincomb(ns, y[0], &Vk[0], 0., NULL, w));
+      for (int i = 1; i < j; ++i) GM(cv_lincomb(ns, 1., w, y[i], &Vk[i], w));
+      GM(cv_pcapply(ns, w, t));
+      GM(cv_lincomb(ns, 1., x, 1., t, x));
     }
     if (conv || ns->reason < 0) break;
   }
   if (ns->reason >= 0 && ns->ksp_rnorm > ttol && ns->ksp_its >= ns->ksp_max_it) ns->reason = -1;
 done:
 #undef GM
-  for (int i = 0; i < nalloc; ++i) cv_free(ns, &Vk[i]);
-  cv_free(ns, &w);
-  cv_free(ns, &t);
-  free(Vk); free(H); free(cs); free(sn); free(g); free(y);
+  free(H); free(cs); free(sn); free(g); free(y);
   return rc;
 }
 
