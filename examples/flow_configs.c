@@ -2,6 +2,8 @@
  * flow_configs.c -- the flow set-ups BASELINE.json lists as whole time steps on one GPU, from C:
  *   -config cavity   N x N x N/2 lid-driven cavity on [0,1]^2 x [0,0.5] (fluca/tests/cavity_flow/cavity_flow_3d.c)
  *   -config channel  N^3 channel on the unit cube: parabolic VELOCITY inlet, PRESSURE_OUTLET p = 0, no-slip walls, periodic span
+ *   -config cylinder the channel with an immersed cylinder of diameter 64 h along the periodic span (BASELINE config 5's body on
+ *                    one GPU: rings of markers one h apart, N rings -- 102 912 markers at N = 512)
  *   -config sphere   the channel with an immersed sphere of diameter 64 h at the centre (markers on a Fibonacci lattice,
  *                    spacing ~ h: L = 12 868), direct-forcing IBM active every step
  * Prints wall time and solver work per step.  Options of the mirror apply (-ns_time_step_size, -ns_max_steps,
@@ -70,7 +72,7 @@ static double now(void)
 int main(int argc, char **argv)
 {
   const char *config = opt(argc, argv, "-config", "cavity");
-  const int   cavity = !strcmp(config, "cavity"), sphere = !strcmp(config, "sphere");
+  const int   cavity = !strcmp(config, "cavity"), cylinder = !strcmp(config, "cylinder"), sphere = !strcmp(config, "sphere") || cylinder;
   if (!cavity && !sphere && strcmp(config, "channel")) {
     fprintf(stderr, "unknown -config %s\n", config);
     return 1;
@@ -113,10 +115,18 @@ int main(int argc, char **argv)
   if (sphere) {
     /* sphere of diameter 64 h: markers on a Fibonacci lattice, one per h^2 of surface; marker volume h^3 */
     const double h = 1. / (double)N, R = 32. * h, PI = 3.14159265358979323846, ga = PI * (3. - sqrt(5.));
-    L = (int64_t)llround(4. * PI * R * R / (h * h));
+    const int64_t ring = (int64_t)llround(2. * PI * R / h);
+    L = cylinder ? ring * P3 : (int64_t)llround(4. * PI * R * R / (h * h));
     double *X = (double *)malloc(sizeof(double) * 4 * (size_t)L);
     if (!X) return 1;
-    for (int64_t l = 0; l < L; ++l) {
+    for (int64_t l = 0; cylinder && l < L; ++l) { /* axis along z through (0.5, 0.5): one ring per cell layer, markers one h apart */
+      const double th = 2. * PI * ((double)(l % ring) + 0.5 * (double)((l / ring) & 1)) / (double)ring;
+      X[l]         = 0.5 + R * cos(th);
+      X[L + l]     = 0.5 + R * sin(th);
+      X[2 * L + l] = ((double)(l / ring) + 0.5) * h;
+      X[3 * L + l] = h * h * h;
+    }
+    for (int64_t l = 0; !cylinder && l < L; ++l) {
       const double z = 1. - 2. * ((double)l + 0.5) / (double)L, r = sqrt(1. - z * z), th = ga * (double)l;
       X[l]         = 0.5 + R * r * cos(th);
       X[L + l]     = 0.5 + R * r * sin(th);

@@ -640,3 +640,9 @@ def test_flow_config_driver_with_immersed_sphere(H):
     ke_c = float(re.search(r"mean kinetic energy (\S+)", run("channel").stdout).group(1))
     assert 0.0 < speed < 0.67          # below the mean speed of the parabolic inflow: the forcing holds the fluid back
     assert ke_s != ke_c                # and the flow differs from the empty channel
+    # BASELINE config 5's body: a cylinder of diameter 64 h along the periodic span, rings of markers one h apart
+    cyl = subprocess.run([exe, "-config", "cylinder", "-n", "128", "-ns_max_steps", "2", "-ns_ksp_type", "preonly", "-ns_abf_schur_pc_type", "mg"],
+                         capture_output=True, text=True, timeout=300)
+    assert cyl.returncode == 0, cyl.stdout + cyl.stderr
+    assert f"markers {201 * 128}" in cyl.stdout and cyl.stdout.count("step ") == 2
+    assert 0.0 < float(re.search(r"rms fluid speed at the markers (\S+)", cyl.stdout).group(1)) < 0.67
