@@ -675,6 +675,10 @@ int fl_apply_padded_dot(fl_poisson *h, double *xpad, double *ypad, double *xy)
   return 0;
 }
 
+// the scalar block handed over BY VALUE (kernel argument): nothing reads the host copy after the launch returns, so the next
+// smoother call may refill it while this one is still queued
+__global__ void k_scal_set(KspScal *dst, KspScal v) { *dst = v; }
+
 // nu Chebyshev(-Jacobi) steps on the handle's padded work vectors: right-hand side in h->r, initial guess in h->xp (taken as
 // zero when guess_zero), the result is left in h->xp (the two x buffers h->xp / h->P0 swap roles as needed).  No convergence
 // test, no null-space bookkeeping (a constant in x never reaches a residual: the caller projects once at the end), the host
@@ -707,7 +711,7 @@ int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero)
   S.ck        = S.mu;
   S.cheb_rho  = 0.;
   S.cheb_c    = S.scale;
-  FL_HIP(hipMemcpyAsync(h->scal, h->scal_host, sizeof(KspScal), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_scal_set, dim3(1), dim3(1), 0, s, h->scal, S);
   double    *X0 = h->xp, *X1 = h->P0, *B = h->r, *D = h->q;
   const bool ghosts = fl_any_ghost_exchange(h);
   auto       finl = [=](const double *partial, int nb, int stride, const double *sums) { hipLaunchKernelGGL(k_cheb_fin, dim3(1), dim3(256), 0, s, partial, nb, stride, sums, h->scal, h->hist, nhist); };
