@@ -437,6 +437,23 @@ __global__ void __launch_bounds__(256) k_mom_pw(GridP g, int64_t cs, const doubl
 }
 
 // y = a x + b z (z may be NULL; y may alias x or z)
+__global__ void __launch_bounds__(256) k_fill(int64_t n, double v, double *__restrict__ out)
+{
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) out[q] = v;
+}
+// out = 1 / in   (VecReciprocal)
+__global__ void __launch_bounds__(256) k_recip(int64_t n, const double *__restrict__ in, double *__restrict__ out)
+{
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) out[q] = 1. / in[q];
+}
+// y = (w - shift) .* x  [+ y]   (VecPointwiseMult with the scaling 1/a or 1/a - 1)
+__global__ void __launch_bounds__(256) k_scale_by(int64_t n, const double *__restrict__ w, double shift, const double *x, double *y, int add)
+{
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
+    const double t = (w[q] - shift) * x[q];
+    y[q]           = add ? y[q] + t : t;
+  }
+}
 __global__ void __launch_bounds__(256) k_lincomb(int64_t n, double a, const double *x, double b, const double *z, double *y)
 {
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) y[q] = a * x[q] + (z ? b * z[q] : 0.);
@@ -503,6 +520,10 @@ struct fl_momentum {
   double     *F = nullptr;   // 12 padded face fields: V0[0..2], v0interp[c*3+d] at 3 + c*3 + d
   double     *dg = nullptr;  // diag(A), 3 padded components (valid after set_state)
   double     *vec[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  // PCABF with schurainv / upperainv != ID (abfpc.c:81-94, 151-171): 1 / diag(A) or 1 / rowsum(A), scratch, FGMRES basis
+  int                   schur_ainv = FL_ABF_AINV_ID, upper_ainv = FL_ABF_AINV_ID;
+  double               *ainv[2] = {nullptr, nullptr}, *zV[3] = {nullptr, nullptr, nullptr}, *gv = nullptr;
+  std::vector<double *> gm;  // cell vectors of the Schur solve with a variable-coefficient S
   bool        have_state = false;
   int         tiles_x = 1, tiles_y = 1, nchunk = 1, zc = 1, nblocks = 1;  // 64 x 4 x zc tiles of the vector-update kernels
   int         anchunk = 1, azc = 1, ablocks = 1;                        // 64 x MOM_RY x azc tiles of k_mom_apply
@@ -651,6 +672,10 @@ extern "C" int fl_momentum_destroy(fl_momentum *m)
   if (m->F) (void)hipFree(m->F);
   if (m->dg) (void)hipFree(m->dg);
   for (double *v : m->vec)
+    if (v) (void)hipFree(v);
+  for (double *v : {m->ainv[0], m->ainv[1], m->zV[0], m->zV[1], m->zV[2], m->gv})
+    if (v) (void)hipFree(v);
+  for (double *v : m->gm)
     if (v) (void)hipFree(v);
   delete m;
   return FL_SUCCESS;
@@ -881,7 +906,217 @@ extern "C" int fl_abf_jacobian_mult(fl_momentum *m, const double *v_dev, const d
   return FL_SUCCESS;
 }
 
-// PCApply_ABF (abfpc.c:48-111) with upperainv = schurainv = ID, start to finish on the device
+// ------------------------------------------------------------------------------------------------ schurainv / upperainv
+// PC_ABF_AINV_DIAG / ROWSUM (abfpc.c:81-94, 151-171).  With a = diag(A) or A 1 and -R = (-T)(kappa G) + kappa Gst:
+//   S     = D ((-T) a^-1 kappa G - (-R)) = -D [ T ((a^-1 - 1) .* kappa G p) + kappa Gst p ]          (schurainv)
+//   stage 2: v = v* - a^-1 .* kappa G p ;  V = V* - T ((a^-1 - 1) .* kappa G p) - kappa Gst p          (upperainv)
+// S is then a variable-coefficient 13-point operator that changes every step.  It is applied as the composition of the
+// kernels that exist (cell gradient + staggered gradient, scaling, face interpolation, divergence) and solved by flexible
+// GMRES preconditioned with the constant-coefficient Schur solve (the ID operator: a = 1 + O(dt) keeps S close to it).  This is
+// the non-default option of the reference; the fused matrix-free path is the ID one.
+namespace {
+
+int nblk_flat(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 8192)); }
+
+// out (3 * cells, unpadded) = 1 / diag(A)  or  1 / (A 1)
+int compute_ainv(fl_momentum *m, int type, double **out)
+{
+  fl_poisson   *h = m->p;
+  const int64_t n3 = 3 * h->ncell;
+  if (!*out) FL_CHK(fl_dev_alloc(h, (void **)out, sizeof(double) * (size_t)n3, true));
+  if (type == FL_ABF_AINV_DIAG) FL_CHK(fl_momentum_diagonal(m, *out));  // MatGetDiagonal(A)
+  else FL_CHK(fl_momentum_rowsum(m, *out));                             // MatGetRowSum(A)
+  hipLaunchKernelGGL(k_recip, dim3(nblk_flat(n3)), dim3(256), 0, h->stream, n3, (const double *)*out, *out);  // VecReciprocal
+  return 0;
+}
+
+int ensure_ainv_scratch(fl_momentum *m)
+{
+  fl_poisson *h = m->p;
+  if (!m->gv) FL_CHK(fl_dev_alloc(h, (void **)&m->gv, sizeof(double) * 3 * (size_t)h->ncell, true));
+  for (int d = 0; d < 3; ++d)
+    if (!m->zV[d]) FL_CHK(fl_dev_alloc(h, (void **)&m->zV[d], sizeof(double) * (size_t)std::max<int64_t>(h->nface[d], 1), true));
+  return 0;
+}
+
+// y = S p with S = D ((-T) a^-1 kappa G - (-R)), a^-1 in m->ainv[0]
+int schur_apply_var(fl_momentum *m, const double *p, double *y)
+{
+  fl_poisson   *h = m->p;
+  const int64_t N = h->ncell, n3 = 3 * N;
+  FL_CHK(ensure_ainv_scratch(m));
+  FL_HIP(hipMemsetAsync(m->gv, 0, sizeof(double) * (size_t)n3, h->stream));
+  for (int d = 0; d < 3; ++d) FL_HIP(hipMemsetAsync(m->zV[d], 0, sizeof(double) * (size_t)h->nface[d], h->stream));
+  FL_CHK(fl_poisson_project(h, p, m->gv, m->gv + N, m->gv + 2 * N, m->zV[0], m->zV[1], m->zV[2]));      // gv = -kappa G p ; zV = -kappa Gst p
+  hipLaunchKernelGGL(k_scale_by, dim3(nblk_flat(n3)), dim3(256), 0, h->stream, n3, (const double *)m->ainv[0], 1., (const double *)m->gv, m->gv, 0);  // gv *= a^-1 - 1
+  FL_CHK(face_interp(m, 1., m->gv, m->zV, m->zV));                                                        // zV += T gv
+  FL_CHK(fl_poisson_rhs(h, m->zV[0], m->zV[1], m->zV[2], nullptr, y));                                    // y = -D zV
+  lincomb(h, N, -1., y, 0., nullptr, y);                                                                  // y = D zV = S p
+  return 0;
+}
+
+int dot_cells(fl_poisson *h, const double *x, const double *y, double *out)
+{
+  const int64_t n = h->ncell;
+  FL_CHK(fl_ensure_partials(h, 1024));
+  const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 1024));
+  hipLaunchKernelGGL(k_dot, dim3(nb), dim3(256), 0, h->stream, n, x, y, h->partial);
+  launch_reduce(h->stream, h->partial, nb, h->partial_stride, 1, h->sums);
+  if (h->multi) FL_CHK(h->comm.allreduce(h->stream, h->sums, NSLOT));
+  FL_HIP(hipMemcpyAsync(out, h->sums, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  FL_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// KSPSolve(kspS) for the variable-coefficient S: flexible GMRES(20), right preconditioner = the constant-coefficient Schur solve
+// with the caller's options (its tolerance loosened to 1e-2: the outer iteration is flexible).  Unpreconditioned residual
+// norm against opts->rtol / atol, zero initial guess.
+int schur_solve_var(fl_momentum *m, const double *b, double *x, const fl_ksp_opts *o, fl_ksp_stats *st)
+{
+  fl_poisson   *h = m->p;
+  const int64_t N = h->ncell;
+  constexpr int M = 20;
+  // vectors: V_0..V_M, Z_0..Z_{M-1}, w
+  while ((int)m->gm.size() < 2 * M + 2) {
+    double *v = nullptr;
+    FL_CHK(fl_dev_alloc(h, (void **)&v, sizeof(double) * (size_t)N, true));
+    m->gm.push_back(v);
+  }
+  double **V = m->gm.data(), **Z = m->gm.data() + M + 1, *w = m->gm[2 * M + 1];
+  fl_ksp_opts inner = *o;
+  inner.rtol        = std::max(o->rtol, 1e-2);
+  inner.history     = nullptr;
+  inner.nhistory    = 0;
+  fl_ksp_stats ist;
+  hipEvent_t   e0, e1;
+  FL_HIP(hipEventCreate(&e0));
+  FL_HIP(hipEventCreate(&e1));
+  FL_HIP(hipEventRecord(e0, h->stream));
+  double H[(M + 1) * M], cs[M], sn[M], g[M + 1], y[M];
+  double bnorm = 0., beta = 0.;
+  FL_CHK(dot_cells(h, b, b, &bnorm));
+  bnorm = std::sqrt(bnorm);
+  const double ttol = std::max(o->rtol * bnorm, o->atol);
+  FL_HIP(hipMemsetAsync(x, 0, sizeof(double) * (size_t)N, h->stream));
+  int    its = 0, reason = 0, nh = 0;
+  double rnorm = bnorm;
+  if (o->history && o->nhistory > 0) o->history[nh++] = bnorm;
+  bool first = true;
+  while (!reason) {
+    if (first) lincomb(h, N, 1., b, 0., nullptr, w);
+    else {
+      FL_CHK(schur_apply_var(m, x, w));
+      lincomb(h, N, -1., w, 1., b, w);  // r = b - S x
+    }
+    first = false;
+    FL_CHK(dot_cells(h, w, w, &beta));
+    beta  = std::sqrt(beta);
+    rnorm = beta;
+    if (std::isnan(beta)) { reason = FL_DIVERGED_NANORINF; break; }
+    if (beta <= ttol) { reason = beta < o->atol ? FL_CONVERGED_ATOL : FL_CONVERGED_RTOL; break; }
+    if (its >= o->maxit) { reason = FL_DIVERGED_ITS; break; }
+    lincomb(h, N, 1. / beta, w, 0., nullptr, V[0]);
+    std::fill(g, g + M + 1, 0.);
+    g[0] = beta;
+    int j = 0;
+    for (; j < M && its < o->maxit; ++j) {
+      FL_CHK(fl_poisson_solve(h, V[j], Z[j], &inner, &ist));  // z_j = S_ID^-1 v_j
+      if (ist.reason < 0 && ist.reason != FL_DIVERGED_ITS) { reason = ist.reason; break; }
+      FL_CHK(schur_apply_var(m, Z[j], w));                    // w = S z_j
+      for (int i = 0; i <= j; ++i) {                          // modified Gram-Schmidt
+        double hij;
+        FL_CHK(dot_cells(h, w, V[i], &hij));
+        H[i * M + j] = hij;
+        lincomb(h, N, 1., w, -hij, V[i], w);
+      }
+      double hn;
+      FL_CHK(dot_cells(h, w, w, &hn));
+      hn = std::sqrt(hn);
+      H[(j + 1) * M + j] = hn;
+      for (int i = 0; i < j; ++i) {
+        const double a = H[i * M + j], c = H[(i + 1) * M + j];
+        H[i * M + j]       = cs[i] * a + sn[i] * c;
+        H[(i + 1) * M + j] = -sn[i] * a + cs[i] * c;
+      }
+      {
+        const double a = H[j * M + j], c = H[(j + 1) * M + j], r = std::hypot(a, c);
+        cs[j] = r > 0. ? a / r : 1.;
+        sn[j] = r > 0. ? c / r : 0.;
+        H[j * M + j]       = r;
+        H[(j + 1) * M + j] = 0.;
+        g[j + 1]           = -sn[j] * g[j];
+        g[j]               = cs[j] * g[j];
+      }
+      ++its;
+      rnorm = std::fabs(g[j + 1]);
+      if (o->history && nh < o->nhistory) o->history[nh++] = rnorm;
+      if (rnorm <= ttol || hn == 0.) {
+        ++j;
+        break;
+      }
+      lincomb(h, N, 1. / hn, w, 0., nullptr, V[j + 1]);
+    }
+    for (int i = j - 1; i >= 0; --i) {  // y = H^-1 g ; x += Z y
+      double acc = g[i];
+      for (int k = i + 1; k < j; ++k) acc -= H[i * M + k] * y[k];
+      y[i] = acc / H[i * M + i];
+    }
+    for (int i = 0; i < j; ++i) lincomb(h, N, 1., x, y[i], Z[i], x);
+    if (reason) break;
+  }
+  FL_HIP(hipEventRecord(e1, h->stream));
+  FL_HIP(hipStreamSynchronize(h->stream));
+  float ms = 0.f;
+  FL_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  st->iters   = its;
+  st->reason  = reason;
+  st->rnorm0  = bnorm;
+  st->rnorm   = rnorm;
+  st->seconds = ms * 1e-3;
+  return 0;
+}
+
+}  // namespace
+
+// MatGetRowSum(A): A applied to the vector of ones (couplings between the components included)
+extern "C" int fl_momentum_rowsum(fl_momentum *m, double *out_dev)
+{
+  if (!m || !out_dev) return FL_ERR_ARG_NULL;
+  if (!m->have_state && m->mp.cC != 0.) return FL_ERR_ARG_WRONGSTATE;
+  fl_poisson   *h = m->p;
+  const int64_t n3 = 3 * h->ncell;
+  FL_HIP(hipSetDevice(h->device));
+  if (!m->tmpv) FL_CHK(fl_dev_alloc(h, (void **)&m->tmpv, sizeof(double) * (size_t)n3, true));
+  hipLaunchKernelGGL(k_fill, dim3(nblk_flat(n3)), dim3(256), 0, h->stream, n3, 1., m->tmpv);
+  return fl_momentum_apply(m, m->tmpv, out_dev);
+}
+
+extern "C" int fl_abf_set_ainv_types(fl_momentum *m, int schur_type, int upper_type)
+{
+  if (!m) return FL_ERR_ARG_NULL;
+  for (int t : {schur_type, upper_type})
+    if (t != FL_ABF_AINV_ID && t != FL_ABF_AINV_DIAG && t != FL_ABF_AINV_ROWSUM) return FL_ERR_SUP;  // "Unsupported Ainv type"
+  m->schur_ainv = schur_type;
+  m->upper_ainv = upper_type;
+  return FL_SUCCESS;
+}
+
+extern "C" int fl_abf_schur_apply(fl_momentum *m, const double *p_dev, double *y_dev)
+{
+  if (!m || !p_dev || !y_dev) return FL_ERR_ARG_NULL;
+  fl_poisson *h = m->p;
+  FL_HIP(hipSetDevice(h->device));
+  if (m->schur_ainv == FL_ABF_AINV_ID) return fl_poisson_apply(h, p_dev, y_dev);
+  if (!m->have_state && m->mp.cC != 0.) return FL_ERR_ARG_WRONGSTATE;
+  FL_CHK(compute_ainv(m, m->schur_ainv, &m->ainv[0]));
+  FL_CHK(schur_apply_var(m, p_dev, y_dev));
+  FL_HIP(hipGetLastError());
+  return FL_SUCCESS;
+}
+
+// PCApply_ABF (abfpc.c:48-111), start to finish on the device; schurainv / upperainv as set by fl_abf_set_ainv_types (default ID)
 extern "C" int fl_abf_apply(fl_momentum *m, const fl_ksp_opts *momentum_opts, const fl_ksp_opts *schur_opts, const double *momrhs_dev, const double *const interprhs_dev[3], const double *contrhs_dev,
                             double *v_dev, double *const V_dev[3], double *p_dev, fl_ksp_stats stats[2])
 {
@@ -893,10 +1128,24 @@ extern "C" int fl_abf_apply(fl_momentum *m, const fl_ksp_opts *momentum_opts, co
   FL_CHK(fl_momentum_solve(m, momrhs_dev, v_dev, momentum_opts, &stats[0]));                        /* :72     v* = A^-1 momrhs */
   FL_CHK(fl_momentum_face_interp(m, v_dev, interprhs_dev, V_dev));                                  /* :73-74  V* = interprhs + T v* */
   FL_CHK(fl_poisson_rhs(h, V_dev[0], V_dev[1], V_dev[2], contrhs_dev, m->srhs));                    /* :75-76  Srhs = contrhs - D V* */
-  FL_CHK(fl_poisson_solve(h, m->srhs, p_dev, schur_opts, &stats[1]));                               /* :77     p = S^-1 Srhs */
-  /* stage 2: the upper-triangular factor; (-T)(Gp) - (-R)p == -kappa Gst p, see DESIGN.md section 1 */
   const size_t N = (size_t)h->ncell;
-  return fl_poisson_project(h, p_dev, v_dev, v_dev + N, v_dev + 2 * N, V_dev[0], V_dev[1], V_dev[2]);   /* :80-101 */
+  if (m->schur_ainv == FL_ABF_AINV_ID) FL_CHK(fl_poisson_solve(h, m->srhs, p_dev, schur_opts, &stats[1]));   /* :77     p = S^-1 Srhs */
+  else {
+    FL_CHK(compute_ainv(m, m->schur_ainv, &m->ainv[0]));                                            /* :155-165 (PCSetUp: S follows A) */
+    FL_CHK(schur_solve_var(m, m->srhs, p_dev, schur_opts, &stats[1]));
+  }
+  /* stage 2: the upper-triangular factor; with upperainv = ID, (-T)(Gp) - (-R)p == -kappa Gst p, see DESIGN.md section 1 */
+  if (m->upper_ainv == FL_ABF_AINV_ID) return fl_poisson_project(h, p_dev, v_dev, v_dev + N, v_dev + 2 * N, V_dev[0], V_dev[1], V_dev[2]);   /* :80-101 */
+  FL_CHK(compute_ainv(m, m->upper_ainv, &m->ainv[1]));                                              /* :84-90 */
+  FL_CHK(ensure_ainv_scratch(m));
+  const int64_t n3 = 3 * (int64_t)N;
+  FL_HIP(hipMemsetAsync(m->gv, 0, sizeof(double) * (size_t)n3, h->stream));
+  FL_CHK(fl_poisson_project(h, p_dev, m->gv, m->gv + N, m->gv + 2 * N, V_dev[0], V_dev[1], V_dev[2]));     /* gv = -kappa G p ; V = V* - kappa Gst p */
+  hipLaunchKernelGGL(k_scale_by, dim3(nblk_flat(n3)), dim3(256), 0, h->stream, n3, (const double *)m->ainv[1], 0., (const double *)m->gv, v_dev, 1);   /* v = v* - a^-1 kappa G p  (:91,95) */
+  hipLaunchKernelGGL(k_scale_by, dim3(nblk_flat(n3)), dim3(256), 0, h->stream, n3, (const double *)m->ainv[1], 1., (const double *)m->gv, m->gv, 0);  /* gv = -(a^-1 - 1) kappa G p */
+  FL_CHK(face_interp(m, 1., m->gv, V_dev, V_dev));                                                  /* V -= T ((a^-1 - 1) kappa G p)  (:96-101) */
+  FL_HIP(hipGetLastError());
+  return FL_SUCCESS;
 }
 
 // ------------------------------------------------------------------------------------------------ device BLAS-1 for hosts

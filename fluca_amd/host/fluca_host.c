@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <strings.h>
 
 /* positive PETSC_ERR_* values */
 enum { E_MEM = 55, E_SUP = 56, E_ARG_WRONG = 62, E_ARG_OUTOFRANGE = 63, E_ARG_WRONGSTATE = 73, E_ARG_NULL = 85, E_ARG_UNKNOWN_TYPE = 86, E_ARG_TYPENOTSET = 89 };
@@ -439,6 +440,7 @@ struct _p_NS {
   double              *ibm_U;
   fl_ksp_opts          schur;    /* -ns_abf_schur_* */
   fl_ksp_opts          mom;      /* -ns_abf_momentum_* */
+  int                  schur_ainv, upper_ainv; /* -ns_pc_abf_schur_ainv_type / -ns_pc_abf_upper_ainv_type (PCABFAinvType), default ID */
   int                  ksp_type;           /* -ns_ksp_type: 0 richardson, 1 preonly, 2 gmres (the reference's default, nssol.c:21-29) */
   int                  gmres_restart;      /* -ns_ksp_gmres_restart (PETSc default 30) */
   double               ksp_rtol, ksp_atol; /* -ns_ksp_rtol 1e-5 (nssol.c:24), unpreconditioned norm (nssol.c:25) */
@@ -634,8 +636,20 @@ FlErrorCode NSSetFromOptions(NS ns, int argc, char **argv)
   if (opt_real(argc, argv, "-ns_abf_momentum_ksp_atol", &v)) ns->mom.atol = v;
   if (opt_real(argc, argv, "-ns_abf_momentum_ksp_divtol", &v)) ns->mom.dtol = v;
   if (opt_int64(argc, argv, "-ns_abf_momentum_ksp_max_it", &iv)) ns->mom.maxit = (int)iv;
-  if ((s = opt_find(argc, argv, "-ns_pc_abf_schur_ainv_type"))) /* abfpc.c:246: only ID is built */
-    if (strcmp(s, "ID") && strcmp(s, "id")) return E_SUP;
+  /* PCABFAinvType of the Schur complement and of the upper-triangular solve (abfpc.c:246-247; PetscOptionsEnum matches the
+   * names without regard to case) */
+  {
+    const char *names[2] = {"-ns_pc_abf_schur_ainv_type", "-ns_pc_abf_upper_ainv_type"};
+    int        *dst[2]   = {&ns->schur_ainv, &ns->upper_ainv};
+    for (int q = 0; q < 2; ++q)
+      if ((s = opt_find(argc, argv, names[q]))) {
+        if (!strcasecmp(s, "ID")) *dst[q] = FL_ABF_AINV_ID;
+        else if (!strcasecmp(s, "DIAG")) *dst[q] = FL_ABF_AINV_DIAG;
+        else if (!strcasecmp(s, "ROWSUM")) *dst[q] = FL_ABF_AINV_ROWSUM;
+        else return E_ARG_UNKNOWN_TYPE;
+      }
+    if (ns->momentum) FLABI(fl_abf_set_ainv_types(ns->momentum, ns->schur_ainv, ns->upper_ainv));
+  }
   return ns->ops->setfromoptions ? ns->ops->setfromoptions(ns, argc, argv) : 0;
 }
 
@@ -860,7 +874,10 @@ FlErrorCode NSSetPreviousState(NS ns, const double *const V0[3], const double *c
 {
   if (!ns || !V0 || !v0interp) return E_ARG_NULL;
   if (!ns->setupcalled) return E_ARG_WRONGSTATE;
-  if (!ns->momentum) FLABI(fl_momentum_create(ns->poisson, &ns->momentum));
+  if (!ns->momentum) {
+    FLABI(fl_momentum_create(ns->poisson, &ns->momentum));
+    FLABI(fl_abf_set_ainv_types(ns->momentum, ns->schur_ainv, ns->upper_ainv));
+  }
   FLABI(fl_momentum_set_state(ns->momentum, ns->dt, ns->rho, ns->mu, V0, v0interp));
   return 0;
 }
@@ -1302,7 +1319,10 @@ static FlErrorCode NSStep_CNLinear(NS ns)
   fl_poisson   *h = ns->poisson;
   const int64_t N = c->sz[0];
   const double  dt = ns->dt, t = ns->t, cv = 0.5 * ns->mu * dt / ns->rho;
-  if (!ns->momentum) FLABI(fl_momentum_create(h, &ns->momentum));
+  if (!ns->momentum) {
+    FLABI(fl_momentum_create(h, &ns->momentum));
+    FLABI(fl_abf_set_ainv_types(ns->momentum, ns->schur_ainv, ns->upper_ainv));
+  }
   /* NSStep: VecCopy(sol, sol0), nsbasic.c:281-282 */
   FLABI(fl_vec_lincomb(h, 3 * N, 1., c->sol_v, 0., NULL, c->sol0_v));
   FLABI(fl_vec_lincomb(h, N, 1., c->sol_p, 0., NULL, c->sol0_p));

@@ -307,6 +307,24 @@ class Momentum:
         self.p._post()
         return d
 
+    def rowsum(self):
+        d = self.p.empty(3 * self.p.ncell)
+        self.p._pre()
+        check(lib.fl_momentum_rowsum(self.h, _ptr(d)), "fl_momentum_rowsum")
+        self.p._post()
+        return d
+
+    def set_ainv_types(self, schur=0, upper=0):
+        """PCABFSetSchurComplementAinvType / PCABFSetUpperTriangularAinvType: 0 ID, 1 DIAG, 2 ROWSUM"""
+        check(lib.fl_abf_set_ainv_types(self.h, int(schur), int(upper)), "fl_abf_set_ainv_types")
+
+    def schur_apply(self, p):
+        y = self.p.empty()
+        self.p._pre()
+        check(lib.fl_abf_schur_apply(self.h, _ptr(p), _ptr(y)), "fl_abf_schur_apply")
+        self.p._post()
+        return y
+
     def solve(self, b, x=None, opts=None, history=False, **kw):
         kw.setdefault("type", capi.KSP_BCGS)
         opts = opts or KspOptions(**kw)

@@ -251,12 +251,24 @@ int fl_momentum_rhs(fl_momentum *m, double dt, double rho, double mu, const doub
  * v_dev (3*cells, component-major), V_dev[3] (faces) and p_dev (cells) are outputs; interprhs_dev / contrhs_dev may be
  * NULL = 0.  stats[0] = KSPSolve(kspA), stats[1] = KSPSolve(kspS).  A non-converged inner solve is reported in stats,
  * not as an error (PETSc's behaviour without -ksp_error_if_not_converged). */
+
 /* MatMult of the 3 x 3 block Jacobian the preconditioner belongs to (MatNest of cnlinearcart3d.c:2885-2941), for an outer
  * Krylov method that keeps its vectors on the device:
  *   fv = A v + kappa G p ;  fV = V - T v - R p,  -R = (-T)(kappa G) + kappa Gst ;  fp = D V */
 int fl_abf_jacobian_mult(fl_momentum *m, const double *v_dev, const double *const V_dev[3], const double *p_dev, double *fv_dev, double *const fV_dev[3], double *fp_dev);
 int fl_abf_apply(fl_momentum *m, const fl_ksp_opts *momentum_opts, const fl_ksp_opts *schur_opts, const double *momrhs_dev, const double *const interprhs_dev[3], const double *contrhs_dev, double *v_dev,
                  double *const V_dev[3], double *p_dev, fl_ksp_stats stats[2]);
+/* PCABFAinvType (flucans.h:99-103): the approximation of A^-1 inside the Schur complement (PCABFSetSchurComplementAinvType,
+ * -pc_abf_schur_ainv_type) and inside the upper-triangular solve (PCABFSetUpperTriangularAinvType, -pc_abf_upper_ainv_type).
+ * ID is the default (abfpc.c:328-329) and the fused matrix-free path; DIAG / ROWSUM make S a variable-coefficient operator
+ * that follows A (abfpc.c:155-165): applied as a composition of kernels and solved by flexible GMRES preconditioned with
+ * the ID Schur solve. */
+enum { FL_ABF_AINV_ID = 0, FL_ABF_AINV_DIAG = 1, FL_ABF_AINV_ROWSUM = 2 };
+int fl_abf_set_ainv_types(fl_momentum *m, int schur_type, int upper_type);
+/* y = S p with the current schurainv type: MatMult(abf->S) */
+int fl_abf_schur_apply(fl_momentum *m, const double *p_dev, double *y_dev);
+/* MatGetRowSum(A) into 3*cells doubles (component-major), like fl_momentum_diagonal */
+int fl_momentum_rowsum(fl_momentum *m, double *out_dev);
 
 /* ---- immersed boundary (build-defined; no reference function) -------------------------------- */
 typedef enum { FL_DELTA_PESKIN4 = 0, FL_DELTA_ROMA3 = 1 } fl_delta_kind;

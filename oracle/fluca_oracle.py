@@ -430,6 +430,38 @@ class MgOracle:
         return proj(x), dict(iters=it, reason=reason, history=np.array(hist))
 
 
+AINV_ID, AINV_DIAG, AINV_ROWSUM = 0, 1, 2   # PCABFAinvType, flucans.h:99-103
+
+
+def abf_ainv(A, kind):
+    """abfpc.c:84-90 / 155-160: MatGetDiagonal or MatGetRowSum of A, then VecReciprocal.  A: the Csr of assemble_momentum."""
+    a = A.diag() if kind == AINV_DIAG else A.mult(np.ones(A.nrow))
+    return 1.0 / a
+
+
+def abf_schur_apply(g, ainv, p):
+    """S p with S = D ((-T) diag(ainv) kappa G - (-R)) and -R = (-T)(kappa G) + kappa Gst, term by term as PCSetUp_ABF
+    forms it (abfpc.c:161-170; cnlinearcart3d.c:2909-2911).  ainv = None is the ID type."""
+    kGp = np.concatenate(g.apply_G(p))
+    t1 = g.apply_T(kGp if ainv is None else ainv * kGp)      # T (a^-1 kappa G p)
+    t2 = g.apply_T(kGp)
+    kGst = g.apply_gst(p)
+    tmp = [-t1[d] + t2[d] - kGst[d] for d in range(3)]
+    return -g.rhs(*tmp)                                       # D tmp  (rhs = contrhs - D V)
+
+
+def abf_schur_dense(g, ainv):
+    """the assembled S of the DIAG / ROWSUM types, dense (small grids only): column j = S e_j"""
+    n = g.ncell
+    S = np.empty((n, n))
+    e = np.zeros(n)
+    for j in range(n):
+        e[j] = 1.0
+        S[:, j] = abf_schur_apply(g, ainv, e)
+        e[j] = 0.0
+    return S
+
+
 class StepOracle:
     """CPU restatement of one CNLinear time step (NSStep_CNLinear_Cart3d_Internal, NSFormJacobian, NSFormFunction:
     cnlinearcart3d.c:2807-3060) for VELOCITY / PERIODIC / SYMMETRY boundaries, composed from the oracle's operators:

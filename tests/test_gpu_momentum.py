@@ -197,6 +197,91 @@ def test_pcapply_abf_matches_composed_oracle(n, bc, nonuni):
     P.close()
 
 
+def _state(M, g, mu=0.05):
+    """a momentum state with a noticeably non-unit diagonal: dt of the pair's kappa, V0 / v0interp scaled up"""
+    V0, W = _fields(g)
+    V0, W = [8.0 * a for a in V0], [8.0 * a for a in W]
+    rho = 1.0
+    dt = g.kappa * rho
+    M.set_state(dt, rho, mu, [dev(a) for a in V0], [dev(a) for a in W])
+    return g.assemble_momentum(1.0, dt, -0.5 * mu * dt / rho, V0, W)
+
+
+@pytest.mark.parametrize("n,bc,nonuni", [CASES[0], CASES[2], CASES[3], CASES[5]])
+@pytest.mark.parametrize("kind", [fo.AINV_DIAG, fo.AINV_ROWSUM])
+def test_schur_complement_of_the_diag_and_rowsum_types(n, bc, nonuni, kind):
+    """fl_abf_schur_apply == S = D ((-T) a^-1 kappa G - (-R)) of PCSetUp_ABF (abfpc.c:151-171), a = diag(A) or A 1."""
+    P, M, g = _pair(n, bc, nonuni)
+    A = _state(M, g)
+    _close(host(M.rowsum()), A.mult(np.ones(3 * g.ncell)))                       # MatGetRowSum
+    ainv = fo.abf_ainv(A, kind)
+    assert np.abs(1.0 / ainv - 1.0).max() > 1e-2                                 # the variant is not the ID operator in disguise
+    p = np.random.default_rng(17).standard_normal(g.ncell)
+    M.set_ainv_types(schur=kind)
+    want = fo.abf_schur_apply(g, ainv, p)
+    # the oracle forms -T(a^-1 kGp) + T(kGp) term by term like MatMatMult + MatAXPY; the device scales by (a^-1 - 1) once: the two
+    # differ by the cancellation in the former, relative to the size of the cancelling terms (larger than the result on stretched grids)
+    _close(host(M.schur_apply(dev(p))), want, tol=2e-10)
+    M.set_ainv_types(schur=fo.AINV_ID)                                           # ID: the 7-point operator of the hot path
+    _close(host(M.schur_apply(dev(p))), g.assemble_S().mult(p), tol=2e-13)
+    _close(fo.abf_schur_apply(g, None, p), g.assemble_S().mult(p), tol=1e-9)     # and the oracle's composition cancels to it (abfpc.c:152-154,169)
+    M.close()
+    P.close()
+
+
+@pytest.mark.parametrize("n,bc,nonuni", [((9, 8, 7), CAVITY, True), CASES[2], CASES[4]])
+@pytest.mark.parametrize("schur,upper", [(fo.AINV_DIAG, fo.AINV_DIAG), (fo.AINV_ROWSUM, fo.AINV_ID), (fo.AINV_ID, fo.AINV_ROWSUM)])
+def test_pcapply_abf_with_diag_and_rowsum_types(n, bc, nonuni, schur, upper):
+    """PCApply_ABF with -pc_abf_schur_ainv_type / -pc_abf_upper_ainv_type != ID (abfpc.c:81-101, 151-171) against the oracle's
+    composition with the assembled (dense) S of that type."""
+    from fluca_amd import capi
+    from fluca_amd.poisson import KspOptions
+    P, M, g = _pair(n, bc, nonuni)
+    A = _state(M, g)
+    rng = np.random.default_rng(5)
+    momrhs = rng.standard_normal(3 * g.ncell)
+    interprhs = [1e-2 * rng.standard_normal(g.nface[d]) for d in range(3)]
+    nullspace = O not in bc
+    if nullspace:
+        fshape = [(n[2], n[1], g.nf[0]), (n[2], g.nf[1], n[0]), (g.nf[2], n[1], n[0])]
+        for d in range(3):
+            if not g.periodic[d]:
+                a = interprhs[d].reshape(fshape[d])
+                sl = [slice(None)] * 3
+                sl[2 - d] = [0, -1]
+                a[tuple(sl)] = 0.0
+    vs, _ = A.solve(momrhs, ksp=fo.KSP_BCGS, pc=fo.PC_JACOBI, nullspace=False, rtol=1e-12, maxit=500)
+    Vs = g.apply_T(vs, interprhs)
+    srhs = g.rhs(*Vs)
+    if schur == fo.AINV_ID:
+        po, _ = g.assemble_S().solve(srhs, ksp=fo.KSP_BCGS, pc=fo.PC_JACOBI, nullspace=nullspace, rtol=1e-12, maxit=5000)
+    else:
+        Sd = fo.abf_schur_dense(g, fo.abf_ainv(A, schur))
+        po = np.linalg.lstsq(Sd, srhs, rcond=1e-12)[0] if nullspace else np.linalg.solve(Sd, srhs)
+        assert np.linalg.norm(Sd @ po - srhs) <= 1e-9 * np.linalg.norm(srhs)       # the right-hand side is consistent
+    kGp = np.concatenate(g.apply_G(po))
+    w = kGp if upper == fo.AINV_ID else fo.abf_ainv(A, upper) * kGp               # :80-94
+    Tw, TkGp, kGst = g.apply_T(w), g.apply_T(kGp), g.apply_gst(po)
+    v_ref = vs - w                                                                 # :95
+    V_ref = [Vs[d] - Tw[d] + TkGp[d] - kGst[d] for d in range(3)]                 # :96-101
+    M.set_ainv_types(schur=schur, upper=upper)
+    v, Vf, p, info = M.abf_apply(dev(momrhs), [dev(r) for r in interprhs], None,
+                                 momentum=KspOptions(type=capi.KSP_BCGS, rtol=1e-12, maxit=500),
+                                 schur=KspOptions(type=capi.KSP_BCGS, rtol=1e-11, maxit=5000, remove_nullspace=int(nullspace)))
+    assert info[0]["reason"] > 0 and info[1]["reason"] > 0, info
+    if schur != fo.AINV_ID:
+        assert info[1]["iters"] <= 40, info[1]       # the constant-coefficient solve is a good preconditioner for the variable one
+    pg = host(p)
+    if nullspace:
+        pg, po = pg - pg.mean(), po - po.mean()
+    assert np.linalg.norm(pg - po) <= 1e-7 * np.linalg.norm(po)
+    assert np.linalg.norm(host(v) - v_ref) <= 1e-7 * np.linalg.norm(v_ref)
+    for d in range(3):
+        assert np.linalg.norm(host(Vf[d]) - V_ref[d]) <= 1e-7 * max(np.linalg.norm(V_ref[d]), 1e-30)
+    M.close()
+    P.close()
+
+
 @pytest.mark.parametrize("n,bc,nonuni", [CASES[0], CASES[1], CASES[3]])
 def test_block_jacobian_mult(n, bc, nonuni):
     """fl_abf_jacobian_mult == the MatNest product of cnlinearcart3d.c:2885-2941 composed from the oracle's operators."""

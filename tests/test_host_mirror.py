@@ -100,8 +100,10 @@ def test_ns_registry_options_and_state_errors(H):
     assert (o.contents.type, o.contents.pc, o.contents.rtol, o.contents.maxit) == (1, 0, 1e-8, 77)
     argc, av = H.argv("-ns_abf_schur_ksp_type", "gmres")
     assert H.lib.NSSetFromOptions(ns, argc, av) == H.ERR_ARG_UNKNOWN_TYPE
-    argc, av = H.argv("-ns_pc_abf_schur_ainv_type", "DIAG")
-    assert H.lib.NSSetFromOptions(ns, argc, av) == H.ERR_SUP
+    argc, av = H.argv("-ns_pc_abf_schur_ainv_type", "DIAG", "-ns_pc_abf_upper_ainv_type", "rowsum")     # PCABFAinvType: ID, DIAG, ROWSUM
+    assert H.lib.NSSetFromOptions(ns, argc, av) == 0
+    argc, av = H.argv("-ns_pc_abf_schur_ainv_type", "lumped")
+    assert H.lib.NSSetFromOptions(ns, argc, av) == H.ERR_ARG_UNKNOWN_TYPE
     assert H.lib.NSStep(ns) == H.ERR_ARG_WRONGSTATE                    # before NSSetUp
     argc, av = H.argv("-ns_ksp_type", "fgmres")                        # outer KSP: gmres (default), richardson, preonly
     assert H.lib.NSSetFromOptions(ns, argc, av) == H.ERR_SUP
@@ -449,7 +451,9 @@ def test_c_cavity_driver_writes_cgns_like_the_reference_options(H, tmp_path):
 
 
 @pytest.mark.gpu
-def test_nsstep_matches_the_oracle_step(H):
+@pytest.mark.parametrize("ainv", [(), ("-ns_pc_abf_schur_ainv_type", "DIAG", "-ns_pc_abf_upper_ainv_type", "DIAG"),
+                                  ("-ns_pc_abf_schur_ainv_type", "rowsum")])
+def test_nsstep_matches_the_oracle_step(H, ainv):
     """Velocity, face velocity and pressure after two lid-driven-cavity steps: the C mirror on the GPU vs the CPU oracle's
     composition of the same reference formulas (StepOracle), including the wall terms of L, C, B and T."""
     from oracle import fluca_oracle as fo
@@ -483,7 +487,8 @@ def test_nsstep_matches_the_oracle_step(H):
     assert H.lib.NSSetBoundaryCondition(ns, idx[H.MESHCART_UP], H.NSBoundaryCondition(type=H.NS_BC_VELOCITY, velocity=moving)) == 0
     assert H.lib.NSSetBoundaryCondition(ns, idx[H.MESHCART_BACK], H.NSBoundaryCondition(type=H.NS_BC_SYMMETRY)) == 0
     argc, av = H.argv("-ns_time_step_size", dt, "-ns_max_steps", 2, "-ns_ksp_rtol", 1e-9, "-ns_abf_schur_ksp_rtol", 1e-10,
-                      "-ns_abf_momentum_ksp_rtol", 1e-10, "-ns_abf_schur_ksp_max_it", 20000)
+                      "-ns_abf_momentum_ksp_rtol", 1e-10, "-ns_abf_schur_ksp_max_it", 20000, *ainv)
+    # the Ainv types only change the preconditioner: the converged step is the same
     assert H.lib.NSSetFromOptions(ns, argc, av) == 0 and H.lib.NSSetUp(ns) == 0
     assert H.lib.NSSolve(ns) == 0
     v, p, Vp = P(), P(), (C.c_void_p * 3)()
