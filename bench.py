@@ -60,10 +60,53 @@ def cpu_baseline(sample_n, iters):
     except Exception as e:  # noqa: BLE001  (never lose the bench line over the cross-check)
         parity = {"error": repr(e)}
     return {"value": its_per_s * (sample_n ** 3) / 512.0 ** 3, "unit": "512^3-equivalent PCG iterations/s", "parity_on_sample": parity,
-            "cores": fo.num_threads(), "kind": "port",
+            "cores": fo.num_threads(), "kind": "port", "petsc_cpu": petsc_cpu(sample_n, iters, fo.num_threads()),
             "sample": f"{sample_n}^3 cavity grid (1/{(512 // sample_n) ** 3} of the cells), {info['iters']} Jacobi-PCG iterations, "
                       f"assembled CSR (AIJ cost model), {info['seconds']:.2f} s, raw {its_per_s:.3f} it/s on the sample",
             "host_GBps_at_104B_per_row": 104.0 * sample_n ** 3 * its_per_s / 1e9}
+
+
+def petsc_cpu(sample_n, iters, cores):
+    """SURVEY 8(d), opportunistic true-reference timing: where a PETSc installation exists, compile oracle/petsc_cg_driver.c
+    (the same S as AIJ, KSPCG + PCJACOBI, fixed iteration count) and run it on the host cores.  Returns a dict with the rate,
+    or a string saying why there is no number (this image ships no PETSc)."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    src = os.path.join(ROOT, "oracle", "petsc_cg_driver.c")
+    flags = None
+    pd, arch = os.environ.get("PETSC_DIR"), os.environ.get("PETSC_ARCH", "")
+    for root in ([os.path.join(pd, arch), pd] if pd else []):
+        if os.path.exists(os.path.join(root, "lib", "libpetsc.so")):
+            incs = {os.path.join(pd, "include"), os.path.join(root, "include")}
+            flags = [f"-I{i}" for i in sorted(incs)] + [f"-L{root}/lib", f"-Wl,-rpath,{root}/lib", "-lpetsc", "-lm"]
+            break
+    if flags is None and shutil.which("pkg-config"):
+        for name in ("PETSc", "petsc"):
+            if subprocess.run(["pkg-config", "--exists", name]).returncode == 0:
+                flags = subprocess.run(["pkg-config", "--cflags", "--libs", name], capture_output=True, text=True).stdout.split() + ["-lm"]
+                break
+    if flags is None:
+        return "unavailable (no PETSC_DIR with lib/libpetsc.so, no pkg-config PETSc)"
+    cc = shutil.which("mpicc") or shutil.which("cc") or "gcc"
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            exe = os.path.join(tmp, "petsc_cg_driver")
+            r = subprocess.run([cc, "-O2", src, "-o", exe] + flags, capture_output=True, text=True, timeout=300)
+            if r.returncode != 0:
+                return "unavailable (driver did not compile: " + r.stderr.strip().splitlines()[-1][:200] + ")"
+            mpi = shutil.which("mpiexec") or shutil.which("mpirun")
+            cmd = ([mpi, "-n", str(cores)] if mpi else []) + [exe, "-n", str(sample_n), "-its", str(iters), "-kappa", "1e-3"]
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+            m = re.search(r"FLUCA_PETSC n=(\d+) ranks=(\d+) its=(\d+) seconds=(\S+) rnorm=(\S+)", r.stdout)
+            if not m:
+                return "unavailable (driver failed: " + (r.stderr.strip().splitlines() or ["no output"])[-1][:200] + ")"
+            its, sec = int(m.group(3)), float(m.group(4))
+            return {"value": its / sec * (sample_n ** 3) / 512.0 ** 3, "unit": "512^3-equivalent PCG iterations/s", "kind": "reference library (PETSc KSPCG + PCJACOBI, AIJ)",
+                    "ranks": int(m.group(2)), "sample": f"{sample_n}^3, {its} iterations, {sec:.2f} s"}
+    except Exception as e:  # noqa: BLE001
+        return f"unavailable ({e!r})"
 
 
 def main():
