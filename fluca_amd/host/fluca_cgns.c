@@ -515,6 +515,7 @@ struct _p_FlucaViewerCGNS {
   char    *tmpl;     /* filename or template */
   int      is_template, batch_size;
   char     mode;
+  int      rank;     /* of the NS that wrote last */
   char    *filename; /* the file being written (NULL: none open) */
   char    *lastname;
   int64_t  last_step;
@@ -571,13 +572,11 @@ static FlErrorCode viewer_close_file(FlucaViewerCGNS v, int rank)
   return rc;
 }
 
-static int viewer_rank = 0; /* rank of the last NS that used a viewer: FlucaViewerCGNSDestroy has no NS argument */
-
 FlErrorCode FlucaViewerCGNSDestroy(FlucaViewerCGNS *viewer)
 {
   if (!viewer || !*viewer) return 0;
   FlucaViewerCGNS   v = *viewer;
-  const FlErrorCode rc = v->mode == 'w' ? viewer_close_file(v, viewer_rank) : 0;
+  const FlErrorCode rc = v->mode == 'w' ? viewer_close_file(v, v->rank) : 0;
   free(v->tmpl);
   free(v->filename);
   free(v->lastname);
@@ -641,7 +640,7 @@ FlErrorCode NSViewSolution(NS ns, FlucaViewerCGNS v)
   FLCHK(NSGetTimeStep(ns, &step));
   FLCHK(NSGetTime(ns, &t));
   FLCHK(NSGetDevice(ns, &device));
-  viewer_rank = lay.rank;
+  v->rank = lay.rank; /* FlucaViewerCGNSDestroy has no NS argument: it closes the file as this rank */
   if (v->last_step == step && v->filename) return 0; /* this step is in the file already (cgv->sol stays set, cartcgns.c:336) */
 
   /* PetscViewerFlucaCGNSCheckBatch_Internal, flucacgns.c:104-115 */
