@@ -429,6 +429,7 @@ struct _p_NS {
   char                 type_name[32];
   double               rho, mu, dt, t;
   int64_t              step, max_steps;
+  double               max_time; /* nsbasic.c:30: PETSC_MAX_REAL = not set */
   Mesh                 mesh;
   NSBoundaryCondition *bcs;
   int                  nb, device, setupcalled;
@@ -474,6 +475,7 @@ FlErrorCode NSCreate(NS *ns)
   n->mu  = 1.;
   n->dt  = 0.;
   n->max_steps = -1;
+  n->max_time  = 1.7976931348623157e308;
   fl_ksp_opts_default(&n->schur);
   fl_ksp_opts_default(&n->mom);
   n->mom.type = FL_KSP_BCGS; /* PETSc's own default for kspA is gmres + ilu: neither has a matrix-free form here */
@@ -547,6 +549,18 @@ FlErrorCode NSSetTimeStepSize(NS ns, double dt)
   ns->dt = dt;
   return 0;
 }
+FlErrorCode NSSetMaxTime(NS ns, double max_time) /* nsopts.c:111-117 */
+{
+  if (!ns) return E_ARG_NULL;
+  ns->max_time = max_time;
+  return 0;
+}
+FlErrorCode NSGetMaxTime(NS ns, double *max_time)
+{
+  if (!ns) return E_ARG_NULL;
+  if (max_time) *max_time = ns->max_time;
+  return 0;
+}
 FlErrorCode NSSetMaxSteps(NS ns, int64_t max_steps)
 {
   if (!ns) return E_ARG_NULL;
@@ -581,6 +595,7 @@ FlErrorCode NSSetFromOptions(NS ns, int argc, char **argv)
   if (opt_real(argc, argv, "-ns_viscosity", &v)) FLCHK(NSSetViscosity(ns, v));
   if (opt_real(argc, argv, "-ns_time_step_size", &v)) FLCHK(NSSetTimeStepSize(ns, v));
   if (opt_int64(argc, argv, "-ns_max_steps", &iv)) ns->max_steps = iv;
+  if (opt_real(argc, argv, "-ns_max_time", &v)) ns->max_time = v; /* nsopts.c:186 */
   /* sub-KSP of the Schur complement: prefix ns_ + abf_schur_ (nssol.c:19, abfpc.c:206) */
   if ((s = opt_find(argc, argv, "-ns_abf_schur_ksp_type"))) {
     if (!strcmp(s, "cg")) ns->schur.type = FL_KSP_CG;
@@ -727,11 +742,12 @@ FlErrorCode NSMonitor(NS ns)
   return 0;
 }
 
-FlErrorCode NSSolve(NS ns) /* nsbasic.c:325-350: monitor, step, ... until -ns_max_steps, monitor once more */
+FlErrorCode NSSolve(NS ns) /* nsbasic.c:325-350: monitor, step, ... until -ns_max_steps or -ns_max_time, monitor once more */
 {
   if (!ns) return E_ARG_NULL;
-  if (ns->max_steps < 0) return E_ARG_WRONGSTATE; /* "At least one of max time or max steps must be specified" */
-  while (ns->step < ns->max_steps) {
+  if (ns->max_steps < 0 && !(ns->max_time < 1.7976931348623157e308)) return E_ARG_WRONGSTATE; /* "At least one of max time or max steps must be specified" */
+  const int64_t max_steps = ns->max_steps < 0 ? INT64_MAX : ns->max_steps;
+  while (ns->step < max_steps && ns->t < ns->max_time) { /* NS_CONVERGED_ITS, else NS_CONVERGED_TIME (:333-334, :342-343) */
     FLCHK(NSMonitor(ns));
     FLCHK(NSStep(ns));
     if (ns->reason < 0) return 91; /* PETSC_ERR_NOT_CONVERGED: "NSStep has failed" */

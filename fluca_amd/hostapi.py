@@ -52,6 +52,7 @@ PROTOTYPES = {
     "MeshCartGetCoordinateArraysRead": [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)], "MeshGetRank": [_P, _ip, _ip],
     "NSGetPressureHalfStep": [_P, C.POINTER(_P)], "NSGetMesh": [_P, C.POINTER(_P)], "NSGetDevice": [_P, _ip],
     "NSSetTimeStepAndTime": [_P, C.c_int64, C.c_double], "NSBarrier": [_P],
+    "NSSetMaxTime": [_P, C.c_double], "NSGetMaxTime": [_P, C.POINTER(C.c_double)],
     "NSMonitorSet": [_P, _P, _P, _P], "NSMonitorCancel": [_P], "NSMonitor": [_P],
 }
 MonitorFunc = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)

@@ -98,6 +98,8 @@ FlErrorCode NSSetDensity(NS ns, double rho);
 FlErrorCode NSSetViscosity(NS ns, double mu);
 FlErrorCode NSSetTimeStepSize(NS ns, double dt);
 FlErrorCode NSSetMaxSteps(NS ns, int64_t max_steps);
+FlErrorCode NSSetMaxTime(NS ns, double max_time); /* -ns_max_time; NSSolve stops at whichever of the two comes first (nsbasic.c:333-334) */
+FlErrorCode NSGetMaxTime(NS ns, double *max_time);
 FlErrorCode NSSetBoundaryCondition(NS ns, int index, NSBoundaryCondition bc);
 FlErrorCode NSGetBoundaryCondition(NS ns, int index, NSBoundaryCondition *bc);
 FlErrorCode NSSetFromOptions(NS ns, int argc, char **argv);

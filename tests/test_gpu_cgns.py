@@ -170,3 +170,17 @@ def test_monitor_writes_batches_of_steps(H, tmp_path):
         assert G.FlucaCGNSReadCellField(f, C.byref(lay), first, b"Pressure", a.ctypes.data) == 0
     assert G.FlucaCGNSReadCellField(f, C.byref(lay), 3, b"Pressure", a.ctypes.data) == 0 and np.array_equal(a, final["p"])
     assert not (tmp_path / "out_1.cgns").exists() and not (tmp_path / "out_3.cgns").exists()
+
+
+def test_nssolve_stops_at_max_time(H):
+    """-ns_max_time / NSSetMaxTime: NSSolve ends at whichever of max_steps and max_time comes first (nsbasic.c:333-343)."""
+    keep = []
+    mesh, ns, _ = make_ns(H, 100, keep)
+    mt = C.c_double()
+    assert H.lib.NSGetMaxTime(ns, C.byref(mt)) == 0 and mt.value > 1e300          # PETSC_MAX_REAL: not set
+    assert H.lib.NSSetMaxTime(ns, 0.025) == 0
+    assert H.lib.NSSolve(ns) == 0
+    step, t = C.c_int64(), C.c_double()
+    H.lib.NSGetTimeStep(ns, C.byref(step)), H.lib.NSGetTime(ns, C.byref(t))
+    assert step.value == 3 and abs(t.value - 0.03) < 1e-15                         # dt = 0.01: t = 0.03 is the first time >= 0.025
+    H.lib.NSDestroy(C.byref(ns)), H.lib.MeshDestroy(C.byref(mesh))
