@@ -430,6 +430,7 @@ struct _p_NS {
   double               rho, mu, dt, t;
   int64_t              step, max_steps;
   double               max_time; /* nsbasic.c:30: PETSC_MAX_REAL = not set */
+  int                  errorifstepfailed; /* nsbasic.c:46: PETSC_TRUE */
   Mesh                 mesh;
   NSBoundaryCondition *bcs;
   int                  nb, device, setupcalled;
@@ -476,6 +477,7 @@ FlErrorCode NSCreate(NS *ns)
   n->dt  = 0.;
   n->max_steps = -1;
   n->max_time  = 1.7976931348623157e308;
+  n->errorifstepfailed = 1;
   fl_ksp_opts_default(&n->schur);
   fl_ksp_opts_default(&n->mom);
   n->mom.type = FL_KSP_BCGS; /* PETSc's own default for kspA is gmres + ilu: neither has a matrix-free form here */
@@ -596,6 +598,7 @@ FlErrorCode NSSetFromOptions(NS ns, int argc, char **argv)
   if (opt_real(argc, argv, "-ns_time_step_size", &v)) FLCHK(NSSetTimeStepSize(ns, v));
   if (opt_int64(argc, argv, "-ns_max_steps", &iv)) ns->max_steps = iv;
   if (opt_real(argc, argv, "-ns_max_time", &v)) ns->max_time = v; /* nsopts.c:186 */
+  if ((s = opt_find(argc, argv, "-ns_error_if_step_failed"))) ns->errorifstepfailed = !(!strcmp(s, "0") || !strcasecmp(s, "false") || !strcasecmp(s, "no")); /* :188 */
   /* sub-KSP of the Schur complement: prefix ns_ + abf_schur_ (nssol.c:19, abfpc.c:206) */
   if ((s = opt_find(argc, argv, "-ns_abf_schur_ksp_type"))) {
     if (!strcmp(s, "cg")) ns->schur.type = FL_KSP_CG;
@@ -713,6 +716,30 @@ FlErrorCode NSStep(NS ns) /* nsbasic.c:276-299 */
     ++ns->step;
     ns->t += ns->dt;
   }
+  if (ns->reason < 0 && ns->errorifstepfailed) { /* :293-297 */
+    NSMonitorCancel(ns);
+    return 91; /* PETSC_ERR_NOT_CONVERGED: "NSStep has failed due to DIVERGED_NONLINEAR_SOLVE" */
+  }
+  return 0;
+}
+
+/* nsopts.c: the plain getters / setters */
+FlErrorCode NSGetDensity(NS ns, double *rho) { if (!ns || !rho) return E_ARG_NULL; *rho = ns->rho; return 0; }
+FlErrorCode NSGetViscosity(NS ns, double *mu) { if (!ns || !mu) return E_ARG_NULL; *mu = ns->mu; return 0; }
+FlErrorCode NSGetTimeStepSize(NS ns, double *dt) { if (!ns || !dt) return E_ARG_NULL; *dt = ns->dt; return 0; }
+FlErrorCode NSGetMaxSteps(NS ns, int64_t *max_steps) { if (!ns || !max_steps) return E_ARG_NULL; *max_steps = ns->max_steps; return 0; }
+FlErrorCode NSSetTime(NS ns, double t) { if (!ns) return E_ARG_NULL; ns->t = t; return 0; }
+FlErrorCode NSSetTimeStep(NS ns, int64_t step) { if (!ns) return E_ARG_NULL; if (step < 0) return E_ARG_OUTOFRANGE; ns->step = step; return 0; }
+FlErrorCode NSSetErrorIfStepFailed(NS ns, int flg) { if (!ns) return E_ARG_NULL; ns->errorifstepfailed = flg != 0; return 0; }
+FlErrorCode NSGetErrorIfStepFailed(NS ns, int *flg) { if (!ns || !flg) return E_ARG_NULL; *flg = ns->errorifstepfailed; return 0; }
+/* NSConvergedReason (flucans.h:13-18): 0 ITERATING, 1 CONVERGED_TIME, 2 CONVERGED_ITS, -1 DIVERGED_NONLINEAR_SOLVE */
+FlErrorCode NSGetConvergedReason(NS ns, int *reason)
+{
+  if (!ns || !reason) return E_ARG_NULL;
+  if (ns->reason < 0) *reason = -1;
+  else if (ns->max_steps >= 0 && ns->step >= ns->max_steps) *reason = 2;
+  else if (ns->t >= ns->max_time) *reason = 1;
+  else *reason = 0;
   return 0;
 }
 
@@ -750,7 +777,7 @@ FlErrorCode NSSolve(NS ns) /* nsbasic.c:325-350: monitor, step, ... until -ns_ma
   while (ns->step < max_steps && ns->t < ns->max_time) { /* NS_CONVERGED_ITS, else NS_CONVERGED_TIME (:333-334, :342-343) */
     FLCHK(NSMonitor(ns));
     FLCHK(NSStep(ns));
-    if (ns->reason < 0) return 91; /* PETSC_ERR_NOT_CONVERGED: "NSStep has failed" */
+    if (ns->reason < 0) break; /* with -ns_error_if_step_failed 0: NS_DIVERGED_NONLINEAR_SOLVE ends the loop (:337-345) */
   }
   FLCHK(NSMonitor(ns));
   return 0;

@@ -52,7 +52,10 @@ PROTOTYPES = {
     "MeshCartGetCoordinateArraysRead": [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)], "MeshGetRank": [_P, _ip, _ip],
     "NSGetPressureHalfStep": [_P, C.POINTER(_P)], "NSGetMesh": [_P, C.POINTER(_P)], "NSGetDevice": [_P, _ip],
     "NSSetTimeStepAndTime": [_P, C.c_int64, C.c_double], "NSBarrier": [_P],
-    "NSSetMaxTime": [_P, C.c_double], "NSGetMaxTime": [_P, C.POINTER(C.c_double)],
+    "NSSetMaxTime": [_P, C.c_double], "NSGetMaxTime": [_P, C.POINTER(C.c_double)], "NSGetMaxSteps": [_P, _i64p],
+    "NSGetDensity": [_P, C.POINTER(C.c_double)], "NSGetViscosity": [_P, C.POINTER(C.c_double)], "NSGetTimeStepSize": [_P, C.POINTER(C.c_double)],
+    "NSSetTime": [_P, C.c_double], "NSSetTimeStep": [_P, C.c_int64], "NSSetErrorIfStepFailed": [_P, C.c_int], "NSGetErrorIfStepFailed": [_P, _ip],
+    "NSGetConvergedReason": [_P, _ip],
     "NSMonitorSet": [_P, _P, _P, _P], "NSMonitorCancel": [_P], "NSMonitor": [_P],
 }
 MonitorFunc = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)

@@ -100,6 +100,17 @@ FlErrorCode NSSetTimeStepSize(NS ns, double dt);
 FlErrorCode NSSetMaxSteps(NS ns, int64_t max_steps);
 FlErrorCode NSSetMaxTime(NS ns, double max_time); /* -ns_max_time; NSSolve stops at whichever of the two comes first (nsbasic.c:333-334) */
 FlErrorCode NSGetMaxTime(NS ns, double *max_time);
+FlErrorCode NSGetMaxSteps(NS ns, int64_t *max_steps);
+FlErrorCode NSGetDensity(NS ns, double *rho);
+FlErrorCode NSGetViscosity(NS ns, double *mu);
+FlErrorCode NSGetTimeStepSize(NS ns, double *dt);
+FlErrorCode NSSetTime(NS ns, double t);
+FlErrorCode NSSetTimeStep(NS ns, int64_t step);
+/* -ns_error_if_step_failed (default true, nsbasic.c:46): a failed step makes NSStep return PETSC_ERR_NOT_CONVERGED (91) */
+FlErrorCode NSSetErrorIfStepFailed(NS ns, int flg);
+FlErrorCode NSGetErrorIfStepFailed(NS ns, int *flg);
+/* NSConvergedReason (flucans.h:13-18): 0 ITERATING, 1 CONVERGED_TIME, 2 CONVERGED_ITS, -1 DIVERGED_NONLINEAR_SOLVE */
+FlErrorCode NSGetConvergedReason(NS ns, int *reason);
 FlErrorCode NSSetBoundaryCondition(NS ns, int index, NSBoundaryCondition bc);
 FlErrorCode NSGetBoundaryCondition(NS ns, int index, NSBoundaryCondition *bc);
 FlErrorCode NSSetFromOptions(NS ns, int argc, char **argv);

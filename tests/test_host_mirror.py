@@ -104,6 +104,19 @@ def test_ns_registry_options_and_state_errors(H):
     assert H.lib.NSSetFromOptions(ns, argc, av) == 0
     argc, av = H.argv("-ns_pc_abf_schur_ainv_type", "lumped")
     assert H.lib.NSSetFromOptions(ns, argc, av) == H.ERR_ARG_UNKNOWN_TYPE
+    rho, mu, dt, ms, flg, why = C.c_double(), C.c_double(), C.c_double(), C.c_int64(), C.c_int(), C.c_int()
+    assert H.lib.NSGetDensity(ns, C.byref(rho)) == 0 and H.lib.NSGetViscosity(ns, C.byref(mu)) == 0 and H.lib.NSGetTimeStepSize(ns, C.byref(dt)) == 0
+    assert (rho.value, mu.value, dt.value) == (2.0, 0.01, 1e-3)
+    assert H.lib.NSGetMaxSteps(ns, C.byref(ms)) == 0 and ms.value == 5
+    assert H.lib.NSGetErrorIfStepFailed(ns, C.byref(flg)) == 0 and flg.value == 1          # nsbasic.c:46
+    argc, av = H.argv("-ns_error_if_step_failed", "0", "-ns_max_time", 0.5)
+    assert H.lib.NSSetFromOptions(ns, argc, av) == 0
+    assert H.lib.NSGetErrorIfStepFailed(ns, C.byref(flg)) == 0 and flg.value == 0
+    assert H.lib.NSGetConvergedReason(ns, C.byref(why)) == 0 and why.value == 0             # NS_CONVERGED_ITERATING
+    assert H.lib.NSSetTimeStep(ns, 5) == 0 and H.lib.NSGetConvergedReason(ns, C.byref(why)) == 0 and why.value == 2   # NS_CONVERGED_ITS
+    assert H.lib.NSSetTimeStep(ns, 0) == 0 and H.lib.NSSetTime(ns, 0.75) == 0
+    assert H.lib.NSGetConvergedReason(ns, C.byref(why)) == 0 and why.value == 1             # NS_CONVERGED_TIME
+    assert H.lib.NSSetTime(ns, 0.0) == 0 and H.lib.NSSetTimeStep(ns, -1) == H.ERR_ARG_OUTOFRANGE
     assert H.lib.NSStep(ns) == H.ERR_ARG_WRONGSTATE                    # before NSSetUp
     argc, av = H.argv("-ns_ksp_type", "fgmres")                        # outer KSP: gmres (default), richardson, preonly
     assert H.lib.NSSetFromOptions(ns, argc, av) == H.ERR_SUP
