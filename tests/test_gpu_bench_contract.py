@@ -1,0 +1,50 @@
+"""-m gpu: the driver's bench.py contract, at toy size -- one JSON line with the required keys at N = 1, and the N = 2 launch
+line of the driver (torch.distributed.run, one rank per process) over the host-staged transport, because a one-GPU box cannot
+give each rank its own device (RCCL refuses two ranks on one GPU; the production transport is exercised by
+tests/test_gpu_rccl_loopback.py)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+        "roofline", "cpu_baseline"}
+
+
+def _line(out):
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout + out.stderr          # ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_has_the_contract_keys():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cells", "64", "--steps", "20", "--warmup", "3", "--cpu-cells", "32", "--cpu-iters", "20",
+                          "--placement-tries", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stdout + out.stderr
+    d = _line(out)
+    assert KEYS <= set(d)
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 3 and d["scaling"] == "weak" and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["value"] > 0 and abs(d["ms_per_step"] * d["value"] * (512 / 64) ** 3 / 1e3 - 1.0) < 1e-6      # value = 512^3-equivalent iterations/s
+    r, c = d["roofline"], d["cpu_baseline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and "petsc_cpu" in c
+    assert c["parity_on_sample"]["iters_gpu"] == c["parity_on_sample"]["iters_cpu"] and c["parity_on_sample"]["rel_max_diff_x"] < 1e-9
+    assert "workload" in d["config"] and "model" not in d["config"]
+
+
+def test_two_ranks_through_the_driver_launch_line():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--cells", "32", "--skip-cpu", "--placement-tries", "0", "--transport", "host"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stdout + out.stderr
+    d = _line(out)
+    assert d["n_gpus"] == 2 and d["config"]["rank_grid"] == [1, 1, 2] and d["config"]["cells_per_gpu"] == 32 ** 3
+    assert "NOT the production transport" in d["config"]["halo"] and d["cpu_baseline"] is None and d["value"] > 0
