@@ -170,6 +170,10 @@ static void sol_name(char out[40], int64_t step) { snprintf(out, 40, "FlowSoluti
 static const char *const face_sol_names[3] = {"IFaceCenteredSolution", "JFaceCenteredSolution", "KFaceCenteredSolution"}; /* cartcgns.c:5 */
 static const char *const face_sol_locs[3]  = {"IFaceCenter", "JFaceCenter", "KFaceCenter"};                               /* cartcgns.c:6 */
 
+/* The ranks take turns on the file and close it between turns: HDF5's advisory file lock adds nothing, and flock() is not
+ * available on every shared file system.  An explicit setting of the user's wins. */
+static void no_hdf5_file_locking(void) { setenv("HDF5_USE_FILE_LOCKING", "FALSE", 0); }
+
 static int layout_ok(const FlucaCGNSLayout *l)
 {
   if (!l) return 0;
@@ -184,6 +188,7 @@ FlErrorCode FlucaCGNSCreateFile(const char *filename, const FlucaCGNSLayout *lay
 {
   if (!filename || !xf || !yf || !zf) return E_ARG_NULL;
   if (!layout_ok(lay)) return E_ARG_OUTOFRANGE;
+  no_hdf5_file_locking();
   hid_t fcpl = H5Pcreate(H5P_FILE_CREATE);
   H5Pset_link_creation_order(fcpl, H5P_CRT_ORDER_TRACKED | H5P_CRT_ORDER_INDEXED);
   hid_t f = H5Fcreate(filename, H5F_ACC_TRUNC, fcpl, H5P_DEFAULT);
@@ -535,6 +540,7 @@ FlErrorCode FlucaViewerCGNSOpen(const char *filename, char mode, FlucaViewerCGNS
   v->batch_size  = 1;                                                                /* flucacgns.c:220 */
   v->mode        = mode;
   v->last_step   = -1;
+  no_hdf5_file_locking();
   H5Eset_auto2(H5E_DEFAULT, NULL, NULL); /* errors are reported through return codes */
   *viewer = v;
   return 0;
