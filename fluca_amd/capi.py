@@ -113,6 +113,8 @@ PROTOTYPES = {
     "fl_poisson_gershgorin": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double)]),
     "fl_vec_lincomb": (C.c_int, [_P, C.c_int64, C.c_double, _P, C.c_double, _P, _P]),
     "fl_vec_dot": (C.c_int, [_P, C.c_int64, _P, _P, C.POINTER(C.c_double)]),
+    "fl_vec_mdot": (C.c_int, [_P, C.c_int64, _P, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_double)]),
+    "fl_vec_maxpy": (C.c_int, [_P, C.c_int64, _P, C.POINTER(C.c_double), C.POINTER(C.c_void_p), C.c_int]),
     "fl_boundary_set_faces": (C.c_int, [_P, C.c_int, C.c_double, _P, _P]),
     "fl_boundary_add_faces": (C.c_int, [_P, C.c_int, C.c_double, _P, _P]),
     "fl_momentum_face_interp_scaled": (C.c_int, [_P, C.c_double, _P, _P, _P]),

@@ -454,6 +454,40 @@ __global__ void __launch_bounds__(256) k_scale_by(int64_t n, const double *__res
     y[q]           = add ? y[q] + t : t;
   }
 }
+// VecMDot / VecMAXPY on up to 8 vectors per launch: x is read once for all of them
+struct Vec8 {
+  const double *p[8];
+};
+struct Coef8 {
+  double a[8];
+};
+// partial[i * stride + block] = sum over the block's elements of x * y_i
+__global__ void __launch_bounds__(256) k_mdot8(int64_t n, const double *__restrict__ x, Vec8 Y, int k, double *__restrict__ partial, int stride)
+{
+  __shared__ double red[8 * 4];
+  double            acc[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
+    const double xv = x[q];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < k) acc[i] += xv * Y.p[i][q];
+  }
+  block_sum<8>(acc, red);
+  if (threadIdx.x == 0)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) partial[(int64_t)i * stride + blockIdx.x] = acc[i];
+}
+// x += sum_i a_i y_i
+__global__ void __launch_bounds__(256) k_maxpy8(int64_t n, double *__restrict__ x, Coef8 A, Vec8 Y, int k)
+{
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
+    double t = x[q];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < k) t += A.a[i] * Y.p[i][q];
+    x[q] = t;
+  }
+}
 __global__ void __launch_bounds__(256) k_lincomb(int64_t n, double a, const double *x, double b, const double *z, double *y)
 {
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) y[q] = a * x[q] + (z ? b * z[q] : 0.);
@@ -1173,6 +1207,52 @@ extern "C" int fl_vec_dot(fl_poisson *h, int64_t n, const double *x_dev, const d
   if (h->multi) FL_CHK(h->comm.allreduce(h->stream, h->sums, NSLOT));   // every rank holds its OWNED entries only
   FL_HIP(hipMemcpyAsync(result, h->sums, sizeof(double), hipMemcpyDeviceToHost, h->stream));
   FL_HIP(hipStreamSynchronize(h->stream));
+  return FL_SUCCESS;
+}
+
+// VecMDot: out[i] = x . y_i for i < k, summed over all ranks; one host wait for all k
+extern "C" int fl_vec_mdot(fl_poisson *h, int64_t n, const double *x_dev, const double *const *ys_dev, int k, double *out)
+{
+  if (!h || !x_dev || !ys_dev || !out) return FL_ERR_ARG_NULL;
+  if (n < 0 || k < 0) return FL_ERR_ARG_OUTOFRANGE;
+  FL_HIP(hipSetDevice(h->device));
+  FL_CHK(fl_ensure_partials(h, 1024));
+  const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 1024));
+  for (int i0 = 0; i0 < k; i0 += 8) {
+    const int kk = std::min(8, k - i0);
+    Vec8      Y;
+    for (int i = 0; i < 8; ++i) {
+      Y.p[i] = i < kk ? ys_dev[i0 + i] : x_dev;
+      if (!Y.p[i]) return FL_ERR_ARG_NULL;
+    }
+    hipLaunchKernelGGL(k_mdot8, dim3(nb), dim3(256), 0, h->stream, n, x_dev, Y, kk, h->partial, h->partial_stride);
+    launch_reduce(h->stream, h->partial, nb, h->partial_stride, 8, h->sums);
+    if (h->multi) FL_CHK(h->comm.allreduce(h->stream, h->sums, NSLOT));
+    FL_HIP(hipMemcpyAsync(out + i0, h->sums, sizeof(double) * kk, hipMemcpyDeviceToHost, h->stream));
+  }
+  FL_HIP(hipStreamSynchronize(h->stream));
+  return FL_SUCCESS;
+}
+
+// VecMAXPY: x += sum_i alpha_i y_i
+extern "C" int fl_vec_maxpy(fl_poisson *h, int64_t n, double *x_dev, const double *alphas, const double *const *ys_dev, int k)
+{
+  if (!h || !x_dev || !ys_dev || !alphas) return FL_ERR_ARG_NULL;
+  if (n < 0 || k < 0) return FL_ERR_ARG_OUTOFRANGE;
+  FL_HIP(hipSetDevice(h->device));
+  const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 8192));
+  for (int i0 = 0; i0 < k && n > 0; i0 += 8) {
+    const int kk = std::min(8, k - i0);
+    Vec8      Y;
+    Coef8     A;
+    for (int i = 0; i < 8; ++i) {
+      Y.p[i] = i < kk ? ys_dev[i0 + i] : x_dev;
+      A.a[i] = i < kk ? alphas[i0 + i] : 0.;
+      if (!Y.p[i]) return FL_ERR_ARG_NULL;
+    }
+    hipLaunchKernelGGL(k_maxpy8, dim3(nb), dim3(256), 0, h->stream, n, x_dev, A, Y, kk);
+  }
+  FL_HIP(hipGetLastError());
   return FL_SUCCESS;
 }
 

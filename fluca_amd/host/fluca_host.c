@@ -1218,6 +1218,41 @@ static FlErrorCode cv_dot(NS ns, const CVec *x, const CVec *y, double *out)
   *out = s;
   return 0;
 }
+/* VecMDot / VecMAXPY on composite vectors: out[i] = x . Y[i] ; x -= sum_i coef[i] Y[i]   (k <= CV_MAXK) */
+#define CV_MAXK 208
+static FlErrorCode cv_mdot(NS ns, const CVec *x, const CVec *Y, int k, double *out)
+{
+  NS_CNLinear  *c = (NS_CNLinear *)ns->data;
+  fl_poisson   *h = ns->poisson;
+  const double *ys[CV_MAXK];
+  double        part[CV_MAXK];
+  if (k > CV_MAXK) return E_ARG_OUTOFRANGE;
+  for (int i = 0; i < k; ++i) out[i] = 0.;
+  for (int a = 0; a < 5; ++a) { /* v, p, V[0..2] */
+    const int64_t n  = a == 0 ? 3 * c->sz[0] : a == 1 ? c->sz[0] : c->sz[a - 1];
+    const double *xa = a == 0 ? x->v : a == 1 ? x->p : x->V[a - 2];
+    for (int i = 0; i < k; ++i) ys[i] = a == 0 ? Y[i].v : a == 1 ? Y[i].p : Y[i].V[a - 2];
+    FLABI(fl_vec_mdot(h, n, xa, ys, k, part));
+    for (int i = 0; i < k; ++i) out[i] += part[i];
+  }
+  return 0;
+}
+static FlErrorCode cv_msub(NS ns, CVec *x, const double *coef, const CVec *Y, int k)
+{
+  NS_CNLinear  *c = (NS_CNLinear *)ns->data;
+  fl_poisson   *h = ns->poisson;
+  const double *ys[CV_MAXK];
+  double        neg[CV_MAXK];
+  if (k > CV_MAXK) return E_ARG_OUTOFRANGE;
+  for (int i = 0; i < k; ++i) neg[i] = -coef[i];
+  for (int a = 0; a < 5; ++a) {
+    const int64_t n  = a == 0 ? 3 * c->sz[0] : a == 1 ? c->sz[0] : c->sz[a - 1];
+    double       *xa = a == 0 ? x->v : a == 1 ? x->p : x->V[a - 2];
+    for (int i = 0; i < k; ++i) ys[i] = a == 0 ? Y[i].v : a == 1 ? Y[i].p : Y[i].V[a - 2];
+    FLABI(fl_vec_maxpy(h, n, xa, neg, ys, k));
+  }
+  return 0;
+}
 static FlErrorCode cv_pcapply(NS ns, const CVec *r, CVec *z) /* z = PCApply_ABF(r) */
 {
   fl_ksp_stats  st[2];
@@ -1236,8 +1271,7 @@ static FlErrorCode cv_jmult(NS ns, const CVec *x, CVec *y) /* y = J x */
 }
 
 /* KSPGMRES as the reference's ns->snes uses it (nssol.c:21-29: rtol 1e-5, unpreconditioned norm => right preconditioning,
- * PETSc defaults: restart 30, classical Gram-Schmidt without refinement -- here modified Gram-Schmidt, the same
- * numbers up to round-off).  Zero initial guess.  x = P^-1 (V y) at every restart / at the end.  PARITY UNPINNED like the
+ * PETSc defaults: restart 30, classical Gram-Schmidt without refinement -- the same here).  Zero initial guess.  x = P^-1 (V y) at every restart / at the end.  PARITY UNPINNED like the
  * inner solvers (PETSc absent): restated from the published algorithm. */
 static FlErrorCode cnl_gmres(NS ns, const CVec *f, CVec *x)
 {
@@ -1297,11 +1331,12 @@ static FlErrorCode cnl_gmres(NS ns, const CVec *f, CVec *x)
       GM(cv_pcapply(ns, &Vk[j], t)); /* z = P^-1 v_j */
       if (ns->reason < 0) break;
       GM(cv_jmult(ns, t, w));       /* w = J z */
-      for (int i = 0; i <= j; ++i) {  /* modified Gram-Schmidt */
-        double hij;
-        GM(cv_dot(ns, w, &Vk[i], &hij));
-        H[i * m + j] = hij;
-        GM(cv_lincomb(ns, 1., w, -hij, &Vk[i], w));
+      { /* classical Gram-Schmidt, no refinement (KSPGMRESClassicalGramSchmidtOrthogonalization, PETSc's default): all the
+         * inner products from the same w in one pass (VecMDot), then one update (VecMAXPY) */
+        double hcol[CV_MAXK];
+        GM(cv_mdot(ns, w, Vk, j + 1, hcol));
+        for (int i = 0; i <= j; ++i) H[i * m + j] = hcol[i];
+        GM(cv_msub(ns, w, hcol, Vk, j + 1));
       }
       double hn;
       GM(cv_dot(ns, w, w, &hn));

@@ -146,6 +146,10 @@ int fl_memcpy_d2h(int device, void *host, const void *dev, size_t bytes);
  * owned entries) -- for hosts that run an outer iteration over device vectors and have no vector library of their own. */
 int fl_vec_lincomb(fl_poisson *h, int64_t n, double a, const double *x_dev, double b, const double *z_dev, double *y_dev);
 int fl_vec_dot(fl_poisson *h, int64_t n, const double *x_dev, const double *y_dev, double *result);
+/* VecMDot / VecMAXPY: out[i] = x . y_i (one host wait for all k) and x += sum_i alpha_i y_i; ys_dev is a HOST array of k device
+ * pointers.  Classical Gram-Schmidt of the outer GMRES reads its work vector once per pass instead of once per basis vector. */
+int fl_vec_mdot(fl_poisson *h, int64_t n, const double *x_dev, const double *const *ys_dev, int k, double *out);
+int fl_vec_maxpy(fl_poisson *h, int64_t n, double *x_dev, const double *alphas, const double *const *ys_dev, int k);
 
 /* Optional one-off tuning step after create (like planning an FFT): any kernel that streams six 1 GB vectors at once runs
  * 10-15 % faster or slower depending on where the driver happened to place them physically (profiles/r01_placement.txt).

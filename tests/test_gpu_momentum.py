@@ -392,3 +392,27 @@ def test_momentum_and_multigrid_full_size_properties_512():
     assert float(div.abs().max()) <= 1e-6 * srhs_scale * 512
     M.close()
     P.close()
+
+
+def test_vec_mdot_and_maxpy():
+    """fl_vec_mdot / fl_vec_maxpy == VecMDot / VecMAXPY, for more vectors than one launch takes (8)."""
+    import ctypes as C
+    import torch
+    from fluca_amd import capi
+    from fluca_amd.poisson import Poisson
+    P = Poisson.uniform((8, 8, 8), CAVITY_BOX, CAVITY, 1e-3)
+    rng = np.random.default_rng(2)
+    n, k = 10007, 11
+    x = rng.standard_normal(n)
+    Y = rng.standard_normal((k, n))
+    xd, Yd = dev(x), [dev(y) for y in Y]
+    ptrs = (C.c_void_p * k)(*[t.data_ptr() for t in Yd])
+    out = (C.c_double * k)()
+    capi.check(capi.lib.fl_vec_mdot(P.h, n, xd.data_ptr(), ptrs, k, out))
+    assert np.allclose(np.array(out[:]), Y @ x, rtol=1e-12, atol=1e-12)
+    a = rng.standard_normal(k)
+    capi.check(capi.lib.fl_vec_maxpy(P.h, n, xd.data_ptr(), (C.c_double * k)(*a), ptrs, k))
+    torch.cuda.synchronize()
+    assert np.allclose(host(xd), x + a @ Y, rtol=1e-13, atol=1e-13)
+    assert capi.lib.fl_vec_mdot(P.h, n, xd.data_ptr(), ptrs, -1, out) == -63
+    P.close()
