@@ -58,3 +58,32 @@ def test_rccl_self_exchange_matches_oracle(loopback, bc):
     assert np.abs(host(M.apply(dev(v))) - want).max() <= 2e-13 * np.abs(want).max()
     M.close()
     P.close()
+
+
+def test_multigrid_levels_share_the_rccl_communicator(loopback):
+    """FL_PC_MG with every level's halo exchange and all-reduce going through the borrowed RCCL communicator: the same
+    iteration history as the same solve with local ghost copies."""
+    from fluca_amd import poisson as flp
+    n = (64, 32, 32)
+    box = [(0, 1), (0, 1), (0, 0.5)]
+    bc = [PER, PER, V, V, PER, PER]
+    rng = np.random.default_rng(9)
+    p = rng.standard_normal(n[0] * n[1] * n[2])
+    p -= p.mean()
+    res = []
+    for loop in (True, False):
+        if not loop:
+            os.environ.pop("FLUCA_COMM_LOOPBACK", None)
+        P = flp.Poisson.uniform(n, box, bc, 1e-3)
+        if loop:
+            P.comm_init_rccl(flp.rccl_unique_id(), 0, 1)
+        b = P.apply(dev(p))
+        x, info = P.solve(b, history=True, type=fo.KSP_CG, pc=2, rtol=1e-10, maxit=60)
+        res.append((host(x), info))
+        P.close()
+    (xa, ia), (xb, ib) = res
+    assert ia["reason"] == ib["reason"] == 2 and ia["iters"] == ib["iters"] and ia["iters"] <= 25
+    assert np.allclose(ia["history"], ib["history"], rtol=1e-9)
+    assert np.linalg.norm(xa - xb) <= 1e-10 * np.linalg.norm(xb)
+    assert np.linalg.norm((xa - xa.mean()) - p) <= 1e-7 * np.linalg.norm(p)
+
