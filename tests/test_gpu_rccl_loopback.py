@@ -87,3 +87,53 @@ def test_multigrid_levels_share_the_rccl_communicator(loopback):
     assert np.linalg.norm(xa - xb) <= 1e-10 * np.linalg.norm(xb)
     assert np.linalg.norm((xa - xa.mean()) - p) <= 1e-7 * np.linalg.norm(p)
 
+
+def test_whole_time_steps_through_rccl(loopback):
+    """Two CNLinear steps of the C host mirror on a periodic box (Taylor-Green) with every ghost exchange of the step -- pressure,
+    three velocity components, twelve face fields, the multigrid levels -- and every reduction going through RCCL."""
+    import ctypes as C
+    from fluca_amd import capi, hostapi as H, poisson as flp
+    P = C.c_void_p
+    L, n = 2 * np.pi, 16
+
+    def run(loop):
+        if not loop:
+            os.environ.pop("FLUCA_COMM_LOOPBACK", None)
+        mesh = P()
+        assert H.lib.MeshCartCreate3d(1, 1, 1, n, n, 8, 1, 1, 1, None, None, None, C.byref(mesh)) == 0 and H.lib.MeshSetUp(mesh) == 0
+        assert H.lib.MeshCartSetUniformCoordinates(mesh, 0., L, 0., L, 0., L * 8 / n) == 0
+        ns = P()
+        assert H.lib.NSCreate(C.byref(ns)) == 0 and H.lib.NSSetType(ns, b"cnlinear") == 0 and H.lib.NSSetMesh(ns, mesh) == 0
+        assert H.lib.NSSetDensity(ns, 1.0) == 0 and H.lib.NSSetViscosity(ns, 0.1) == 0
+        for b in range(6):
+            assert H.lib.NSSetBoundaryCondition(ns, b, H.NSBoundaryCondition(type=H.NS_BC_PERIODIC)) == 0
+        argc, av = H.argv("-ns_time_step_size", 0.05, "-ns_max_steps", 2, "-ns_ksp_rtol", 1e-9, "-ns_abf_schur_ksp_rtol", 1e-11,
+                          "-ns_abf_momentum_ksp_rtol", 1e-11, "-ns_abf_schur_pc_type", "mg")
+        assert H.lib.NSSetFromOptions(ns, argc, av) == 0 and H.lib.NSSetUp(ns) == 0
+        if loop:
+            hp = P()
+            assert H.lib.NSGetPoisson(ns, C.byref(hp)) == 0
+            idb = (C.c_char * capi.UNIQUE_ID_BYTES).from_buffer_copy(flp.rccl_unique_id())
+            capi.check(capi.lib.fl_poisson_comm_init_rccl(hp, idb, 0, 1))
+        v, p, V = P(), P(), (C.c_void_p * 3)()
+        assert H.lib.NSGetSolutionArrays(ns, C.byref(v), V, C.byref(p)) == 0
+        h = L / n
+        xc, xf = (np.arange(n) + 0.5) * h, np.arange(n) * h
+        Z = np.ones((8, 1, 1))
+        put = lambda ptr, a: capi.check(capi.lib.fl_memcpy_h2d(0, ptr, np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(C.c_void_p), a.size * 8))
+        u0 = Z * np.sin(xc)[None, None, :] * np.cos(xc)[None, :, None]
+        w0 = Z * (-np.cos(xc)[None, None, :] * np.sin(xc)[None, :, None])
+        put(v, np.stack([u0, w0, np.zeros_like(u0)]))
+        put(C.c_void_p(V[0]), Z * np.sin(xf)[None, None, :] * np.cos(xc)[None, :, None])
+        put(C.c_void_p(V[1]), Z * (-np.cos(xc)[None, None, :] * np.sin(xf)[None, :, None]))
+        X, Y = np.meshgrid(xc, xc, indexing="xy")
+        put(p, Z * (0.25 * (np.cos(2 * X) + np.cos(2 * Y)))[None, :, :])
+        assert H.lib.NSSolve(ns) == 0
+        out = np.empty(3 * 8 * n * n)
+        capi.check(capi.lib.fl_memcpy_d2h(0, out.ctypes.data_as(C.c_void_p), v, out.size * 8))
+        H.lib.NSDestroy(C.byref(ns)), H.lib.MeshDestroy(C.byref(mesh))
+        return out
+
+    a, b = run(True), run(False)
+    assert np.abs(b).max() > 0.5 and np.abs(a - b).max() <= 1e-9 * np.abs(b).max()
+
