@@ -137,3 +137,38 @@ def test_whole_time_steps_through_rccl(loopback):
     a, b = run(True), run(False)
     assert np.abs(b).max() > 0.5 and np.abs(a - b).max() <= 1e-9 * np.abs(b).max()
 
+
+def test_ibm_interpolation_reduces_through_rccl(loopback):
+    """fl_ibm_interp of a multi-rank handle ends with an all-reduce of 3 L doubles (markers are replicated on the ranks): here
+    through ncclAllReduce, against the oracle; spreading needs no communication."""
+    import ctypes as C
+    import torch
+    from fluca_amd import capi, poisson as flp
+    n, box, bc = (24, 20, 16), [(0.0, 1.0)] * 3, [PER, PER, V, V, PER, PER]
+    P = flp.Poisson.uniform(n, box, bc, 1e-3)
+    P.comm_init_rccl(flp.rccl_unique_id(), 0, 1)
+    g = fo.Grid.uniform(n, box, bc, 1e-3)
+    rng = np.random.default_rng(17)
+    L = 1001
+    X = [rng.uniform(0.0, 1.0, L) for _ in range(3)]
+    X[1] = 0.1 + 0.8 * X[1]                      # keep the supports off the walls in y
+    X[0][:2], X[2][:2] = [0.003, 0.998], [0.999, 0.001]   # across the periodic seams
+    Xd = [dev(a) for a in X]
+    m = C.c_void_p()
+    P._pre()
+    capi.check(capi.lib.fl_ibm_create(P.h, 0, L, *[C.c_void_p(t.data_ptr()) for t in Xd], C.byref(m)))
+    u = rng.standard_normal((3, g.ncell))
+    ud = dev(u)
+    U = torch.empty(3 * L, dtype=torch.float64, device="cuda")
+    capi.check(capi.lib.fl_ibm_interp(m, 3, C.c_void_p(ud.data_ptr()), C.c_void_p(U.data_ptr())))
+    P.synchronize()
+    assert np.allclose(host(U).reshape(3, L), g.ibm_interp(0, X, u), rtol=1e-12, atol=1e-13)
+    F, dV, f0 = rng.standard_normal((3, L)), rng.uniform(0.5, 1.5, L) * 1e-3, rng.standard_normal((3, g.ncell))
+    fd, Fd, dVd = dev(f0), dev(F), dev(dV)
+    capi.check(capi.lib.fl_ibm_spread(m, 3, C.c_void_p(Fd.data_ptr()), C.c_void_p(dVd.data_ptr()), C.c_void_p(fd.data_ptr())))
+    P.synchronize()
+    want = g.ibm_spread(0, X, dV, F, f0.copy())
+    assert np.allclose(host(fd).reshape(3, -1), want, rtol=1e-12, atol=1e-12 * np.abs(want).max())
+    capi.lib.fl_ibm_destroy(m)
+    P.close()
+
