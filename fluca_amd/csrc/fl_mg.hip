@@ -331,9 +331,17 @@ int fl_solve_cg_mg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts 
   const int    nb = nblk_pairs(g);
   hipStream_t  s = h->stream;
   // the level-0 smoother runs on this very handle and may use h->ev0 / h->ev1: own events for the timing
-  hipEvent_t e0, e1;
-  FL_HIP(hipEventCreate(&e0));
-  FL_HIP(hipEventCreate(&e1));
+  struct Events {  // released on every return path
+    hipEvent_t a = nullptr, b = nullptr;
+    ~Events()
+    {
+      if (a) (void)hipEventDestroy(a);
+      if (b) (void)hipEventDestroy(b);
+    }
+  } ev;
+  FL_HIP(hipEventCreate(&ev.a));
+  FL_HIP(hipEventCreate(&ev.b));
+  hipEvent_t e0 = ev.a, e1 = ev.b;
   FL_HIP(hipEventRecord(e0, s));
   double *X = h->w0, *P = h->w1, *Q = h->w2;  // padded; r = h->r (the cycle's right-hand side), z = h->xp after the cycle
   double  d[5], rz = 0., rz_old = 1., dp = 0., pq = 0., m = 0.;
@@ -397,8 +405,6 @@ int fl_solve_cg_mg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts 
   FL_HIP(hipStreamSynchronize(s));
   float ms = 0.f;
   FL_HIP(hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   st->iters   = it;
   st->reason  = reason;
   st->rnorm0  = rnorm0;

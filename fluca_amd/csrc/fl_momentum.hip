@@ -1022,9 +1022,17 @@ int schur_solve_var(fl_momentum *m, const double *b, double *x, const fl_ksp_opt
   inner.history     = nullptr;
   inner.nhistory    = 0;
   fl_ksp_stats ist;
-  hipEvent_t   e0, e1;
-  FL_HIP(hipEventCreate(&e0));
-  FL_HIP(hipEventCreate(&e1));
+  struct Events {  // released on every return path
+    hipEvent_t a = nullptr, b = nullptr;
+    ~Events()
+    {
+      if (a) (void)hipEventDestroy(a);
+      if (b) (void)hipEventDestroy(b);
+    }
+  } ev;
+  FL_HIP(hipEventCreate(&ev.a));
+  FL_HIP(hipEventCreate(&ev.b));
+  hipEvent_t e0 = ev.a, e1 = ev.b;
   FL_HIP(hipEventRecord(e0, h->stream));
   double H[(M + 1) * M], cs[M], sn[M], g[M + 1], y[M];
   double bnorm = 0., beta = 0.;
@@ -1102,8 +1110,6 @@ int schur_solve_var(fl_momentum *m, const double *b, double *x, const fl_ksp_opt
   FL_HIP(hipStreamSynchronize(h->stream));
   float ms = 0.f;
   FL_HIP(hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   st->iters   = its;
   st->reason  = reason;
   st->rnorm0  = bnorm;
