@@ -252,6 +252,24 @@ def main():
             out["time_to_solution"] = tts
         except Exception as e:  # noqa: BLE001
             out["time_to_solution"] = {"error": repr(e)}
+    if world == 1 and not args.skip_extras:
+        # the attainable streaming rate on THIS box, reported beside the nominal peak: a plain device copy of a
+        # 512^3 vector (1 GiB read + 1 GiB written per pass)
+        try:
+            src = torch.empty(512 ** 3, dtype=torch.float64, device="cuda").normal_()
+            dst = torch.empty_like(src)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(3):
+                dst.copy_(src)
+            e0.record()
+            for _ in range(10):
+                dst.copy_(src)
+            e1.record()
+            torch.cuda.synchronize()
+            out["roofline"]["measured_copy_GBps"] = 10 * 2 * src.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            del src, dst
+        except Exception as e:  # noqa: BLE001
+            out["roofline"]["measured_copy_GBps"] = None
     if rank == 0 and world == 1 and not args.skip_cpu:
         out["cpu_baseline"] = cpu_baseline(args.cpu_cells, args.cpu_iters)
     elif rank == 0:
