@@ -48,4 +48,17 @@ __device__ __forceinline__ int converged_default(const KspScal *s, double dp)
   return 0;
 }
 
+// Chebyshev coefficient recurrence (KSPCHEBYSHEV, oracle/fluca_oracle.c):  c_{k+1} = 2 mu c_k - c_{k-1};
+// omega = omegaprod c_k / c_{k+1};  d' = (omega - 1) d + omega scale z.  From the state (ck, ckm1) left behind by the
+// previous step to the state and the (rho, c) of the next one.
+__device__ __forceinline__ void cheb_advance(const KspScal *s, double ck, double ckm1, double &ck_out, double &ckm1_out, double &rho, double &c)
+{
+  const double ckp1  = 2. * s->mu * ck - ckm1;
+  const double omega = s->omegaprod * ck / ckp1;
+  ckm1_out           = ck;
+  ck_out             = ckp1;
+  rho                = omega - 1.;
+  c                  = omega * s->scale;
+}
+
 }  // namespace fl

@@ -247,6 +247,7 @@ struct fl_poisson {
   int         nv_il = 1, sx0 = 0;  // row-interleave factor of the padded vectors and the un-interleaved row length
   // solver workspace (padded vectors)
   double *r = nullptr, *P0 = nullptr, *P1 = nullptr, *q = nullptr, *xp = nullptr, *w0 = nullptr, *w1 = nullptr, *w2 = nullptr;
+  double *cd1 = nullptr;  // second d buffer of the fused two-step Chebyshev kernel (fl_cheb2.hip)
   std::vector<void *> vec_bases;
   void               *slab = nullptr;
   int                 nvec = 0;
@@ -286,6 +287,13 @@ int fl_bcgs_fin_step(fl_poisson *h, int mode, int nblocks, int nslot, int nhist)
 int fl_ksp_finish(fl_poisson *h, const fl_ksp_opts *o, fl_ksp_stats *st);
 int fl_solve_cheb(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *o, fl_ksp_stats *st);
 double fl_gershgorin_bound(const fl_poisson *h, bool jac);
+// fl_cheb2.hip
+struct Cheb2Plan {
+  int nw, tiles_x, tiles, nchunk, zc, nblocks;
+};
+bool      fl_cheb2_usable(const fl_poisson *h);
+Cheb2Plan fl_cheb2_plan(const GridP &g);
+void      fl_launch_cheb2(fl_poisson *h, const Cheb2Plan &p, bool jac, double *X0, double *X1, const double *B, double *D0, double *D1);
 // fl_mg.hip
 int  fl_solve_cg_mg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *o, fl_ksp_stats *st);
 void fl_mg_destroy(fl_poisson *h);

@@ -80,7 +80,8 @@ struct KspScal {
   double rho, rho_old, omega, omega_old, d1, d2, vshift, tshift, rshift;
   // Chebyshev (lazy constant shifts of x and d)
   double ck, ckm1, mu, omegaprod, scale, xshift, dshift, cheb_rho, cheb_c;
-  int    it, maxit, reason, norm_type, nullspace, pending_x, cur, pad_;
+  int    it, maxit, reason, norm_type, nullspace, pending_x, cur;
+  int    dcur;  // Chebyshev: which of the two d buffers holds the current d (the fused two-step kernel flips it)
 };
 
 constexpr int MAX_PARTIAL_BLOCKS = 4096;

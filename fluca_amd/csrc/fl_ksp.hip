@@ -318,13 +318,14 @@ __global__ void __launch_bounds__(256) k_bcgs_fin(int mode, const double *__rest
 // One fused step: z = M (b - S x) ; d = rho d + c z ; x' = x + d   (x -> the other buffer, d in place)
 // sums: 0 sum z  1 z.z  2 r.r
 template <int RY, bool JAC>
-__global__ void __launch_bounds__(256) k_cheb(GridP g, const double *X0, const double *X1, double *X0w, double *X1w, const double *__restrict__ b, double *__restrict__ d,
+__global__ void __launch_bounds__(256) k_cheb(GridP g, const double *X0, const double *X1, double *X0w, double *X1w, const double *__restrict__ b, double *D0, double *D1,
                                               const KspScal *__restrict__ s, double *__restrict__ partial, int stride, int nchunk, int zc, int tiles_x)
 {
   __shared__ double red[3 * 4];
   if (s->reason != 0) return;
   const double *x  = s->cur ? X1 : X0;
   double       *xn = s->cur ? X0w : X1w;
+  double *__restrict__ d = s->dcur ? D1 : D0;  // updated in place (the fused two-step kernel of fl_cheb2.hip flips dcur)
   const double  rho = s->cheb_rho, cc = s->cheb_c;
   const Tile    t = make_tile<RY>(g, nchunk, zc, tiles_x);
   const double  xl0 = g.sl[0][min(t.i, g.nx)], xc0 = g.sc[0][min(t.i, g.nx)], xh0 = g.sh[0][min(t.i, g.nx)];
@@ -432,10 +433,11 @@ __global__ void __launch_bounds__(256) k_cheb(GridP g, const double *X0, const d
 // from a zeroed x (S 0 = +0, b - 0 = b, 0 + d = d), without zeroing x, reading it and d, or the stencil: 8 B/cell read and
 // 16 written instead of 8 (memset) + 24 + 16.  No sums: only for the smoother call (KSP_NORM_NONE, no null space).
 template <bool JAC>
-__global__ void __launch_bounds__(256) k_cheb_first(GridP g, double *X0w, double *X1w, const double *__restrict__ b, double *__restrict__ d, const KspScal *__restrict__ s)
+__global__ void __launch_bounds__(256) k_cheb_first(GridP g, double *X0w, double *X1w, const double *__restrict__ b, double *D0, double *D1, const KspScal *__restrict__ s)
 {
   if (s->reason != 0) return;
   double       *xn = s->cur ? X0w : X1w;
+  double *__restrict__ d = s->dcur ? D1 : D0;
   const double  cc = s->cheb_c;
   const int64_t npr = (g.nx + 1) / 2, total = npr * (int64_t)g.ny * g.nz;
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
@@ -501,12 +503,43 @@ __global__ void __launch_bounds__(256) k_cheb_fin(const double *__restrict__ par
     return;
   }
   // next step: c_{k+1} = 2 mu c_k - c_{k-1}; omega = omegaprod c_k / c_{k+1}; d' = (omega-1) d + omega*scale z
-  const double ckp1  = 2. * s->mu * s->ck - s->ckm1;
-  const double omega = s->omegaprod * s->ck / ckp1;
-  s->ckm1            = s->ck;
-  s->ck              = ckp1;
-  s->cheb_rho        = omega - 1.;
-  s->cheb_c          = omega * s->scale;
+  double ck, ckm1, rho, c;
+  cheb_advance(s, s->ck, s->ckm1, ck, ckm1, rho, c);
+  s->ck       = ck;
+  s->ckm1     = ckm1;
+  s->cheb_rho = rho;
+  s->cheb_c   = c;
+}
+
+// after one launch of k_cheb2 (steps j and j+1, KSP_NORM_NONE only): both updates are accepted; slots 0..2 step j, 3..5 step j+1
+__global__ void __launch_bounds__(256) k_cheb_fin2(const double *__restrict__ partial, int nblocks, int stride, const double *__restrict__ sums, KspScal *__restrict__ s)
+{
+  __shared__ double out[NSLOT], red[NSLOT * 4];
+  if (s->reason != 0) return;
+  if (nblocks > 0) reduce_partials(partial, nblocks, stride, 6, out, red);
+  else {
+    if (threadIdx.x < NSLOT) out[threadIdx.x] = sums[threadIdx.x];
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  const double N  = s->ncell_global;
+  const double m0 = s->nullspace ? out[0] / N : 0., m1 = s->nullspace ? out[3] / N : 0.;
+  double       ck, ckm1, rho1, c1, rho2, c2;
+  cheb_advance(s, s->ck, s->ckm1, ck, ckm1, rho1, c1);  // the coefficients k_cheb2 used for its second step
+  s->dshift = s->cheb_rho * s->dshift + s->cheb_c * m0;
+  s->xshift += s->dshift;
+  s->dshift = rho1 * s->dshift + c1 * m1;
+  s->xshift += s->dshift;
+  s->cur ^= 1;   // x'' went to the other x buffer,
+  s->dcur ^= 1;  // d'' to the other d buffer
+  s->it += 2;
+  if (s->it >= s->maxit) {
+    s->reason = FL_CONVERGED_ITS;
+    return;
+  }
+  cheb_advance(s, ck, ckm1, s->ck, s->ckm1, rho2, c2);
+  s->cheb_rho = rho2;
+  s->cheb_c   = c2;
 }
 
 }  // namespace fl
@@ -568,20 +601,41 @@ void launch_pw(fl_poisson *h, const TP &tp, bool jac, const double *a0, const do
 }
 
 template <int RY, bool JAC>
-void cheb_t(fl_poisson *h, const TP &tp, double *X0, double *X1, const double *B, double *D)
+void cheb_t(fl_poisson *h, const TP &tp, double *X0, double *X1, const double *B, double *D0, double *D1)
 {
-  hipLaunchKernelGGL((k_cheb<RY, JAC>), dim3(tp.nblocks), dim3(256), 0, h->stream, h->g, X0, X1, X0, X1, B, D, h->scal, h->partial, h->partial_stride, tp.nchunk, tp.zc, tp.tiles_x);
+  hipLaunchKernelGGL((k_cheb<RY, JAC>), dim3(tp.nblocks), dim3(256), 0, h->stream, h->g, X0, X1, X0, X1, B, D0, D1, h->scal, h->partial, h->partial_stride, tp.nchunk, tp.zc, tp.tiles_x);
 }
-void launch_cheb(fl_poisson *h, const TP &tp, bool jac, double *X0, double *X1, const double *B, double *D)
+void launch_cheb(fl_poisson *h, const TP &tp, bool jac, double *X0, double *X1, const double *B, double *D0, double *D1)
 {
   if (jac) {
-    if (tp.ry == 2) cheb_t<2, true>(h, tp, X0, X1, B, D);
-    else cheb_t<1, true>(h, tp, X0, X1, B, D);
+    if (tp.ry == 2) cheb_t<2, true>(h, tp, X0, X1, B, D0, D1);
+    else cheb_t<1, true>(h, tp, X0, X1, B, D0, D1);
   } else {
-    if (tp.ry == 2) cheb_t<2, false>(h, tp, X0, X1, B, D);
-    else cheb_t<1, false>(h, tp, X0, X1, B, D);
+    if (tp.ry == 2) cheb_t<2, false>(h, tp, X0, X1, B, D0, D1);
+    else cheb_t<1, false>(h, tp, X0, X1, B, D0, D1);
   }
 }
+
+// "cheb_fuse" (fl_tuning_set; initial value from FLUCA_CHEB_FUSE): 0 never use the fused two-step kernel, 1 (default) where it
+// pays (grids of at least 32^3 cells), 2 wherever it is legal (tests)
+int &cheb_fuse_mode()
+{
+  static int m = []() {
+    const char *e = std::getenv("FLUCA_CHEB_FUSE");
+    return e ? std::atoi(e) : 1;
+  }();
+  return m;
+}
+bool cheb_fuse(const fl_poisson *h)
+{
+  const int m = cheb_fuse_mode();
+  if (m <= 0 || !fl_cheb2_usable(h)) return false;
+  return m >= 2 || h->ncell >= 32768;
+}
+
+// the scalar block handed over BY VALUE (kernel argument): nothing reads the host copy after the launch returns, so the next
+// call may refill it while this one is still queued
+__global__ void k_scal_set(KspScal *dst, KspScal v) { *dst = v; }
 
 // partial sums -> scalar kernel, with the all-reduce in between when there is more than one rank
 template <class F>
@@ -632,6 +686,25 @@ int finish_stats(fl_poisson *h, const fl_ksp_opts *o, fl_ksp_stats *st)
 
 }  // namespace
 
+extern "C" int fl_tuning_set(const char *name, int value)
+{
+  if (!name) return FL_ERR_ARG_NULL;
+  if (std::strcmp(name, "cheb_fuse") == 0) {
+    cheb_fuse_mode() = value;
+    return FL_SUCCESS;
+  }
+  return FL_ERR_ARG_WRONG;
+}
+extern "C" int fl_tuning_get(const char *name, int *value)
+{
+  if (!name || !value) return FL_ERR_ARG_NULL;
+  if (std::strcmp(name, "cheb_fuse") == 0) {
+    *value = cheb_fuse_mode();
+    return FL_SUCCESS;
+  }
+  return FL_ERR_ARG_WRONG;
+}
+
 int fl_apply_tiled(fl_poisson *h, const double *xpad, double *y, int unpadded_y)
 {
   const TP tp = tile_plan(h->g);
@@ -675,10 +748,6 @@ int fl_apply_padded_dot(fl_poisson *h, double *xpad, double *ypad, double *xy)
   return 0;
 }
 
-// the scalar block handed over BY VALUE (kernel argument): nothing reads the host copy after the launch returns, so the next
-// smoother call may refill it while this one is still queued
-__global__ void k_scal_set(KspScal *dst, KspScal v) { *dst = v; }
-
 // nu Chebyshev(-Jacobi) steps on the handle's padded work vectors: right-hand side in h->r, initial guess in h->xp (taken as
 // zero when guess_zero), the result is left in h->xp (the two x buffers h->xp / h->P0 swap roles as needed).  No convergence
 // test, no null-space bookkeeping (a constant in x never reaches a residual: the caller projects once at the end), the host
@@ -712,22 +781,38 @@ int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero)
   S.cheb_rho  = 0.;
   S.cheb_c    = S.scale;
   hipLaunchKernelGGL(k_scal_set, dim3(1), dim3(1), 0, s, h->scal, S);
-  double    *X0 = h->xp, *X1 = h->P0, *B = h->r, *D = h->q;
+  const bool fuse = cheb_fuse(h) && nu - (guess_zero ? 1 : 0) >= 2;
+  Cheb2Plan  cp{};
+  if (fuse) {
+    cp = fl_cheb2_plan(h->g);
+    FL_CHK(fl_ensure_vec(h, &h->cd1));
+    FL_CHK(fl_ensure_partials(h, cp.nblocks));
+  }
+  double    *X0 = h->xp, *X1 = h->P0, *B = h->r, *D0 = h->q, *D1 = fuse ? h->cd1 : h->q;
   const bool ghosts = fl_any_ghost_exchange(h);
   auto       finl = [=](const double *partial, int nb, int stride, const double *sums) { hipLaunchKernelGGL(k_cheb_fin, dim3(1), dim3(256), 0, s, partial, nb, stride, sums, h->scal, h->hist, nhist); };
+  auto       fin2 = [=](const double *partial, int nb, int stride, const double *sums) { hipLaunchKernelGGL(k_cheb_fin2, dim3(1), dim3(256), 0, s, partial, nb, stride, sums, h->scal); };
   int        cur = 0;
-  for (int j = 0; j < nu; ++j) {
+  for (int j = 0; j < nu;) {
     if (j == 0 && guess_zero) {
       // the sums k_cheb_fin would look at are not used without a norm and a null space: it only advances the recurrence
       const int64_t pairs = (int64_t)((h->g.nx + 1) / 2) * h->g.ny * h->g.nz;
       const int     nb    = (int)std::max<int64_t>(1, std::min<int64_t>((pairs + 255) / 256, 8192));
-      if (jac) hipLaunchKernelGGL((k_cheb_first<true>), dim3(nb), dim3(256), 0, s, h->g, X0, X1, B, D, h->scal);
-      else hipLaunchKernelGGL((k_cheb_first<false>), dim3(nb), dim3(256), 0, s, h->g, X0, X1, B, D, h->scal);
+      if (jac) hipLaunchKernelGGL((k_cheb_first<true>), dim3(nb), dim3(256), 0, s, h->g, X0, X1, B, D0, D1, h->scal);
+      else hipLaunchKernelGGL((k_cheb_first<false>), dim3(nb), dim3(256), 0, s, h->g, X0, X1, B, D0, D1, h->scal);
+      FL_CHK(fin_step(h, tp.nblocks, 3, finl));
+      j += 1;
+    } else if (fuse && j + 2 <= nu) {
+      // two steps in one sweep; reads no ghost layer (fl_cheb2.hip)
+      fl_launch_cheb2(h, cp, jac, X0, X1, B, D0, D1);
+      FL_CHK(fin_step(h, cp.nblocks, 6, fin2));
+      j += 2;
     } else {
       if (ghosts) FL_CHK(fl_fill_ghosts(h, cur ? X1 : X0));
-      launch_cheb(h, tp, jac, X0, X1, B, D);
+      launch_cheb(h, tp, jac, X0, X1, B, D0, D1);
+      FL_CHK(fin_step(h, tp.nblocks, 3, finl));
+      j += 1;
     }
-    FL_CHK(fin_step(h, tp.nblocks, 3, finl));
     cur ^= 1;
   }
   if (cur) std::swap(h->xp, h->P0);
@@ -830,15 +915,24 @@ int fl_solve_cheb(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *
   S.cheb_rho  = 0.;        // step 0: d_1 = scale * z_0
   S.cheb_c    = S.scale;
   FL_HIP(hipEventRecord(h->ev0, s));
-  FL_HIP(hipMemcpyAsync(h->scal, h->scal_host, sizeof(KspScal), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_scal_set, dim3(1), dim3(1), 0, s, h->scal, S);  // by value: the host copy may be refilled at once
   // X1 (P0) is fully written by the first step before anything reads it; its wall ghosts are zero since allocation
   for (double *v : {h->q, h->xp}) FL_CHK(fl_zero_vec(h, v));
   launch_pad_copy(s, g, b, h->r);
-  double    *X0 = h->xp, *X1 = h->P0, *B = h->r, *D = h->q;
-  const bool ghosts = fl_any_ghost_exchange(h);
   const int  every  = o->check_every > 0 ? o->check_every : 16;
   const int  total  = o->norm_type == FL_NORM_NONE ? o->maxit : o->maxit + 1;  // with a norm, launch maxit is only the final check
+  // without a convergence test between the steps two of them share one sweep over memory (fl_cheb2.hip)
+  const bool fuse = o->norm_type == FL_NORM_NONE && total >= 2 && cheb_fuse(h);
+  Cheb2Plan  cp{};
+  if (fuse) {
+    cp = fl_cheb2_plan(g);
+    FL_CHK(fl_ensure_vec(h, &h->cd1));
+    FL_CHK(fl_ensure_partials(h, cp.nblocks));
+  }
+  double    *X0 = h->xp, *X1 = h->P0, *B = h->r, *D0 = h->q, *D1 = fuse ? h->cd1 : h->q;
+  const bool ghosts = fl_any_ghost_exchange(h);
   auto       finl   = [=](const double *partial, int nb, int stride, const double *sums) { hipLaunchKernelGGL(k_cheb_fin, dim3(1), dim3(256), 0, s, partial, nb, stride, sums, h->scal, h->hist, nhist); };
+  auto       fin2   = [=](const double *partial, int nb, int stride, const double *sums) { hipLaunchKernelGGL(k_cheb_fin2, dim3(1), dim3(256), 0, s, partial, nb, stride, sums, h->scal); };
   int        j = 0, hostcur = 0;
   bool       done = total <= 0;
   // check_every < 0 with KSP_NORM_NONE: a smoother call -- exactly maxit steps, nothing to test, so the host never waits for
@@ -846,10 +940,17 @@ int fl_solve_cheb(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *
   const bool nopoll = o->check_every < 0 && o->norm_type == FL_NORM_NONE;
   while (!done) {
     const int stop = std::min(total, j + every);
-    for (; j < stop; ++j) {
-      if (ghosts && j > 0) FL_CHK(fl_fill_ghosts(h, hostcur ? X1 : X0));
-      launch_cheb(h, tp, jac, X0, X1, B, D);
-      FL_CHK(fin_step(h, tp.nblocks, 3, finl));
+    while (j < stop) {
+      if (fuse && j + 2 <= total) {
+        fl_launch_cheb2(h, cp, jac, X0, X1, B, D0, D1);
+        FL_CHK(fin_step(h, cp.nblocks, 6, fin2));
+        j += 2;
+      } else {
+        if (ghosts && j > 0) FL_CHK(fl_fill_ghosts(h, hostcur ? X1 : X0));
+        launch_cheb(h, tp, jac, X0, X1, B, D0, D1);
+        FL_CHK(fin_step(h, tp.nblocks, 3, finl));
+        j += 1;
+      }
       hostcur ^= 1;
     }
     if (nopoll) done = j >= total;
@@ -862,6 +963,7 @@ int fl_solve_cheb(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *
     launch_unpad_copy(s, g, hostcur ? X1 : X0, x, S.nullspace ? &h->scal->xshift : nullptr);
     st->iters  = total;
     st->reason = FL_CONVERGED_ITS;
+    st->rnorm0 = st->rnorm = st->seconds = 0.;  // nothing was measured: the host never waited
     return 0;
   }
   FL_CHK(fl_poll_scal(h));

@@ -151,6 +151,14 @@ int fl_vec_dot(fl_poisson *h, int64_t n, const double *x_dev, const double *y_de
 int fl_vec_mdot(fl_poisson *h, int64_t n, const double *x_dev, const double *const *ys_dev, int k, double *out);
 int fl_vec_maxpy(fl_poisson *h, int64_t n, double *x_dev, const double *alphas, const double *const *ys_dev, int k);
 
+/* Build-specific tuning knobs (no reference counterpart; results never change beyond round-off).  Names:
+ *   "cheb_fuse"  0 = one kernel launch per Chebyshev step; 1 (default) = two steps per sweep over memory wherever no convergence
+ *                test sits between them (KSP_NORM_NONE sweeps, the multigrid smoother) and the grid is large enough to gain;
+ *                2 = the same on every grid where it is legal.
+ * Returns FL_ERR_ARG_WRONG for an unknown name.  Process-wide; set before the solve it should affect. */
+int fl_tuning_set(const char *name, int value);
+int fl_tuning_get(const char *name, int *value);
+
 /* Optional one-off tuning step after create (like planning an FFT): any kernel that streams six 1 GB vectors at once runs
  * 10-15 % faster or slower depending on where the driver happened to place them physically (profiles/r01_placement.txt).
  * This allocates up to max_tries candidate sets of the solver vectors, times a 3-read/3-write streaming probe on each
