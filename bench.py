@@ -8,6 +8,11 @@ reference's -cart_ranks_{x,y,z}).  Right-hand side: SURVEY 8d micro-benchmark b 
 iteration count (rtol = atol = 0), inputs resident in HBM before the timed region.
 
 One JSON line on rank 0.  value = (cells of the whole job / 512^3) * K / seconds  ==  iterations/s of a 512^3 grid at N=1.
+At N = 1 the line also carries "configs": driver-timed lines for the other single-GPU configurations of BASELINE.json (C2 256^3
+cavity CG, C3 512^3 channel Chebyshev-Jacobi sweeps, C4 512^3 with the IBM kernels on an immersed sphere), each with its own
+roofline object, and "value_unplaced": the same K steps on plainly allocated vectors (see "placement" in include/fluca_hip.h).
+For N > 1 the halo transport is RCCL; if RCCL cannot be initialised the run FAILS (a host-staged curve would be worthless) --
+the host-staged rehearsal has to be asked for with --transport host.
 """
 import argparse
 import json
@@ -26,6 +31,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); measur
 B_ITER_ALGO = 88               # algorithmic bytes / cell / PCG iteration
 B_KERNEL_A_ALGO = 64           # of those, the textbook steps k_cg_A fuses: direction 24 + SpMV/dot 16 + x-update 24
 B_KERNEL_A_REAL = 48           # what k_cg_A actually moves: reads r,p,x  writes p,q,x
+B_CHEB_ALGO = 40               # algorithmic bytes / cell / Chebyshev-Jacobi step: read x, b, d; write x', d'
+IBM_B_PER_MARKER = 1584        # L * (4^3 * 3 * 8 + 6 * 8) bytes per interp or spread of three components
 RANK_GRIDS = {1: (1, 1, 1), 2: (1, 1, 2), 4: (1, 2, 2), 8: (2, 2, 2)}
 
 
@@ -109,6 +116,110 @@ def petsc_cpu(sample_n, iters, cores):
         return f"unavailable ({e!r})"
 
 
+def other_configs(stream):
+    """Driver-timed lines for the other single-GPU configurations of BASELINE.json, each with its own roofline object (same
+    conventions as the headline: inputs resident, host clock around a synchronised region, HIP events for the dominant kernel)."""
+    import ctypes as C
+
+    from fluca_amd import capi
+    from fluca_amd import poisson as flp
+    box = [(0.0, 1.0), (0.0, 1.0), (0.0, 0.5)]
+    cfg = {}
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize()
+        return r, time.perf_counter() - t0
+
+    def rhs(P, seed):
+        gen = torch.Generator(device="cuda").manual_seed(seed)
+        p = torch.rand(P.ncell, generator=gen, dtype=torch.float64, device="cuda") * 2 - 1
+        stream.wait_stream(torch.cuda.current_stream())
+        return P.apply(p)
+
+    # C2: 256^3 lid-driven cavity, matrix-free Jacobi-PCG
+    P = flp.Poisson.uniform((256,) * 3, box, [1, 1, 1, 1, 4, 1], 1e-3)
+    P.set_stream(stream)
+    b, x = rhs(P, 2), P.empty()
+    kw = dict(rtol=0.0, atol=0.0, check_every=64)
+    P.solve(b, x=x, maxit=50, **kw)
+    K = 400
+    (_, info), dt = timed(lambda: P.solve(b, x=x, maxit=K, profile=1, **kw))
+    ach = B_KERNEL_A_ALGO * P.ncell / (info["kernel_ms"] * 1e-3) / 1e9
+    cfg["C2"] = {"workload": "256^3 lid-driven cavity, matrix-free Jacobi-PCG, fixed 400 iterations", "metric": "PCG iterations/s", "value": K / dt, "steps": K,
+                 "ms_per_step": dt / K * 1e3, "iteration_algorithmic_GBps": B_ITER_ALGO * P.ncell * K / dt / 1e9,
+                 "roofline": {"bound": "hbm", "kernel": "k_cg_A", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                              "algorithmic_bytes_per_cell": B_KERNEL_A_ALGO, "avg_launch_ms": info["kernel_ms"], "launches_timed": info["kernel_launches"]}}
+    P.close()
+    del b, x
+
+    # C3: 512^3 channel (inlet VELOCITY, PRESSURE_OUTLET, walls in y, periodic span), Chebyshev-Jacobi, fixed 100-step sweeps
+    P = flp.Poisson.uniform((512,) * 3, box, [1, 2, 1, 1, 3, 3], 1e-3)
+    P.set_stream(stream)
+    b, x = rhs(P, 3), P.empty()
+    kw = dict(type=2, norm_type=3, remove_nullspace=0, check_every=100)
+    P.solve(b, x=x, maxit=20, **kw)
+    K = 100
+    (_, info), dt = timed(lambda: P.solve(b, x=x, maxit=K, profile=1, **kw))
+    fused = info["kernel_launches"] * 2 == K            # the fused kernel applies two steps per launch
+    per_launch = (2 if fused else 1) * B_CHEB_ALGO * P.ncell
+    ach = per_launch / (info["kernel_ms"] * 1e-3) / 1e9
+    pmc = os.path.join(ROOT, "profiles", "pmc_k_cheb2.json")
+    traffic = None
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        except Exception:  # noqa: BLE001
+            traffic = None
+    cfg["C3"] = {"workload": "512^3 channel [VELOCITY, PRESSURE_OUTLET, wall, wall, PERIODIC, PERIODIC], Chebyshev-Jacobi, KSP_NORM_NONE, fixed 100 steps",
+                 "metric": "Chebyshev-Jacobi steps/s", "value": K / dt, "steps": K, "ms_per_step": dt / K * 1e3,
+                 "step_algorithmic_GBps": B_CHEB_ALGO * P.ncell * K / dt / 1e9,
+                 "roofline": {"bound": "hbm", "kernel": "k_cheb2 (two fused Chebyshev-Jacobi steps per launch)" if fused else "k_cheb", "achieved": ach, "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_cell_per_launch": per_launch / P.ncell,
+                              "steps_per_launch": 2 if fused else 1, "avg_launch_ms": info["kernel_ms"], "launches_timed": info["kernel_launches"]}}
+    P.close()
+    del b, x
+
+    # C4: 512^3 with an immersed sphere D = 64 h (Fibonacci lattice, spacing ~ h): interpolation + spreading of three components
+    n = 512
+    P = flp.Poisson.uniform((n,) * 3, [(0, 1), (0, 1), (0, 1)], [1] * 6, 1e-3)
+    P.set_stream(stream)
+    h = 1.0 / n
+    R = 32 * h
+    L = int(round(4 * np.pi * R * R / (h * h)))
+    i = np.arange(L) + 0.5
+    phi, th = np.arccos(1 - 2 * i / L), np.pi * (1 + 5 ** 0.5) * i
+    X = [torch.as_tensor(a, device="cuda") for a in (0.5 + R * np.cos(th) * np.sin(phi), 0.5 + R * np.sin(th) * np.sin(phi), 0.5 + R * np.cos(phi))]
+    u = torch.rand(3 * P.ncell, dtype=torch.float64, device="cuda")
+    F = torch.rand(3 * L, dtype=torch.float64, device="cuda")
+    dV = torch.full((L,), h ** 3, dtype=torch.float64, device="cuda")
+    U = torch.empty(3 * L, dtype=torch.float64, device="cuda")
+    f = torch.zeros(3 * P.ncell, dtype=torch.float64, device="cuda")
+    ptr = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    m = C.c_void_p()
+    stream.wait_stream(torch.cuda.current_stream())
+    capi.check(capi.lib.fl_ibm_create(P.h, capi.DELTA_PESKIN4, L, ptr(X[0]), ptr(X[1]), ptr(X[2]), C.byref(m)), "fl_ibm_create")
+
+    def ibm_step():
+        capi.check(capi.lib.fl_ibm_interp(m, 3, ptr(u), ptr(U)))
+        capi.check(capi.lib.fl_ibm_spread(m, 3, ptr(F), ptr(dV), ptr(f)))
+        P.synchronize()
+    ibm_step()
+    K = 50
+    _, dt = timed(lambda: [ibm_step() for _ in range(K)])
+    ach = 2 * IBM_B_PER_MARKER * L * K / dt / 1e9
+    cfg["C4"] = {"workload": f"512^3 grid, immersed sphere D = 64 h, {L} markers (Peskin 4-point): interpolation + spreading of 3 components per step",
+                 "metric": "IBM interpolate+spread steps/s", "value": K / dt, "steps": K, "ms_per_step": dt / K * 1e3, "markers": L,
+                 "roofline": {"bound": "hbm", "kernel": "k_ibm_interp + k_ibm_spread", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                              "traffic": None, "algorithmic_bytes_per_marker": IBM_B_PER_MARKER,
+                              "note": "latency-bound by construction (20 MB of traffic per step): reported, not a roofline target (SURVEY 8d)"}}
+    capi.lib.fl_ibm_destroy(m)
+    P.close()
+    return cfg
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,8 +231,11 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=500, help="iterations of the CPU sample (about 10 s on 16 cores at 256^3)")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-extras", action="store_true", help="skip the time-to-solution comparison after the timed region")
-    ap.add_argument("--placement-tries", type=int, default=24,
-                    help="candidate placements of the solver vectors probed before the run (0 = take what the driver gives)")
+    ap.add_argument("--placement", choices=["auto", "off"], default="auto",
+                    help="auto: the library carves the solver vectors out of one arena where a probe of k_cg_A runs fastest (its "
+                         "default); off: one plain allocation per vector")
+    ap.add_argument("--placement-tries", type=int, default=None, help="(accepted for compatibility, ignored: placement is no longer a lottery)")
+    ap.add_argument("--skip-configs", action="store_true", help="skip the C2 / C3 / C4 lines after the timed region")
     ap.add_argument("--transport", choices=["rccl", "host"], default="rccl",
                     help="halo transport for N > 1: RCCL Send/Recv (production) or the host-staged gloo callbacks "
                          "(rehearsal on a box with fewer GPUs than ranks; never used for a reported number)")
@@ -141,8 +255,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)   # control plane only; data path = RCCL inside the library
 
+    from fluca_amd import capi
     from fluca_amd import poisson as flp
     from fluca_amd.capi import BC_SYMMETRY, BC_VELOCITY
+    capi.check(capi.lib.fl_tuning_set(b"placement", 1 if args.placement == "auto" else 0), "fl_tuning_set")
 
     ranks = RANK_GRIDS[args.gpus]
     n = tuple(args.cells * r for r in ranks)
@@ -153,14 +269,12 @@ def main():
     transport = args.transport
     if world > 1 and transport == "rccl":
         # rank 0 creates the ncclUniqueId, the control plane (gloo) broadcasts it, every rank joins the RCCL communicator.
-        # If RCCL cannot be initialised on this node the run continues on the host-staged transport and SAYS SO in the
-        # JSON line ("halo"): still the GPU kernels, only the wire differs.
-        ok = 1
+        # No fallback: a run that cannot use the production wire fails on every rank.
+        ok, why = 1, ""
         try:
             idb = [flp.rccl_unique_id() if rank == 0 else None]
         except Exception as e:  # noqa: BLE001
-            print(f"[bench] rank {rank}: RCCL unique id failed: {e}", file=sys.stderr, flush=True)
-            idb, ok = [None], 0
+            idb, ok, why = [None], 0, f"RCCL unique id failed: {e}"
         dist.broadcast_object_list(idb, src=0)
         if idb[0] is None:
             ok = 0
@@ -168,19 +282,20 @@ def main():
             try:
                 P.comm_init_rccl(idb[0], rank, world)
             except Exception as e:  # noqa: BLE001
-                print(f"[bench] rank {rank}: RCCL init failed: {e}", file=sys.stderr, flush=True)
-                ok = 0
+                ok, why = 0, f"RCCL init failed: {e}"
         t_ok = torch.tensor([ok], dtype=torch.int32)
         dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
         if int(t_ok[0]) == 0:
-            transport = "host"
+            print(f"[bench] rank {rank}: RCCL transport unavailable ({why or 'another rank failed'}); refusing to fall back to the "
+                  f"host-staged transport (ask for it with --transport host)", file=sys.stderr, flush=True)
+            dist.destroy_process_group()
+            sys.exit(3)
     if world > 1 and transport == "host":
-        from tests import mp_common as mpc
-        P.comm_init_host(mpc.gloo_exchange, mpc.gloo_allreduce, rank, world)
+        from fluca_amd import hostcomm
+        P.comm_init_host(hostcomm.gloo_exchange, hostcomm.gloo_allreduce, rank, world)
     stream = torch.cuda.Stream()
     P.set_stream(stream)
 
-    probe = P.tune_placement(args.placement_tries) if args.placement_tries > 0 else None   # one-off, outside the timed region
     gen = torch.Generator(device="cuda").manual_seed(20260313 + rank)
     pstar = torch.rand(P.ncell, generator=gen, dtype=torch.float64, device="cuda") * 2 - 1
     stream.wait_stream(torch.cuda.current_stream())
@@ -197,7 +312,8 @@ def main():
         torch.cuda.synchronize()
 
     if args.warmup > 0:
-        run(args.warmup, False)
+        run(args.warmup, False)      # the first solve places the vectors (one-off, outside the timed region)
+    probe = P.tune_placement()       # idempotent: the probe times the placement step recorded
     barrier()
     t0 = time.perf_counter()
     info = run(args.steps, True)
@@ -209,6 +325,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
     assert info["iters"] == args.steps, info
+    per_rank = None
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {"rank": rank, "device": local, "k_cg_A_ms": info["kernel_ms"], "seconds_device": info["seconds"],
+                                          "placement_probe_ms": list(probe)})
 
     cells_job = float(P.ncell) * world
     value = cells_job / 512.0 ** 3 * args.steps / dt
@@ -232,7 +353,9 @@ def main():
                    "halo": ("RCCL Send/Recv" if transport == "rccl" else "host-staged gloo (NOT the production transport)") if world > 1 else "none"},
         "iteration_algorithmic_GBps_per_gpu": B_ITER_ALGO * P.ncell * args.steps / dt / 1e9,
         "solve_seconds_device": info["seconds"],
-        "placement_probe_ms": {"first": probe[0], "best": probe[1], "tries": args.placement_tries} if probe else None,
+        "ranks": per_rank, "transport_ranks": world if world > 1 else None,
+        "placement": {"mode": args.placement, "probe_ms_all_vectors_in_one_block": probe[0], "probe_ms_chosen": probe[1],
+                      "note": "k_cg_A probe; deterministic arena search, see include/fluca_hip.h fl_poisson_tune_placement"},
         "roofline": {"bound": "hbm", "kernel": "k_cg_A (p-update + S*p + dot + deferred x-update)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
@@ -252,6 +375,37 @@ def main():
             out["time_to_solution"] = tts
         except Exception as e:  # noqa: BLE001
             out["time_to_solution"] = {"error": repr(e)}
+    if world == 1 and not args.skip_extras and args.placement == "auto":
+        # the same K steps on plainly allocated vectors (what the library did before the placement step existed)
+        try:
+            capi.check(capi.lib.fl_tuning_set(b"placement", 0))
+            Pu = flp.Poisson.uniform(n, box, bc, 1e-3, device=local)
+            Pu.set_stream(stream)
+            xu = Pu.empty()
+            kw = dict(rtol=0.0, atol=0.0, variant=args.variant, check_every=64)
+            Pu.solve(b, x=xu, maxit=max(args.warmup, 1), **kw)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            iu = Pu.solve(b, x=xu, maxit=args.steps, profile=1, **kw)[1]
+            Pu.synchronize()
+            torch.cuda.synchronize()
+            du = time.perf_counter() - t0
+            out["value_unplaced"] = cells_job / 512.0 ** 3 * args.steps / du
+            out["unplaced_k_cg_A_ms"] = iu["kernel_ms"]
+            Pu.close()
+            del xu
+        except Exception as e:  # noqa: BLE001
+            out["value_unplaced"] = {"error": repr(e)}
+        finally:
+            capi.check(capi.lib.fl_tuning_set(b"placement", 1))
+    if world == 1 and not args.skip_configs:
+        P.close()
+        del b, x, pstar
+        torch.cuda.empty_cache()
+        try:
+            out["configs"] = other_configs(stream)
+        except Exception as e:  # noqa: BLE001
+            out["configs"] = {"error": repr(e)}
     if world == 1 and not args.skip_extras:
         # the attainable streaming rate on THIS box, reported beside the nominal peak: a plain device copy of a
         # 512^3 vector (1 GiB read + 1 GiB written per pass)
@@ -274,7 +428,8 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args.cpu_cells, args.cpu_iters)
     elif rank == 0:
         out["cpu_baseline"] = None
-    P.close()
+    if P.h:
+        P.close()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -267,6 +267,165 @@ extern "C" int fl_poisson_sizes(const fl_poisson *h, int64_t out[4])
   return FL_SUCCESS;
 }
 
+// ------------------------------------------------------------------------------------------------ placement
+// Kernels that stream five or six gigabyte-sized vectors in lock step (k_cg_A: reads r, p, x, writes p', q, x) run in one
+// of two modes on MI355X, 1.10 ms or 1.27 ms per launch at 512^3.  Measured cause (profiles/r02_placement.md): the mode is
+// a property of WHERE IN PHYSICAL MEMORY the vectors live relative to each other.  Vectors that sit in one physically
+// contiguous block of HBM -- what back-to-back hipMallocs, and any layout inside the first 16 GiB of one large allocation,
+// produce -- are slow at every spacing and alignment; as soon as two or three of the five come from a different block the
+// kernel runs 13 % faster (a sliding window of five packed vectors inside one 96 GiB allocation is slow everywhere except
+// where it straddles the seams between the driver's blocks, at 16 GiB and 64 GiB into the allocation).
+// So placement is no lottery: ONE arena large enough to contain a seam is allocated, a window of five packed vectors slides
+// through it (k_cg_A itself is the probe, ~20 positions of a few ms), and the solver vectors are carved out where the window
+// was fastest; the vectors outside the window come alternately from the arena's two sides.  Done once per handle, by the
+// first fl_ensure_vec of a large handle (tuning knob "placement", default 1) or explicitly by fl_poisson_tune_placement.
+
+int &fl_placement_mode()
+{
+  static int m = []() {
+    const char *e = std::getenv("FLUCA_PLACEMENT");
+    return e ? std::atoi(e) : 1;
+  }();
+  return m;
+}
+namespace {
+constexpr size_t PL_MIN_VEC   = (size_t)256 << 20;  // smaller vectors: nothing to gain, plain allocations
+constexpr size_t PL_SEAM      = (size_t)16 << 30;   // where the first seam of a fresh allocation has been found on every box
+constexpr int    PL_WIN       = 5;                   // r, P0, P1, q, xp
+constexpr int    PL_SIDE      = 3;                   // pool slots on either side of the window
+
+int place_vectors(fl_poisson *h)
+{
+  if (h->placed || h->nv_il > 1) return 0;
+  h->placed = true;  // whatever happens below is final for this handle
+  hipStream_t  s    = h->stream;
+  const size_t vecb = ((sizeof(double) * h->padlen + ((size_t)2 << 20) - 1) / ((size_t)2 << 20)) * ((size_t)2 << 20);
+  const int    nslot = PL_WIN + 2 * PL_SIDE;
+  if (vecb < PL_MIN_VEC) return 0;  // small vectors: the kernels are not bandwidth-bound enough to notice; plain allocations
+  size_t       freeb = 0, total = 0;
+  if (hipMemGetInfo(&freeb, &total) != hipSuccess) return 0;
+  size_t want = ((PL_SEAM + (size_t)(PL_WIN + PL_SIDE) * vecb + ((size_t)1 << 30) - 1) >> 30) << 30;
+  const size_t reserve = (size_t)16 << 30;
+  if (freeb < want + reserve) want = freeb > reserve + (size_t)nslot * vecb ? ((freeb - reserve) >> 30) << 30 : 0;
+  if (want < (size_t)nslot * vecb) return 0;  // not enough memory for an arena: plain allocations
+  void *arena = nullptr;
+  if (hipMalloc(&arena, want) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  FL_HIP(hipMemsetAsync(arena, 0, want, s));
+  PlanA plan = plan_cg_A(h->g, 0, 0);
+  plan.probe = 1;  // launches k_cg_A_probe: identical code, separate name in profiles
+  FL_CHK(fl_ensure_partials(h, plan.nblocks));
+  struct Scal2 {  // two scalar blocks: direction buffer parity 0 and 1; released on every return path
+    KspScal *p = nullptr;
+    ~Scal2()
+    {
+      if (p) (void)hipFree(p);
+    }
+  } sc;
+  FL_HIP(hipMalloc((void **)&sc.p, 2 * sizeof(KspScal)));
+  {
+    KspScal S2[2];
+    std::memset(S2, 0, sizeof(S2));
+    for (int a = 0; a < 2; ++a) {
+      S2[a].beta = 0.5; S2[a].alpha = 1e-3; S2[a].zshift = 1e-4; S2[a].ncell_global = (double)h->ncell; S2[a].maxit = 1 << 30; S2[a].cur = a;
+    }
+    FL_HIP(hipMemcpy(sc.p, S2, sizeof(S2), hipMemcpyHostToDevice));
+  }
+  auto vec = [&](size_t b, int k) { return (double *)((char *)arena + b + (size_t)k * vecb); };
+  auto probe = [&](size_t b, double *ms_out) -> int {
+    auto run = [&](int reps) {
+      for (int r = 0; r < reps; ++r)
+        for (int par = 0; par < 2; ++par) launch_cg_A(s, h->g, true, plan, vec(b, 0), vec(b, 1), vec(b, 2), vec(b, 3), vec(b, 4), sc.p + par, h->partial, nullptr, nullptr, 0);
+    };
+    run(1);
+    FL_HIP(hipEventRecord(h->ev0, s));
+    run(2);
+    FL_HIP(hipEventRecord(h->ev1, s));
+    FL_HIP(hipStreamSynchronize(s));
+    float ms = 0.f;
+    FL_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *ms_out = ms / 4.;
+    return 0;
+  };
+  const size_t lo = (size_t)PL_SIDE * vecb, hi = want - (size_t)(PL_WIN + PL_SIDE) * vecb;
+  const size_t step = std::max(vecb / 2, (((hi - lo) / 48) >> 21) << 21);  // half a vector, at most ~50 probes
+  size_t       best = lo;
+  double       first_ms = 0., best_ms = 0.;
+  int          nprobe = 0;
+  for (size_t b = lo; b <= hi; b += step, ++nprobe) {
+    double ms = 0.;
+    FL_CHK(probe(b, &ms));
+    if (nprobe == 0) first_ms = best_ms = ms;
+    if (ms < best_ms) {
+      best_ms = ms;
+      best    = b;
+    }
+  }
+  // the probes wrote into the arena: ghost layers of fresh solver vectors are zero by contract
+  FL_HIP(hipMemsetAsync(arena, 0, want, s));
+  FL_HIP(hipStreamSynchronize(s));
+  h->arena       = arena;
+  h->arena_bytes = want;
+  h->vec_bases.push_back(arena);
+  double **win[PL_WIN] = {&h->r, &h->P0, &h->P1, &h->q, &h->xp};
+  for (int k = 0; k < PL_WIN; ++k) *win[k] = vec(best, k);
+  h->pool_next[0] = (char *)arena + best - (size_t)PL_SIDE * vecb;
+  h->pool_end[0]  = (char *)arena + best;
+  h->pool_next[1] = (char *)arena + best + (size_t)PL_WIN * vecb;
+  h->pool_end[1]  = h->pool_next[1] + (size_t)PL_SIDE * vecb;
+  h->pool_vec     = vecb;
+  h->nvec += PL_WIN;
+  h->placed_ms[0] = first_ms;
+  h->placed_ms[1] = best_ms;
+  h->placed_at    = (double)best / (double)((size_t)1 << 30);
+  return 0;
+}
+}  // namespace
+
+// a padded vector from the arena's side pools (alternating sides), or nullptr when there is no arena / no slot left
+static double *pool_take(fl_poisson *h)
+{
+  if (!h->arena) return nullptr;
+  for (int t = 0; t < 2; ++t) {
+    const int side = (h->pool_flip + t) & 1;
+    if (h->pool_next[side] + h->pool_vec <= h->pool_end[side]) {
+      double *v = (double *)h->pool_next[side];
+      h->pool_next[side] += h->pool_vec;
+      h->pool_flip = side ^ 1;
+      return v;
+    }
+  }
+  return nullptr;
+}
+
+// Explicit form of the placement step (idempotent; max_tries is kept for source compatibility and only has to be >= 1).
+// probe_ms_out: {k_cg_A probe time with the window at the start of the arena (all vectors in one physical block: what plain
+// back-to-back allocations give), probe time at the chosen position}; {0, 0} when the handle is too small to be placed.
+extern "C" int fl_poisson_tune_placement(fl_poisson *h, int max_tries, double probe_ms_out[2])
+{
+  if (!h) return FL_ERR_ARG_NULL;
+  if (max_tries < 1) return FL_ERR_ARG_OUTOFRANGE;
+  FL_HIP(hipSetDevice(h->device));
+  if (!h->placed && h->nv_il == 1) {
+    FL_HIP(hipStreamSynchronize(h->stream));
+    // vectors that exist already (a solve ran before this call) are dropped: every solve re-creates what it needs
+    fl_mg_destroy(h);
+    for (void *p : h->vec_bases) (void)hipFree(p);
+    h->vec_bases.clear();
+    h->nvec = 0;
+    h->slab = nullptr;
+    for (double **v : {&h->r, &h->P0, &h->P1, &h->q, &h->xp, &h->w0, &h->w1, &h->w2, &h->cd1}) *v = nullptr;
+    FL_CHK(place_vectors(h));
+  }
+  if (probe_ms_out) {
+    probe_ms_out[0] = h->placed_ms[0];
+    probe_ms_out[1] = h->placed_ms[1];
+  }
+  return FL_SUCCESS;
+}
+
 // ------------------------------------------------------------------------------------------------ workspace / ghosts
 
 // Padded solver vectors.  Each one starts at a different offset inside its allocation (multiples of FLUCA_SKEW bytes,
@@ -275,6 +434,15 @@ extern "C" int fl_poisson_sizes(const fl_poisson *h, int64_t out[4])
 int fl_ensure_vec(fl_poisson *h, double **v)
 {
   if (*v) return 0;
+  if (h->nv_il == 1 && !h->placed && h->nvec == 0 && fl_placement_mode() > 0 && sizeof(double) * h->padlen >= PL_MIN_VEC) {
+    FL_CHK(place_vectors(h));  // carves r, P0, P1, q, xp out of one arena (see "placement" above)
+    if (*v) return 0;
+  }
+  if (double *p = pool_take(h)) {
+    *v = p;
+    h->nvec++;
+    return 0;
+  }
   if (h->nv_il > 1) {
     // interleaved: one slab, vector k starts k*sx0 doubles into it
     if (!h->slab) {
@@ -397,97 +565,6 @@ int fl_fill_ghosts(fl_poisson *h, double *v)
 }
 
 bool fl_any_ghost_exchange(const fl_poisson *h) { return h->multi || h->wrap_local[0] || h->wrap_local[1] || h->wrap_local[2]; }
-
-// ------------------------------------------------------------------------------------------------ placement tuning
-
-extern "C" int fl_poisson_tune_placement(fl_poisson *h, int max_tries, double probe_ms_out[2])
-{
-  if (!h) return FL_ERR_ARG_NULL;
-  if (max_tries < 1) return FL_ERR_ARG_OUTOFRANGE;
-  if (h->nv_il > 1) return FL_SUCCESS;  // interleaved slab: nothing to choose
-  FL_HIP(hipSetDevice(h->device));
-  hipStream_t s = h->stream;
-  FL_HIP(hipStreamSynchronize(s));
-  double **slots[6] = {&h->r, &h->P0, &h->P1, &h->q, &h->xp, &h->w0};
-  struct Set {
-    double *v[6];
-    std::vector<void *> bases;
-    double ms;
-  };
-  std::vector<Set> sets;
-  const size_t     set_bytes = 6 * sizeof(double) * h->padlen;
-  PlanA            plan = plan_cg_A(h->g, 0, 0);
-  plan.probe            = 1;  // launches k_cg_A_probe: identical code, separate name in profiles
-  FL_CHK(fl_ensure_partials(h, plan.nblocks));
-  // two scalar blocks: direction buffer parity 0 and 1
-  KspScal *scal2 = nullptr;
-  FL_HIP(hipMalloc((void **)&scal2, 2 * sizeof(KspScal)));
-  {
-    KspScal S2[2];
-    std::memset(S2, 0, sizeof(S2));
-    for (int a = 0; a < 2; ++a) {
-      S2[a].beta = 0.5; S2[a].alpha = 1e-3; S2[a].zshift = 1e-4; S2[a].ncell_global = (double)h->ncell; S2[a].maxit = 1 << 30; S2[a].cur = a;
-    }
-    FL_HIP(hipMemcpy(scal2, S2, sizeof(S2), hipMemcpyHostToDevice));
-  }
-  // start from whatever is allocated already
-  auto detach = [&]() {
-    h->vec_bases.clear();
-    h->nvec = 0;
-    h->slab = nullptr;
-    for (double **v : {&h->r, &h->P0, &h->P1, &h->q, &h->xp, &h->w0, &h->w1, &h->w2}) *v = nullptr;
-  };
-  if (h->nvec != 0) {
-    for (void *p : h->vec_bases) (void)hipFree(p);
-    detach();
-  }
-  for (int t = 0; t < max_tries; ++t) {
-    size_t freeb = 0, total = 0;
-    if (hipMemGetInfo(&freeb, &total) == hipSuccess && freeb < 2 * set_bytes + ((size_t)8 << 30)) break;
-    for (double **v : slots) FL_CHK(fl_ensure_vec(h, v));
-    Set c;
-    for (int a = 0; a < 6; ++a) c.v[a] = *slots[a];
-    c.bases = h->vec_bases;
-    // The probe is the dominant kernel itself, in both roles of the two direction buffers (k_cg_A reads one and writes
-    // the other, alternating every iteration): which vectors are read and which are written at the same time matters.
-    for (int a : {0, 1, 2, 4}) FL_HIP(hipMemsetAsync(c.v[a], 0x3f, sizeof(double) * h->padlen, s));
-    auto probe = [&](int reps) {
-      for (int r = 0; r < reps; ++r)
-        for (int par = 0; par < 2; ++par) launch_cg_A(s, h->g, true, plan, c.v[0], c.v[1], c.v[2], c.v[3], c.v[4], scal2 + par, h->partial, nullptr, nullptr, 0);
-    };
-    probe(1);
-    FL_HIP(hipEventRecord(h->ev0, s));
-    probe(2);
-    FL_HIP(hipEventRecord(h->ev1, s));
-    FL_HIP(hipStreamSynchronize(s));
-    float ms = 0.f;
-    FL_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
-    ms *= 3.f / 4.f;  // 4 launches; keep the "/ 3" below
-    c.ms = ms / 3.;
-    sets.push_back(c);
-    detach();  // keep it allocated: the next candidate must land somewhere else
-  }
-  (void)hipFree(scal2);
-  if (sets.empty()) return FL_ERR_MEM;
-  size_t best = 0;
-  for (size_t a = 1; a < sets.size(); ++a)
-    if (sets[a].ms < sets[best].ms) best = a;
-  for (size_t a = 0; a < sets.size(); ++a)
-    if (a != best)
-      for (void *p : sets[a].bases) (void)hipFree(p);
-  for (int a = 0; a < 6; ++a) {
-    *slots[a] = sets[best].v[a];
-    FL_HIP(hipMemsetAsync(sets[best].v[a], 0, sizeof(double) * h->padlen, s));
-  }
-  h->vec_bases = sets[best].bases;
-  h->nvec      = 6;
-  FL_HIP(hipStreamSynchronize(s));
-  if (probe_ms_out) {
-    probe_ms_out[0] = sets[0].ms;
-    probe_ms_out[1] = sets[best].ms;
-  }
-  return FL_SUCCESS;
-}
 
 // ------------------------------------------------------------------------------------------------ operator entry points
 
@@ -709,11 +786,9 @@ static int solve_cg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts
     return 0;
   };
 
-  std::vector<hipEvent_t> pev;
-  if (o->profile) {
-    pev.resize(2 * (size_t)std::min(o->maxit, 4096));
-    for (auto &e : pev) FL_HIP(hipEventCreate(&e));
-  }
+  ProfEvents               prof_events;
+  std::vector<hipEvent_t> &pev = prof_events.ev;
+  if (o->profile) FL_CHK(prof_events.create(2 * (size_t)std::min(o->maxit, 4096)));
 
   const int every = o->check_every > 0 ? o->check_every : 16;
   int       it    = 0;
@@ -760,20 +835,7 @@ static int solve_cg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts
   st->seconds      = ms * 1e-3;
   st->kernel_ms    = 0.;
   st->kernel_launches = 0;
-  if (o->profile) {
-    double tot = 0.;
-    int    cnt = 0;
-    for (int a = 0; a < R.it && (size_t)(2 * a + 1) < pev.size(); ++a) {
-      float t = 0.f;
-      if (hipEventElapsedTime(&t, pev[2 * a], pev[2 * a + 1]) == hipSuccess) {
-        tot += t;
-        ++cnt;
-      }
-    }
-    st->kernel_ms       = cnt ? tot / cnt : 0.;
-    st->kernel_launches = cnt;
-    for (auto &e : pev) (void)hipEventDestroy(e);
-  }
+  if (o->profile) prof_events.mean(R.it, &st->kernel_ms, &st->kernel_launches);
   if (o->history && o->nhistory > 0) {
     const int n = std::min(o->nhistory, R.it + 1);
     FL_HIP(hipMemcpy(o->history, h->hist, sizeof(double) * n, hipMemcpyDeviceToHost));
@@ -1031,4 +1093,119 @@ extern "C" int fldbg_pool_probe(fl_poisson *h, int K, int M, unsigned seed, doub
   (void)hipFree(scal2);
   for (double *p : pool) (void)hipFree(p);
   return 0;
+}
+
+// Experiment behind the placement note in DESIGN.md (tools/experiments/arena_probe.py): one arena allocated once, six
+// streams (nr reads, nw writes of n doubles each) placed at caller-chosen byte offsets inside it, launch time of the plain
+// streaming kernel.  Not part of the public C-ABI.
+extern "C" int fldbg_arena_probe(fl_poisson *h, int64_t arena_bytes, const int64_t *off_bytes, int64_t n, int nr, int nw, int reps, double *ms_out, void **arena_out)
+{
+  if (!h || !off_bytes || !ms_out) return FL_ERR_ARG_NULL;
+  FL_HIP(hipSetDevice(h->device));
+  static void   *arena = nullptr;
+  static int64_t cap   = 0;
+  if (arena_bytes < 0) {  // release
+    if (arena) (void)hipFree(arena);
+    arena = nullptr;
+    cap   = 0;
+    return FL_SUCCESS;
+  }
+  if (cap < arena_bytes) {
+    if (arena) (void)hipFree(arena);
+    arena = nullptr;
+    FL_HIP(hipMalloc(&arena, (size_t)arena_bytes));
+    FL_HIP(hipMemset(arena, 0, (size_t)arena_bytes));
+    cap = arena_bytes;
+  }
+  if (arena_out) *arena_out = arena;
+  double *v[6];
+  for (int a = 0; a < 6; ++a) {
+    if (off_bytes[a] < 0 || off_bytes[a] + n * 8 > cap || (off_bytes[a] & 15)) return FL_ERR_ARG_OUTOFRANGE;
+    v[a] = (double *)((char *)arena + off_bytes[a]);
+  }
+  hipStream_t s = h->stream;
+  auto once = [&]() { launch_stream_ref(s, nr, nw, n / 2, v[0], v[1], v[2], v[3], v[4], v[5]); };
+  once();
+  FL_HIP(hipEventRecord(h->ev0, s));
+  for (int a = 0; a < reps; ++a) once();
+  FL_HIP(hipEventRecord(h->ev1, s));
+  FL_HIP(hipStreamSynchronize(s));
+  FL_HIP(hipGetLastError());
+  float ms = 0.f;
+  FL_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  *ms_out = ms / reps;
+  return FL_SUCCESS;
+}
+
+// tools/experiments/arena_probe3.py: the plain streaming kernel on six caller-owned device pointers.  Not part of the C-ABI.
+extern "C" int fldbg_stream_ptrs(fl_poisson *h, void *const *ptrs, int64_t n, int nr, int nw, int reps, double *ms_out)
+{
+  if (!h || !ptrs || !ms_out) return FL_ERR_ARG_NULL;
+  FL_HIP(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  double     *v[6];
+  for (int a = 0; a < 6; ++a) v[a] = (double *)ptrs[a];
+  auto once = [&]() { launch_stream_ref(s, nr, nw, n / 2, v[0], v[1], v[2], v[3], v[4], v[5]); };
+  once();
+  once();
+  FL_HIP(hipEventRecord(h->ev0, s));
+  for (int a = 0; a < reps; ++a) once();
+  FL_HIP(hipEventRecord(h->ev1, s));
+  FL_HIP(hipStreamSynchronize(s));
+  FL_HIP(hipGetLastError());
+  float ms = 0.f;
+  FL_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  *ms_out = ms / reps;
+  return FL_SUCCESS;
+}
+
+// tools/experiments/phase_scan.py: k_cg_A (kernel 0: pointers r, P0, P1, q, x) or the fused two-step Chebyshev kernel
+// (kernel 1: X0, X1, B, D0, D1) on five caller-owned padded vectors, both parities of the double buffers.  Not part of the C-ABI.
+extern "C" int fldbg_kernel_ptrs(fl_poisson *h, int kernel, void *const *ptrs, int nchunk, int reps, double *ms_out)
+{
+  if (!h || !ptrs || !ms_out) return FL_ERR_ARG_NULL;
+  FL_HIP(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  double     *v[5];
+  for (int a = 0; a < 5; ++a) v[a] = (double *)ptrs[a];
+  KspScal *scal2 = nullptr;
+  FL_HIP(hipMalloc((void **)&scal2, 2 * sizeof(KspScal)));
+  KspScal S2[2];
+  std::memset(S2, 0, sizeof(S2));
+  for (int a = 0; a < 2; ++a) {
+    S2[a].beta = 0.5; S2[a].alpha = 1e-3; S2[a].zshift = 1e-4; S2[a].ncell_global = (double)h->ncell; S2[a].maxit = 1 << 30; S2[a].cur = a; S2[a].dcur = a;
+    S2[a].cheb_rho = 0.3; S2[a].cheb_c = 0.2; S2[a].mu = 1.2; S2[a].ck = 1.5; S2[a].ckm1 = 1.2; S2[a].omegaprod = 2.4; S2[a].scale = 0.9;
+  }
+  FL_HIP(hipMemcpy(scal2, S2, sizeof(S2), hipMemcpyHostToDevice));
+  PlanA     plan = plan_cg_A(h->g, 0, nchunk);
+  Cheb2Plan cp   = fl_cheb2_plan(h->g);
+  if (nchunk > 0 && kernel == 1) {
+    cp.nchunk  = nchunk;
+    cp.zc      = (h->g.nz + nchunk - 1) / nchunk;
+    cp.nchunk  = (h->g.nz + cp.zc - 1) / cp.zc;
+    cp.nblocks = cp.tiles * cp.nchunk;
+  }
+  FL_CHK(fl_ensure_partials(h, std::max(plan.nblocks, cp.nblocks)));
+  KspScal *keep = h->scal;
+  auto     once = [&]() {
+    for (int par = 0; par < 2; ++par) {
+      if (kernel == 0) launch_cg_A(s, h->g, true, plan, v[0], v[1], v[2], v[3], v[4], scal2 + par, h->partial, nullptr, nullptr, 0);
+      else {
+        h->scal = scal2 + par;
+        fl_launch_cheb2(h, cp, true, v[0], v[1], v[2], v[3], v[4]);
+      }
+    }
+  };
+  once();
+  FL_HIP(hipEventRecord(h->ev0, s));
+  for (int a = 0; a < reps; ++a) once();
+  FL_HIP(hipEventRecord(h->ev1, s));
+  FL_HIP(hipStreamSynchronize(s));
+  h->scal = keep;
+  (void)hipFree(scal2);
+  FL_HIP(hipGetLastError());
+  float ms = 0.f;
+  FL_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  *ms_out = ms / (2 * reps);
+  return FL_SUCCESS;
 }

@@ -250,6 +250,13 @@ struct fl_poisson {
   double *cd1 = nullptr;  // second d buffer of the fused two-step Chebyshev kernel (fl_cheb2.hip)
   std::vector<void *> vec_bases;
   void               *slab = nullptr;
+  // placement (fl_api.hip): one arena, the five CG vectors in a window found by probing, two side pools for the rest
+  void  *arena = nullptr;
+  size_t arena_bytes = 0, pool_vec = 0;
+  char  *pool_next[2] = {nullptr, nullptr}, *pool_end[2] = {nullptr, nullptr};
+  int    pool_flip = 0;
+  bool   placed = false;
+  double placed_ms[2] = {0., 0.}, placed_at = 0.;
   int                 nvec = 0;
   double *partial = nullptr;
   int     partial_stride = 0;
@@ -266,9 +273,44 @@ struct fl_poisson {
 };
 
 
+// HIP events bracketing the dominant kernel of every iteration (fl_ksp_opts.profile); released on every return path
+struct ProfEvents {
+  std::vector<hipEvent_t> ev;
+  int create(size_t n)
+  {
+    ev.reserve(n);
+    for (size_t a = 0; a < n; ++a) {
+      hipEvent_t e = nullptr;
+      FL_HIP(hipEventCreate(&e));
+      ev.push_back(e);
+    }
+    return 0;
+  }
+  // mean of the first `pairs` (start, stop) pairs
+  void mean(int pairs, double *ms_out, int *count_out) const
+  {
+    double tot = 0.;
+    int    cnt = 0;
+    for (int a = 0; a < pairs && (size_t)(2 * a + 1) < ev.size(); ++a) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, ev[2 * a], ev[2 * a + 1]) == hipSuccess) {
+        tot += t;
+        ++cnt;
+      }
+    }
+    *ms_out    = cnt ? tot / cnt : 0.;
+    *count_out = cnt;
+  }
+  ~ProfEvents()
+  {
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+  }
+};
+
 // shared host helpers (fl_api.hip)
 int  fl_dev_alloc(fl_poisson *h, void **p, size_t bytes, bool zero);
 int  fl_ensure_vec(fl_poisson *h, double **v);
+int &fl_placement_mode();
 int  fl_ensure_partials(fl_poisson *h, int nblocks);
 int  fl_ensure_hist(fl_poisson *h, int nhist);
 int  fl_zero_vec(fl_poisson *h, double *v);

@@ -693,6 +693,10 @@ extern "C" int fl_tuning_set(const char *name, int value)
     cheb_fuse_mode() = value;
     return FL_SUCCESS;
   }
+  if (std::strcmp(name, "placement") == 0) {
+    fl_placement_mode() = value;
+    return FL_SUCCESS;
+  }
   return FL_ERR_ARG_WRONG;
 }
 extern "C" int fl_tuning_get(const char *name, int *value)
@@ -700,6 +704,10 @@ extern "C" int fl_tuning_get(const char *name, int *value)
   if (!name || !value) return FL_ERR_ARG_NULL;
   if (std::strcmp(name, "cheb_fuse") == 0) {
     *value = cheb_fuse_mode();
+    return FL_SUCCESS;
+  }
+  if (std::strcmp(name, "placement") == 0) {
+    *value = fl_placement_mode();
     return FL_SUCCESS;
   }
   return FL_ERR_ARG_WRONG;
@@ -933,8 +941,10 @@ int fl_solve_cheb(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *
   const bool ghosts = fl_any_ghost_exchange(h);
   auto       finl   = [=](const double *partial, int nb, int stride, const double *sums) { hipLaunchKernelGGL(k_cheb_fin, dim3(1), dim3(256), 0, s, partial, nb, stride, sums, h->scal, h->hist, nhist); };
   auto       fin2   = [=](const double *partial, int nb, int stride, const double *sums) { hipLaunchKernelGGL(k_cheb_fin2, dim3(1), dim3(256), 0, s, partial, nb, stride, sums, h->scal); };
-  int        j = 0, hostcur = 0;
+  int        j = 0, hostcur = 0, nprof = 0;
   bool       done = total <= 0;
+  ProfEvents prof;  // profile = 1: HIP events around every launch of the dominant kernel (the fused sweep where it is used)
+  if (o->profile) FL_CHK(prof.create(2 * (size_t)std::min(total, 2048)));
   // check_every < 0 with KSP_NORM_NONE: a smoother call -- exactly maxit steps, nothing to test, so the host never waits for
   // the device (the buffer that holds the answer follows from the step count) and no statistics are gathered
   const bool nopoll = o->check_every < 0 && o->norm_type == FL_NORM_NONE;
@@ -942,12 +952,18 @@ int fl_solve_cheb(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *
     const int stop = std::min(total, j + every);
     while (j < stop) {
       if (fuse && j + 2 <= total) {
+        const bool pr = (size_t)(2 * nprof + 1) < prof.ev.size();
+        if (pr) FL_HIP(hipEventRecord(prof.ev[2 * nprof], s));
         fl_launch_cheb2(h, cp, jac, X0, X1, B, D0, D1);
+        if (pr) FL_HIP(hipEventRecord(prof.ev[2 * nprof++ + 1], s));
         FL_CHK(fin_step(h, cp.nblocks, 6, fin2));
         j += 2;
       } else {
         if (ghosts && j > 0) FL_CHK(fl_fill_ghosts(h, hostcur ? X1 : X0));
+        const bool pr = !fuse && (size_t)(2 * nprof + 1) < prof.ev.size();
+        if (pr) FL_HIP(hipEventRecord(prof.ev[2 * nprof], s));
         launch_cheb(h, tp, jac, X0, X1, B, D0, D1);
+        if (pr) FL_HIP(hipEventRecord(prof.ev[2 * nprof++ + 1], s));
         FL_CHK(fin_step(h, tp.nblocks, 3, finl));
         j += 1;
       }
@@ -970,7 +986,11 @@ int fl_solve_cheb(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *
   const KspScal &R = *h->scal_host;
   // answer: buffer `cur`, minus the accumulated constant (null-space removal done lazily)
   launch_unpad_copy(s, g, R.cur ? X1 : X0, x, R.nullspace ? &h->scal->xshift : nullptr);
-  return finish_stats(h, o, st);
+  FL_CHK(finish_stats(h, o, st));
+  st->kernel_ms       = 0.;
+  st->kernel_launches = 0;
+  if (o->profile) prof.mean(nprof, &st->kernel_ms, &st->kernel_launches);  // fused: per launch = per TWO steps
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------ shared with fl_momentum.hip

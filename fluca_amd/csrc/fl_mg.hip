@@ -279,7 +279,14 @@ int vcycle(fl_mg *mg, size_t l, const fl_ksp_opts *o)
     so.rtol  = 1e-2;
     so.maxit = 200;
     launch_unpad_copy(h->stream, h->g, h->r, L.b, nullptr);
+    // a one-level hierarchy runs this solve on the OUTER handle, whose h->r is the outer residual and is the inner
+    // solve's work vector as well: keep it aside
+    if (l == 0) {
+      FL_CHK(fl_ensure_vec(h, &h->cd1));
+      FL_HIP(hipMemcpyAsync(h->cd1, h->r, sizeof(double) * h->padlen, hipMemcpyDeviceToDevice, h->stream));
+    }
     FL_CHK(fl_poisson_solve(h, L.b, L.x, &so, &st));
+    if (l == 0) FL_HIP(hipMemcpyAsync(h->r, h->cd1, sizeof(double) * h->padlen, hipMemcpyDeviceToDevice, h->stream));
     launch_pad_copy(h->stream, h->g, L.x, h->xp);
     return 0;
   }
@@ -323,6 +330,8 @@ int fl_solve_cg_mg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts 
   if (o->norm_type != FL_NORM_PRECONDITIONED && o->norm_type != FL_NORM_UNPRECONDITIONED) return FL_ERR_SUP;
   if (h->mg && o->mg_levels > 0 && (int)h->mg->lv.size() != std::min<int>(o->mg_levels, (int)h->mg->lv.size()) ) fl_mg_destroy(h);
   if (!h->mg) FL_CHK(mg_build(h, o->mg_levels));
+  // the placement step (and nothing else) may have dropped the fine level's vectors since the hierarchy was built
+  for (double **v : {&h->r, &h->P0, &h->q, &h->xp, &h->w0, &h->w1, &h->w2}) FL_CHK(fl_ensure_vec(h, v));
   fl_mg       *mg = h->mg;
   const GridP &g = h->g;
   const bool   ns = o->remove_nullspace != 0;

@@ -131,8 +131,9 @@ class Poisson:
     def empty(self, n=None):
         return torch.empty(self.ncell if n is None else n, dtype=torch.float64, device=self.device)
 
-    def tune_placement(self, max_tries=12):
-        """One-off search for a fast physical placement of the solver vectors (see fl_poisson_tune_placement)."""
+    def tune_placement(self, max_tries=1):
+        """Placement of the solver vectors inside one arena (see fl_poisson_tune_placement) -> (probe ms with all vectors in
+        one physical block, probe ms at the chosen place); (0, 0) for handles too small to be placed."""
         out = (C.c_double * 2)()
         self._pre()
         check(lib.fl_poisson_tune_placement(self.h, int(max_tries), out), "fl_poisson_tune_placement")

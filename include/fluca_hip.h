@@ -155,15 +155,21 @@ int fl_vec_maxpy(fl_poisson *h, int64_t n, double *x_dev, const double *alphas, 
  *   "cheb_fuse"  0 = one kernel launch per Chebyshev step; 1 (default) = two steps per sweep over memory wherever no convergence
  *                test sits between them (KSP_NORM_NONE sweeps, the multigrid smoother) and the grid is large enough to gain;
  *                2 = the same on every grid where it is legal.
+ *   "placement"  1 (default) = the first solve on a handle whose padded vectors are >= 256 MiB allocates ONE arena (16 GiB +
+ *                8 vectors) and carves the solver vectors out of it where a probe of the CG stencil kernel runs fastest
+ *                (see fl_poisson_tune_placement); 0 = one plain allocation per vector.
  * Returns FL_ERR_ARG_WRONG for an unknown name.  Process-wide; set before the solve it should affect. */
 int fl_tuning_set(const char *name, int value);
 int fl_tuning_get(const char *name, int *value);
 
-/* Optional one-off tuning step after create (like planning an FFT): any kernel that streams six 1 GB vectors at once runs
- * 10-15 % faster or slower depending on where the driver happened to place them physically (profiles/r01_placement.txt).
- * This allocates up to max_tries candidate sets of the solver vectors, times a 3-read/3-write streaming probe on each
- * (a few ms), keeps the fastest set and frees the rest.  Transient memory: up to max_tries x 6 vectors.  probe_ms_out
- * (may be NULL) receives {first, best} probe times in ms.  Safe to skip; never changes results. */
+/* Placement of the solver vectors in HBM.  A kernel that streams five gigabyte-sized vectors in lock step runs 13 % slower
+ * when all of them sit in one physically contiguous block of memory (what back-to-back allocations give) than when two or
+ * three of them come from a different block (measurements: profiles/r02_placement.md).  This call -- made implicitly by the
+ * first solve of a large handle unless the tuning knob "placement" is 0 -- allocates one arena, slides a window of five packed
+ * vectors through it with the CG stencil kernel as the probe (about 20 launches) and carves the vectors out where the window
+ * was fastest.  Deterministic, idempotent, never changes results.  max_tries >= 1 (kept from the earlier interface, unused).
+ * probe_ms_out (may be NULL): {probe time with all vectors in one block, probe time at the chosen place}; {0, 0} if the
+ * handle is too small to be placed or memory is short. */
 int fl_poisson_tune_placement(fl_poisson *h, int max_tries, double probe_ms_out[2]);
 
 /* ---- operator -------------------------------------------------------------------------------- */

@@ -53,24 +53,7 @@ def run_ranks(world, fn, *args, timeout=600):
         raise AssertionError("multi-process test failed:\n" + "\n".join(msgs) + f"\nexit codes {[p.exitcode for p in procs]}")
 
 
-def gloo_exchange(msgs):
-    """msgs: list of (peer, sendtag, recvtag, send ndarray | None, recv ndarray | None) -- the fl_exchange_fn contract."""
-    reqs, keep = [], []
-    for peer, stag, rtag, s, r in msgs:
-        if r is not None:
-            t = torch.from_numpy(r)
-            reqs.append(dist.irecv(t, src=int(peer), tag=int(rtag)))
-        if s is not None:
-            t = torch.from_numpy(np.ascontiguousarray(s).copy())
-            keep.append(t)
-            reqs.append(dist.isend(t, dst=int(peer), tag=int(stag)))
-    for q in reqs:
-        q.wait()
-
-
-def gloo_allreduce(vals):
-    t = torch.from_numpy(vals)
-    dist.all_reduce(t)
+from fluca_amd.hostcomm import gloo_allreduce, gloo_exchange  # noqa: E402,F401  (the transport lives in the package)
 
 
 def decomp_of(capi, n, ranks, rank):

@@ -23,8 +23,7 @@ def _line(out):
 
 
 def test_single_gpu_line_has_the_contract_keys():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cells", "64", "--steps", "20", "--warmup", "3", "--cpu-cells", "32", "--cpu-iters", "20",
-                          "--placement-tries", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cells", "64", "--steps", "20", "--warmup", "3", "--cpu-cells", "32", "--cpu-iters", "20", "--skip-configs"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stdout + out.stderr
     d = _line(out)
     assert KEYS <= set(d)
@@ -42,9 +41,23 @@ def test_two_ranks_through_the_driver_launch_line():
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--cells", "32", "--skip-cpu", "--placement-tries", "0", "--transport", "host"]
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--cells", "32", "--skip-cpu", "--transport", "host"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stdout + out.stderr
     d = _line(out)
     assert d["n_gpus"] == 2 and d["config"]["rank_grid"] == [1, 1, 2] and d["config"]["cells_per_gpu"] == 32 ** 3
     assert "NOT the production transport" in d["config"]["halo"] and d["cpu_baseline"] is None and d["value"] > 0
+    assert [r["rank"] for r in d["ranks"]] == [0, 1] and d["transport_ranks"] == 2
+
+
+def test_two_ranks_without_rccl_fail_instead_of_falling_back():
+    """One GPU, two ranks, production transport: RCCL cannot give both ranks the device, so the run must exit non-zero and print
+    no JSON line (a silently host-staged scaling curve would be worthless)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--cells", "32", "--skip-cpu"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]

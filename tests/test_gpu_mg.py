@@ -75,3 +75,25 @@ def test_mg_vs_jacobi_iteration_counts_and_reuse():
     with pytest.raises(RuntimeError):
         P.solve(b, type=1, pc=2)                                      # BiCGStab + MG: not built
     P.close()
+
+
+@pytest.mark.parametrize("n,levels", [((15, 15, 15), 0), ((32, 32, 16), 1)])
+def test_one_level_hierarchy_keeps_the_outer_residual(n, levels):
+    """No axis can be coarsened (odd cell counts) or -pc_mg_levels 1: the "cycle" is the coarse solve on the fine handle
+    itself, whose work vectors are the outer CG's too.  The outer residual must survive every preconditioner apply."""
+    P, g = make_pair(n, CAVITY, kappa=1e-3)
+    S = g.assemble_S()
+    rng = np.random.default_rng(3)
+    p = rng.standard_normal(g.ncell)
+    p -= p.mean()
+    b = S.mult(p)
+    mg = fo.MgOracle(g, max_levels=levels, nullspace=True)
+    assert mg.nlevels == 1
+    xo, io = mg.pcg(b, rtol=1e-8, maxit=100)
+    xg, ig = P.solve(dev(b), history=True, type=0, pc=2, remove_nullspace=1, rtol=1e-8, maxit=100, mg_levels=levels)
+    assert ig["reason"] == io["reason"] == 2
+    assert abs(ig["iters"] - io["iters"]) <= 1, (ig["iters"], io["iters"])
+    xg = host(xg)
+    assert np.linalg.norm(b - S.mult(xg)) / np.linalg.norm(b) < 1e-6      # a clobbered residual reports convergence with a wrong x
+    assert np.linalg.norm((xg - xg.mean()) - xo) <= 1e-5 * np.linalg.norm(xo)
+    P.close()
