@@ -763,10 +763,16 @@ static int solve_cg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts
 
   FL_HIP(hipEventRecord(h->ev0, s));
   FL_HIP(hipMemcpyAsync(h->scal, h->scal_host, sizeof(KspScal), hipMemcpyHostToDevice, s));
-  FL_CHK(fl_zero_vec(h, h->P0));
-  FL_CHK(fl_zero_vec(h, h->P1));
-  FL_CHK(fl_zero_vec(h, h->xp));
-  launch_cg_init(s, g, jac, b, h->r, h->partial, h->partial_stride, nsb);
+  // The direction buffers need no zeroing: the first iteration multiplies the old direction by beta = 0 and by alpha_prev = 0,
+  // so whatever FINITE numbers an earlier solve left there drop out (wall ghosts included: they only ever meet the stencil
+  // coefficient 0).  After a solve that produced NaN / Inf they are cleared.  x is zeroed by the kernel that pads b into r.
+  if (h->poisoned) {
+    FL_CHK(fl_zero_vec(h, h->P0));
+    FL_CHK(fl_zero_vec(h, h->P1));
+    FL_CHK(fl_zero_vec(h, h->xp));
+    h->poisoned = false;
+  }
+  launch_cg_init(s, g, jac, b, h->r, h->xp, h->partial, h->partial_stride, nsb);
   FL_CHK(cg_fin(h, 0, nsb, 5, h->hist, nhist));
   const bool ghosts = fl_any_ghost_exchange(h);
   if (ghosts) FL_CHK(fl_fill_ghosts(h, h->r));
@@ -820,8 +826,7 @@ static int solve_cg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts
     FL_CHK(fl_poll_scal(h));
     if (h->scal_host->reason != 0 || it >= o->maxit) done = true;
   }
-  launch_cg_flush(s, g, h->P0, h->P1, h->xp, h->scal, nsb);
-  launch_unpad_copy(s, g, h->xp, x, nullptr);
+  launch_cg_finish(s, g, h->P0, h->P1, h->xp, x, h->scal, nsb);  // x = xp + the x-update still owed
   FL_HIP(hipEventRecord(h->ev1, s));
   FL_CHK(fl_poll_scal(h));
   FL_HIP(hipGetLastError());
@@ -830,6 +835,7 @@ static int solve_cg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts
   const KspScal &R = *h->scal_host;
   st->iters        = R.it;
   st->reason       = R.reason ? R.reason : FL_DIVERGED_ITS;
+  if (R.reason == FL_DIVERGED_NANORINF || R.reason == FL_DIVERGED_DTOL || !std::isfinite(R.dp)) h->poisoned = true;
   st->rnorm0       = R.rnorm0;
   st->rnorm        = R.dp;
   st->seconds      = ms * 1e-3;

@@ -41,8 +41,8 @@ void launch_pressure_update(hipStream_t, int64_t, int, const double *, const dou
 void launch_reduce(hipStream_t, const double *, int, int, int, double *);
 void launch_cg_fin(hipStream_t, int, const double *, int, int, const double *, KspScal *, double *, int);
 int  stream_blocks(const GridP &);
-void launch_cg_init(hipStream_t, const GridP &, bool, const double *, double *, double *, int, int);
-void launch_cg_flush(hipStream_t, const GridP &, const double *, const double *, double *, const KspScal *, int);
+void launch_cg_init(hipStream_t, const GridP &, bool, const double *, double *, double *, double *, int, int);
+void launch_cg_finish(hipStream_t, const GridP &, const double *, const double *, const double *, double *, const KspScal *, int);
 struct PlanA {
   int ry, nw, tiles_x, tiles_y, nchunk, zc, nblocks, pf, nt, remap, probe;
 };
@@ -256,6 +256,7 @@ struct fl_poisson {
   char  *pool_next[2] = {nullptr, nullptr}, *pool_end[2] = {nullptr, nullptr};
   int    pool_flip = 0;
   bool   placed = false;
+  bool   poisoned = false;  // a solve ended with NaN / Inf / divergence: work vectors are zeroed before the next one
   double placed_ms[2] = {0., 0.}, placed_at = 0.;
   int                 nvec = 0;
   double *partial = nullptr;

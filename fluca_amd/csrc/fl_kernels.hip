@@ -462,7 +462,7 @@ struct SegIter {
 
 // r_pad = b ; five partial sums.  b unpadded.
 template <bool JAC>
-__global__ void __launch_bounds__(256) k_cg_init(GridP g, const double *__restrict__ b, double *__restrict__ r, double *__restrict__ partial, int stride)
+__global__ void __launch_bounds__(256) k_cg_init(GridP g, const double *__restrict__ b, double *__restrict__ r, double *__restrict__ x0, double *__restrict__ partial, int stride, int pairs)
 {
   __shared__ double red[5 * 4];
   const int         lane = threadIdx.x & 63;
@@ -474,20 +474,34 @@ __global__ void __launch_bounds__(256) k_cg_init(GridP g, const double *__restri
     const int64_t R  = seg / nxs;
     const int     j = (int)(R % g.ny), k = (int)(R / g.ny);
     const double  dyz = g.sc[1][j] + g.sc[2][k];
+    const int     i = xs * 128 + 2 * lane;
+    double        rv[2] = {0., 0.};
+    const int64_t ob = ((int64_t)k * g.ny + j) * g.nx + i, op = pidx(g, i, j, k);
+    if (pairs && i + 1 < g.nx) {  // even nx, 16-byte aligned b: one 16-byte access per stream
+      const double2 v = *reinterpret_cast<const double2 *>(b + ob);
+      rv[0] = v.x;
+      rv[1] = v.y;
+      *reinterpret_cast<double2 *>(r + op) = v;
+      if (x0) *reinterpret_cast<double2 *>(x0 + op) = make_double2(0., 0.);
+    } else {
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int i = xs * 128 + 2 * lane + c;
-      if (i < g.nx) {
-        const double rv = b[((int64_t)k * g.ny + j) * g.nx + i];
-        r[pidx(g, i, j, k)] = rv;
-        const double z0 = JAC ? rv / (g.sc[0][i] + dyz) : rv;
-        acc[0] += rv * z0;
+      for (int c = 0; c < 2; ++c)
+        if (i + c < g.nx) {
+          rv[c]      = b[ob + c];
+          r[op + c]  = rv[c];
+          if (x0) x0[op + c] = 0.;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+      if (i + c < g.nx) {
+        const double z0 = JAC ? rv[c] / (g.sc[0][i + c] + dyz) : rv[c];
+        acc[0] += rv[c] * z0;
         acc[1] += z0 * z0;
         acc[2] += z0;
-        acc[3] += rv;
-        acc[4] += rv * rv;
+        acc[3] += rv[c];
+        acc[4] += rv[c] * rv[c];
       }
-    }
   }
   block_sum<5>(acc, red);
   if (threadIdx.x == 0)
@@ -579,12 +593,14 @@ __global__ void __launch_bounds__(256) k_cg_B(GridP g, const double *__restrict_
     for (int a = 0; a < 5; ++a) partial[(int64_t)a * stride + blockIdx.x] = acc[a];
 }
 
-// the x-update still owed when the iteration stops:  x += alpha p   (p = the current direction)
-__global__ void __launch_bounds__(256) k_cg_flush(GridP g, const double *__restrict__ P0, const double *__restrict__ P1, double *__restrict__ x, const KspScal *__restrict__ s)
+// the x-update still owed when the iteration stops, fused with the copy into the caller's (unpadded) array:
+//   xout = x + alpha p   (p = the current direction; plain copy when nothing is pending).  The padded x is not updated: the
+// next solve starts from its own zeroed copy.
+__global__ void __launch_bounds__(256) k_cg_finish(GridP g, const double *__restrict__ P0, const double *__restrict__ P1, const double *__restrict__ x, double *__restrict__ xout, const KspScal *__restrict__ s, int pairs)
 {
-  if (!s->pending_x) return;
   const double *p     = s->cur ? P1 : P0;
-  const double  alpha = s->alpha;
+  const double  alpha = s->pending_x ? s->alpha : 0.;
+  const bool    upd   = s->pending_x != 0;
   const int     lane  = threadIdx.x & 63;
   const int     nxs   = (g.nx + 127) / 128;
   const int64_t nseg  = (int64_t)nxs * g.ny * g.nz;
@@ -592,13 +608,20 @@ __global__ void __launch_bounds__(256) k_cg_flush(GridP g, const double *__restr
     const int     xs = (int)(seg % nxs);
     const int64_t R  = seg / nxs;
     const int     j = (int)(R % g.ny), k = (int)(R / g.ny);
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int i = xs * 128 + 2 * lane + c;
-      if (i < g.nx) {
-        const int64_t o = pidx(g, i, j, k);
-        x[o] += alpha * p[o];
+    const int     i = xs * 128 + 2 * lane;
+    const int64_t ob = ((int64_t)k * g.ny + j) * g.nx + i, op = pidx(g, i, j, k);
+    if (pairs && i + 1 < g.nx) {
+      double2 v = *reinterpret_cast<const double2 *>(x + op);
+      if (upd) {
+        const double2 pv = *reinterpret_cast<const double2 *>(p + op);
+        v.x += alpha * pv.x;
+        v.y += alpha * pv.y;
       }
+      *reinterpret_cast<double2 *>(xout + ob) = v;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        if (i + c < g.nx) xout[ob + c] = upd ? x[op + c] + alpha * p[op + c] : x[op + c];
     }
   }
 }
@@ -1068,12 +1091,19 @@ int stream_blocks(const GridP &g)
   return (int)std::max<int64_t>(1, std::min<int64_t>((nseg + 7) / 8, 2048));
 }
 
-void launch_cg_init(hipStream_t st, const GridP &g, bool jac, const double *b, double *r, double *partial, int stride, int nblocks)
+// 16-byte accesses to a caller's unpadded array need even rows and an aligned base
+static int unpadded_pairs(const GridP &g, const void *a) { return (g.nx % 2 == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0) ? 1 : 0; }
+
+void launch_cg_init(hipStream_t st, const GridP &g, bool jac, const double *b, double *r, double *x0, double *partial, int stride, int nblocks)
 {
-  if (jac) hipLaunchKernelGGL(k_cg_init<true>, dim3(nblocks), dim3(256), 0, st, g, b, r, partial, stride);
-  else hipLaunchKernelGGL(k_cg_init<false>, dim3(nblocks), dim3(256), 0, st, g, b, r, partial, stride);
+  const int pairs = unpadded_pairs(g, b);
+  if (jac) hipLaunchKernelGGL(k_cg_init<true>, dim3(nblocks), dim3(256), 0, st, g, b, r, x0, partial, stride, pairs);
+  else hipLaunchKernelGGL(k_cg_init<false>, dim3(nblocks), dim3(256), 0, st, g, b, r, x0, partial, stride, pairs);
 }
-void launch_cg_flush(hipStream_t st, const GridP &g, const double *P0, const double *P1, double *x, const KspScal *s, int nblocks) { hipLaunchKernelGGL(k_cg_flush, dim3(nblocks), dim3(256), 0, st, g, P0, P1, x, s); }
+void launch_cg_finish(hipStream_t st, const GridP &g, const double *P0, const double *P1, const double *x, double *xout, const KspScal *s, int nblocks)
+{
+  hipLaunchKernelGGL(k_cg_finish, dim3(nblocks), dim3(256), 0, st, g, P0, P1, x, xout, s, unpadded_pairs(g, xout));
+}
 
 // tiling of k_cg_A: returns the number of blocks
 struct PlanA {
@@ -1110,7 +1140,15 @@ PlanA plan_cg_A(const GridP &g, int ry_force, int nchunk_force)
 {
   const int ry = ry_force > 0 ? ry_force : (g.ny >= 8 ? 2 : 1);
   const int nw = (ry == 2 && g.ny >= 32) ? 8 : 4;
-  PlanA     p  = plan_tiles(g, ry, nw, nchunk_force, 512);
+  // blocks aimed at: one per CU when the tiles alone nearly fill the chip (512^3: 128 tiles x 2 chunks of 256 planes -- fewer chunk
+  // prologues, 1.097 against 1.109 ms per launch with 4 chunks, profiles/r02_bench_nchunk.txt), two per CU otherwise
+  static const int target_env = []() {
+    const char *e = std::getenv("FLUCA_CGA_TARGET");
+    return e ? std::atoi(e) : 0;
+  }();
+  const int tiles0 = ((g.nx + 127) / 128) * ((g.ny + nw * ry - 1) / (nw * ry));
+  const int target = target_env > 0 ? target_env : (tiles0 >= 64 ? 256 : 512);
+  PlanA     p  = plan_tiles(g, ry, nw, nchunk_force, target);
   if (ry_force <= 0 && nchunk_force <= 0 && p.nblocks < MIN_BLOCKS) {
     p = plan_tiles(g, ry, 4, 0, 512, 2);
     if (p.nblocks < MIN_BLOCKS && ry == 2) p = plan_tiles(g, 1, 4, 0, 512, 2);

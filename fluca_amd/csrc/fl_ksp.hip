@@ -674,6 +674,7 @@ int finish_stats(fl_poisson *h, const fl_ksp_opts *o, fl_ksp_stats *st)
   const KspScal &R = *h->scal_host;
   st->iters        = R.it;
   st->reason       = R.reason ? R.reason : FL_DIVERGED_ITS;
+  if (R.reason == FL_DIVERGED_NANORINF || R.reason == FL_DIVERGED_DTOL || !std::isfinite(R.dp)) h->poisoned = true;  // see solve_cg
   st->rnorm0       = R.rnorm0;
   st->rnorm        = R.dp;
   st->seconds      = ms * 1e-3;

@@ -416,6 +416,9 @@ int fl_solve_cg_mg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts 
   FL_HIP(hipEventElapsedTime(&ms, e0, e1));
   st->iters   = it;
   st->reason  = reason;
+  if (reason == FL_DIVERGED_NANORINF || reason == FL_DIVERGED_DTOL) {
+    for (MgLevel &L : mg->lv) L.h->poisoned = true;  // work vectors of every level may hold NaN: cleared before their next CG solve
+  }
   st->rnorm0  = rnorm0;
   st->rnorm   = dp;
   st->seconds = ms * 1e-3;
