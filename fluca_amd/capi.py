@@ -62,6 +62,10 @@ class fl_ksp_stats(C.Structure):
                 ("seconds", C.c_double), ("kernel_ms", C.c_double), ("kernel_launches", C.c_int)]
 
 
+class fl_dmstag_local(C.Structure):
+    _fields_ = [("gstart", C.c_int64 * 3), ("gsize", C.c_int64 * 3), ("start", C.c_int64 * 3), ("entries", C.c_int)]
+
+
 class fl_halo_msg(C.Structure):
     _fields_ = [("peer", C.c_int), ("send_boundary", C.c_int), ("recv_boundary", C.c_int), ("sendtag", C.c_int), ("recvtag", C.c_int)]
 
@@ -81,6 +85,7 @@ PROTOTYPES = {
     "fl_poisson_sizes": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "fl_ksp_opts_default": (None, [C.POINTER(fl_ksp_opts)]),
     "fl_version": (C.c_char_p, []),
+    "fl_current_device": (C.c_int, [C.POINTER(C.c_int)]),
     "fl_malloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(_P)]),
     "fl_free": (C.c_int, [C.c_int, _P]),
     "fl_memcpy_h2d": (C.c_int, [C.c_int, _P, _P, C.c_size_t]),
@@ -95,6 +100,11 @@ PROTOTYPES = {
     "fl_poisson_project": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "fl_poisson_gst_bc": (C.c_int, [_P, C.c_int, _P, _P]),
     "fl_pressure_update": (C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
+    "fl_layout_from_dmstag_local": (C.c_int, [_P, C.POINTER(fl_dmstag_local), C.c_int, C.c_int, _P, _P]),
+    "fl_layout_to_dmstag_local": (C.c_int, [_P, C.POINTER(fl_dmstag_local), C.c_int, C.c_int, _P, _P]),
+    "fl_layout_from_dmstag_global": (C.c_int, [_P, C.POINTER(C.c_int), C.c_int, C.c_int, _P, _P]),
+    "fl_layout_to_dmstag_global": (C.c_int, [_P, C.POINTER(C.c_int), C.c_int, C.c_int, _P, _P]),
+    "fl_dmstag_global_entries": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "fl_comm_unique_id": (C.c_int, [_P]),
     "fl_poisson_comm_init_rccl": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "fl_poisson_comm_init_host": (C.c_int, [_P, EXCHANGE_FN, ALLREDUCE_FN, _P, C.c_int, C.c_int]),

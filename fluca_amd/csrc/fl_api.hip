@@ -886,6 +886,13 @@ extern "C" int fl_poisson_gershgorin(const fl_poisson *h, int pc, double *bound)
 
 // ------------------------------------------------------------------------------------------------ plain device memory
 
+extern "C" int fl_current_device(int *device)
+{
+  if (!device) return FL_ERR_ARG_NULL;
+  FL_HIP(hipGetDevice(device));
+  return FL_SUCCESS;
+}
+
 extern "C" int fl_malloc(int device, size_t bytes, void **dev_out)
 {
   if (!dev_out) return FL_ERR_ARG_NULL;

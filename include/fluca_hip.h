@@ -137,6 +137,7 @@ void fl_ksp_opts_default(fl_ksp_opts *o); /* PETSc defaults + cg/jacobi/precondi
 const char *fl_version(void);
 
 /* ---- device memory for hosts that have no allocator of their own (the C host mirror, a PETSc host without HIP Vecs) - */
+int fl_current_device(int *device);                      /* the calling thread's current HIP device (hipGetDevice) */
 int fl_malloc(int device, size_t bytes, void **dev_out); /* zero-initialised */
 int fl_free(int device, void *dev);
 int fl_memcpy_h2d(int device, void *dev, const void *host, size_t bytes);
@@ -197,6 +198,29 @@ int fl_boundary_add_cells(fl_poisson *h, int boundary, double coeff, const doubl
 int fl_boundary_add_faces(fl_poisson *h, int boundary, double coeff, const double *plane_dev, double *face_dev); /* ADD_VALUES into the boundary faces */
 /* first != 0: p = p0 + 2 dp, phalf = p0 + dp ; else p = phalf + 1.5 dp, phalf += dp */
 int fl_pressure_update(fl_poisson *h, int first, const double *dp_dev, const double *p0_dev, double *phalf_dev, double *p_dev);
+
+/* ---- DMStag vectors <-> the arrays above (what a PETSc-side caller needs around every other call) ---------------
+ * The reference keeps p on sdm (1 dof per element), v on vdm (3 dof per element), V on Sdm (1 dof per face) and v0interp on Vdm
+ * (3 dof per face) -- fluca/src/mesh/impl/cart/cart.c:88-116, cnlinearcart3d.c:896-905.  `what`: 0 = cells (DMSTAG_ELEMENT),
+ * 1 / 2 / 3 = the x / y / z faces (DMSTAG_LEFT / DMSTAG_DOWN / DMSTAG_BACK).  All on the device, on the handle's stream.
+ * LOCAL: the array DMStagVecGetArray[Read] returns for a local vector (or its device copy): arr[k][j][i][slot] over the ghosted
+ * box; fill the struct from DMStagGetGhostCorners, DMStagGetCorners and DMStagGetEntriesPerElement, `slot` from
+ * DMStagGetLocationSlot(dm, loc, c, &slot).  "to" writes the owned entries only (INSERT_VALUES), ghosts are left alone.
+ * GLOBAL: the array of a global vector of this rank (what PCApply_ABF's sub-vectors are): dof[4] = DMStagGetDOF (strata 0 and
+ * 1 must be 0), `comp` = the dof index c within the location.  The partial elements PETSc appends behind the last element of a
+ * non-periodic axis are handled; fl_dmstag_global_entries returns the local size such a vector must have.
+ * Ordering per PETSc's DMStag (DMSetUp_Stag_3d); checked against an independent enumeration, not against PETSc (absent here). */
+typedef struct fl_dmstag_local {
+  int64_t gstart[3]; /* DMStagGetGhostCorners: first element of the ghosted box (may be -1) */
+  int64_t gsize[3];  /*                        its extents */
+  int64_t start[3];  /* DMStagGetCorners: first owned element (must equal fl_decomp.lo) */
+  int     entries;   /* DMStagGetEntriesPerElement */
+} fl_dmstag_local;
+int fl_layout_from_dmstag_local(fl_poisson *h, const fl_dmstag_local *D, int what, int slot, const double *local_dev, double *out_dev);
+int fl_layout_to_dmstag_local(fl_poisson *h, const fl_dmstag_local *D, int what, int slot, const double *in_dev, double *local_dev);
+int fl_layout_from_dmstag_global(fl_poisson *h, const int dof[4], int what, int comp, const double *global_dev, double *out_dev);
+int fl_layout_to_dmstag_global(fl_poisson *h, const int dof[4], int what, int comp, const double *in_dev, double *global_dev);
+int fl_dmstag_global_entries(const fl_poisson *h, const int dof[4], int64_t *entries);
 
 /* ---- multi-GPU: one process per GPU, halo exchange + scalar all-reduce ----------------------- */
 #define FL_UNIQUE_ID_BYTES 128
