@@ -19,7 +19,7 @@ if not os.path.exists(LIB_PATH):
 lib = C.CDLL(LIB_PATH)
 
 BC_NONE, BC_VELOCITY, BC_PRESSURE_OUTLET, BC_PERIODIC, BC_SYMMETRY = range(5)
-KSP_CG, KSP_BCGS, KSP_CHEBYSHEV = range(3)
+KSP_CG, KSP_BCGS, KSP_CHEBYSHEV, KSP_GMRES = range(4)
 PC_NONE, PC_JACOBI = range(2)
 NORM_PRECONDITIONED, NORM_UNPRECONDITIONED, NORM_NATURAL, NORM_NONE = range(4)
 DELTA_PESKIN4, DELTA_ROMA3 = range(2)
@@ -54,7 +54,7 @@ class fl_ksp_opts(C.Structure):
                 ("maxit", C.c_int), ("rtol", C.c_double), ("atol", C.c_double), ("dtol", C.c_double),
                 ("emin", C.c_double), ("emax", C.c_double), ("variant", C.c_int), ("check_every", C.c_int),
                 ("profile", C.c_int), ("history", C.POINTER(C.c_double)), ("nhistory", C.c_int),
-                ("mg_levels", C.c_int), ("mg_smooth_its", C.c_int)]
+                ("mg_levels", C.c_int), ("mg_smooth_its", C.c_int), ("gmres_restart", C.c_int)]
 
 
 class fl_ksp_stats(C.Structure):

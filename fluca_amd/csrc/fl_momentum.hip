@@ -558,6 +558,7 @@ struct fl_momentum {
   int                   schur_ainv = FL_ABF_AINV_ID, upper_ainv = FL_ABF_AINV_ID;
   double               *ainv[2] = {nullptr, nullptr}, *zV[3] = {nullptr, nullptr, nullptr}, *gv = nullptr;
   std::vector<double *> gm;  // cell vectors of the Schur solve with a variable-coefficient S
+  std::vector<double *> kb;  // KSPGMRES on A: Krylov basis (3*cells each, allocated as the iteration needs them), w, x, r
   bool        have_state = false;
   int         tiles_x = 1, tiles_y = 1, nchunk = 1, zc = 1, nblocks = 1;  // 64 x 4 x zc tiles of the vector-update kernels
   int         anchunk = 1, azc = 1, ablocks = 1;                        // 64 x MOM_RY x azc tiles of k_mom_apply
@@ -711,6 +712,8 @@ extern "C" int fl_momentum_destroy(fl_momentum *m)
     if (v) (void)hipFree(v);
   for (double *v : m->gm)
     if (v) (void)hipFree(v);
+  for (double *v : m->kb)
+    if (v) (void)hipFree(v);
   delete m;
   return FL_SUCCESS;
 }
@@ -781,11 +784,15 @@ extern "C" int fl_momentum_diagonal(fl_momentum *m, double *d_dev)
   return FL_SUCCESS;
 }
 
-// KSPSolve(kspA): left-preconditioned BiCGStab (KSPBCGS), zero initial guess, PCJACOBI or PCNONE
+static int momentum_gmres(fl_momentum *m, const double *b_dev, double *x_dev, const fl_ksp_opts *opts, fl_ksp_stats *stats);
+
+// KSPSolve(kspA): left-preconditioned BiCGStab (KSPBCGS) or restarted GMRES (KSPGMRES, the reference's default type for kspA,
+// abfpc.c:72), zero initial guess, PCJACOBI or PCNONE
 extern "C" int fl_momentum_solve(fl_momentum *m, const double *b_dev, double *x_dev, const fl_ksp_opts *opts, fl_ksp_stats *stats)
 {
   if (!m || !b_dev || !x_dev || !opts || !stats) return FL_ERR_ARG_NULL;
   if (!m->have_state && m->mp.cC != 0.) return FL_ERR_ARG_WRONGSTATE;
+  if (opts->type == FL_KSP_GMRES) return momentum_gmres(m, b_dev, x_dev, opts, stats);
   if (opts->type != FL_KSP_BCGS) return FL_ERR_SUP;
   if (opts->pc != FL_PC_JACOBI && opts->pc != FL_PC_NONE) return FL_ERR_SUP;
   if (opts->norm_type != FL_NORM_PRECONDITIONED) return FL_ERR_SUP;
@@ -1304,3 +1311,146 @@ extern "C" int fldbg_mom_stream(fl_momentum *m, int reps, int blocks, double *ms
   *ms_out = ms / reps;
   return 0;
 }
+
+// KSPGMRES as PETSc runs it by default: restart 30 (-ksp_gmres_restart), classical Gram-Schmidt without refinement, left
+// preconditioning, the preconditioned residual norm from the Givens recurrence as the monitored norm, KSPConvergedDefault, the
+// residual re-formed at every restart.  Host control flow over device vectors: per iteration one operator application, one
+// VecMDot (one host wait), one VecMAXPY and one norm (a second wait) -- PETSc's own sequence.  The basis lives in unpadded
+// component-major vectors; they are allocated as the iteration reaches them (PETSc's GMRES_DELTA_DIRECTIONS idea): a 512^3
+// basis vector is 3.2 GB.
+__global__ void __launch_bounds__(256) k_div(int64_t n, const double *__restrict__ a, const double *__restrict__ d, double *__restrict__ out)
+{
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = a[i] / d[i];
+}
+
+static int momentum_gmres(fl_momentum *m, const double *b_dev, double *x_dev, const fl_ksp_opts *opts, fl_ksp_stats *stats)
+{
+  if (opts->pc != FL_PC_JACOBI && opts->pc != FL_PC_NONE) return FL_ERR_SUP;
+  if (opts->norm_type != FL_NORM_PRECONDITIONED) return FL_ERR_SUP;
+  if (opts->maxit < 0) return FL_ERR_ARG_OUTOFRANGE;
+  const int restart = opts->gmres_restart > 0 ? opts->gmres_restart : 30;
+  if (restart > 1000) return FL_ERR_ARG_OUTOFRANGE;
+  fl_poisson *h = m->p;
+  FL_HIP(hipSetDevice(h->device));
+  std::memset(stats, 0, sizeof(*stats));
+  const bool    jac = opts->pc == FL_PC_JACOBI;
+  const int64_t n = 3 * (int64_t)h->ncell;
+  hipStream_t   s = h->stream;
+  FL_CHK(mom_vec(m, 7));
+  // kb[0] = w, kb[1] = x, kb[2] = r, kb[3] = M b, kb[4 + k] = v_k
+  auto kvec = [&](size_t i) -> int {
+    if (m->kb.size() <= i) m->kb.resize(i + 1, nullptr);
+    if (!m->kb[i]) FL_CHK(fl_dev_alloc(h, (void **)&m->kb[i], sizeof(double) * (size_t)n, true));
+    return 0;
+  };
+  for (size_t i = 0; i < 4; ++i) FL_CHK(kvec(i));
+  double *W = m->kb[0], *X = m->kb[1], *R = m->kb[2];
+  // y = M A x for unpadded x, y
+  auto apply = [&](const double *xin, double *yout) -> int {
+    for (int c = 0; c < 3; ++c) launch_pad_copy(s, h->g, xin + (size_t)c * h->ncell, m->vec[7] + (size_t)c * h->padlen);
+    FL_CHK(mom_ghosts(m, m->vec[7]));
+    if (jac) mom_apply_t<false, true, 1>(m, m->vec[7], yout, nullptr, nullptr);
+    else mom_apply_t<false, false, 1>(m, m->vec[7], yout, nullptr, nullptr);
+    return 0;
+  };
+  // M b, once: b ./ diag(A) (PCJACOBI) or b
+  double *MB = m->kb[3];
+  if (jac) {
+    FL_CHK(fl_momentum_diagonal(m, W));  // unpadded diag(A); W is free at this point
+    hipLaunchKernelGGL(k_div, dim3(nblk_flat(n)), dim3(256), 0, s, n, b_dev, (const double *)W, MB);
+  } else lincomb(h, n, 1., b_dev, 0., nullptr, MB);
+  hipEvent_t e0 = h->ev0, e1 = h->ev1;
+  FL_HIP(hipEventRecord(e0, s));
+  std::vector<double> hist, H((size_t)(restart + 1) * restart, 0.), cs(restart, 0.), sn(restart, 0.), g(restart + 1, 0.), hcol(restart + 1, 0.), y(restart, 0.);
+  std::vector<const double *> basis(restart + 1, nullptr);
+  FL_HIP(hipMemsetAsync(X, 0, sizeof(double) * (size_t)n, s));
+  lincomb(h, n, 1., MB, 0., nullptr, R);  // x = 0: r = M b
+  double beta = 0.;
+  FL_CHK(fl_vec_dot(h, n, R, R, &beta));
+  beta = std::sqrt(beta);
+  const double rnorm0 = beta, ttol = std::max(opts->rtol * rnorm0, opts->atol);
+  auto converged = [&](double v) {
+    if (std::isnan(v) || std::isinf(v)) return (int)FL_DIVERGED_NANORINF;
+    if (v <= ttol) return v < opts->atol ? (int)FL_CONVERGED_ATOL : (int)FL_CONVERGED_RTOL;
+    if (v >= opts->dtol * rnorm0) return (int)FL_DIVERGED_DTOL;
+    return 0;
+  };
+  hist.push_back(beta);
+  int    it = 0, reason = converged(beta);
+  double res = beta;
+  if (!reason && opts->maxit == 0) reason = FL_DIVERGED_ITS;
+  while (!reason) {
+    // one restart cycle
+    FL_CHK(kvec(4));
+    lincomb(h, n, 1. / beta, R, 0., nullptr, m->kb[4]);
+    std::fill(g.begin(), g.end(), 0.);
+    g[0] = beta;
+    int k = 0;
+    for (; k < restart && !reason; ++k) {
+      FL_CHK(kvec(4 + (size_t)k + 1));
+      for (int i = 0; i <= k; ++i) basis[i] = m->kb[4 + (size_t)i];
+      FL_CHK(apply(m->kb[4 + (size_t)k], W));
+      FL_CHK(fl_vec_mdot(h, n, W, basis.data(), k + 1, hcol.data()));            // h_i = w . v_i   (classical Gram-Schmidt)
+      for (int i = 0; i <= k; ++i) y[i] = -hcol[i];
+      FL_CHK(fl_vec_maxpy(h, n, W, y.data(), basis.data(), k + 1));              // w -= sum h_i v_i
+      double hk1 = 0.;
+      FL_CHK(fl_vec_dot(h, n, W, W, &hk1));
+      hk1 = std::sqrt(hk1);
+      hcol[k + 1] = hk1;
+      const bool happy = !(hk1 > 1e-30 * rnorm0);                                 // KSPGMRES happy breakdown: the Krylov space is invariant
+      if (!happy) lincomb(h, n, 1. / hk1, W, 0., nullptr, m->kb[4 + (size_t)k + 1]);
+      // previous rotations, then the new one
+      for (int i = 0; i < k; ++i) {
+        const double t = cs[i] * hcol[i] + sn[i] * hcol[i + 1];
+        hcol[i + 1]    = -sn[i] * hcol[i] + cs[i] * hcol[i + 1];
+        hcol[i]        = t;
+      }
+      const double d = std::hypot(hcol[k], hcol[k + 1]);
+      cs[k] = d > 0. ? hcol[k] / d : 1.;
+      sn[k] = d > 0. ? hcol[k + 1] / d : 0.;
+      hcol[k]     = d;
+      hcol[k + 1] = 0.;
+      g[k + 1]    = -sn[k] * g[k];
+      g[k]        = cs[k] * g[k];
+      for (int i = 0; i <= k; ++i) H[(size_t)i * restart + k] = hcol[i];
+      res = std::fabs(g[k + 1]);
+      ++it;
+      hist.push_back(res);
+      reason = converged(res);
+      if (!reason && happy) reason = FL_CONVERGED_RTOL;  // exact solution in the current space (PETSc: CONVERGED_HAPPY_BREAKDOWN maps to converged)
+      if (!reason && it >= opts->maxit) reason = FL_DIVERGED_ITS;
+    }
+    // x += V y,  H y = g  (upper triangular, k columns)
+    for (int i = k - 1; i >= 0; --i) {
+      double t = g[i];
+      for (int j = i + 1; j < k; ++j) t -= H[(size_t)i * restart + j] * y[j];
+      y[i] = t / H[(size_t)i * restart + i];
+    }
+    for (int i = 0; i < k; ++i) basis[i] = m->kb[4 + (size_t)i];
+    FL_CHK(fl_vec_maxpy(h, n, X, y.data(), basis.data(), k));
+    if (reason) break;
+    // restart: r = M (b - A x)
+    FL_CHK(apply(X, W));                    // W = M A x
+    lincomb(h, n, 1., MB, -1., W, R);
+    FL_CHK(fl_vec_dot(h, n, R, R, &beta));
+    beta = std::sqrt(beta);
+    if (!(beta > 0.)) {
+      reason = std::isnan(beta) ? FL_DIVERGED_NANORINF : FL_CONVERGED_ATOL;
+      break;
+    }
+  }
+  lincomb(h, n, 1., X, 0., nullptr, x_dev);
+  FL_HIP(hipEventRecord(e1, s));
+  FL_HIP(hipStreamSynchronize(s));
+  FL_HIP(hipGetLastError());
+  float ms = 0.f;
+  FL_HIP(hipEventElapsedTime(&ms, e0, e1));
+  stats->iters   = it;
+  stats->reason  = reason;
+  stats->rnorm0  = rnorm0;
+  stats->rnorm   = res;
+  stats->seconds = ms * 1e-3;
+  if (opts->history && opts->nhistory > 0) std::memcpy(opts->history, hist.data(), sizeof(double) * std::min<size_t>((size_t)opts->nhistory, hist.size()));
+  return FL_SUCCESS;
+}
+

@@ -643,8 +643,15 @@ FlErrorCode NSSetFromOptions(NS ns, int argc, char **argv)
   if (opt_real(argc, argv, "-ns_ksp_atol", &v)) ns->ksp_atol = v;
   if (opt_int64(argc, argv, "-ns_ksp_max_it", &iv)) ns->ksp_max_it = (int)iv;
   /* sub-KSP of the momentum block: prefix ns_ + abf_momentum_ (abfpc.c:205) */
-  if ((s = opt_find(argc, argv, "-ns_abf_momentum_ksp_type")))
-    if (strcmp(s, "bcgs")) return !strcmp(s, "gmres") || !strcmp(s, "cg") || !strcmp(s, "fgmres") ? E_SUP : E_ARG_UNKNOWN_TYPE;
+  if ((s = opt_find(argc, argv, "-ns_abf_momentum_ksp_type"))) {
+    if (!strcmp(s, "bcgs")) ns->mom.type = FL_KSP_BCGS;
+    else if (!strcmp(s, "gmres")) ns->mom.type = FL_KSP_GMRES; /* the reference's own default type of kspA (abfpc.c:72) */
+    else return !strcmp(s, "cg") || !strcmp(s, "fgmres") ? E_SUP : E_ARG_UNKNOWN_TYPE;
+  }
+  if (opt_int64(argc, argv, "-ns_abf_momentum_ksp_gmres_restart", &iv)) {
+    if (iv < 1 || iv > 1000) return E_ARG_OUTOFRANGE;
+    ns->mom.gmres_restart = (int)iv;
+  }
   if ((s = opt_find(argc, argv, "-ns_abf_momentum_pc_type"))) {
     if (!strcmp(s, "jacobi")) ns->mom.pc = FL_PC_JACOBI;
     else if (!strcmp(s, "none")) ns->mom.pc = FL_PC_NONE;

@@ -75,7 +75,7 @@ typedef struct fl_decomp {
   int64_t lo[3], len[3];
 } fl_decomp;
 
-typedef enum { FL_KSP_CG = 0, FL_KSP_BCGS = 1, FL_KSP_CHEBYSHEV = 2 } fl_ksp_type;             /* -ksp_type cg|bcgs|chebyshev */
+typedef enum { FL_KSP_CG = 0, FL_KSP_BCGS = 1, FL_KSP_CHEBYSHEV = 2, FL_KSP_GMRES = 3 } fl_ksp_type; /* -ksp_type cg|bcgs|chebyshev|gmres (gmres: fl_momentum_solve only) */
 typedef enum { FL_PC_NONE = 0, FL_PC_JACOBI = 1, FL_PC_MG = 2 } fl_pc_type;                     /* -pc_type none|jacobi|mg (mg: fl_ksp_cg only) */
 typedef enum { FL_NORM_PRECONDITIONED = 0, FL_NORM_UNPRECONDITIONED = 1, FL_NORM_NATURAL = 2, FL_NORM_NONE = 3 } fl_norm_type; /* -ksp_norm_type */
 
@@ -106,6 +106,7 @@ typedef struct fl_ksp_opts {
   int     nhistory;
   int     mg_levels;        /* FL_PC_MG: number of grid levels, 0 = coarsen as far as possible (-pc_mg_levels) */
   int     mg_smooth_its;    /* FL_PC_MG: Chebyshev-Jacobi steps before and after the coarse correction, 0 = 3 (-mg_levels_ksp_max_it) */
+  int     gmres_restart;    /* FL_KSP_GMRES: -ksp_gmres_restart, 0 = 30 (PETSc's default) */
 } fl_ksp_opts;
 
 typedef struct fl_ksp_stats {

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 BC_NONE, BC_VELOCITY, BC_PRESSURE_OUTLET, BC_PERIODIC, BC_SYMMETRY = range(5)
-KSP_CG, KSP_BCGS, KSP_CHEBYSHEV = range(3)
+KSP_CG, KSP_BCGS, KSP_CHEBYSHEV, KSP_GMRES = range(4)
 PC_NONE, PC_JACOBI = range(2)
 NORM_PRECONDITIONED, NORM_UNPRECONDITIONED, NORM_NATURAL, NORM_NONE = range(4)
 DELTA_PESKIN4, DELTA_ROMA3 = range(2)
@@ -324,6 +324,80 @@ class Csr:
         if history:
             info["history"] = hist[:st.iters + 1].copy()
         return x, info
+
+
+def gmres(A, b, pc=PC_JACOBI, rtol=1e-5, atol=1e-50, dtol=1e5, maxit=10000, restart=30):
+    """KSPGMRES with PETSc's defaults, restated from PETSc's documented algorithm (the reference's default type for kspA,
+    fluca/src/ns/utils/abfpc/abfpc.c:72; unverified vs PETSc source, PARITY UNPINNED like the other Krylov restatements):
+    restart 30, classical Gram-Schmidt without refinement, left preconditioning (PCJACOBI = 1/diag(A) or PCNONE), zero initial
+    guess, monitored norm = the preconditioned residual norm from the Givens recurrence, KSPConvergedDefault, the residual
+    re-formed from x at every restart.  A: Csr.  -> (x, dict(iters, reason, rnorm0, rnorm, history))"""
+    n = A.nrow
+    dinv = 1.0 / A.diag() if pc == PC_JACOBI else np.ones(n)
+    Mb = dinv * b
+    x = np.zeros(n)
+    r = Mb.copy()
+    beta = float(np.sqrt(r @ r))
+    rnorm0 = beta
+    ttol = max(rtol * rnorm0, atol)
+
+    def conv(v):
+        if not np.isfinite(v):
+            return -9
+        if v <= ttol:
+            return 3 if v < atol else 2
+        if v >= dtol * rnorm0:
+            return -4
+        return 0
+    hist = [beta]
+    it, reason, res = 0, conv(beta), beta
+    if not reason and maxit == 0:
+        reason = -3
+    while not reason:
+        V = [r / beta]
+        H = np.zeros((restart + 1, restart))
+        cs, sn, g = np.zeros(restart), np.zeros(restart), np.zeros(restart + 1)
+        g[0] = beta
+        k = 0
+        while k < restart and not reason:
+            w = dinv * A.mult(V[k])
+            h = np.array([w @ v for v in V])             # classical Gram-Schmidt: all dots against the unmodified w
+            for hi, v in zip(h, V):
+                w = w - hi * v
+            hk1 = float(np.sqrt(w @ w))
+            col = np.append(h, hk1)
+            happy = not (hk1 > 1e-30 * rnorm0)
+            if not happy:
+                V.append(w / hk1)
+            for i in range(k):
+                t = cs[i] * col[i] + sn[i] * col[i + 1]
+                col[i + 1] = -sn[i] * col[i] + cs[i] * col[i + 1]
+                col[i] = t
+            d = float(np.hypot(col[k], col[k + 1]))
+            cs[k], sn[k] = (col[k] / d, col[k + 1] / d) if d > 0 else (1.0, 0.0)
+            col[k], col[k + 1] = d, 0.0
+            g[k + 1] = -sn[k] * g[k]
+            g[k] = cs[k] * g[k]
+            H[:k + 1, k] = col[:k + 1]
+            res = abs(g[k + 1])
+            it += 1
+            hist.append(res)
+            reason = conv(res)
+            if not reason and happy:
+                reason = 2
+            if not reason and it >= maxit:
+                reason = -3
+            k += 1
+        y = np.linalg.solve(np.triu(H[:k, :k]), g[:k]) if k else np.zeros(0)
+        for yi, v in zip(y, V):
+            x = x + yi * v
+        if reason:
+            break
+        r = Mb - dinv * A.mult(x)
+        beta = float(np.sqrt(r @ r))
+        if not beta > 0:
+            reason = 3
+    return x, dict(iters=it, reason=reason, rnorm0=rnorm0, rnorm=res, history=np.array(hist))
 
 
 def num_threads():

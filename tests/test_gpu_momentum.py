@@ -2,6 +2,7 @@
 (literal restatement of cnlinearcart3d.c:425-632, 873-1294, 2930-2941)."""
 import numpy as np
 import pytest
+import torch
 
 from oracle import fluca_oracle as fo
 from tests.gpu_common import CAVITY, CAVITY_BOX, O, PER, SYM, V, dev, host, stretched
@@ -415,4 +416,46 @@ def test_vec_mdot_and_maxpy():
     torch.cuda.synchronize()
     assert np.allclose(host(xd), x + a @ Y, rtol=1e-13, atol=1e-13)
     assert capi.lib.fl_vec_mdot(P.h, n, xd.data_ptr(), ptrs, -1, out) == -63
+    P.close()
+
+
+@pytest.mark.parametrize("n,bc,nonuni", [((20, 9, 6), CAVITY, True), ((12, 10, 9), [PER] * 6, False), ((17, 9, 11), [V, O, V, V, PER, PER], True)])
+@pytest.mark.parametrize("pc,restart", [(fo.PC_JACOBI, 30), (fo.PC_JACOBI, 5), (fo.PC_NONE, 8)])
+def test_gmres_matches_oracle(n, bc, nonuni, pc, restart):
+    """KSPSolve(kspA) with the reference's default Krylov type (abfpc.c:72): restarted GMRES, classical Gram-Schmidt, left PC,
+    against the oracle's restatement of the same algorithm -- iteration count, reason, the monitored-norm history and the answer."""
+    from fluca_amd import capi
+    P, M, g = _pair(n, bc, nonuni)
+    V0, W = _fields(g)
+    # CFL ~ 1 convection and a stiff viscous part, as in the BiCGStab test: a handful to a few dozen iterations
+    hmin = min(np.diff(g.xf[d]).min() for d in range(3))
+    dt, rho, mu = 0.5 * hmin, 1.0, 0.5 * hmin
+    M.set_state(dt, rho, mu, [dev(a) for a in V0], [dev(a) for a in W])
+    A = g.assemble_momentum(1.0, dt, -0.5 * mu * dt / rho, V0, W)
+    b = np.random.default_rng(9).standard_normal(A.nrow)
+    rtol = 1e-8
+    xo, io = fo.gmres(A, b, pc=pc, rtol=rtol, restart=restart, maxit=300)
+    assert io["iters"] > restart or restart == 30            # the short restarts are really exercised
+    xg, ig = M.solve(dev(b), history=True, type=capi.KSP_GMRES, pc=pc, rtol=rtol, maxit=300, gmres_restart=restart)
+    assert ig["reason"] == io["reason"] == 2
+    assert abs(ig["iters"] - io["iters"]) <= 1, (ig["iters"], io["iters"])
+    m = min(len(ig["history"]), len(io["history"]))
+    assert np.allclose(ig["history"][:m], io["history"][:m], rtol=1e-6, atol=1e-12 * io["history"][0])
+    assert np.linalg.norm(host(xg) - xo) <= 1e-6 * np.linalg.norm(xo)
+    M.close()
+    P.close()
+
+
+def test_gmres_edge_cases():
+    from fluca_amd import capi
+    P, M, g = _pair((10, 8, 6), CAVITY, False)
+    b = dev(np.zeros(3 * g.ncell))
+    x, info = M.solve(b, type=capi.KSP_GMRES)                     # zero right-hand side: converged at once (atol), x = 0
+    assert info["iters"] == 0 and info["reason"] == 3 and float(x.abs().max()) == 0.0
+    b = dev(np.random.default_rng(1).standard_normal(3 * g.ncell))
+    x, info = M.solve(b, type=capi.KSP_GMRES, maxit=3, rtol=1e-30)   # before set_state A = I: exact after one step (happy breakdown)
+    assert info["reason"] in (2, 3) and info["iters"] == 1 and torch.allclose(x, b)   # residual exactly 0: below atol
+    with pytest.raises(capi.FlucaError):
+        P.solve(b[:g.ncell].contiguous(), type=capi.KSP_GMRES)        # kspS: gmres is not offered there
+    M.close()
     P.close()

@@ -265,9 +265,14 @@ def test_momentum_options_and_state_checks(H):
     o = C.POINTER(H.capi.fl_ksp_opts)()
     assert H.lib.NSGetMomentumKSPOptions(ns, C.byref(o)) == 0
     assert (o.contents.type, o.contents.pc, o.contents.rtol, o.contents.maxit) == (H.capi.KSP_BCGS, 0, 1e-9, 77)
-    for bad, rc in (("gmres", 56), ("nonsense", 86)):          # PETSC_ERR_SUP, PETSC_ERR_ARG_UNKNOWN_TYPE
+    for bad, rc in (("fgmres", 56), ("nonsense", 86)):         # PETSC_ERR_SUP, PETSC_ERR_ARG_UNKNOWN_TYPE
         argc, av = H.argv("-ns_abf_momentum_ksp_type", bad)
         assert H.lib.NSSetFromOptions(ns, argc, av) == rc
+    argc, av = H.argv("-ns_abf_momentum_ksp_type", "gmres", "-ns_abf_momentum_ksp_gmres_restart", 12)   # the reference's default type of kspA
+    assert H.lib.NSSetFromOptions(ns, argc, av) == 0
+    assert (o.contents.type, o.contents.gmres_restart) == (H.capi.KSP_GMRES, 12)
+    argc, av = H.argv("-ns_abf_momentum_ksp_type", "bcgs")
+    assert H.lib.NSSetFromOptions(ns, argc, av) == 0
     argc, av = H.argv("-ns_abf_momentum_pc_type", "ilu")
     assert H.lib.NSSetFromOptions(ns, argc, av) == 56
     # before NSSetUp / NSSetPreviousState there is no A
@@ -465,7 +470,9 @@ def test_c_cavity_driver_writes_cgns_like_the_reference_options(H, tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("ainv", [(), ("-ns_pc_abf_schur_ainv_type", "DIAG", "-ns_pc_abf_upper_ainv_type", "DIAG"),
-                                  ("-ns_pc_abf_schur_ainv_type", "rowsum")])
+                                  ("-ns_pc_abf_schur_ainv_type", "rowsum"),
+                                  ("-ns_abf_momentum_ksp_type", "gmres"),          # kspA as the reference runs it (abfpc.c:72), Jacobi for ILU
+                                  ("-ns_abf_momentum_ksp_type", "gmres", "-ns_abf_momentum_ksp_gmres_restart", 4)])
 def test_nsstep_matches_the_oracle_step(H, ainv):
     """Velocity, face velocity and pressure after two lid-driven-cavity steps: the C mirror on the GPU vs the CPU oracle's
     composition of the same reference formulas (StepOracle), including the wall terms of L, C, B and T."""
@@ -501,7 +508,7 @@ def test_nsstep_matches_the_oracle_step(H, ainv):
     assert H.lib.NSSetBoundaryCondition(ns, idx[H.MESHCART_BACK], H.NSBoundaryCondition(type=H.NS_BC_SYMMETRY)) == 0
     argc, av = H.argv("-ns_time_step_size", dt, "-ns_max_steps", 2, "-ns_ksp_rtol", 1e-9, "-ns_abf_schur_ksp_rtol", 1e-10,
                       "-ns_abf_momentum_ksp_rtol", 1e-10, "-ns_abf_schur_ksp_max_it", 20000, *ainv)
-    # the Ainv types only change the preconditioner: the converged step is the same
+    # the Ainv types and the Krylov type of kspA only change the preconditioner: the converged step is the same
     assert H.lib.NSSetFromOptions(ns, argc, av) == 0 and H.lib.NSSetUp(ns) == 0
     assert H.lib.NSSolve(ns) == 0
     v, p, Vp = P(), P(), (C.c_void_p * 3)()

@@ -78,3 +78,33 @@ def test_momentum_bicgstab_matches_scipy():
     m = min(len(hist), io["iters"], 8)
     assert np.allclose(io["history"][1:m + 1], hist[:m], rtol=1e-5)
     assert np.linalg.norm(xo - xs) <= 1e-7 * np.linalg.norm(xs)
+
+
+def test_gmres_restatement_against_scipy():
+    """The oracle's KSPGMRES restatement (oracle/fluca_oracle.py::gmres) on the assembled momentum matrix: same restarted,
+    left-preconditioned algorithm as SciPy's gmres when SciPy is handed the Jacobi-scaled system -- iterates after every restart
+    cycle and the final answer must agree (independent implementation of the same published algorithm)."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    rng = np.random.default_rng(4)
+    n = (9, 8, 7)
+    xf = [np.linspace(0.0, 1.0, m + 1) ** (1.0 + 0.2 * d) for d, m in enumerate(n)]
+    g = fo.Grid(n, xf, [fo.BC_VELOCITY] * 4 + [fo.BC_PERIODIC] * 2, kappa=1e-2)
+    V0 = [rng.standard_normal(nf) for nf in g.nface]
+    W = [rng.standard_normal(g.nface[d]) for c in range(3) for d in range(3)]
+    A = g.assemble_momentum(1.0, 0.05, -0.02, V0, W)
+    b = rng.standard_normal(A.nrow)
+    x, info = fo.gmres(A, b, rtol=1e-9, restart=7, maxit=400)
+    assert info["reason"] == 2
+    As = A.to_scipy()
+    Dinv = sp.diags(1.0 / A.diag())
+    MA, Mb = (Dinv @ As).tocsr(), Dinv @ b
+    xs, flag = spla.gmres(MA, Mb, rtol=1e-9, atol=0.0, restart=7, maxiter=400)
+    assert flag == 0
+    assert np.linalg.norm(x - xs) <= 1e-7 * np.linalg.norm(xs)
+    assert np.linalg.norm(Mb - MA @ x) <= 1.01e-9 * np.linalg.norm(Mb)
+    # the recurrence norm is the true preconditioned residual norm (in exact arithmetic): check at the end of the first cycle
+    x7, i7 = fo.gmres(A, b, rtol=1e-30, restart=7, maxit=7)
+    assert i7["iters"] == 7 and i7["reason"] == -3
+    assert abs(np.linalg.norm(Mb - MA @ x7) - i7["history"][-1]) <= 1e-10 * i7["history"][0]
+    assert np.all(np.diff(i7["history"]) <= 1e-14 * i7["history"][0])     # GMRES residuals never grow inside a cycle
