@@ -221,6 +221,10 @@ extern "C" int fl_poisson_destroy(fl_poisson *h)
   if (h->scal) (void)hipFree(h->scal);
   if (h->tickets) (void)hipFree(h->tickets);
   if (h->scal_host) (void)hipHostFree(h->scal_host);
+  if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
+  if (h->ev_packed) (void)hipEventDestroy(h->ev_packed);
+  if (h->ev_ghosts) (void)hipEventDestroy(h->ev_ghosts);
+  if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -531,14 +535,9 @@ static int ensure_facebufs(fl_poisson *h)
   return 0;
 }
 
-// ghosts of a padded vector: local periodic images + neighbour ranks' boundary cells (DMGlobalToLocal of the reference)
-int fl_fill_ghosts(fl_poisson *h, double *v)
+// the messages of one ghost exchange (fl_halo_plan + the self-messages of the loopback mode) and the buffers they use
+static int halo_messages(fl_poisson *h, std::vector<Msg> &msgs, double *sbuf[6], double *rbuf[6])
 {
-  const GridP &g = h->g;
-  for (int d = 0; d < 3; ++d)
-    if (h->wrap_local[d]) launch_wrap(h->stream, g, v, d);
-  if (!h->multi) return 0;
-  if (h->comm.kind == Comm::NONE) return FL_ERR_ARG_WRONGSTATE;
   FL_CHK(ensure_facebufs(h));
   int periodic[3];
   for (int d = 0; d < 3; ++d) periodic[d] = h->ax[d].periodic;
@@ -550,17 +549,64 @@ int fl_fill_ghosts(fl_poisson *h, double *v)
         plan[np++] = {0, 2 * ax + 1, 2 * ax, 2 * ax + 1, 2 * ax + 1};
         plan[np++] = {0, 2 * ax, 2 * ax + 1, 2 * ax, 2 * ax};
       }
-  std::vector<Msg> msgs;
-  double          *sbuf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, *rbuf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  for (int b = 0; b < 6; ++b) sbuf[b] = rbuf[b] = nullptr;
   for (int a = 0; a < np; ++a) {
     const int sb = plan[a].send_boundary, rb = plan[a].recv_boundary;
     sbuf[sb] = h->fsend[sb];
     rbuf[rb] = h->frecv[rb];
     msgs.push_back({plan[a].peer, h->fsend[sb], h->frecv[rb], (int64_t)plane_size(h, sb / 2), plan[a].sendtag, plan[a].recvtag});
   }
-  if (np > 0) launch_pack_faces(h->stream, g, v, sbuf);    // all boundary layers in one launch
+  return 0;
+}
+
+// ghosts of a padded vector: local periodic images + neighbour ranks' boundary cells (DMGlobalToLocal of the reference)
+int fl_fill_ghosts(fl_poisson *h, double *v)
+{
+  const GridP &g = h->g;
+  for (int d = 0; d < 3; ++d)
+    if (h->wrap_local[d]) launch_wrap(h->stream, g, v, d);
+  if (!h->multi) return 0;
+  if (h->comm.kind == Comm::NONE) return FL_ERR_ARG_WRONGSTATE;
+  std::vector<Msg> msgs;
+  double          *sbuf[6], *rbuf[6];
+  FL_CHK(halo_messages(h, msgs, sbuf, rbuf));
+  if (!msgs.empty()) launch_pack_faces(h->stream, g, v, sbuf);    // all boundary layers in one launch
   FL_CHK(h->comm.exchange(h->stream, msgs));
-  if (np > 0) launch_unpack_faces(h->stream, g, v, rbuf);  // all ghost layers in one launch
+  if (!msgs.empty()) launch_unpack_faces(h->stream, g, v, rbuf);  // all ghost layers in one launch
+  return 0;
+}
+
+// The CG iteration's ghost exchange of r, hidden behind k_cg_B (the DMGlobalToLocalBegin / ...End pair of the reference,
+// fdapply.c:71, cnlinearcart3d.c:893-894).  begin: the boundary layers of r - alpha q are packed on the handle's stream BEFORE
+// k_cg_B forms the new r; a second stream waits for the pack, runs the transfers and writes the ghost layers, which k_cg_B neither
+// reads nor writes.  end: the handle's stream waits for the ghosts (and fills the locally wrapped axes) before k_cg_A needs them.
+int fl_exchange_r_begin(fl_poisson *h, double *r, const double *q)
+{
+  if (!h->multi) return 0;
+  if (h->comm.kind == Comm::NONE) return FL_ERR_ARG_WRONGSTATE;
+  if (!h->comm_stream) {
+    FL_HIP(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+    FL_HIP(hipEventCreateWithFlags(&h->ev_packed, hipEventDisableTiming));
+    FL_HIP(hipEventCreateWithFlags(&h->ev_ghosts, hipEventDisableTiming));
+  }
+  std::vector<Msg> msgs;
+  double          *sbuf[6], *rbuf[6];
+  FL_CHK(halo_messages(h, msgs, sbuf, rbuf));
+  if (!msgs.empty()) launch_pack_faces_rq(h->stream, h->g, r, q, h->scal, sbuf);
+  FL_HIP(hipEventRecord(h->ev_packed, h->stream));
+  FL_HIP(hipStreamWaitEvent(h->comm_stream, h->ev_packed, 0));
+  FL_CHK(h->comm.exchange(h->comm_stream, msgs));
+  if (!msgs.empty()) launch_unpack_faces(h->comm_stream, h->g, r, rbuf);
+  FL_HIP(hipEventRecord(h->ev_ghosts, h->comm_stream));
+  return 0;
+}
+
+int fl_exchange_r_end(fl_poisson *h, double *r)
+{
+  for (int d = 0; d < 3; ++d)
+    if (h->wrap_local[d]) launch_wrap(h->stream, h->g, r, d);
+  if (!h->multi) return 0;
+  FL_HIP(hipStreamWaitEvent(h->stream, h->ev_ghosts, 0));
   return 0;
 }
 
@@ -781,6 +827,10 @@ static int solve_cg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts
     const char *e = std::getenv("FLUCA_FUSEDFIN");
     return e ? std::atoi(e) != 0 : true;
   }();
+  static const bool overlap_env = []() {
+    const char *e = std::getenv("FLUCA_OVERLAP");  // 0: pack / transfer / unpack after k_cg_B, on the handle's stream (A/B measurements)
+    return e ? std::atoi(e) != 0 : true;
+  }();
   const bool fusedfin = !h->multi && o->variant != 1 && fusedfin_env;
   // several ranks: the last block of k_cg_A / k_cg_B still reduces the rank's partial sums (no k_reduce launch); the
   // all-reduce and the scalar kernel follow
@@ -818,10 +868,14 @@ static int solve_cg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts
       if (fusedsum) FL_CHK(fin_sums(1));
       else if (!fusedfin) FL_CHK(cg_fin(h, 1, nab, 1, h->hist, nhist));
       hostcur ^= 1;
+      // several ranks: the boundary layers of the new r leave now (packed as r - alpha q), the transfers overlap k_cg_B
+      const bool overlap = ghosts && o->variant != 1 && h->multi && overlap_env;
+      if (overlap) FL_CHK(fl_exchange_r_begin(h, h->r, h->q));
       launch_cg_B(s, g, jac, planB, h->q, h->r, h->scal, h->partial, h->partial_stride, (fusedfin || fusedsum) ? h->tickets + 1 : nullptr, h->hist, nhist, fusedsum ? h->sums : nullptr);
       if (fusedsum) FL_CHK(fin_sums(2));
       else if (!fusedfin) FL_CHK(cg_fin(h, 2, planB.nblocks, 5, h->hist, nhist));
-      if (ghosts && o->variant != 1) FL_CHK(fl_fill_ghosts(h, h->r));
+      if (overlap) FL_CHK(fl_exchange_r_end(h, h->r));
+      else if (ghosts && o->variant != 1) FL_CHK(fl_fill_ghosts(h, h->r));
     }
     FL_CHK(fl_poll_scal(h));
     if (h->scal_host->reason != 0 || it >= o->maxit) done = true;

@@ -29,6 +29,7 @@ void launch_pack(hipStream_t, const GridP &, const double *, double *, int, int)
 void launch_unpack(hipStream_t, const GridP &, double *, const double *, int, int);
 void launch_pack_faces(hipStream_t, const GridP &, const double *, double *const bufs[6]);
 void launch_unpack_faces(hipStream_t, const GridP &, double *, double *const bufs[6]);
+void launch_pack_faces_rq(hipStream_t, const GridP &, const double *, const double *, const KspScal *, double *const bufs[6]);
 void launch_apply(hipStream_t, const GridP &, const double *, double *, int);
 void launch_diagonal(hipStream_t, const GridP &, double *);
 void launch_rhs(hipStream_t, const GridP &, const double *, const double *, const double *, const double *, const double *, const double *, const double *, double *);
@@ -270,6 +271,9 @@ struct fl_poisson {
   double  *hiface[3] = {nullptr, nullptr, nullptr}, *loface_send[3] = {nullptr, nullptr, nullptr};
   Comm     comm;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // halo exchange overlapped with k_cg_B (fl_exchange_r_begin / _end): its own stream and the two events that order it
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t  ev_packed = nullptr, ev_ghosts = nullptr;
   fl_mg     *mg = nullptr;  // multigrid hierarchy, built by the first solve with FL_PC_MG (fl_mg.hip)
 };
 
@@ -316,6 +320,8 @@ int  fl_ensure_partials(fl_poisson *h, int nblocks);
 int  fl_ensure_hist(fl_poisson *h, int nhist);
 int  fl_zero_vec(fl_poisson *h, double *v);
 int  fl_fill_ghosts(fl_poisson *h, double *v);
+int  fl_exchange_r_begin(fl_poisson *h, double *r, const double *q);
+int  fl_exchange_r_end(fl_poisson *h, double *r);
 bool fl_any_ghost_exchange(const fl_poisson *h);
 int  fl_poll_scal(fl_poisson *h);
 // fl_ksp.hip

@@ -149,6 +149,22 @@ __global__ void k_pack_faces(GridP g, const double *__restrict__ v, FaceBufs fb)
   const int64_t p = axis == 0 ? pidx(g, c, a, b) : (axis == 1 ? pidx(g, a, c, b) : pidx(g, a, b, c));
   buf[(int64_t)b * na + a] = v[p];
 }
+// The boundary layers of the NEW residual r - alpha q, packed before k_cg_B has formed it anywhere: the halo exchange then runs on
+// a second stream while k_cg_B streams the whole block (same fma as k_cg_B, so the neighbour's ghost equals this rank's cell bit
+// for bit).  After the iteration has stopped (reason != 0) k_cg_B leaves r alone: so does this.
+__global__ void k_pack_faces_rq(GridP g, const double *__restrict__ r, const double *__restrict__ q, const KspScal *__restrict__ s, FaceBufs fb)
+{
+  const int bnd = blockIdx.z, axis = bnd / 2, side = bnd % 2;
+  double   *buf = fb.buf[bnd];
+  if (!buf) return;
+  const int a = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y * 4 + threadIdx.y;
+  const int na = axis == 0 ? g.ny : g.nx, nb = axis == 2 ? g.ny : g.nz;
+  if (a >= na || b >= nb) return;
+  const double  alpha = s->reason != 0 ? 0. : s->alpha;
+  const int     n = axis == 0 ? g.nx : (axis == 1 ? g.ny : g.nz), c = side ? n - 1 : 0;
+  const int64_t p = axis == 0 ? pidx(g, c, a, b) : (axis == 1 ? pidx(g, a, c, b) : pidx(g, a, b, c));
+  buf[(int64_t)b * na + a] = s->reason != 0 ? r[p] : fma(-alpha, q[p], r[p]);
+}
 __global__ void k_unpack_faces(GridP g, double *__restrict__ v, FaceBufs fb)
 {
   const int     bnd = blockIdx.z, axis = bnd / 2, side = bnd % 2;
@@ -560,8 +576,8 @@ __global__ void __launch_bounds__(256) k_cg_B(GridP g, const double *__restrict_
 #pragma unroll
     for (int m = 0; m < RY; ++m) {
       double2 rn;
-      rn.x = C.r[m].x - alpha * C.q[m].x;
-      rn.y = C.r[m].y - alpha * C.q[m].y;
+      rn.x = fma(-alpha, C.q[m].x, C.r[m].x);  // the same rounding as k_pack_faces_rq
+      rn.y = fma(-alpha, C.q[m].y, C.r[m].y);
       const double dyz = yc[m] + C.zc;
       const double z0 = JAC ? rn.x / (xc0 + dyz) : rn.x;
       const double z1 = JAC ? rn.y / (xc1 + dyz) : rn.y;
@@ -1038,6 +1054,14 @@ void launch_pack_faces(hipStream_t st, const GridP &g, const double *v, double *
   const int na = std::max(g.nx, g.ny), nb = std::max(g.ny, g.nz);
   dim3      grid((na + 63) / 64, (nb + 3) / 4, 6);
   hipLaunchKernelGGL(k_pack_faces, grid, dim3(64, 4), 0, st, g, v, fb);
+}
+void launch_pack_faces_rq(hipStream_t st, const GridP &g, const double *r, const double *q, const KspScal *s, double *const bufs[6])
+{
+  FaceBufs fb;
+  for (int b = 0; b < 6; ++b) fb.buf[b] = bufs[b];
+  const int na = std::max(g.nx, g.ny), nb = std::max(g.ny, g.nz);
+  dim3      grid((na + 63) / 64, (nb + 3) / 4, 6);
+  hipLaunchKernelGGL(k_pack_faces_rq, grid, dim3(64, 4), 0, st, g, r, q, s, fb);
 }
 void launch_unpack_faces(hipStream_t st, const GridP &g, double *v, double *const bufs[6])
 {

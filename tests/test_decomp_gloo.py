@@ -1,4 +1,4 @@
-"""CPU, world_size 2 and 4 over gloo: the product's decomposition + ghost-exchange plan (host-only C-ABI functions
+"""CPU, world_size 2, 4 and 8 over gloo: the product's decomposition + ghost-exchange plan (host-only C-ABI functions
 fl_decomp_default / fl_decomp_neighbor / fl_halo_plan -- the same plan fl_poisson_* executes on the GPU) moves exactly the
 cells DMGlobalToLocal would: every ghost layer ends up holding the neighbouring block's boundary cells, periodic wrap
 included; scalar all-reduce sums over ranks."""
@@ -69,6 +69,8 @@ def _worker(rank, world, n, ranks, periodic):
     (2, (7, 9, 4), (1, 2, 1), (True, True, False)),
     (4, (9, 8, 6), (1, 2, 2), (False, True, True)),
     (4, (12, 5, 4), (4, 1, 1), (True, False, False)),     # >2 ranks on a periodic axis
+    (8, (16, 16, 8), (2, 2, 2), (False, False, True)),    # BASELINE config 5's decomposition (1024 x 1024 x 512 on 2 x 2 x 2 GPUs,
+                                                          # periodic span) at toy size: every rank has three face neighbours
 ])
 def test_halo_plan_moves_the_right_cells(world, n, ranks, periodic):
     mpc.run_ranks(world, _worker, n, ranks, periodic)
