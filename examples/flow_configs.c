@@ -148,13 +148,17 @@ int main(int argc, char **argv)
     double rnorm, t0 = now();
     CHK(NSStep(ns));
     const double dtw = now() - t0;
+    double rnorm0;
     CHK(NSGetLinearSolveInfo(ns, &its, &rnorm, &reason));
+    CHK(NSGetLinearSolveResidualNorms(ns, &rnorm0, NULL));
     CHK(NSGetInnerIterations(ns, &mi, &si));
     if (reason < 0) {
       fprintf(stderr, "step %lld failed\n", (long long)(s + 1));
       return 2;
     }
-    printf("step %lld  wall %.3f s  outer its %d  kspA its %d  kspS its %d  residual %.2e\n", (long long)(s + 1), dtw, its, mi, si, rnorm);
+    /* |r| / |f|: the quantity -ns_ksp_rtol bounds (with -ns_ksp_type preonly no residual is formed: one PCApply_ABF per step) */
+    printf("step %lld  wall %.3f s  outer its %d  kspA its %d  kspS its %d  |r|/|f| %.2e  (|f| %.2e)\n", (long long)(s + 1), dtw, its, mi, si,
+           rnorm0 > 0. ? rnorm / rnorm0 : 0., rnorm0);
     fflush(stdout);
   }
   ABI(fl_memcpy_d2h(0, v, v_dev, sizeof(double) * 3 * (size_t)sz[0]));

@@ -450,6 +450,7 @@ struct _p_NS {
   int                  ksp_its, reason;    /* of the last step */
   int                  mom_its, schur_its; /* inner Krylov iterations summed over the last step's outer iterations */
   double               ksp_rnorm;
+  double               ksp_rnorm0; /* norm of the right-hand side the outer solve started from (the reference norm of its rtol test) */
   /* NSMonitorSet list (nsimpl.h: monitor[], monitorctx[], monitordestroy[], MAXNSMONITORS) */
   int                  nmon;
   FlErrorCode (*mon[MAXNSMONITORS])(NS, void *);
@@ -678,7 +679,41 @@ FlErrorCode NSSetFromOptions(NS ns, int argc, char **argv)
   return ns->ops->setfromoptions ? ns->ops->setfromoptions(ns, argc, argv) : 0;
 }
 
-FlErrorCode NSSetUp(NS ns) /* nsbasic.c:153-274, restricted to what the Poisson path needs */
+/* Tracing: roctx ranges with the names of the reference's PetscLogEvents (nspkg.c:21-24: NSSetUp, NSStep, NSFormJacobian,
+ * NSFormFunction), so that a rocprofv3 --marker-trace timeline reads like the reference's -log_view.  libroctx64 is looked up at
+ * run time; without it the ranges are no-ops. */
+#include <dlfcn.h>
+static int (*roctx_push)(const char *) = NULL;
+static int (*roctx_pop)(void)          = NULL;
+static void trace_init(void)
+{
+  static int tried = 0;
+  if (tried) return;
+  tried = 1;
+  void *lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) lib = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) lib = dlopen("/opt/rocm/lib/libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) return;
+  roctx_push = (int (*)(const char *))dlsym(lib, "roctxRangePushA");
+  roctx_pop  = (int (*)(void))dlsym(lib, "roctxRangePop");
+  if (!roctx_push || !roctx_pop) roctx_push = NULL, roctx_pop = NULL;
+}
+static void trace_begin(const char *name)
+{
+  trace_init();
+  if (roctx_push) (void)roctx_push(name);
+}
+static void trace_end(void)
+{
+  if (roctx_pop) (void)roctx_pop();
+}
+int FlucaTraceEnabled(void)
+{
+  trace_init();
+  return roctx_push != NULL;
+}
+
+static FlErrorCode NSSetUp_Body(NS ns) /* nsbasic.c:153-274, restricted to what the Poisson path needs */
 {
   if (!ns) return E_ARG_NULL;
   if (ns->setupcalled) return 0;
@@ -713,7 +748,7 @@ FlErrorCode NSSetUp(NS ns) /* nsbasic.c:153-274, restricted to what the Poisson 
   return 0;
 }
 
-FlErrorCode NSStep(NS ns) /* nsbasic.c:276-299 */
+static FlErrorCode NSStep_Body(NS ns) /* nsbasic.c:276-299 */
 {
   if (!ns) return E_ARG_NULL;
   if (!ns->setupcalled) return E_ARG_WRONGSTATE;
@@ -728,6 +763,21 @@ FlErrorCode NSStep(NS ns) /* nsbasic.c:276-299 */
     return 91; /* PETSC_ERR_NOT_CONVERGED: "NSStep has failed due to DIVERGED_NONLINEAR_SOLVE" */
   }
   return 0;
+}
+
+FlErrorCode NSSetUp(NS ns)
+{
+  trace_begin("NSSetUp"); /* PetscLogEventBegin(NS_SetUp), nsbasic.c:160 */
+  const FlErrorCode rc = NSSetUp_Body(ns);
+  trace_end();
+  return rc;
+}
+FlErrorCode NSStep(NS ns)
+{
+  trace_begin("NSStep"); /* PetscLogEventBegin(NS_Step), nsbasic.c:283 */
+  const FlErrorCode rc = NSStep_Body(ns);
+  trace_end();
+  return rc;
 }
 
 /* nsopts.c: the plain getters / setters */
@@ -804,6 +854,13 @@ FlErrorCode NSGetLinearSolveInfo(NS ns, int *its, double *rnorm, int *reason)
   if (its) *its = ns->ksp_its;
   if (rnorm) *rnorm = ns->ksp_rnorm;
   if (reason) *reason = ns->reason;
+  return 0;
+}
+FlErrorCode NSGetLinearSolveResidualNorms(NS ns, double *rnorm0, double *rnorm)
+{
+  if (!ns) return E_ARG_NULL;
+  if (rnorm0) *rnorm0 = ns->ksp_rnorm0;
+  if (rnorm) *rnorm = ns->ksp_rnorm;
   return 0;
 }
 FlErrorCode NSGetTimeStep(NS ns, int64_t *step)
@@ -1313,8 +1370,9 @@ static FlErrorCode cnl_gmres(NS ns, const CVec *f, CVec *x)
   fnorm = sqrt(fnorm);
   const double ttol = ns->ksp_rtol * fnorm > ns->ksp_atol ? ns->ksp_rtol * fnorm : ns->ksp_atol;
   GM(cv_lincomb(ns, 0., f, 0., NULL, x)); /* x = 0 */
-  ns->ksp_its   = 0;
-  ns->ksp_rnorm = fnorm;
+  ns->ksp_its    = 0;
+  ns->ksp_rnorm  = fnorm;
+  ns->ksp_rnorm0 = fnorm;
   int first = 1;
   while (ns->reason >= 0) {
     /* r = f - J x */
@@ -1413,6 +1471,7 @@ static FlErrorCode NSStep_CNLinear(NS ns)
   FLABI(fl_vec_lincomb(h, N, 1., c->sol_p, 0., NULL, c->sol0_p));
   for (int d = 0; d < 3; ++d) FLABI(fl_vec_lincomb(h, c->sz[1 + d], 1., c->sol_V[d], 0., NULL, c->sol0_V[d]));
 
+  trace_begin("NSFormFunction"); /* the right-hand side of the step: PetscLogEvent NS_FormFunction (nsbasic.c:131) */
   /* v0interp = B v0 + vbc(t), cnlinearcart3d.c:2826-2829; vbc: :1749-1932 */
   FLABI(fl_momentum_interp_faces(ns->momentum, c->sol0_v, NULL, c->W));
   /* momrhs = v0 + cv L v0 - kappa G p, :2976-2993 (p0 on the first step, phalf afterwards) */
@@ -1507,12 +1566,15 @@ static FlErrorCode NSStep_CNLinear(NS ns)
       FLABI(fl_momentum_face_interp_scaled(ns->momentum, -1., w, rhs, c->f_V));
     }
   }
+  trace_end(); /* NSFormFunction */
   /* NSFormJacobian: A = I + dt C(V0, v0interp) - cv L, :2930-2941 */
   {
     const double *V0[3] = {c->sol0_V[0], c->sol0_V[1], c->sol0_V[2]};
     const double *W[9];
     for (int q = 0; q < 9; ++q) W[q] = c->W[q];
+    trace_begin("NSFormJacobian"); /* PetscLogEvent NS_FormJacobian (nsbasic.c:118) */
     FLABI(fl_momentum_set_state(ns->momentum, dt, ns->rho, ns->mu, V0, W));
+    trace_end();
   }
   /* KSPSolve(J, f, x) with PC_ABF */
   fl_ksp_stats  st[2];
@@ -1542,6 +1604,7 @@ static FlErrorCode NSStep_CNLinear(NS ns)
       fnorm += part;
     }
     fnorm = sqrt(fnorm);
+    ns->ksp_rnorm0 = fnorm;
     const double ttol = ns->ksp_rtol * fnorm > ns->ksp_atol ? ns->ksp_rtol * fnorm : ns->ksp_atol;
     for (;;) {
       FLCHK(cnl_residual(ns, &rnorm));

@@ -44,7 +44,7 @@ PROTOTYPES = {
     "NSGetPoisson": [_P, C.POINTER(_P)], "NSGetSchurKSPOptions": [_P, C.POINTER(C.POINTER(capi.fl_ksp_opts))], "NSGetNeedsNullSpace": [_P, _ip],
     "NSGetLocalSizes": [_P, _i64p], "NSPressureCorrection": [_P, _dp3, _dp3, _P, _P, C.POINTER(capi.fl_ksp_stats)],
     "NSSolve": [_P], "NSSetImmersedBoundary": [_P, C.c_int, C.c_int64, _P, _P, _P, _P, _P], "NSGetSolutionArrays": [_P, C.POINTER(_P), _dp3, C.POINTER(_P)],
-    "NSGetLinearSolveInfo": [_P, _ip, C.POINTER(C.c_double), _ip], "NSGetInnerIterations": [_P, _ip, _ip], "NSGetImmersedBoundary": [_P, C.POINTER(_P)],
+    "NSGetLinearSolveInfo": [_P, _ip, C.POINTER(C.c_double), _ip], "NSGetLinearSolveResidualNorms": [_P, C.POINTER(C.c_double), C.POINTER(C.c_double)], "NSGetInnerIterations": [_P, _ip, _ip], "NSGetImmersedBoundary": [_P, C.POINTER(_P)],
     "NSSetPreviousState": [_P, _dp3, _dp3], "NSGetMomentum": [_P, C.POINTER(_P)],
     "NSGetMomentumKSPOptions": [_P, C.POINTER(C.POINTER(capi.fl_ksp_opts))],
     "NSApplyPreconditioner": [_P, _P, _dp3, _P, _P, _dp3, _P, C.POINTER(capi.fl_ksp_stats)],
@@ -57,6 +57,7 @@ PROTOTYPES = {
     "NSSetTime": [_P, C.c_double], "NSSetTimeStep": [_P, C.c_int64], "NSSetErrorIfStepFailed": [_P, C.c_int], "NSGetErrorIfStepFailed": [_P, _ip],
     "NSGetConvergedReason": [_P, _ip],
     "NSMonitorSet": [_P, _P, _P, _P], "NSMonitorCancel": [_P], "NSMonitor": [_P],
+    "FlucaTraceEnabled": [],
 }
 MonitorFunc = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
 for _n, _a in PROTOTYPES.items():

@@ -152,6 +152,12 @@ FlErrorCode NSMonitorSet(NS ns, FlErrorCode (*monitor)(NS, void *), void *ctx, F
 FlErrorCode NSMonitorCancel(NS ns);
 FlErrorCode NSMonitor(NS ns);
 FlErrorCode NSGetLinearSolveInfo(NS ns, int *its, double *rnorm, int *reason);
+/* norm of the right-hand side the last outer solve started from (the reference norm of its rtol test, nssol.c:24-25: the
+ * unpreconditioned norm) and the residual norm it stopped at: rnorm / rnorm0 is what -ns_ksp_rtol is compared with */
+FlErrorCode NSGetLinearSolveResidualNorms(NS ns, double *rnorm0, double *rnorm);
+/* 1 when libroctx64 was found: NSSetUp, NSStep, NSFormFunction and NSFormJacobian then emit roctx ranges under the names of the
+ * reference's PetscLogEvents (nspkg.c:21-24); rocprofv3 --marker-trace shows them */
+int FlucaTraceEnabled(void);
 /* kspA / kspS iterations summed over the outer iterations of the last step */
 FlErrorCode NSGetInnerIterations(NS ns, int *momentum_its, int *schur_its);
 /* The A block of NSFormJacobian (cnlinearcart3d.c:2930-2941): hands over sol0's face-normal velocity V0 (3 face arrays)

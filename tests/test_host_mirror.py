@@ -255,6 +255,12 @@ def test_c_driver_runs_without_python(H):
     assert "1 NS dt 0.001 time 0.001" in out.stdout and "reason 2" in out.stdout
 
 
+def test_tracing_hooks_find_roctx(H):
+    """NSSetUp / NSStep / NSFormFunction / NSFormJacobian emit roctx ranges named like the reference's PetscLogEvents
+    (nspkg.c:21-24) when libroctx64 can be loaded -- it ships with ROCm, so it must be found in this image."""
+    assert H.lib.FlucaTraceEnabled() == 1
+
+
 def test_momentum_options_and_state_checks(H):
     """-ns_abf_momentum_* (abfpc.c:205): what is built is accepted, PETSc's own defaults are refused as unsupported."""
     mesh = cavity_mesh(H, ("-cart_grid_x", 8, "-cart_grid_y", 8, "-cart_grid_z", 8))
@@ -511,6 +517,9 @@ def test_nsstep_matches_the_oracle_step(H, ainv):
     # the Ainv types and the Krylov type of kspA only change the preconditioner: the converged step is the same
     assert H.lib.NSSetFromOptions(ns, argc, av) == 0 and H.lib.NSSetUp(ns) == 0
     assert H.lib.NSSolve(ns) == 0
+    r0, r1 = C.c_double(), C.c_double()
+    assert H.lib.NSGetLinearSolveResidualNorms(ns, C.byref(r0), C.byref(r1)) == 0
+    assert r0.value > 0 and r1.value <= 1e-9 * r0.value                  # the normalised residual is what -ns_ksp_rtol bounds
     v, p, Vp = P(), P(), (C.c_void_p * 3)()
     assert H.lib.NSGetSolutionArrays(ns, C.byref(v), Vp, C.byref(p)) == 0
     bc = [fo.BC_VELOCITY] * 4 + [fo.BC_SYMMETRY, fo.BC_VELOCITY]
