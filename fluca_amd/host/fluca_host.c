@@ -707,7 +707,7 @@ static void trace_end(void)
 {
   if (roctx_pop) (void)roctx_pop();
 }
-int FlucaTraceEnabled(void)
+FlErrorCode FlucaTraceEnabled(void)
 {
   trace_init();
   return roctx_push != NULL;

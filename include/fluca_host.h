@@ -157,7 +157,7 @@ FlErrorCode NSGetLinearSolveInfo(NS ns, int *its, double *rnorm, int *reason);
 FlErrorCode NSGetLinearSolveResidualNorms(NS ns, double *rnorm0, double *rnorm);
 /* 1 when libroctx64 was found: NSSetUp, NSStep, NSFormFunction and NSFormJacobian then emit roctx ranges under the names of the
  * reference's PetscLogEvents (nspkg.c:21-24); rocprofv3 --marker-trace shows them */
-int FlucaTraceEnabled(void);
+FlErrorCode FlucaTraceEnabled(void);
 /* kspA / kspS iterations summed over the outer iterations of the last step */
 FlErrorCode NSGetInnerIterations(NS ns, int *momentum_its, int *schur_its);
 /* The A block of NSFormJacobian (cnlinearcart3d.c:2930-2941): hands over sol0's face-normal velocity V0 (3 face arrays)
