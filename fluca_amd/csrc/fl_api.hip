@@ -999,6 +999,8 @@ extern "C" int fl_comm_unique_id(void *out128)
 
 extern "C" int fl_poisson_comm_init_rccl(fl_poisson *h, const void *id128, int rank, int nranks)
 {
+  if (h) fl_mg_destroy(h);  // the levels of a multigrid hierarchy borrow this handle's communicator: rebuilt on the next solve
+
   if (!h || !id128) return FL_ERR_ARG_NULL;
   if (nranks != h->dec.ranks[0] * h->dec.ranks[1] * h->dec.ranks[2] || rank < 0 || rank >= nranks) return FL_ERR_ARG_WRONG;
   FL_CHK(g_rccl.load());
@@ -1015,6 +1017,8 @@ extern "C" int fl_poisson_comm_init_rccl(fl_poisson *h, const void *id128, int r
 
 extern "C" int fl_poisson_comm_init_host(fl_poisson *h, fl_exchange_fn xchg, fl_allreduce_fn allred, void *ctx, int rank, int nranks)
 {
+  if (h) fl_mg_destroy(h);  // the levels of a multigrid hierarchy borrow this handle's communicator: rebuilt on the next solve
+
   if (!h || !xchg || !allred) return FL_ERR_ARG_NULL;
   if (nranks != h->dec.ranks[0] * h->dec.ranks[1] * h->dec.ranks[2] || rank < 0 || rank >= nranks) return FL_ERR_ARG_WRONG;
   h->comm.destroy();

@@ -137,11 +137,17 @@ struct Comm {
     if (m.empty()) return 0;
     if (kind == RCCL) {
       FL_NCCL(g_rccl.GroupStart());
+      // a failing Send / Recv must not leave the communicator inside an open group: remember the error, close the group, report
+      ncclResult_t bad = ncclSuccess;
       for (const Msg &x : m) {
-        if (x.send) FL_NCCL(g_rccl.Send(x.send, (size_t)x.count, ncclDouble, x.peer, nccl, st));
-        if (x.recv) FL_NCCL(g_rccl.Recv(x.recv, (size_t)x.count, ncclDouble, x.peer, nccl, st));
+        if (bad == ncclSuccess && x.send) bad = g_rccl.Send(x.send, (size_t)x.count, ncclDouble, x.peer, nccl, st);
+        if (bad == ncclSuccess && x.recv) bad = g_rccl.Recv(x.recv, (size_t)x.count, ncclDouble, x.peer, nccl, st);
       }
-      FL_NCCL(g_rccl.GroupEnd());
+      const ncclResult_t end = g_rccl.GroupEnd();
+      if (bad != ncclSuccess || end != ncclSuccess) {
+        std::fprintf(stderr, "[flucahip] halo exchange over RCCL failed: %s\n", g_rccl.GetErrorString(bad != ncclSuccess ? bad : end));
+        return FL_ERR_LIB;
+      }
       return 0;
     }
     if (kind == HOST) {

@@ -1160,19 +1160,23 @@ PlanA plan_tiles(const GridP &g, int ry, int nw, int nchunk_force, int target_bl
 // cavity makes 16) are latency-bound, not bandwidth-bound: they get smaller tiles and short z chunks instead, the chunk
 // prologue no longer matters (tools/experiments/small_grid_plan.py: k_cg_A 23.4 -> 6.9 us, k_cg_B 9.6 -> 4.7 us there).
 constexpr int MIN_BLOCKS = 256;  // one per CU
+// Plans from the sweeps of tools/experiments/sweep256.py at 128^3, 256^3 and 512^3 (profiles/r02_plan_sweep.txt): both kernels are
+// fastest with about one block per CU (k_cg_A) or one to two (k_cg_B) and as few z chunks as that allows -- every chunk pays a
+// two-plane prologue in k_cg_A and a ramp in both.  512^3: k_cg_A 128 x 16 tiles x 2 chunks (1094 us; 4 chunks 1106, 128 x 8 tiles
+// 1123), k_cg_B 128 x 16 x 2 chunks (543 us; the 1024 blocks of round 1: 585).  256^3: k_cg_A 128 x 8 x 4 chunks (151 us; the
+// round-1 plan of 128 x 16 x 16 chunks: 164), k_cg_B 128 x 4 x 4 chunks (70 us; round 1: 128 x 16 x 32 chunks, 108).
 PlanA plan_cg_A(const GridP &g, int ry_force, int nchunk_force)
 {
-  const int ry = ry_force > 0 ? ry_force : (g.ny >= 8 ? 2 : 1);
-  const int nw = (ry == 2 && g.ny >= 32) ? 8 : 4;
-  // blocks aimed at: one per CU when the tiles alone nearly fill the chip (512^3: 128 tiles x 2 chunks of 256 planes -- fewer chunk
-  // prologues, 1.097 against 1.109 ms per launch with 4 chunks, profiles/r02_bench_nchunk.txt), two per CU otherwise
   static const int target_env = []() {
     const char *e = std::getenv("FLUCA_CGA_TARGET");
     return e ? std::atoi(e) : 0;
   }();
-  const int tiles0 = ((g.nx + 127) / 128) * ((g.ny + nw * ry - 1) / (nw * ry));
-  const int target = target_env > 0 ? target_env : (tiles0 >= 64 ? 256 : 512);
-  PlanA     p  = plan_tiles(g, ry, nw, nchunk_force, target);
+  const int target = target_env > 0 ? target_env : 256;
+  const int ry = ry_force > 0 ? ry_force : (g.ny >= 8 ? 2 : 1);
+  // 128 x 16 tiles (8 waves) when they alone nearly fill the chip, 128 x 8 (4 waves) below that
+  const int tiles16 = ((g.nx + 127) / 128) * ((g.ny + 8 * ry - 1) / (8 * ry));
+  const int nw      = (ry == 2 && g.ny >= 32 && tiles16 >= 128) ? 8 : 4;
+  PlanA     p       = plan_tiles(g, ry, nw, nchunk_force, target);
   if (ry_force <= 0 && nchunk_force <= 0 && p.nblocks < MIN_BLOCKS) {
     p = plan_tiles(g, ry, 4, 0, 512, 2);
     if (p.nblocks < MIN_BLOCKS && ry == 2) p = plan_tiles(g, 1, 4, 0, 512, 2);
@@ -1183,10 +1187,13 @@ PlanA plan_cg_A(const GridP &g, int ry_force, int nchunk_force)
 }
 PlanA plan_cg_B(const GridP &g)
 {
-  int   ry = g.ny >= 32 ? 4 : (g.ny >= 8 ? 2 : 1);
-  PlanA p  = plan_tiles(g, ry, 4, 0, 1024);
+  const int64_t cells = (int64_t)g.nx * g.ny * g.nz;
+  const bool    big   = cells >= ((int64_t)1 << 26);  // 512^3: few fat blocks; below: one row per wave, two blocks per CU
+  int           ry = big ? (g.ny >= 32 ? 4 : (g.ny >= 8 ? 2 : 1)) : 1;
+  const int     target = big ? 256 : 512;
+  PlanA         p  = plan_tiles(g, ry, 4, 0, target);
   while (p.nblocks < MIN_BLOCKS) {
-    p = plan_tiles(g, ry, 4, 0, 1024, 2);
+    p = plan_tiles(g, ry, 4, 0, target, 2);
     if (p.nblocks >= MIN_BLOCKS || ry == 1) break;
     ry /= 2;
   }

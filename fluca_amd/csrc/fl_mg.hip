@@ -210,8 +210,21 @@ int mg_build_levels(fl_poisson *h, fl_mg *mg, int max_levels)
       const int64_t n = hf->ax[d].n, m = hf->dec.ranks[d];
       // every rank's share must stay even and >= 8: with DMStag's default split that means n divisible by 2 m
       r[d] = (n % (2 * m) == 0 && n / m >= 8 && hf->dec.lo[d] % 2 == 0 && hf->dec.len[d] % 2 == 0) ? 2 : 1;
-      any |= r[d] == 2;
     }
+    if (hf->multi) {
+      // the ranks must build the SAME hierarchy (their halo exchanges and all-reduces pair up level by level): with a caller-supplied
+      // uneven split the local parity tests can differ from rank to rank, so an axis is coarsened only if every rank can
+      FL_HIP(hipStreamSynchronize(hf->stream));
+      double ok[NSLOT] = {0., 0., 0., 0., 0., 0., 0., 0.};
+      for (int d = 0; d < 3; ++d) ok[d] = r[d] == 2 ? 0. : 1.;  // number of ranks that cannot
+      FL_HIP(hipMemcpy(hf->sums, ok, sizeof(ok), hipMemcpyHostToDevice));
+      FL_CHK(hf->comm.allreduce(hf->stream, hf->sums, NSLOT));
+      FL_HIP(hipMemcpyAsync(ok, hf->sums, sizeof(ok), hipMemcpyDeviceToHost, hf->stream));
+      FL_HIP(hipStreamSynchronize(hf->stream));
+      for (int d = 0; d < 3; ++d)
+        if (ok[d] != 0.) r[d] = 1;
+    }
+    for (int d = 0; d < 3; ++d) any |= r[d] == 2;
     if (!any) break;
     // coarse grid: every other face of the coarsened axes, centres = midpoints
     std::vector<double> xf[3];
