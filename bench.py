@@ -66,7 +66,18 @@ def cpu_baseline(sample_n, iters):
         Pc.close()
     except Exception as e:  # noqa: BLE001  (never lose the bench line over the cross-check)
         parity = {"error": repr(e)}
+    # the CPU leg may run the whole 512^3 grid only where the host has the memory (>= 32 GB free for the 12 GB CSR + vectors)
+    # AND the time: 512^3 costs 8x the sample per iteration (about 1 s each on 16 cores), so the default stays a bounded 256^3 sample
+    mem_avail_gb = None
+    try:
+        with open("/proc/meminfo") as fh:
+            for line in fh:
+                if line.startswith("MemAvailable:"):
+                    mem_avail_gb = int(line.split()[1]) / 1e6
+    except OSError:
+        pass
     return {"value": its_per_s * (sample_n ** 3) / 512.0 ** 3, "unit": "512^3-equivalent PCG iterations/s", "parity_on_sample": parity,
+            "host_mem_available_GB": mem_avail_gb, "full_grid_possible": bool(mem_avail_gb and mem_avail_gb >= 32.0),
             "cores": fo.num_threads(), "kind": "port", "petsc_cpu": petsc_cpu(sample_n, iters, fo.num_threads()),
             "sample": f"{sample_n}^3 cavity grid (1/{(512 // sample_n) ** 3} of the cells), {info['iters']} Jacobi-PCG iterations, "
                       f"assembled CSR (AIJ cost model), {info['seconds']:.2f} s, raw {its_per_s:.3f} it/s on the sample",

@@ -872,10 +872,12 @@ static int solve_cg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts
       const bool overlap = ghosts && o->variant != 1 && h->multi && overlap_env;
       if (overlap) FL_CHK(fl_exchange_r_begin(h, h->r, h->q));
       launch_cg_B(s, g, jac, planB, h->q, h->r, h->scal, h->partial, h->partial_stride, (fusedfin || fusedsum) ? h->tickets + 1 : nullptr, h->hist, nhist, fusedsum ? h->sums : nullptr);
+      // the handle's stream joins the exchange BEFORE the all-reduce is enqueued: the two RCCL operations never run at the same time
+      // (one communicator, two streams), only the transfers and k_cg_B do
+      if (overlap) FL_CHK(fl_exchange_r_end(h, h->r));
       if (fusedsum) FL_CHK(fin_sums(2));
       else if (!fusedfin) FL_CHK(cg_fin(h, 2, planB.nblocks, 5, h->hist, nhist));
-      if (overlap) FL_CHK(fl_exchange_r_end(h, h->r));
-      else if (ghosts && o->variant != 1) FL_CHK(fl_fill_ghosts(h, h->r));
+      if (!overlap && ghosts && o->variant != 1) FL_CHK(fl_fill_ghosts(h, h->r));
     }
     FL_CHK(fl_poll_scal(h));
     if (h->scal_host->reason != 0 || it >= o->maxit) done = true;
