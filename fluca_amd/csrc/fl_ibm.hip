@@ -2,9 +2,13 @@
 //
 // There is NO reference implementation (thecasterian/fluca THEORY_GUIDE.md:130-132 is an empty TODO); the specification
 // is DESIGN.md "IBM":  U_l = sum_x u(x) delta_h(x - X_l) h^3,  f(x) += sum_l F_l delta_h(x - X_l) dV_l,
-// delta_h = prod_d phi(r_d / h_d) / h_d, phi = Peskin 4-point or Roma 3-point, uniform spacing, collocated fields
-// (all velocity components live at cell centres in Fluca, fluca/src/ns/interface/nsbasic.c:180) so one weight set serves
-// every component.
+// delta_h = prod_d phi(r_d / h_d) / h_d, phi = Peskin 4-point or Roma 3-point, collocated fields (all velocity components live
+// at cell centres in Fluca, fluca/src/ns/interface/nsbasic.c:180) so one weight set serves every component.
+// Stretched axes (round 2): the delta function lives in INDEX space -- the marker is mapped to the continuous cell-centre index s
+// (piecewise linear through the centres; beyond the first / last one through its mirror image in the wall or the periodic image),
+// the weights are phi(s - i), interpolation is U = sum u w and spreading divides by the volume of the TARGET cell:
+// f_i += F dV w / (dx_i dy_j dz_k).  sum w = 1, <interp u, F dV> = sum_i u_i f_i V_i and sum_i f_i V_i = sum F dV hold on any
+// grid; on a uniform one this is exactly the formula above.
 //
 // Kernels (gfx950, 64-lane wavefronts):
 //   k_ibm_weights   one lane per marker: first support cell and the S 1-D weights per axis
@@ -44,6 +48,9 @@ struct IbmP {
   int     periodic[3]; // periodic axis of the GLOBAL grid (support indices wrap modulo ng, then ownership is tested)
   double  x0[3], h[3]; // global origin, spacing
   int     nt[3];       // tiles
+  int     uniform[3];  // axis with equal spacing: s = (X - x0) / h - 1/2; else the search through xcg
+  const double *xcg[3];  // GLOBAL cell centres of a stretched axis, index -1..ng (ghost centres: mirror image / periodic image)
+  const double *idx[3];  // LOCAL 1/dx (GridP::idx): the target cell's volume
 };
 
 // i0[d*L + l] = first support cell (GLOBAL index, may be out of range); w[(d*4 + a)*L + l] = phi weights
@@ -54,7 +61,19 @@ __global__ void k_ibm_weights(IbmP P, const double *__restrict__ X, const double
   const double pos[3] = {X[l], Y[l], Z[l]};
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
-    const double s = (pos[d] - P.x0[d]) / P.h[d] - 0.5;  // position in units of the cell-centre index
+    double s;  // position in units of the cell-centre index
+    if (P.uniform[d]) s = (pos[d] - P.x0[d]) / P.h[d] - 0.5;
+    else {
+      // the interval [centre(c), centre(c+1)) that holds the marker, c = -1 .. ng-1 (linear extension beyond the ghost centres)
+      const double *xc = P.xcg[d];
+      int           lo = -1, hi = P.ng[d] - 1;
+      while (lo < hi) {
+        const int mid = lo + (hi - lo + 1) / 2;
+        if (xc[mid] <= pos[d]) lo = mid;
+        else hi = mid - 1;
+      }
+      s = (double)lo + (pos[d] - xc[lo]) / (xc[lo + 1] - xc[lo]);
+    }
     const int    i = (P.kind == FL_DELTA_PESKIN4) ? (int)floor(s) - 1 : (int)floor(s + 0.5) - 1;
     for (int a = 0; a < 4; ++a) {
       const double r          = s - (double)(i + a);
@@ -182,7 +201,8 @@ __global__ void __launch_bounds__(256) k_ibm_spread(IbmP P, const int *__restric
   const int beg = off[tile], end = off[tile + 1];
   if (beg == end) return;
   const int tx = tile % P.nt[0], ty = (tile / P.nt[0]) % P.nt[1], tz = tile / (P.nt[0] * P.nt[1]);
-  const double ih = 1. / (P.h[0] * P.h[1] * P.h[2]);
+  const bool   uni = P.uniform[0] && P.uniform[1] && P.uniform[2];
+  const double ih  = uni ? 1. / (P.h[0] * P.h[1] * P.h[2]) : 1.;  // stretched grids: 1 / (volume of the target cell), applied per cell below
   // this thread's two cells: (ci, cj, ck) and (ci, cj, ck + 4)
   const int li = threadIdx.x & 7, lj = (threadIdx.x >> 3) & 7, lk = threadIdx.x >> 6;
   const int ci = tx * TB + li, cj = ty * TB + lj;
@@ -233,8 +253,9 @@ __global__ void __launch_bounds__(256) k_ibm_spread(IbmP P, const int *__restric
       const int ck = tz * TB + lk + 4 * half;
       if (ck >= P.n[2]) continue;
       const int64_t cell = ((int64_t)ck * P.n[1] + cj) * P.n[0] + ci;
+      const double  vinv = uni ? 1. : P.idx[0][ci] * P.idx[1][cj] * P.idx[2][ck];
       for (int c = 0; c < ncomp && c < 3; ++c)
-        if (acc[half][c] != 0.) f[(int64_t)c * ncell + cell] += acc[half][c];
+        if (acc[half][c] != 0.) f[(int64_t)c * ncell + cell] += acc[half][c] * vinv;
     }
 }
 
@@ -271,6 +292,7 @@ struct fl_ibm {
   double     *X = nullptr, *Y = nullptr, *Z = nullptr, *w = nullptr;
   int        *i0 = nullptr, *cnt = nullptr, *off = nullptr, *list = nullptr, *scratch = nullptr, *active = nullptr, *nact_dev = nullptr;
   int         ntiles = 0, listcap = 0, nactive = 0;
+  double     *xcg[3] = {nullptr, nullptr, nullptr};  // device copies of the extended global centre arrays (stretched axes only)
 };
 
 static int ibm_rebin(fl_ibm *m)
@@ -316,14 +338,27 @@ extern "C" int fl_ibm_create(fl_poisson *h, int kind, int64_t L, const double *X
     P.periodic[d] = A.periodic ? 1 : 0;
     P.x0[d]       = A.xf[0];
     P.h[d]        = (A.xf[A.n] - A.xf[0]) / (double)A.n;
-    // the delta function is only defined on uniformly spaced grids
+    P.uniform[d]  = 1;
     for (int64_t i = 0; i < A.n; ++i)
-      if (std::fabs((A.xf[i + 1] - A.xf[i]) - P.h[d]) > 1e-10 * P.h[d]) {
-        delete m;
-        return FL_ERR_SUP;
+      if (std::fabs((A.xf[i + 1] - A.xf[i]) - P.h[d]) > 1e-10 * P.h[d]) P.uniform[d] = 0;
+    P.xcg[d] = nullptr;
+    P.idx[d] = h->g.idx[d];
+    if (!P.uniform[d]) {
+      // extended centres, index -1..n: the periodic images (stored by build_axis) or the mirror images in the walls
+      std::vector<double> xc((size_t)A.n + 2);
+      for (int64_t i = -1; i <= A.n; ++i) xc[(size_t)(i + 1)] = A.xcc(i);
+      if (!A.periodic) {
+        xc[0]                  = 2. * A.xf[0] - A.xcc(0);
+        xc[(size_t)A.n + 1]    = 2. * A.xf[A.n] - A.xcc(A.n - 1);
       }
+      if (hipMalloc((void **)&m->xcg[d], sizeof(double) * xc.size()) != hipSuccess || hipMemcpy(m->xcg[d], xc.data(), sizeof(double) * xc.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        fl_ibm_destroy(m);
+        return FL_ERR_GPU;
+      }
+      P.xcg[d] = m->xcg[d] + 1;
+    }
     if (P.periodic[d] && P.ng[d] < 2 * P.S) {
-      delete m;
+      fl_ibm_destroy(m);
       return FL_ERR_ARG_OUTOFRANGE;
     }
     P.nt[d] = (P.n[d] + TB - 1) / TB;
@@ -392,7 +427,8 @@ extern "C" int fl_ibm_destroy(fl_ibm *m)
 {
   if (!m) return FL_SUCCESS;
   if (m->gp) (void)hipStreamSynchronize(m->gp->stream);
-  for (void *p : {(void *)m->X, (void *)m->Y, (void *)m->Z, (void *)m->w, (void *)m->i0, (void *)m->cnt, (void *)m->off, (void *)m->list, (void *)m->scratch, (void *)m->active, (void *)m->nact_dev})
+  for (void *p : {(void *)m->X, (void *)m->Y, (void *)m->Z, (void *)m->w, (void *)m->i0, (void *)m->cnt, (void *)m->off, (void *)m->list, (void *)m->scratch, (void *)m->active, (void *)m->nact_dev, (void *)m->xcg[0],
+                  (void *)m->xcg[1], (void *)m->xcg[2]})
     if (p) (void)hipFree(p);
   delete m;
   return FL_SUCCESS;

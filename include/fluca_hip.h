@@ -315,7 +315,9 @@ int fl_momentum_rowsum(fl_momentum *m, double *out_dev);
 
 /* ---- immersed boundary (build-defined; no reference function) -------------------------------- */
 typedef enum { FL_DELTA_PESKIN4 = 0, FL_DELTA_ROMA3 = 1 } fl_delta_kind;
-/* markers X,Y,Z (device, length L) are binned per cell at create / update */
+/* markers X,Y,Z (device, length L) are binned per cell at create / update.  Any tensor-product grid: on a stretched axis the delta
+ * function is evaluated in index space (marker position -> continuous cell-centre index, piecewise linear through the centres) and
+ * spreading divides by the volume of the target cell; on uniform axes that is the textbook delta_h. */
 int fl_ibm_create(fl_poisson *grid_from, int kind, int64_t L, const double *X_dev, const double *Y_dev, const double *Z_dev, fl_ibm **out);
 int fl_ibm_update(fl_ibm *m, const double *X_dev, const double *Y_dev, const double *Z_dev);
 /* U[c*L + l] = sum_x u[c*ncell + x] delta_h(x - X_l) h^3 */

@@ -910,11 +910,42 @@ static double phi_roma3(double r)
 
 /* support of marker coordinate X along axis d: first cell index i0 and weights w[0..S) (phi only, the
  * 1/h of delta_h cancels against the h of the quadrature); S = 4 or 3.  Uniform spacing required. */
+/* Uniform axis (spacing equal to 1e-10 relative): the spec of round 1.  Stretched axis (round 2): the delta function lives in INDEX
+ * space -- the marker position is mapped to the continuous cell-centre index s (piecewise linear through the cell centres; beyond the
+ * first / last centre through the mirror image of that centre in the wall, or the periodic image) and phi is evaluated at s - i.  On a
+ * uniform axis both definitions coincide. */
+static int ibm_axis_uniform(const fo_grid *g, int d)
+{
+  const double h = (g->xf[d][g->n[d]] - g->xf[d][0]) / g->n[d];
+  for (int i = 0; i < g->n[d]; ++i)
+    if (fabs((g->xf[d][i + 1] - g->xf[d][i]) - h) > 1e-10 * h) return 0;
+  return 1;
+}
+static double ibm_centre(const fo_grid *g, int d, int i) /* i = -1 .. n */
+{
+  const int n = g->n[d];
+  if (i >= 0 && i < n) return g->xc[d][i];
+  if (g->periodic[d]) return g->xc[d][i]; /* the periodic images are stored */
+  return i < 0 ? 2. * g->xf[d][0] - g->xc[d][0] : 2. * g->xf[d][n] - g->xc[d][n - 1];
+}
 static int ibm_weights_1d(const fo_grid *g, int d, int kind, double X, int *i0, double w[4])
 {
   int    S  = (kind == FO_DELTA_PESKIN4) ? 4 : 3;
-  double h  = (g->xf[d][g->n[d]] - g->xf[d][0]) / g->n[d];
-  double s  = (X - g->xf[d][0]) / h - 0.5; /* position in cell-centre index units */
+  double s;
+  if (ibm_axis_uniform(g, d)) {
+    double h = (g->xf[d][g->n[d]] - g->xf[d][0]) / g->n[d];
+    s        = (X - g->xf[d][0]) / h - 0.5; /* position in cell-centre index units */
+  } else {
+    /* the interval [centre(c), centre(c+1)) that holds X, c = -1 .. n-1 (clamped: linear extension beyond the ghost centres) */
+    int lo = -1, hi = g->n[d] - 1;
+    while (lo < hi) {
+      int mid = lo + (hi - lo + 1) / 2;
+      if (ibm_centre(g, d, mid) <= X) lo = mid;
+      else hi = mid - 1;
+    }
+    const double a = ibm_centre(g, d, lo), b = ibm_centre(g, d, lo + 1);
+    s              = (double)lo + (X - a) / (b - a);
+  }
   int    i  = (kind == FO_DELTA_PESKIN4) ? (int)floor(s) - 1 : (int)floor(s + 0.5) - 1;
   for (int a = 0; a < S; ++a) {
     double r = s - (double)(i + a);
@@ -959,6 +990,8 @@ void fo_ibm_spread(const fo_grid *g, int kind, int64_t L, const double *X, const
   double hy = (g->xf[1][g->n[1]] - g->xf[1][0]) / g->n[1];
   double hz = (g->xf[2][g->n[2]] - g->xf[2][0]) / g->n[2];
   double ih = 1. / (hx * hy * hz);
+  /* stretched grids: the force density of a cell is per ITS volume: 1 / (dx_i dy_j dz_k), formed as a product of reciprocals */
+  const int uni = ibm_axis_uniform(g, 0) && ibm_axis_uniform(g, 1) && ibm_axis_uniform(g, 2);
   for (int64_t l = 0; l < L; ++l) {
     int    i0[3], S;
     double w[3][4];
@@ -973,7 +1006,8 @@ void fo_ibm_spread(const fo_grid *g, int kind, int64_t L, const double *X, const
           if (g->periodic[1]) jj = ((jj % g->n[1]) + g->n[1]) % g->n[1];
           if (g->periodic[2]) kk = ((kk % g->n[2]) + g->n[2]) % g->n[2];
           if (ii < 0 || ii >= g->n[0] || jj < 0 || jj >= g->n[1] || kk < 0 || kk >= g->n[2]) continue;
-          double wt = w[0][a] * w[1][b] * w[2][c3] * ih * dV[l];
+          const double vinv = uni ? ih : (1. / (g->xf[0][ii + 1] - g->xf[0][ii])) * (1. / (g->xf[1][jj + 1] - g->xf[1][jj])) * (1. / (g->xf[2][kk + 1] - g->xf[2][kk]));
+          double       wt   = w[0][a] * w[1][b] * w[2][c3] * vinv * dV[l];
           for (int c = 0; c < ncomp; ++c) f[(int64_t)c * g->ncell + cell_index(g, ii, jj, kk)] += wt * F[(int64_t)c * L + l];
         }
   }

@@ -107,13 +107,46 @@ def test_moment_conditions_on_device(kind):
     P.close()
 
 
-def test_nonuniform_grid_is_rejected():
-    from tests.gpu_common import stretched
+@pytest.mark.parametrize("kind", [fo.DELTA_PESKIN4, fo.DELTA_ROMA3])
+@pytest.mark.parametrize("bc,n", [([V] * 6, (24, 20, 18)), ([PER, PER, V, V, PER, PER], (33, 17, 16)), ([V, V, V, V, PER, PER], (140, 12, 9))])
+def test_stretched_grids_match_oracle_and_invariants(kind, bc, n):
+    """Stretched axes (wall-refined channels, BASELINE configs 3-5): the delta function in index space, spreading per target-cell
+    volume.  Against the oracle, and the three invariants that hold on ANY grid: sum of the weights = 1 (a constant is interpolated
+    exactly), <interp(u), F dV> = sum_i u_i f_i V_i (adjointness with the cell volumes), sum_i f_i V_i = sum F dV (force conserved)."""
     from fluca_amd.poisson import Poisson
-    xf = [stretched(8, 0, 1), np.linspace(0, 1, 9), np.linspace(0, 1, 9)]
-    P = Poisson((8, 8, 8), xf, [V] * 6, 1.0)
-    from fluca_amd.capi import lib
-    h = C.c_void_p()
-    X = [dev(np.array([0.5]))] * 3
-    assert lib.fl_ibm_create(P.h, 0, 1, *[C.c_void_p(t.data_ptr()) for t in X], C.byref(h)) == -56   # PETSC_ERR_SUP
+    from tests.gpu_common import stretched
+    box = [(0.0, 1.0), (0.0, 2.0), (0.0, 1.5)]
+    xf = [stretched(n[d], box[d][0], box[d][1], 1.4 + 0.3 * d) for d in range(3)]
+    if bc[4] == PER:
+        xf[2] = np.linspace(box[2][0], box[2][1], n[2] + 1)              # one uniform axis next to two stretched ones
+    P, g = Poisson(n, xf, bc, 1e-3), fo.Grid(n, xf, bc, 1e-3)
+    rng = np.random.default_rng(4)
+    L = 400
+    X = sphere_markers(L, (0.5, 1.0, 0.75), 0.35)
+    X[0][:6] = [0.003, 0.997, 0.5, 0.02, 0.97, 0.5]                      # next to the walls (mirror-image ghost centres) / the seam
+    X[1][:6] = [1.0, 1.0, 0.004, 1.99, 0.03, 1.0]
+    X[2][:6] = [0.03, 0.7, 1.49, 0.7, 0.7, 0.001]
+    m = Ibm(P, kind, X)
+    u = rng.standard_normal((3, g.ncell))
+    U = host(m.interp(dev(u), 3)).reshape(3, L)
+    assert np.allclose(U, g.ibm_interp(kind, X, u), rtol=1e-12, atol=1e-13)
+    F = rng.standard_normal((3, L))
+    dV = rng.uniform(0.5, 1.5, L) * 1e-3
+    f0 = rng.standard_normal((3, g.ncell))
+    f = host(m.spread(dev(F), dev(dV), dev(f0), 3)).reshape(3, -1)
+    ref = g.ibm_spread(kind, X, dV, F, f0.copy())
+    assert np.allclose(f, ref, rtol=1e-12, atol=1e-12 * abs(ref).max())
+    # invariants, for the markers whose whole support lies inside the domain or wraps (drop the six wall-hugging ones)
+    inner = slice(6, None)
+    one = host(m.interp(dev(np.ones(g.ncell)), 1))
+    assert np.allclose(one[inner], 1.0, rtol=0, atol=1e-13)
+    vol = np.einsum("k,j,i->kji", np.diff(xf[2]), np.diff(xf[1]), np.diff(xf[0])).ravel()
+    Fi, dVi = F.copy(), dV.copy()
+    Fi[:, :6] = 0.0
+    fz = host(m.spread(dev(Fi), dev(dVi), torch.zeros(3 * g.ncell, dtype=torch.float64, device="cuda"), 3)).reshape(3, -1)
+    lhs = (U * Fi * dVi).sum()
+    rhs = (u * fz * vol).sum()
+    assert abs(lhs - rhs) <= 1e-12 * max(abs(lhs), abs(rhs), 1.0)
+    assert np.allclose((fz * vol).sum(axis=1), (Fi * dVi).sum(axis=1), rtol=1e-12, atol=1e-15)
+    m.close()
     P.close()
