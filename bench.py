@@ -228,6 +228,51 @@ def other_configs(stream):
                               "note": "latency-bound by construction (20 MB of traffic per step): reported, not a roofline target (SURVEY 8d)"}}
     capi.lib.fl_ibm_destroy(m)
     P.close()
+    del u, f, F, U, dV, X
+
+    # C5 needs 8 GPUs (1024 x 1024 x 512 over 2 x 2 x 2).  What ONE rank of it does, rehearsed on this GPU without the halo exchange:
+    # a 512 x 512 x 256 block with config 5's boundary types, the Jacobi-PCG iteration on it and the IBM kernels on the cylinder
+    # (diameter 64 h along the periodic span; markers are replicated on every rank, so the full set of the 256-plane block is used)
+    nb = (512, 512, 256)
+    hc = 1.0 / 1024
+    P = flp.Poisson.uniform(nb, [(0, 0.5), (0, 0.5), (0, 0.25)], [1, 2, 1, 1, 3, 3], 1e-3)
+    P.set_stream(stream)
+    b, x = rhs(P, 5), P.empty()
+    kw = dict(rtol=0.0, atol=0.0, check_every=64, remove_nullspace=0)
+    P.solve(b, x=x, maxit=10, **kw)
+    K = 40
+    (_, info), dt = timed(lambda: P.solve(b, x=x, maxit=K, profile=1, **kw))
+    Rc = 32 * hc
+    nth = int(round(2 * np.pi * Rc / hc))
+    th = (np.arange(nth) + 0.5) * 2 * np.pi / nth
+    zc = (np.arange(nb[2]) + 0.5) * hc
+    Xc = [torch.as_tensor(a, device="cuda") for a in (np.tile(0.25 + Rc * np.cos(th), nb[2]), np.tile(0.25 + Rc * np.sin(th), nb[2]), np.repeat(zc, nth))]
+    Lc = nb[2] * nth
+    uc = torch.rand(3 * P.ncell, dtype=torch.float64, device="cuda")
+    Fc = torch.rand(3 * Lc, dtype=torch.float64, device="cuda")
+    dVc = torch.full((Lc,), hc ** 3, dtype=torch.float64, device="cuda")
+    Uc = torch.empty(3 * Lc, dtype=torch.float64, device="cuda")
+    fc = torch.zeros(3 * P.ncell, dtype=torch.float64, device="cuda")
+    mc = C.c_void_p()
+    stream.wait_stream(torch.cuda.current_stream())
+    capi.check(capi.lib.fl_ibm_create(P.h, capi.DELTA_PESKIN4, Lc, ptr(Xc[0]), ptr(Xc[1]), ptr(Xc[2]), C.byref(mc)), "fl_ibm_create")
+
+    def cyl_step():
+        capi.check(capi.lib.fl_ibm_interp(mc, 3, ptr(uc), ptr(Uc)))
+        capi.check(capi.lib.fl_ibm_spread(mc, 3, ptr(Fc), ptr(dVc), ptr(fc)))
+        P.synchronize()
+    cyl_step()
+    _, dti = timed(lambda: [cyl_step() for _ in range(20)])
+    ach = B_KERNEL_A_ALGO * P.ncell / (info["kernel_ms"] * 1e-3) / 1e9
+    cfg["C5_rank_rehearsal"] = {
+        "workload": "ONE rank's share of config 5 on one GPU, no halo exchange: 512x512x256 block [VELOCITY, PRESSURE_OUTLET, wall, wall, PERIODIC, PERIODIC], "
+                    f"Jacobi-PCG fixed {K} iterations; immersed cylinder D = 64 h along the span, {Lc} markers",
+        "metric": "PCG iterations/s on the block", "value": K / dt, "steps": K, "ms_per_step": dt / K * 1e3,
+        "ibm_interp_plus_spread_ms": dti / 20 * 1e3, "markers": Lc,
+        "roofline": {"bound": "hbm", "kernel": "k_cg_A", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_cell": B_KERNEL_A_ALGO, "avg_launch_ms": info["kernel_ms"], "launches_timed": info["kernel_launches"]}}
+    capi.lib.fl_ibm_destroy(mc)
+    P.close()
     return cfg
 
 
