@@ -10,7 +10,7 @@ iteration count (rtol = atol = 0), inputs resident in HBM before the timed regio
 One JSON line on rank 0.  value = (cells of the whole job / 512^3) * K / seconds  ==  iterations/s of a 512^3 grid at N=1.
 At N = 1 the line also carries "configs": driver-timed lines for the other single-GPU configurations of BASELINE.json (C2 256^3
 cavity CG, C3 512^3 channel Chebyshev-Jacobi sweeps, C4 512^3 with the IBM kernels on an immersed sphere), each with its own
-roofline object, and "value_unplaced": the same K steps on plainly allocated vectors (see "placement" in include/fluca_hip.h).
+roofline object, "C5_rank_rehearsal" (one rank's share of config 5 without the halo exchange), and "value_unplaced": the same K steps on plainly allocated vectors (see "placement" in include/fluca_hip.h).
 For N > 1 the halo transport is RCCL; if RCCL cannot be initialised the run FAILS (a host-staged curve would be worthless) --
 the host-staged rehearsal has to be asked for with --transport host.
 """
@@ -30,7 +30,8 @@ import torch.distributed as dist
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); measured streaming peak ~6290 GB/s
 B_ITER_ALGO = 88               # algorithmic bytes / cell / PCG iteration
 B_KERNEL_A_ALGO = 64           # of those, the textbook steps k_cg_A fuses: direction 24 + SpMV/dot 16 + x-update 24
-B_KERNEL_A_REAL = 48           # what k_cg_A actually moves: reads r,p,x  writes p,q,x
+B_KERNEL_A_REAL = {0: 40, 2: 48, 1: None}   # what k_cg_A actually moves: reads r,p,x writes p',x (variant 0: q is never stored) / + q (variant 2)
+B_ITER_REAL = {0: 64, 2: 72, 1: 136}        # ... and the whole iteration: + k_cg_Bq reads p',r writes r (24) / k_cg_B reads q,r writes r (24)
 B_CHEB_ALGO = 40               # algorithmic bytes / cell / Chebyshev-Jacobi step: read x, b, d; write x', d'
 IBM_B_PER_MARKER = 1584        # L * (4^3 * 3 * 8 + 6 * 8) bytes per interp or spread of three components
 RANK_GRIDS = {1: (1, 1, 1), 2: (1, 1, 2), 4: (1, 2, 2), 8: (2, 2, 2)}
@@ -405,7 +406,8 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{n[0]}x{n[1]}x{n[2]} lid-driven-cavity Schur complement S=-kappa*D*Gst (7-pt, Neumann), "
                                f"matrix-free Jacobi-PCG with constant-null-space removal, b=S*p* seeded, fixed {args.steps} iterations",
-                   "cells_per_gpu": int(P.ncell), "rank_grid": list(ranks), "variant": "fused" if args.variant == 0 else "unfused",
+                   "cells_per_gpu": int(P.ncell), "rank_grid": list(ranks), "variant": {0: "fused, q = S p formed twice and never stored (k_cg_A + k_cg_Bq)", 1: "unfused (one kernel per step)",
+                                                                          2: "fused, q stored (k_cg_A + k_cg_B)"}.get(args.variant, str(args.variant)),
                    "halo": ("RCCL Send/Recv" if transport == "rccl" else "host-staged gloo (NOT the production transport)") if world > 1 else "none"},
         "iteration_algorithmic_GBps_per_gpu": B_ITER_ALGO * P.ncell * args.steps / dt / 1e9,
         "solve_seconds_device": info["seconds"],
@@ -415,9 +417,12 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "k_cg_A (p-update + S*p + dot + deferred x-update)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                     "algorithmic_bytes_per_cell": B_KERNEL_A_ALGO, "moved_bytes_per_cell": B_KERNEL_A_REAL,
+                     "algorithmic_bytes_per_cell": B_KERNEL_A_ALGO, "moved_bytes_per_cell": B_KERNEL_A_REAL.get(args.variant),
                      "avg_launch_ms": ka_ms, "launches_timed": info["kernel_launches"],
-                     "moved_GBps": (B_KERNEL_A_REAL * P.ncell / (ka_ms * 1e-3) / 1e9) if ka_ms > 0 else None},
+                     "moved_GBps": (B_KERNEL_A_REAL[args.variant] * P.ncell / (ka_ms * 1e-3) / 1e9) if ka_ms > 0 and B_KERNEL_A_REAL.get(args.variant) else None,
+                     "iteration": {"algorithmic_bytes_per_cell": B_ITER_ALGO, "moved_bytes_per_cell": B_ITER_REAL.get(args.variant),
+                                   "achieved": B_ITER_ALGO * P.ncell * args.steps / dt / 1e9, "frac": B_ITER_ALGO * P.ncell * args.steps / dt / 1e9 / HBM_PEAK_GBS,
+                                   "note": "all kernels of one iteration (k_cg_A + k_cg_Bq), driver-timed: ms_per_step"}},
     }
     if world == 1 and not args.skip_extras:
         # not part of the metric: what the iteration rate buys -- time to a converged pressure with the Jacobi preconditioner of

@@ -580,7 +580,7 @@ int fl_fill_ghosts(fl_poisson *h, double *v)
 // fdapply.c:71, cnlinearcart3d.c:893-894).  begin: the boundary layers of r - alpha q are packed on the handle's stream BEFORE
 // k_cg_B forms the new r; a second stream waits for the pack, runs the transfers and writes the ghost layers, which k_cg_B neither
 // reads nor writes.  end: the handle's stream waits for the ghosts (and fills the locally wrapped axes) before k_cg_A needs them.
-int fl_exchange_r_begin(fl_poisson *h, double *r, const double *q)
+int fl_exchange_r_begin(fl_poisson *h, double *r, const double *q)  // q == NULL: q is formed from the current direction (k_cg_Bq's way)
 {
   if (!h->multi) return 0;
   if (h->comm.kind == Comm::NONE) return FL_ERR_ARG_WRONGSTATE;
@@ -592,7 +592,10 @@ int fl_exchange_r_begin(fl_poisson *h, double *r, const double *q)
   std::vector<Msg> msgs;
   double          *sbuf[6], *rbuf[6];
   FL_CHK(halo_messages(h, msgs, sbuf, rbuf));
-  if (!msgs.empty()) launch_pack_faces_rq(h->stream, h->g, r, q, h->scal, sbuf);
+  if (!msgs.empty()) {
+    if (q) launch_pack_faces_rq(h->stream, h->g, r, q, h->scal, sbuf);
+    else launch_pack_faces_rp(h->stream, h->g, r, h->P0, h->P1, h->scal, sbuf);
+  }
   FL_HIP(hipEventRecord(h->ev_packed, h->stream));
   FL_HIP(hipStreamWaitEvent(h->comm_stream, h->ev_packed, 0));
   FL_CHK(h->comm.exchange(h->comm_stream, msgs));
@@ -788,9 +791,23 @@ static int solve_cg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts
   FL_CHK(fl_ensure_vec(h, &h->P1));
   FL_CHK(fl_ensure_vec(h, &h->q));
   FL_CHK(fl_ensure_vec(h, &h->xp));
-  const PlanA plan = plan_cg_A(g, 0, 0), planB = plan_cg_B(g);
+  // variant 0 (default): k_cg_A<SQ = false> + k_cg_Bq, q = S p' formed twice and never stored (64 B/cell/iteration);
+  // variant 2: k_cg_A stores q, k_cg_B reads it back (72 B/cell; the default until round 2); variant 1: one kernel per step
+  static const int variant_env = []() {
+    const char *e = std::getenv("FLUCA_CG_VARIANT");
+    return e ? std::atoi(e) : -1;
+  }();
+  const int variant = (o->variant == 0 && variant_env >= 0) ? variant_env : o->variant;
+  const bool storeq = variant != 0;  // variants 1 and 2 keep q in memory and update r with k_cg_B
+  PlanA       plan = plan_cg_A(g, 0, 0);
+  plan.sq          = storeq ? 1 : 0;
+  static const int bq_chunks_env = []() {
+    const char *e = std::getenv("FLUCA_CGBQ_CHUNKS");  // experiments: z chunks of k_cg_Bq (default: those of k_cg_A)
+    return e ? std::atoi(e) : 0;
+  }();
+  const PlanA planB = storeq ? plan_cg_B(g) : (bq_chunks_env > 0 ? plan_tiles(g, plan.ry, plan.nw, bq_chunks_env, 0) : plan);  // k_cg_Bq walks the tiles of k_cg_A
   const int   nsb  = stream_blocks(g);
-  const int   nab  = o->variant == 1 ? apply_dot_blocks(g) : plan.nblocks;
+  const int   nab  = variant == 1 ? apply_dot_blocks(g) : plan.nblocks;
   FL_CHK(fl_ensure_partials(h, std::max(std::max(nsb, nab), planB.nblocks)));
   const int nhist = o->maxit + 1;
   FL_CHK(fl_ensure_hist(h, nhist));
@@ -831,10 +848,10 @@ static int solve_cg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts
     const char *e = std::getenv("FLUCA_OVERLAP");  // 0: pack / transfer / unpack after k_cg_B, on the handle's stream (A/B measurements)
     return e ? std::atoi(e) != 0 : true;
   }();
-  const bool fusedfin = !h->multi && o->variant != 1 && fusedfin_env;
+  const bool fusedfin = !h->multi && variant != 1 && fusedfin_env;
   // several ranks: the last block of k_cg_A / k_cg_B still reduces the rank's partial sums (no k_reduce launch); the
   // all-reduce and the scalar kernel follow
-  const bool fusedsum = h->multi && o->variant != 1 && fusedfin_env;
+  const bool fusedsum = h->multi && variant != 1 && fusedfin_env;
   if (fusedfin || fusedsum) FL_HIP(hipMemsetAsync(h->tickets, 0, sizeof(unsigned) * 2, s));
   auto fin_sums = [&](int mode) -> int {
     FL_CHK(h->comm.allreduce(s, h->sums, NSLOT));
@@ -854,7 +871,7 @@ static int solve_cg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts
     const int stop = std::min(o->maxit, it + every);
     for (; it < stop; ++it) {
       const bool prof = o->profile && (size_t)(2 * it + 1) < pev.size();
-      if (o->variant == 1) {
+      if (variant == 1) {
         launch_cg_pupdate(s, g, jac, h->r, h->P0, h->P1, h->scal);
         if (ghosts) FL_CHK(fl_fill_ghosts(h, hostcur ? h->P0 : h->P1));
         if (prof) FL_HIP(hipEventRecord(pev[2 * it], s));
@@ -869,15 +886,16 @@ static int solve_cg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts
       else if (!fusedfin) FL_CHK(cg_fin(h, 1, nab, 1, h->hist, nhist));
       hostcur ^= 1;
       // several ranks: the boundary layers of the new r leave now (packed as r - alpha q), the transfers overlap k_cg_B
-      const bool overlap = ghosts && o->variant != 1 && h->multi && overlap_env;
-      if (overlap) FL_CHK(fl_exchange_r_begin(h, h->r, h->q));
-      launch_cg_B(s, g, jac, planB, h->q, h->r, h->scal, h->partial, h->partial_stride, (fusedfin || fusedsum) ? h->tickets + 1 : nullptr, h->hist, nhist, fusedsum ? h->sums : nullptr);
+      const bool overlap = ghosts && variant != 1 && h->multi && overlap_env;
+      if (overlap) FL_CHK(fl_exchange_r_begin(h, h->r, storeq ? h->q : nullptr));
+      if (storeq) launch_cg_B(s, g, jac, planB, h->q, h->r, h->scal, h->partial, h->partial_stride, (fusedfin || fusedsum) ? h->tickets + 1 : nullptr, h->hist, nhist, fusedsum ? h->sums : nullptr);
+      else launch_cg_Bq(s, g, jac, plan, h->P0, h->P1, h->r, h->scal, h->partial, h->partial_stride, (fusedfin || fusedsum) ? h->tickets + 1 : nullptr, h->hist, nhist, fusedsum ? h->sums : nullptr);
       // the handle's stream joins the exchange BEFORE the all-reduce is enqueued: the two RCCL operations never run at the same time
       // (one communicator, two streams), only the transfers and k_cg_B do
       if (overlap) FL_CHK(fl_exchange_r_end(h, h->r));
       if (fusedsum) FL_CHK(fin_sums(2));
       else if (!fusedfin) FL_CHK(cg_fin(h, 2, planB.nblocks, 5, h->hist, nhist));
-      if (!overlap && ghosts && o->variant != 1) FL_CHK(fl_fill_ghosts(h, h->r));
+      if (!overlap && ghosts && variant != 1) FL_CHK(fl_fill_ghosts(h, h->r));
     }
     FL_CHK(fl_poll_scal(h));
     if (h->scal_host->reason != 0 || it >= o->maxit) done = true;

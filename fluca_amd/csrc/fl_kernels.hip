@@ -12,6 +12,8 @@
 //           (2 buffers, one barrier per plane), z-neighbours in registers, global loads prefetched one plane ahead.
 //   k_cg_B  r -= alpha q with the five partial sums the PETSc-style convergence test needs: 24 B/cell.
 // Together 72 B/cell/iteration against the 88 B/cell of the textbook sequence.
+//   k_cg_Bq the same update with q = S p' formed again from the stored direction (k_cg_A<SQ = false> writes no q): the
+//           pair moves 40 + 24 = 64 B/cell/iteration (+ tile rings).  The solver's default since round 2.
 #include "fl_internal.h"
 
 namespace fl {
@@ -104,6 +106,13 @@ __global__ void k_wrap_ghosts(GridP g, double *__restrict__ v, int axis)
   }
 }
 
+// One row of S in a fixed rounding order (explicit fma chain): k_cg_A (for p.q), k_cg_Bq (for r - alpha q) and the boundary-layer
+// pack of the overlapped halo exchange all form q = S p' with it, so the three agree bit for bit.  dc = xc + (yc + zc).
+__device__ __forceinline__ double st7(double dc, double c, double xl, double w, double xh, double e, double yl, double s, double yh, double n, double zl, double b, double zh, double a)
+{
+  return fma(zh, a, fma(zl, b, fma(yh, n, fma(yl, s, fma(xh, e, fma(xl, w, dc * c))))));
+}
+
 // faces <-> contiguous buffers (multi-rank halo exchange).  side 0 = low, 1 = high.  pack reads owned boundary cells,
 // unpack writes the ghost layer.
 __global__ void k_pack_face(GridP g, const double *__restrict__ v, double *__restrict__ buf, int axis, int side)
@@ -164,6 +173,27 @@ __global__ void k_pack_faces_rq(GridP g, const double *__restrict__ r, const dou
   const int     n = axis == 0 ? g.nx : (axis == 1 ? g.ny : g.nz), c = side ? n - 1 : 0;
   const int64_t p = axis == 0 ? pidx(g, c, a, b) : (axis == 1 ? pidx(g, a, c, b) : pidx(g, a, b, c));
   buf[(int64_t)b * na + a] = s->reason != 0 ? r[p] : fma(-alpha, q[p], r[p]);
+}
+// the same when k_cg_A does not store q (k_cg_Bq): q = S p' of the boundary cell from the direction k_cg_A wrote, through st7 like k_cg_Bq
+__global__ void k_pack_faces_rp(GridP g, const double *__restrict__ r, const double *__restrict__ P0, const double *__restrict__ P1, const KspScal *__restrict__ s, FaceBufs fb)
+{
+  const int bnd = blockIdx.z, axis = bnd / 2, side = bnd % 2;
+  double   *buf = fb.buf[bnd];
+  if (!buf) return;
+  const int a = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y * 4 + threadIdx.y;
+  const int na = axis == 0 ? g.ny : g.nx, nb = axis == 2 ? g.ny : g.nz;
+  if (a >= na || b >= nb) return;
+  const int n = axis == 0 ? g.nx : (axis == 1 ? g.ny : g.nz), c = side ? n - 1 : 0;
+  const int i = axis == 0 ? c : a, j = axis == 0 ? a : (axis == 1 ? c : b), k = axis == 2 ? c : b;
+  const int64_t o = pidx(g, i, j, k);
+  double        v = r[o];
+  if (s->reason == 0) {
+    const double *p  = s->cur ? P1 : P0;
+    const double  q  = st7(g.sc[0][i] + (g.sc[1][j] + g.sc[2][k]), p[o], g.sl[0][i], p[o - 1], g.sh[0][i], p[o + 1], g.sl[1][j], p[o - g.sx], g.sh[1][j], p[o + g.sx], g.sl[2][k], p[o - g.sxy],
+                           g.sh[2][k], p[o + g.sxy]);
+    v = fma(-s->alpha, q, v);
+  }
+  buf[(int64_t)b * na + a] = v;
 }
 __global__ void k_unpack_faces(GridP g, double *__restrict__ v, FaceBufs fb)
 {
@@ -656,7 +686,7 @@ __device__ __forceinline__ int xcd_remap(int b, int nblocks) { return (nblocks &
 
 // RY rows per wave, NW waves per block (tile 128 x NW*RY), PF prefetch mode, NT: 0 plain, 1 non-temporal stores,
 // 2 non-temporal stores and tile loads (halo loads stay plain: they are meant to hit in L2)
-template <int RY, int NW, bool JAC, int PF, int NT>
+template <int RY, int NW, bool JAC, int PF, int NT, bool SQ>
 __device__ __forceinline__ void cg_A_body(const GridP &g, const double *__restrict__ r, double *__restrict__ P0, double *__restrict__ P1, double *__restrict__ q, double *__restrict__ x, KspScal *__restrict__ s,
                                                       double *__restrict__ partial, int nchunk, int zc, int tiles_x, int tiles, int remap, FinCtx fin)
 {
@@ -836,14 +866,14 @@ __device__ __forceinline__ void cg_A_body(const GridP &g, const double *__restri
         const double  west = lds[bc][lr][lc - 1], east = lds[bc][lr][lc + 2];
         const double  dyc = yc[m] + zcc;
         double2       qq;
-        qq.x = (xc0 + dyc) * cen.x + xl0 * west + xh0 * cen.y + yl[m] * south.x + yh[m] * north.x + zlc * below.x + zhc * pnext[m].x;
-        qq.y = (xc1 + dyc) * cen.y + xl1 * cen.x + xh1 * east + yl[m] * south.y + yh[m] * north.y + zlc * below.y + zhc * pnext[m].y;
+        qq.x = st7(xc0 + dyc, cen.x, xl0, west, xh0, cen.y, yl[m], south.x, yh[m], north.x, zlc, below.x, zhc, pnext[m].x);
+        qq.y = st7(xc1 + dyc, cen.y, xl1, cen.x, xh1, east, yl[m], south.y, yh[m], north.y, zlc, below.y, zhc, pnext[m].y);
         if (rown[m]) {
           if (own1) {
-            st2<NTS>(q + RO(m) + pc, qq);
+            if (SQ) st2<NTS>(q + RO(m) + pc, qq);
             dot += cen.x * qq.x + cen.y * qq.y;
           } else if (own0) {
-            q[RO(m) + pc] = qq.x;
+            if (SQ) q[RO(m) + pc] = qq.x;
             dot += cen.x * qq.x;
           }
         }
@@ -890,19 +920,176 @@ __device__ __forceinline__ void cg_A_body(const GridP &g, const double *__restri
 }
 
 #define FL_CG_A_ARGS GridP g, const double *__restrict__ r, double *__restrict__ P0, double *__restrict__ P1, double *__restrict__ q, double *__restrict__ x, KspScal *__restrict__ s, double *__restrict__ partial, int nchunk, int zc, int tiles_x, int tiles, int remap, FinCtx fin
-template <int RY, int NW, bool JAC, int PF, int NT>
+template <int RY, int NW, bool JAC, int PF, int NT, bool SQ>
 __global__ void __launch_bounds__(64 * NW, 2) k_cg_A(FL_CG_A_ARGS)
 {
-  cg_A_body<RY, NW, JAC, PF, NT>(g, r, P0, P1, q, x, s, partial, nchunk, zc, tiles_x, tiles, remap, fin);
+  cg_A_body<RY, NW, JAC, PF, NT, SQ>(g, r, P0, P1, q, x, s, partial, nchunk, zc, tiles_x, tiles, remap, fin);
 }
 // The same code under another name: launched only by fl_poisson_tune_placement, so that profiles keep the probe
 // launches (half of them on deliberately rejected placements) apart from the solver's own launches.
-template <int RY, int NW, bool JAC, int PF, int NT>
+template <int RY, int NW, bool JAC, int PF, int NT, bool SQ>
 __global__ void __launch_bounds__(64 * NW, 2) k_cg_A_probe(FL_CG_A_ARGS)
 {
-  cg_A_body<RY, NW, JAC, PF, NT>(g, r, P0, P1, q, x, s, partial, nchunk, zc, tiles_x, tiles, remap, fin);
+  cg_A_body<RY, NW, JAC, PF, NT, SQ>(g, r, P0, P1, q, x, s, partial, nchunk, zc, tiles_x, tiles, remap, fin);
 }
 #undef FL_CG_A_ARGS
+
+// r -= alpha q with q = S p' FORMED AGAIN from the direction k_cg_A has just written, instead of being read back: k_cg_A<SQ = false>
+// then never writes q.  Per cell this kernel reads p' (plus the tile's one-cell ring) and r and writes r -- 24 B + ring -- where the
+// q store of k_cg_A and the q load of k_cg_B moved 16 B: an iteration moves 64 B/cell instead of 72.  Same tile walk as k_cg_A
+// (128 x NW*RY tile marching through a z chunk, three p' planes in LDS, raw planes fetched one trip ahead into a second register
+// set, unconditional loads on clamped addresses, masked stores); q comes out of st7 exactly as in k_cg_A.  The ghost layer of p'
+// is complete: k_cg_A stores p' on every star-ghost cell it forms (rows / columns / planes -1 and n).  Sums as in k_cg_B.
+template <int RY, int NW, bool JAC, int NT>
+__global__ void __launch_bounds__(64 * NW, 2) k_cg_Bq(GridP g, const double *__restrict__ P0, const double *__restrict__ P1, double *__restrict__ r, KspScal *__restrict__ s, double *__restrict__ partial, int stride,
+                                                      int nchunk, int zc, int tiles_x, int tiles, int remap, FinCtx fin)
+{
+  using T               = TileA<RY, NW>;
+  constexpr int TX = T::TX, TY = T::TY, LX = T::LX, LY = T::LY;
+  constexpr int NTL = NT >= 2, NTS = NT >= 1;
+  __shared__ __attribute__((aligned(16))) double lds[3][LY][LX];
+  __shared__ double                              red[5 * NW];
+  __shared__ int                                 flag;
+  if (s->reason != 0) return;
+  const double *p     = s->cur ? P1 : P0;  // the scalar step after k_cg_A has flipped cur: this is the direction it wrote
+  const double  alpha = s->alpha;
+
+  const int b     = remap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int chunk = b / tiles, tile = b % tiles;
+  const int i0 = (tile % tiles_x) * TX, j0 = (tile / tiles_x) * TY;
+  const int k0 = chunk * zc, k1 = min(k0 + zc, g.nz);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w  = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i  = i0 + 2 * lane;
+  const int jb = j0 + w * RY;
+
+  const bool   own0 = i < g.nx, own1 = i + 1 < g.nx;
+  const int    il  = min(i, g.nx & ~1);
+  const int    ic0 = min(i, g.nx), ic1 = min(i + 1, g.nx);
+  const double xl0 = g.sl[0][ic0], xc0 = g.sc[0][ic0], xh0 = g.sh[0][ic0];
+  const double xl1 = g.sl[0][ic1], xc1 = g.sc[0][ic1], xh1 = g.sh[0][ic1];
+  int64_t rob[RY];
+  bool    rown[RY];
+  double  yl[RY], yc[RY], yh[RY];
+#pragma unroll
+  for (int m = 0; m < RY; ++m) {
+    const int j = jb + m, jc = min(j, g.ny);
+    rown[m]     = j < g.ny;
+    rob[m]      = g.off0 + (int64_t)jc * g.sx;
+    yl[m]       = g.sl[1][jc];
+    yc[m]       = g.sc[1][jc];
+    yh[m]       = g.sh[1][jc];
+  }
+#define RO(m) (rob[m] + il)
+  // ring cells of this thread: as in k_cg_A (A: rows -1 / TY, B: columns -1 / TX)
+  constexpr int HB0 = NW > 4 ? 256 : 0;
+  const int     tb  = tid - HB0;
+  const int     hAi = i0 + (tid & 127), hAj = j0 + (tid < 128 ? -1 : TY);
+  const bool    hAok = tid < 256 && hAi < g.nx && hAj <= g.ny;
+  const int     hBi = i0 + ((tb & 1) ? TX : -1), hBj = j0 + (tb >> 1);
+  const bool    hBok = tb >= 0 && tb < 2 * TY && hBj < g.ny && hBi <= g.nx;
+  const int64_t tbase = g.off0 + (int64_t)j0 * g.sx + i0;
+  const int     hAo   = hAok ? (hAj - j0) * g.sx + (hAi - i0) : 0;
+  const int     hBo   = hBok ? (hBj - j0) * g.sx + (hBi - i0) : 0;
+  const int     hAr = hAok ? (tid < 128 ? 0 : TY + 1) : 0, hAc = hAok ? (tid & 127) + 2 : 0;  // (0,0) is a dead corner slot
+  const int     hBr = hBok ? (tb >> 1) + 1 : 0, hBc = hBok ? ((tb & 1) ? TX + 2 : 1) : 0;
+
+  double acc[5] = {0., 0., 0., 0., 0.};
+  double zlc = 0., zcc = 0., zhc = 0.;  // z-row of plane kk-1 (the plane whose q is formed)
+  struct Raw {
+    double2 p[RY], r[RY];  // p' of plane kn, r of plane kn - 1
+    double  hpA, hpB;
+    double  zl, zc, zh;
+  };
+  auto load = [&](int kn_, Raw &R) {
+    const int     kn = min(kn_, k1);
+    const int64_t pl = (int64_t)kn * g.sxy, pr = (int64_t)min(max(kn_ - 1, k0), k1 - 1) * g.sxy;
+#pragma unroll
+    for (int m = 0; m < RY; ++m) {
+      R.p[m] = ld2<NTL>(p + RO(m) + pl);
+      R.r[m] = ld2<NTL>(r + RO(m) + pr);
+    }
+    R.hpA = p[tbase + pl + hAo];
+    R.hpB = p[tbase + pl + hBo];
+    R.zl  = g.sl[2][kn];
+    R.zc  = g.sc[2][kn];
+    R.zh  = g.sh[2][kn];
+  };
+  auto step = [&](int kk, Raw &C, Raw &N) {
+    load(kk + 1, N);
+    const double nzl = C.zl, nzc = C.zc, nzh = C.zh;
+    const int    buf = (kk + 3) % 3;
+    const int    kc  = kk - 1;
+    if (kc >= k0) {
+      const int     bc = (kc + 3) % 3, bp = (kc + 2) % 3;
+      const int64_t pc = (int64_t)kc * g.sxy;
+      const int     lc = 2 * lane + 2;
+#pragma unroll
+      for (int m = 0; m < RY; ++m) {
+        const int     lr = w * RY + m + 1;
+        const double2 cen   = *reinterpret_cast<const double2 *>(&lds[bc][lr][lc]);
+        const double2 south = *reinterpret_cast<const double2 *>(&lds[bc][lr - 1][lc]);
+        const double2 north = *reinterpret_cast<const double2 *>(&lds[bc][lr + 1][lc]);
+        const double2 below = *reinterpret_cast<const double2 *>(&lds[bp][lr][lc]);
+        const double  west = lds[bc][lr][lc - 1], east = lds[bc][lr][lc + 2];
+        const double  dyc = yc[m] + zcc;
+        const double  q0 = st7(xc0 + dyc, cen.x, xl0, west, xh0, cen.y, yl[m], south.x, yh[m], north.x, zlc, below.x, zhc, C.p[m].x);
+        const double  q1 = st7(xc1 + dyc, cen.y, xl1, cen.x, xh1, east, yl[m], south.y, yh[m], north.y, zlc, below.y, zhc, C.p[m].y);
+        double2       rn;
+        rn.x = fma(-alpha, q0, C.r[m].x);  // the same rounding as k_pack_faces_rp
+        rn.y = fma(-alpha, q1, C.r[m].y);
+        const double z0 = JAC ? rn.x / (xc0 + dyc) : rn.x;
+        const double z1 = JAC ? rn.y / (xc1 + dyc) : rn.y;
+        if (rown[m]) {
+          if (own1) st2<NTS>(r + RO(m) + pc, rn);
+          else if (own0) r[RO(m) + pc] = rn.x;
+        }
+        // selects, not 0/1 factors: outside the block q is inf * 0 (the ghost diagonal is +inf)
+        const bool   o0 = rown[m] && own0, o1 = rown[m] && own1;
+        const double r0 = o0 ? rn.x : 0., r1 = o1 ? rn.y : 0., zz0 = o0 ? z0 : 0., zz1 = o1 ? z1 : 0.;
+        acc[0] += r0 * zz0 + r1 * zz1;
+        acc[1] += zz0 * zz0 + zz1 * zz1;
+        acc[2] += zz0 + zz1;
+        acc[3] += r0 + r1;
+        acc[4] += r0 * r0 + r1 * r1;
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < RY; ++m) *reinterpret_cast<double2 *>(&lds[buf][w * RY + m + 1][2 * lane + 2]) = C.p[m];
+    lds[buf][hAr][hAc] = C.hpA;
+    lds[buf][hBr][hBc] = C.hpB;
+    __syncthreads();
+    zlc = nzl;
+    zcc = nzc;
+    zhc = nzh;
+  };
+  {
+    Raw A, B;
+    load(k0 - 1, A);
+    for (int kk = k0 - 1; kk <= k1; kk += 2) {
+      step(kk, A, B);
+      if (kk + 1 <= k1) step(kk + 1, B, A);
+    }
+  }
+#undef RO
+#pragma unroll
+  for (int a = 0; a < 5; ++a) {
+    acc[a] = wave_sum(acc[a]);
+    if (lane == 0) red[a * NW + w] = acc[a];
+  }
+  __syncthreads();
+  double tot[5] = {0., 0., 0., 0., 0.};
+  if (tid == 0) {
+#pragma unroll
+    for (int a = 0; a < 5; ++a)
+#pragma unroll
+      for (int q = 0; q < NW; ++q) tot[a] += red[a * NW + q];
+  }
+  if (fin.enabled) fused_fin<5, 64 * NW>(2, tot, partial, stride, fin, s, red, &flag);
+  else if (tid == 0)
+#pragma unroll
+    for (int a = 0; a < 5; ++a) partial[(int64_t)a * stride + blockIdx.x] = tot[a];
+}
 
 // ------------------------------------------------------------------------------------------------ unfused CG pieces (variant 1)
 
@@ -1063,6 +1250,13 @@ void launch_pack_faces_rq(hipStream_t st, const GridP &g, const double *r, const
   dim3      grid((na + 63) / 64, (nb + 3) / 4, 6);
   hipLaunchKernelGGL(k_pack_faces_rq, grid, dim3(64, 4), 0, st, g, r, q, s, fb);
 }
+void launch_pack_faces_rp(hipStream_t st, const GridP &g, const double *r, const double *P0, const double *P1, const KspScal *s, double *const bufs[6])
+{
+  FaceBufs fb;
+  for (int a = 0; a < 6; ++a) fb.buf[a] = bufs[a];
+  const int na = std::max(g.nx, g.ny), nb = std::max(g.ny, g.nz);
+  hipLaunchKernelGGL(k_pack_faces_rp, dim3((na + 63) / 64, (nb + 3) / 4, 6), dim3(64, 4, 1), 0, st, g, r, P0, P1, s, fb);
+}
 void launch_unpack_faces(hipStream_t st, const GridP &g, double *v, double *const bufs[6])
 {
   FaceBufs fb;
@@ -1132,6 +1326,7 @@ void launch_cg_finish(hipStream_t st, const GridP &g, const double *P0, const do
 // tiling of k_cg_A: returns the number of blocks
 struct PlanA {
   int ry, nw, tiles_x, tiles_y, nchunk, zc, nblocks, pf, nt, remap, probe;
+  int sq;  // 1: k_cg_A stores q (k_cg_B reads it back); 0: q is formed again by k_cg_Bq (the default of the solver)
 };
 // tiling of k_cg_A / k_cg_B (K_B always runs 4-wave blocks: it reuses ry, nchunk, zc with nw = 4)
 PlanA plan_tiles(const GridP &g, int ry, int nw, int nchunk_force, int target_blocks, int min_zc = 8)
@@ -1143,6 +1338,7 @@ PlanA plan_tiles(const GridP &g, int ry, int nw, int nchunk_force, int target_bl
   p.nt = 0;
   p.remap   = 1;
   p.probe   = 0;
+  p.sq      = 0;
   p.tiles_x = (g.nx + 127) / 128;
   p.tiles_y = (g.ny + nw * ry - 1) / (nw * ry);
   const int tiles = p.tiles_x * p.tiles_y;
@@ -1201,18 +1397,24 @@ PlanA plan_cg_B(const GridP &g)
   return p;
 }
 
-template <int RY, int NW, int PF, int NT>
-static void launch_cg_A_t(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const double *r, double *P0, double *P1, double *q, double *x, KspScal *s, double *partial, const FinCtx &fin)
+template <int RY, int NW, int PF, int NT, bool SQ>
+static void launch_cg_A_q(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const double *r, double *P0, double *P1, double *q, double *x, KspScal *s, double *partial, const FinCtx &fin)
 {
   const int  tiles = p.tiles_x * p.tiles_y;
   const dim3 gr(p.nblocks), bl(64 * NW);
   if (p.probe) {
-    if (jac) hipLaunchKernelGGL((k_cg_A_probe<RY, NW, true, PF, NT>), gr, bl, 0, st, g, r, P0, P1, q, x, s, partial, p.nchunk, p.zc, p.tiles_x, tiles, p.remap, fin);
-    else hipLaunchKernelGGL((k_cg_A_probe<RY, NW, false, PF, NT>), gr, bl, 0, st, g, r, P0, P1, q, x, s, partial, p.nchunk, p.zc, p.tiles_x, tiles, p.remap, fin);
+    if (jac) hipLaunchKernelGGL((k_cg_A_probe<RY, NW, true, PF, NT, SQ>), gr, bl, 0, st, g, r, P0, P1, q, x, s, partial, p.nchunk, p.zc, p.tiles_x, tiles, p.remap, fin);
+    else hipLaunchKernelGGL((k_cg_A_probe<RY, NW, false, PF, NT, SQ>), gr, bl, 0, st, g, r, P0, P1, q, x, s, partial, p.nchunk, p.zc, p.tiles_x, tiles, p.remap, fin);
   } else {
-    if (jac) hipLaunchKernelGGL((k_cg_A<RY, NW, true, PF, NT>), gr, bl, 0, st, g, r, P0, P1, q, x, s, partial, p.nchunk, p.zc, p.tiles_x, tiles, p.remap, fin);
-    else hipLaunchKernelGGL((k_cg_A<RY, NW, false, PF, NT>), gr, bl, 0, st, g, r, P0, P1, q, x, s, partial, p.nchunk, p.zc, p.tiles_x, tiles, p.remap, fin);
+    if (jac) hipLaunchKernelGGL((k_cg_A<RY, NW, true, PF, NT, SQ>), gr, bl, 0, st, g, r, P0, P1, q, x, s, partial, p.nchunk, p.zc, p.tiles_x, tiles, p.remap, fin);
+    else hipLaunchKernelGGL((k_cg_A<RY, NW, false, PF, NT, SQ>), gr, bl, 0, st, g, r, P0, P1, q, x, s, partial, p.nchunk, p.zc, p.tiles_x, tiles, p.remap, fin);
   }
+}
+template <int RY, int NW, int PF, int NT>
+static void launch_cg_A_t(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const double *r, double *P0, double *P1, double *q, double *x, KspScal *s, double *partial, const FinCtx &fin)
+{
+  if (p.sq) launch_cg_A_q<RY, NW, PF, NT, true>(st, g, jac, p, r, P0, P1, q, x, s, partial, fin);
+  else launch_cg_A_q<RY, NW, PF, NT, false>(st, g, jac, p, r, P0, P1, q, x, s, partial, fin);
 }
 template <int RY, int NW>
 static void launch_cg_A_v(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const double *r, double *P0, double *P1, double *q, double *x, KspScal *s, double *partial, const FinCtx &fin)
@@ -1272,6 +1474,30 @@ void launch_cg_B(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const
   case 4: launch_cg_B_ry<4>(st, g, jac, p, q, r, s, partial, stride, fin); break;
   case 2: launch_cg_B_ry<2>(st, g, jac, p, q, r, s, partial, stride, fin); break;
   default: launch_cg_B_ry<1>(st, g, jac, p, q, r, s, partial, stride, fin); break;
+  }
+}
+
+// k_cg_Bq on the tiling of k_cg_A (plan_cg_A)
+template <int RY, int NW>
+static void launch_cg_Bq_t(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const double *P0, const double *P1, double *r, KspScal *s, double *partial, int stride, const FinCtx &fin)
+{
+  const int  tiles = p.tiles_x * p.tiles_y;
+  const dim3 gr(p.nblocks), bl(64 * NW);
+  if (jac) hipLaunchKernelGGL((k_cg_Bq<RY, NW, true, 2>), gr, bl, 0, st, g, P0, P1, r, s, partial, stride, p.nchunk, p.zc, p.tiles_x, tiles, p.remap, fin);
+  else hipLaunchKernelGGL((k_cg_Bq<RY, NW, false, 2>), gr, bl, 0, st, g, P0, P1, r, s, partial, stride, p.nchunk, p.zc, p.tiles_x, tiles, p.remap, fin);
+}
+void launch_cg_Bq(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const double *P0, const double *P1, double *r, KspScal *s, double *partial, int stride, unsigned *counter, double *hist, int nhist, double *sums)
+{
+  FinCtx fin;
+  fin.sums    = sums;
+  fin.counter = counter;
+  fin.hist    = hist;
+  fin.nhist   = nhist;
+  fin.enabled = counter != nullptr;
+  switch (p.ry * 10 + p.nw) {
+  case 28: launch_cg_Bq_t<2, 8>(st, g, jac, p, P0, P1, r, s, partial, stride, fin); break;
+  case 24: launch_cg_Bq_t<2, 4>(st, g, jac, p, P0, P1, r, s, partial, stride, fin); break;
+  default: launch_cg_Bq_t<1, 4>(st, g, jac, p, P0, P1, r, s, partial, stride, fin); break;
   }
 }
 

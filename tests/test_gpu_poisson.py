@@ -98,7 +98,7 @@ def _check_solve(P, g, b, ksp=None, variant=0, rtol=1e-5, nullspace=True, norm=f
     return ig, io
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("n,bc", [((6, 5, 4), [V] * 6), ((17, 9, 11), CAVITY), ((16, 16, 8), [PER, PER, V, V, V, V]),
                                    ((12, 10, 9), [PER] * 6), ((130, 37, 20), CAVITY), ((136, 70, 12), [PER, PER, V, V, PER, PER])])
 def test_cg_neumann_matches_oracle(n, bc, variant):
@@ -189,9 +189,11 @@ def test_full_size_properties_256():
     res = rhs - P.apply(sol)
     assert float(res.norm()) <= 1e-4 * float(rhs.norm())
     # variant 0 (fused) and variant 1 (one kernel per step) are the same algorithm
-    sol1, info1 = P.solve(rhs, norm_type=fo.NORM_NATURAL, rtol=1e-6, maxit=3000, variant=1)
-    assert abs(info1["iters"] - info["iters"]) <= 2
-    assert float((sol1 - sol).norm()) <= 1e-4 * float(sol.norm())
+    # and variant 2 (k_cg_A stores q, k_cg_B reads it back) against variant 0 (q formed twice, never stored)
+    for variant in (1, 2):
+        sol1, info1 = P.solve(rhs, norm_type=fo.NORM_NATURAL, rtol=1e-6, maxit=3000, variant=variant)
+        assert abs(info1["iters"] - info["iters"]) <= 2
+        assert float((sol1 - sol).norm()) <= 1e-4 * float(sol.norm())
     P.close()
 
 
@@ -245,8 +247,9 @@ def test_full_size_properties_512():
     res = rhs - P.apply(sol)
     assert float(res.norm()) <= 1e-5 * float(rhs.norm())
     assert float(((sol - sol.mean()) - p).abs().max()) <= 1e-4 * float(p.abs().max())
-    sol1, info1 = P.solve(rhs, rtol=1e-8, maxit=4000, variant=1)
-    assert abs(info1["iters"] - info["iters"]) <= 2 and float((sol1 - sol).norm()) <= 1e-6 * float(sol.norm())
+    for variant in (1, 2):
+        sol1, info1 = P.solve(rhs, rtol=1e-8, maxit=4000, variant=variant)
+        assert abs(info1["iters"] - info["iters"]) <= 2 and float((sol1 - sol).norm()) <= 1e-6 * float(sol.norm())
     # 40 Chebyshev-Jacobi steps: residual strictly smaller than after 20
     r = []
     for its in (20, 40):
