@@ -1,0 +1,53 @@
+"""Turn the outputs of tools/experiments/r02_profile.sh (gpurun_out/r02_prof) into profiles/: per-kernel HBM traffic of the 512^3
+launches from the FETCH_SIZE / WRITE_SIZE passes (KB; FETCH doubled per MI355X_MICROARCH.md, calibrated on k_pad_copy: a 1 GiB read
+reports 524 300 KB) and rocprofv3's kernel durations of the trace pass.  usage: python tools/experiments/pmc_summary.py <dir> <tag>"""
+import collections
+import csv
+import json
+import os
+import statistics
+import sys
+
+R, tag = sys.argv[1], sys.argv[2]
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+N = 512 ** 3
+
+
+def pmc(path):
+    acc = collections.defaultdict(list)
+    for row in csv.DictReader(open(path)):
+        acc[row["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(row["Counter_Value"]))
+    return acc
+
+
+def top_cluster(vals):
+    """launches of the largest problem (the bench's 512^3 solve): values within 2 % of the maximum"""
+    m = max(vals)
+    return [v for v in vals if v >= 0.98 * m]
+
+
+f, w = pmc(os.path.join(R, "fetch", "k_counter_collection.csv")), pmc(os.path.join(R, "write", "k_counter_collection.csv"))
+dur = collections.defaultdict(list)
+for row in csv.DictReader(open(os.path.join(R, "trace", "k_kernel_trace.csv"))):
+    dur[row["Kernel_Name"].split("(")[0].replace("void ", "")].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6)
+calib = statistics.median(top_cluster(f["fl::k_pad_copy"])) * 2 * 1024 / (N * 8.0)
+out = {"calibration_k_pad_copy_fetch_over_1GiB": calib}
+for k in sorted(f):
+    if not any(t in k for t in ("k_cg_A<2, 8", "k_cg_Bq<2, 8", "k_cheb2<2, 8", "k_cg_B<4")):
+        continue
+    fv, wv = top_cluster(f[k]), top_cluster(w.get(k, [0.0]))
+    fb, wb = statistics.median(fv) * 2 * 1024, statistics.median(wv) * 1024
+    d = top_cluster(dur.get(k, [0.0]))
+    big = [x for x in dur.get(k, []) if x >= 0.8 * max(dur[k])]
+    out[k] = {"launches_counted": len(fv), "fetch_GB": round(fb / 1e9, 3), "write_GB": round(wb / 1e9, 3), "hbm_bytes_per_launch": fb + wb,
+              "B_per_cell": round((fb + wb) / N, 2), "rocprof_avg_ms_512cubed_launches": round(statistics.mean(big), 4) if big else None,
+              "rocprof_median_ms": round(statistics.median(big), 4) if big else None, "rocprof_launches": len(big)}
+json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json"), "w"), indent=1)
+for k, name in (("fl::k_cg_A<2, 8, true, 1, 2, false>", "pmc_k_cg_A.json"), ("fl::k_cheb2<2, 8, true, 2>", "pmc_k_cheb2.json"), ("fl::k_cg_Bq<2, 8, true, 2>", "pmc_k_cg_Bq.json")):
+    if k in out:
+        o = dict(out[k])
+        o.update({"kernel": k, "fetch_bytes_corrected": o["fetch_GB"] * 1e9, "write_bytes": o["write_GB"] * 1e9,
+                  "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `python3 bench.py --steps 8 --warmup 2 --skip-cpu --skip-extras` "
+                            f"(tools/experiments/r02_profile.sh, summarised by tools/experiments/pmc_summary.py, {tag}); FETCH_SIZE in KB doubled per MI355X_MICROARCH.md"})
+        json.dump(o, open(os.path.join(ROOT, "profiles", name), "w"), indent=1)
+print(json.dumps(out, indent=1))
