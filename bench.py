@@ -29,9 +29,34 @@ import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); measured streaming peak ~6290 GB/s
 B_ITER_ALGO = 88               # algorithmic bytes / cell / PCG iteration
-B_KERNEL_A_ALGO = 64           # of those, the textbook steps k_cg_A fuses: direction 24 + SpMV/dot 16 + x-update 24
-B_KERNEL_A_REAL = {0: 40, 2: 48, 1: None}   # what k_cg_A actually moves: reads r,p,x writes p',x (variant 0: q is never stored) / + q (variant 2)
-B_ITER_REAL = {0: 64, 2: 72, 1: 136}        # ... and the whole iteration: + k_cg_Bq reads p',r writes r (24) / k_cg_B reads q,r writes r (24)
+# The textbook steps each kernel of an iteration replaces (direction 24 + SpMV/dot 16 + update 48 = 88 B/cell) and what it moves:
+#   variant 0 (default)  k_cg_A: direction + SpMV/dot = 40 algorithmic; reads r,p writes p' = 24 moved (q is formed, never stored)
+#                        k_cg_Bq: update = 48 algorithmic; reads p',r writes r = 24 on even iterations, + p_old, x read and x written = 48 on
+#                        odd ones (both x-updates of the pair) = 36 moved on average
+#   variant 2            k_cg_A: direction + SpMV/dot + x-half of the update = 64; reads r,p,x writes p',q,x = 48.  k_cg_B: r-half = 24; 24
+CG_KERNELS = {0: (("k_cg_A (p-update + S*p + dot; q never stored)", 40, 24), ("k_cg_Bq (q = S*p again, r-update + sums; both x-updates on odd iterations)", 48, 36)),
+              2: (("k_cg_A (p-update + S*p + dot + deferred x-update, q stored)", 64, 48), ("k_cg_B (r-update + sums)", 24, 24)),
+              1: (("k_cg_apply_dot (unfused)", 16, 16), ("k_cg_B", 24, 24))}
+B_ITER_REAL = {0: 60, 2: 72, 1: 136}
+
+
+def cg_roofline(info, ncell, variant, ms_per_iter, traffic=None):
+    """roofline object of a CG run: the kernel with the larger share of the iteration is the headline entry ("dominant kernel"), the other
+    one and the whole iteration (every kernel, driver-timed) are listed beside it.  Durations: HIP events around each launch inside the
+    timed region (fl_ksp_opts.profile)."""
+    ks = []
+    for (name, algo, moved), ms, n in zip(CG_KERNELS[variant], (info["kernel_ms"], info["kernel2_ms"]), (info["kernel_launches"], info["kernel2_launches"])):
+        ach = algo * ncell / (ms * 1e-3) / 1e9 if ms > 0 else None
+        ks.append({"kernel": name, "algorithmic_bytes_per_cell": algo, "moved_bytes_per_cell": moved, "avg_launch_ms": ms, "launches_timed": n, "achieved": ach,
+                   "frac": ach / HBM_PEAK_GBS if ach else None, "moved_GBps": moved * ncell / (ms * 1e-3) / 1e9 if ms > 0 else None})
+    dom = max(ks, key=lambda k: k["avg_launch_ms"] or 0.0)
+    it_ach = B_ITER_ALGO * ncell / (ms_per_iter * 1e-3) / 1e9
+    tr = traffic.get(dom["kernel"].split(" ")[0]) if isinstance(traffic, dict) else traffic
+    return {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": tr,
+            "algorithmic_bytes_per_cell": dom["algorithmic_bytes_per_cell"], "moved_bytes_per_cell": dom["moved_bytes_per_cell"],
+            "avg_launch_ms": dom["avg_launch_ms"], "launches_timed": dom["launches_timed"], "moved_GBps": dom["moved_GBps"], "kernels": ks,
+            "iteration": {"algorithmic_bytes_per_cell": B_ITER_ALGO, "moved_bytes_per_cell": B_ITER_REAL.get(variant), "ms": ms_per_iter, "achieved": it_ach,
+                          "frac": it_ach / HBM_PEAK_GBS, "note": "all kernels of one iteration, driver-timed (ms_per_step)"}}
 B_CHEB_ALGO = 40               # algorithmic bytes / cell / Chebyshev-Jacobi step: read x, b, d; write x', d'
 IBM_B_PER_MARKER = 1584        # SURVEY 8d: L * (4^3 * 3 * 8 + 6 * 8) bytes per interp or spread of three components
 RANK_GRIDS = {1: (1, 1, 1), 2: (1, 1, 2), 4: (1, 2, 2), 8: (2, 2, 2)}
@@ -158,12 +183,10 @@ def other_configs(stream):
     kw = dict(rtol=0.0, atol=0.0, check_every=64)
     P.solve(b, x=x, maxit=50, **kw)
     K = 400
-    (_, info), dt = timed(lambda: P.solve(b, x=x, maxit=K, profile=1, **kw))
-    ach = B_KERNEL_A_ALGO * P.ncell / (info["kernel_ms"] * 1e-3) / 1e9
+    (_, info), dt = timed(lambda: P.solve(b, x=x, maxit=K, profile=4, **kw))
     cfg["C2"] = {"workload": "256^3 lid-driven cavity, matrix-free Jacobi-PCG, fixed 400 iterations", "metric": "PCG iterations/s", "value": K / dt, "steps": K,
                  "ms_per_step": dt / K * 1e3, "iteration_algorithmic_GBps": B_ITER_ALGO * P.ncell * K / dt / 1e9,
-                 "roofline": {"bound": "hbm", "kernel": "k_cg_A", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                              "algorithmic_bytes_per_cell": B_KERNEL_A_ALGO, "avg_launch_ms": info["kernel_ms"], "launches_timed": info["kernel_launches"]}}
+                 "roofline": cg_roofline(info, P.ncell, 0, dt / K * 1e3)}
     P.close()
     del b, x
 
@@ -264,14 +287,12 @@ def other_configs(stream):
         P.synchronize()
     cyl_step()
     _, dti = timed(lambda: [cyl_step() for _ in range(20)])
-    ach = B_KERNEL_A_ALGO * P.ncell / (info["kernel_ms"] * 1e-3) / 1e9
     cfg["C5_rank_rehearsal"] = {
         "workload": "ONE rank's share of config 5 on one GPU, no halo exchange: 512x512x256 block [VELOCITY, PRESSURE_OUTLET, wall, wall, PERIODIC, PERIODIC], "
                     f"Jacobi-PCG fixed {K} iterations; immersed cylinder D = 64 h along the span, {Lc} markers",
         "metric": "PCG iterations/s on the block", "value": K / dt, "steps": K, "ms_per_step": dt / K * 1e3,
         "ibm_interp_plus_spread_ms": dti / 20 * 1e3, "markers": Lc,
-        "roofline": {"bound": "hbm", "kernel": "k_cg_A", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                     "algorithmic_bytes_per_cell": B_KERNEL_A_ALGO, "avg_launch_ms": info["kernel_ms"], "launches_timed": info["kernel_launches"]}}
+        "roofline": cg_roofline(info, P.ncell, 0, dt / K * 1e3)}
     capi.lib.fl_ibm_destroy(mc)
     P.close()
     return cfg
@@ -361,7 +382,8 @@ def main():
     P.synchronize()
 
     def run(iters, profile):
-        return P.solve(b, x=x, rtol=0.0, atol=0.0, maxit=iters, variant=args.variant, profile=int(profile), check_every=64)[1]
+        # profile = 2: the kernels of every second PAIR of iterations are bracketed by HIP events (every pair costs 1.3 % of the rate)
+        return P.solve(b, x=x, rtol=0.0, atol=0.0, maxit=iters, variant=args.variant, profile=2 if profile else 0, check_every=64)[1]
 
     def barrier():
         if world > 1:
@@ -385,20 +407,21 @@ def main():
     per_rank = None
     if world > 1:
         per_rank = [None] * world
-        dist.all_gather_object(per_rank, {"rank": rank, "device": local, "k_cg_A_ms": info["kernel_ms"], "seconds_device": info["seconds"],
+        dist.all_gather_object(per_rank, {"rank": rank, "device": local, "k_cg_A_ms": info["kernel_ms"], "k_cg_Bq_ms": info["kernel2_ms"], "seconds_device": info["seconds"],
                                           "placement_probe_ms": list(probe)})
 
     cells_job = float(P.ncell) * world
     value = cells_job / 512.0 ** 3 * args.steps / dt
-    ka_ms = info["kernel_ms"]
-    achieved = B_KERNEL_A_ALGO * P.ncell / (ka_ms * 1e-3) / 1e9 if ka_ms > 0 else None
+    # HBM traffic per 512^3 launch from rocprofv3 --pmc passes over this command (profiles/README.md): counters cannot be read from
+    # inside the run, so the last committed pass is quoted (null when the workload is not the one that was profiled)
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "pmc_k_cg_A.json")     # written from a rocprofv3 --pmc pass (see profiles/README.md)
-    if os.path.exists(pmc) and args.cells == 512:
-        try:
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    if args.cells == 512 and args.variant == 0:
+        traffic = {}
+        for kname in ("k_cg_A", "k_cg_Bq"):
+            try:
+                traffic[kname] = json.load(open(os.path.join(ROOT, "profiles", f"pmc_{kname}.json"))).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic[kname] = None
     out = {
         "metric": "pressure-Poisson Jacobi-PCG iterations/s, 512^3 cells per GPU",
         "value": value, "unit": "512^3-equivalent PCG iterations/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
@@ -413,16 +436,8 @@ def main():
         "solve_seconds_device": info["seconds"],
         "ranks": per_rank, "transport_ranks": world if world > 1 else None,
         "placement": {"mode": args.placement, "probe_ms_all_vectors_in_one_block": probe[0], "probe_ms_chosen": probe[1],
-                      "note": "k_cg_A probe; deterministic arena search, see include/fluca_hip.h fl_poisson_tune_placement"},
-        "roofline": {"bound": "hbm", "kernel": "k_cg_A (p-update + S*p + dot + deferred x-update)",
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                     "algorithmic_bytes_per_cell": B_KERNEL_A_ALGO, "moved_bytes_per_cell": B_KERNEL_A_REAL.get(args.variant),
-                     "avg_launch_ms": ka_ms, "launches_timed": info["kernel_launches"],
-                     "moved_GBps": (B_KERNEL_A_REAL[args.variant] * P.ncell / (ka_ms * 1e-3) / 1e9) if ka_ms > 0 and B_KERNEL_A_REAL.get(args.variant) else None,
-                     "iteration": {"algorithmic_bytes_per_cell": B_ITER_ALGO, "moved_bytes_per_cell": B_ITER_REAL.get(args.variant),
-                                   "achieved": B_ITER_ALGO * P.ncell * args.steps / dt / 1e9, "frac": B_ITER_ALGO * P.ncell * args.steps / dt / 1e9 / HBM_PEAK_GBS,
-                                   "note": "all kernels of one iteration (k_cg_A + k_cg_Bq), driver-timed: ms_per_step"}},
+                      "note": "probe = one k_cg_A + one odd-iteration k_cg_Bq; deterministic arena search, see include/fluca_hip.h fl_poisson_tune_placement"},
+        "roofline": cg_roofline(info, P.ncell, args.variant, dt / args.steps * 1e3, traffic),
     }
     if world == 1 and not args.skip_extras:
         # not part of the metric: what the iteration rate buys -- time to a converged pressure with the Jacobi preconditioner of
@@ -453,6 +468,7 @@ def main():
             du = time.perf_counter() - t0
             out["value_unplaced"] = cells_job / 512.0 ** 3 * args.steps / du
             out["unplaced_k_cg_A_ms"] = iu["kernel_ms"]
+            out["unplaced_k_cg_Bq_ms"] = iu["kernel2_ms"]
             Pu.close()
             del xu
         except Exception as e:  # noqa: BLE001

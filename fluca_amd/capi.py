@@ -59,7 +59,8 @@ class fl_ksp_opts(C.Structure):
 
 class fl_ksp_stats(C.Structure):
     _fields_ = [("iters", C.c_int), ("reason", C.c_int), ("rnorm0", C.c_double), ("rnorm", C.c_double),
-                ("seconds", C.c_double), ("kernel_ms", C.c_double), ("kernel_launches", C.c_int)]
+                ("seconds", C.c_double), ("kernel_ms", C.c_double), ("kernel_launches", C.c_int),
+                ("kernel2_ms", C.c_double), ("kernel2_launches", C.c_int)]
 
 
 class fl_dmstag_local(C.Structure):

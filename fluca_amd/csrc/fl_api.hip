@@ -306,26 +306,17 @@ int place_vectors(fl_poisson *h)
   const size_t vecb = ((sizeof(double) * h->padlen + ((size_t)2 << 20) - 1) / ((size_t)2 << 20)) * ((size_t)2 << 20);
   const int    nslot = PL_WIN + 2 * PL_SIDE;
   if (vecb < PL_MIN_VEC) return 0;  // small vectors: the kernels are not bandwidth-bound enough to notice; plain allocations
-  size_t       freeb = 0, total = 0;
-  if (hipMemGetInfo(&freeb, &total) != hipSuccess) return 0;
-  size_t want = ((PL_SEAM + (size_t)(PL_WIN + PL_SIDE) * vecb + ((size_t)1 << 30) - 1) >> 30) << 30;
-  const size_t reserve = (size_t)16 << 30;
-  if (freeb < want + reserve) want = freeb > reserve + (size_t)nslot * vecb ? ((freeb - reserve) >> 30) << 30 : 0;
-  if (want < (size_t)nslot * vecb) return 0;  // not enough memory for an arena: plain allocations
-  void *arena = nullptr;
-  if (hipMalloc(&arena, want) != hipSuccess) {
-    (void)hipGetLastError();
-    return 0;
-  }
-  FL_HIP(hipMemsetAsync(arena, 0, want, s));
   PlanA plan = plan_cg_A(h->g, 0, 0);
-  plan.probe = 1;  // launches k_cg_A_probe: identical code, separate name in profiles
+  plan.probe = 1;  // launches k_cg_A_probe / k_cg_Bq_probe: identical code, separate names in profiles
   FL_CHK(fl_ensure_partials(h, plan.nblocks));
-  struct Scal2 {  // two scalar blocks: direction buffer parity 0 and 1; released on every return path
-    KspScal *p = nullptr;
-    ~Scal2()
+  struct Held {  // two scalar blocks (direction buffer parity 0 and 1) and the arenas: whatever is not handed to the handle is released
+    KspScal            *p = nullptr;
+    std::vector<void *> arenas;
+    ~Held()
     {
       if (p) (void)hipFree(p);
+      for (void *a : arenas)
+        if (a) (void)hipFree(a);
     }
   } sc;
   FL_HIP(hipMalloc((void **)&sc.p, 2 * sizeof(KspScal)));
@@ -333,15 +324,23 @@ int place_vectors(fl_poisson *h)
     KspScal S2[2];
     std::memset(S2, 0, sizeof(S2));
     for (int a = 0; a < 2; ++a) {
-      S2[a].beta = 0.5; S2[a].alpha = 1e-3; S2[a].zshift = 1e-4; S2[a].ncell_global = (double)h->ncell; S2[a].maxit = 1 << 30; S2[a].cur = a;
+      S2[a].beta = 0.5; S2[a].alpha = 1e-3; S2[a].alpha_old = 1e-3; S2[a].zshift = 1e-4; S2[a].ncell_global = (double)h->ncell; S2[a].maxit = 1 << 30; S2[a].cur = a;
     }
     FL_HIP(hipMemcpy(sc.p, S2, sizeof(S2), hipMemcpyHostToDevice));
   }
-  auto vec = [&](size_t b, int k) { return (double *)((char *)arena + b + (size_t)k * vecb); };
-  auto probe = [&](size_t b, double *ms_out) -> int {
+  static const int verbose = []() {
+    const char *e = std::getenv("FLUCA_PLACEMENT_VERBOSE");
+    return e ? std::atoi(e) : 0;
+  }();
+  // probe = the pair the solver runs: k_cg_A (r, p -> p') and the odd-iteration k_cg_Bq (p', p_old, r, x -> r, x: every window vector but q)
+  auto probe = [&](void *arena, size_t b, double *ms_out) -> int {
+    auto vec = [&](int k) { return (double *)((char *)arena + b + (size_t)k * vecb); };
     auto run = [&](int reps) {
       for (int r = 0; r < reps; ++r)
-        for (int par = 0; par < 2; ++par) launch_cg_A(s, h->g, true, plan, vec(b, 0), vec(b, 1), vec(b, 2), vec(b, 3), vec(b, 4), sc.p + par, h->partial, nullptr, nullptr, 0);
+        for (int par = 0; par < 2; ++par) {
+          launch_cg_A(s, h->g, true, plan, vec(0), vec(1), vec(2), vec(3), vec(4), sc.p + par, h->partial, nullptr, nullptr, 0);
+          launch_cg_Bq(s, h->g, true, plan, 2, vec(1), vec(2), vec(0), vec(4), sc.p + par, h->partial, h->partial_stride, nullptr, nullptr, 0);
+        }
     };
     run(1);
     FL_HIP(hipEventRecord(h->ev0, s));
@@ -353,20 +352,61 @@ int place_vectors(fl_poisson *h)
     *ms_out = ms / 4.;
     return 0;
   };
-  const size_t lo = (size_t)PL_SIDE * vecb, hi = want - (size_t)(PL_WIN + PL_SIDE) * vecb;
-  const size_t step = std::max(vecb / 2, (((hi - lo) / 48) >> 21) << 21);  // half a vector, at most ~50 probes
-  size_t       best = lo;
-  double       first_ms = 0., best_ms = 0.;
-  int          nprobe = 0;
-  for (size_t b = lo; b <= hi; b += step, ++nprobe) {
-    double ms = 0.;
-    FL_CHK(probe(b, &ms));
-    if (nprobe == 0) first_ms = best_ms = ms;
-    if (ms < best_ms) {
-      best_ms = ms;
-      best    = b;
+  // Where the seams of an allocation lie depends on what the device's memory manager handed out before (on most fresh boxes one is
+  // found 16 GiB in; on some the whole arena answers flat).  A flat arena is kept allocated -- so that the next one comes from other
+  // physical memory -- and the search repeated, at most PL_ARENAS times; the losers are freed at the end.
+  constexpr int PL_ARENAS = 3;
+  void  *arena = nullptr;
+  size_t want = 0, best = 0;
+  double first_ms = 0., best_ms = 0.;
+  for (int attempt = 0; attempt < PL_ARENAS; ++attempt) {
+    size_t freeb = 0, total = 0;
+    if (hipMemGetInfo(&freeb, &total) != hipSuccess) break;
+    size_t w = ((PL_SEAM + (size_t)(PL_WIN + PL_SIDE) * vecb + ((size_t)1 << 30) - 1) >> 30) << 30;
+    const size_t reserve = (size_t)16 << 30;
+    if (freeb < w + reserve) {
+      if (attempt > 0) break;  // further arenas only while memory is plentiful
+      w = freeb > reserve + (size_t)nslot * vecb ? ((freeb - reserve) >> 30) << 30 : 0;
     }
+    if (w < (size_t)nslot * vecb) break;  // not enough memory for an arena
+    void *a = nullptr;
+    if (hipMalloc(&a, w) != hipSuccess) {
+      (void)hipGetLastError();
+      break;
+    }
+    sc.arenas.push_back(a);
+    FL_HIP(hipMemsetAsync(a, 0, w, s));
+    const size_t lo = (size_t)PL_SIDE * vecb, hi = w - (size_t)(PL_WIN + PL_SIDE) * vecb;
+    const size_t step = std::max(vecb / 2, (((hi - lo) / 48) >> 21) << 21);  // half a vector, at most ~50 probes
+    size_t       abest = lo;
+    double       afirst = 0., abest_ms = 0.;
+    int          nprobe = 0;
+    for (size_t b = lo; b <= hi; b += step, ++nprobe) {
+      double ms = 0.;
+      FL_CHK(probe(a, b, &ms));
+      if (verbose) std::fprintf(stderr, "[fluca placement] arena %d, window at %.2f GiB: %.4f ms\n", attempt, (double)b / (double)((size_t)1 << 30), ms);
+      if (nprobe == 0) afirst = abest_ms = ms;
+      if (ms < abest_ms) {
+        abest_ms = ms;
+        abest    = b;
+      }
+    }
+    if (attempt == 0) first_ms = afirst;
+    if (!arena || abest_ms < best_ms) {
+      arena   = a;
+      want    = w;
+      best    = abest;
+      best_ms = abest_ms;
+    }
+    static const double thresh = []() {
+      const char *e = std::getenv("FLUCA_PLACEMENT_THRESH");  // experiments: 0 walks through all PL_ARENAS arenas
+      return e ? std::atof(e) : 0.97;
+    }();
+    if (best_ms <= thresh * first_ms) break;  // a seam was found
   }
+  if (!arena) return 0;  // no memory for an arena: plain allocations
+  for (void *&a : sc.arenas)
+    if (a == arena) a = nullptr;  // this one goes to the handle
   // the probes wrote into the arena: ghost layers of fresh solver vectors are zero by contract
   FL_HIP(hipMemsetAsync(arena, 0, want, s));
   FL_HIP(hipStreamSynchronize(s));
@@ -374,7 +414,7 @@ int place_vectors(fl_poisson *h)
   h->arena_bytes = want;
   h->vec_bases.push_back(arena);
   double **win[PL_WIN] = {&h->r, &h->P0, &h->P1, &h->q, &h->xp};
-  for (int k = 0; k < PL_WIN; ++k) *win[k] = vec(best, k);
+  for (int k = 0; k < PL_WIN; ++k) *win[k] = (double *)((char *)arena + best + (size_t)k * vecb);
   h->pool_next[0] = (char *)arena + best - (size_t)PL_SIDE * vecb;
   h->pool_end[0]  = (char *)arena + best;
   h->pool_next[1] = (char *)arena + best + (size_t)PL_WIN * vecb;
@@ -848,6 +888,10 @@ static int solve_cg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts
     const char *e = std::getenv("FLUCA_OVERLAP");  // 0: pack / transfer / unpack after k_cg_B, on the handle's stream (A/B measurements)
     return e ? std::atoi(e) != 0 : true;
   }();
+  static const bool xbatch_env = []() {
+    const char *e = std::getenv("FLUCA_CG_XBATCH");
+    return e ? std::atoi(e) != 0 : true;
+  }();
   const bool fusedfin = !h->multi && variant != 1 && fusedfin_env;
   // several ranks: the last block of k_cg_A / k_cg_B still reduces the rank's partial sums (no k_reduce launch); the
   // all-reduce and the scalar kernel follow
@@ -861,40 +905,51 @@ static int solve_cg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts
 
   ProfEvents               prof_events;
   std::vector<hipEvent_t> &pev = prof_events.ev;
-  if (o->profile) FL_CHK(prof_events.create(2 * (size_t)std::min(o->maxit, 4096)));
+  if (o->profile) FL_CHK(prof_events.create(4 * (size_t)std::min(o->maxit, 4096)));  // around k_cg_A, around k_cg_Bq / k_cg_B
 
   const int every = o->check_every > 0 ? o->check_every : 16;
   int       it    = 0;
+  int       nprof = 0;    // iterations whose kernels are bracketed by events so far
   int       hostcur = 0;  // host's view of KspScal::cur (exact while the device has not stopped)
   bool      done  = false;
   while (!done) {
     const int stop = std::min(o->maxit, it + every);
     for (; it < stop; ++it) {
-      const bool prof = o->profile && (size_t)(2 * it + 1) < pev.size();
+      // profile = n: the kernels of every n-th PAIR of iterations are bracketed (k_cg_Bq alternates between two forms)
+      const bool prof = o->profile > 0 && (it >> 1) % o->profile == 0 && (size_t)(4 * nprof + 3) < pev.size();
+      const int  pi   = 4 * nprof;
+      if (prof) ++nprof;
       if (variant == 1) {
         launch_cg_pupdate(s, g, jac, h->r, h->P0, h->P1, h->scal);
         if (ghosts) FL_CHK(fl_fill_ghosts(h, hostcur ? h->P0 : h->P1));
-        if (prof) FL_HIP(hipEventRecord(pev[2 * it], s));
+        if (prof) FL_HIP(hipEventRecord(pev[pi], s));
         launch_cg_apply_dot(s, g, h->P0, h->P1, h->q, h->xp, h->scal, h->partial);
-        if (prof) FL_HIP(hipEventRecord(pev[2 * it + 1], s));
+        if (prof) FL_HIP(hipEventRecord(pev[pi + 1], s));
       } else {
-        if (prof) FL_HIP(hipEventRecord(pev[2 * it], s));
+        if (prof) FL_HIP(hipEventRecord(pev[pi], s));
         launch_cg_A(s, g, jac, plan, h->r, h->P0, h->P1, h->q, h->xp, h->scal, h->partial, (fusedfin || fusedsum) ? h->tickets : nullptr, h->hist, nhist, fusedsum ? h->sums : nullptr);
-        if (prof) FL_HIP(hipEventRecord(pev[2 * it + 1], s));
+        if (prof) FL_HIP(hipEventRecord(pev[pi + 1], s));
       }
-      if (fusedsum) FL_CHK(fin_sums(1));
-      else if (!fusedfin) FL_CHK(cg_fin(h, 1, nab, 1, h->hist, nhist));
+      const int modeA = storeq ? 1 : 3;  // q-free pair: k_cg_A does not touch x (see cg_fin_apply)
+      if (fusedsum) FL_CHK(fin_sums(modeA));
+      else if (!fusedfin) FL_CHK(cg_fin(h, modeA, nab, 1, h->hist, nhist));
       hostcur ^= 1;
       // several ranks: the boundary layers of the new r leave now (packed as r - alpha q), the transfers overlap k_cg_B
+      // q-free pair: k_cg_Bq owns the x-update -- both updates of an iteration pair on the odd one (x is read and written every second
+      // iteration only), or one per iteration with FLUCA_CG_XBATCH=0
+      const int  xmode   = xbatch_env ? ((it & 1) ? 2 : 0) : 1;
       const bool overlap = ghosts && variant != 1 && h->multi && overlap_env;
       if (overlap) FL_CHK(fl_exchange_r_begin(h, h->r, storeq ? h->q : nullptr));
+      if (prof) FL_HIP(hipEventRecord(pev[pi + 2], s));
       if (storeq) launch_cg_B(s, g, jac, planB, h->q, h->r, h->scal, h->partial, h->partial_stride, (fusedfin || fusedsum) ? h->tickets + 1 : nullptr, h->hist, nhist, fusedsum ? h->sums : nullptr);
-      else launch_cg_Bq(s, g, jac, plan, h->P0, h->P1, h->r, h->scal, h->partial, h->partial_stride, (fusedfin || fusedsum) ? h->tickets + 1 : nullptr, h->hist, nhist, fusedsum ? h->sums : nullptr);
+      else launch_cg_Bq(s, g, jac, planB, xmode, h->P0, h->P1, h->r, h->xp, h->scal, h->partial, h->partial_stride, (fusedfin || fusedsum) ? h->tickets + 1 : nullptr, h->hist, nhist, fusedsum ? h->sums : nullptr);
+      if (prof) FL_HIP(hipEventRecord(pev[pi + 3], s));
       // the handle's stream joins the exchange BEFORE the all-reduce is enqueued: the two RCCL operations never run at the same time
       // (one communicator, two streams), only the transfers and k_cg_B do
       if (overlap) FL_CHK(fl_exchange_r_end(h, h->r));
-      if (fusedsum) FL_CHK(fin_sums(2));
-      else if (!fusedfin) FL_CHK(cg_fin(h, 2, planB.nblocks, 5, h->hist, nhist));
+      const int modeB = (!storeq && xmode) ? 4 : 2;
+      if (fusedsum) FL_CHK(fin_sums(modeB));
+      else if (!fusedfin) FL_CHK(cg_fin(h, modeB, planB.nblocks, 5, h->hist, nhist));
       if (!overlap && ghosts && variant != 1) FL_CHK(fl_fill_ghosts(h, h->r));
     }
     FL_CHK(fl_poll_scal(h));
@@ -915,7 +970,16 @@ static int solve_cg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts
   st->seconds      = ms * 1e-3;
   st->kernel_ms    = 0.;
   st->kernel_launches = 0;
-  if (o->profile) prof_events.mean(R.it, &st->kernel_ms, &st->kernel_launches);
+  st->kernel2_ms   = 0.;
+  st->kernel2_launches = 0;
+  if (o->profile) {
+    // iterations enqueued after the device had stopped are early exits: count only those that ran
+    int ran = 0;
+    for (int a = 0, q = 0; a < R.it; ++a)
+      if ((a >> 1) % o->profile == 0 && q++ < nprof) ++ran;
+    prof_events.mean_of(ran, 4, 0, 1, &st->kernel_ms, &st->kernel_launches);
+    prof_events.mean_of(ran, 4, 2, 3, &st->kernel2_ms, &st->kernel2_launches);
+  }
   if (o->history && o->nhistory > 0) {
     const int n = std::min(o->nhistory, R.it + 1);
     FL_HIP(hipMemcpy(o->history, h->hist, sizeof(double) * n, hipMemcpyDeviceToHost));

@@ -53,7 +53,8 @@ PlanA plan_tiles(const GridP &, int ry, int nw, int nchunk_force, int target_blo
 PlanA plan_cg_A(const GridP &, int, int);
 PlanA plan_cg_B(const GridP &);
 void  launch_cg_A(hipStream_t, const GridP &, bool, const PlanA &, const double *, double *, double *, double *, double *, KspScal *, double *, unsigned *, double *, int, double *sums = nullptr);
-void  launch_cg_Bq(hipStream_t, const GridP &, bool, const PlanA &, const double *P0, const double *P1, double *r, KspScal *, double *partial, int stride, unsigned *counter, double *hist, int nhist, double *sums = nullptr);
+void  launch_cg_Bq(hipStream_t, const GridP &, bool, const PlanA &, int xmode, const double *P0, const double *P1, double *r, double *x, KspScal *, double *partial, int stride, unsigned *counter, double *hist, int nhist,
+                   double *sums = nullptr);
 void  launch_cg_B(hipStream_t, const GridP &, bool, const PlanA &, const double *, double *, KspScal *, double *, int, unsigned *, double *, int, double *sums = nullptr);
 void  launch_stream_ref(hipStream_t, int, int, int64_t, const double *, const double *, const double *, double *, double *, double *);
 void  launch_stream_par(hipStream_t, int, int, int, int, int, int64_t, const double *, const double *, const double *, double *, double *, double *);
@@ -308,6 +309,21 @@ struct ProfEvents {
     for (int a = 0; a < pairs && (size_t)(2 * a + 1) < ev.size(); ++a) {
       float t = 0.f;
       if (hipEventElapsedTime(&t, ev[2 * a], ev[2 * a + 1]) == hipSuccess) {
+        tot += t;
+        ++cnt;
+      }
+    }
+    *ms_out    = cnt ? tot / cnt : 0.;
+    *count_out = cnt;
+  }
+  // mean of ev[stride * a + o1] - ev[stride * a + o0] over the first n groups
+  void mean_of(int n, int stride, int o0, int o1, double *ms_out, int *count_out) const
+  {
+    double tot = 0.;
+    int    cnt = 0;
+    for (int a = 0; a < n && (size_t)(stride * a + o1) < ev.size(); ++a) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, ev[stride * a + o0], ev[stride * a + o1]) == hipSuccess) {
         tot += t;
         ++cnt;
       }

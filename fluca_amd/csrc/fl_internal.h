@@ -74,6 +74,7 @@ struct GridP {
 // device-side scalar state of a Krylov solve (one per handle)
 struct KspScal {
   double rz, rz_old, pq, alpha, beta, zshift, dp, rnorm0, ttol;
+  double alpha_old;  // CG: the step length of the iteration before (k_cg_Bq applies two x-updates every second iteration)
   double rtol, atol, dtol;
   double ncell_global;
   // BiCGStab

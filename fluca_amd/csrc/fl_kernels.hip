@@ -390,19 +390,25 @@ __device__ __forceinline__ double cg_norms(KspScal *s, const double *sum, double
   }
 }
 
-// mode 0: after k_cg_init.  mode 1: after k_cg_A (alpha).  mode 2: after k_cg_B (beta, convergence).  One thread.
+// mode 0: after k_cg_init.  mode 1: after k_cg_A (alpha).  mode 2: after k_cg_B / k_cg_Bq (beta, convergence).  One thread.
+// Who owes x what (pending_x = 1: x still lacks alpha * p of the current direction; k_cg_finish adds it):
+//   stored-q pair: k_cg_A applies the update deferred from the iteration before (mode 1 clears the flag), k_cg_B leaves one (mode 2);
+//   q-free pair:   k_cg_A never touches x (mode 3 = mode 1 without clearing); k_cg_Bq applies none on even iterations (mode 2) and
+//                  the two it then owes on odd ones (mode 4 = mode 2 with nothing left pending).
 __device__ __forceinline__ void cg_fin_apply(int mode, const double *out, KspScal *__restrict__ s, double *__restrict__ hist, int nhist)
 {
-  if (mode == 1) {
-    s->pending_x = 0;
-    s->cur ^= 1;
+  if (mode == 1 || mode == 3) {
+    if (mode == 1) s->pending_x = 0;
     const double pq = out[0];
     s->pq           = pq;
     if (!(pq > 0.)) {
+      // the direction just written is never used: cur keeps pointing at the one a pending x-update refers to
       s->reason = isnan(pq) ? FL_DIVERGED_NANORINF : FL_DIVERGED_INDEFINITE_MAT;
       return;
     }
-    s->alpha = s->rz / pq;
+    s->cur ^= 1;
+    s->alpha_old = s->alpha;
+    s->alpha     = s->rz / pq;
     return;
   }
   double       rz;
@@ -419,7 +425,7 @@ __device__ __forceinline__ void cg_fin_apply(int mode, const double *out, KspSca
     s->rz        = rz;
     s->beta      = rz / s->rz_old;
     s->it += 1;
-    s->pending_x = 1;
+    s->pending_x = mode == 4 ? 0 : 1;
   }
   s->dp = dp;
   if (hist && s->it < nhist) hist[s->it] = dp;
@@ -436,7 +442,7 @@ __global__ void __launch_bounds__(256) k_cg_fin(int mode, const double *__restri
 {
   __shared__ double out[NSLOT], red[NSLOT * 4];
   if (s->reason != 0) return;
-  if (nblocks > 0) reduce_partials(partial, nblocks, stride, mode == 1 ? 1 : 5, out, red);
+  if (nblocks > 0) reduce_partials(partial, nblocks, stride, (mode == 1 || mode == 3) ? 1 : 5, out, red);
   else {
     if (threadIdx.x < NSLOT) out[threadIdx.x] = sums[threadIdx.x];
     __syncthreads();
@@ -686,6 +692,8 @@ __device__ __forceinline__ int xcd_remap(int b, int nblocks) { return (nblocks &
 
 // RY rows per wave, NW waves per block (tile 128 x NW*RY), PF prefetch mode, NT: 0 plain, 1 non-temporal stores,
 // 2 non-temporal stores and tile loads (halo loads stay plain: they are meant to hit in L2)
+// SQ: store q (k_cg_B reads it back) and apply the x-update deferred from the iteration before; !SQ: neither -- q is formed again and
+// x is updated by k_cg_Bq, so this kernel reads r, p and writes p' (24 B/cell).
 template <int RY, int NW, bool JAC, int PF, int NT, bool SQ>
 __device__ __forceinline__ void cg_A_body(const GridP &g, const double *__restrict__ r, double *__restrict__ P0, double *__restrict__ P1, double *__restrict__ q, double *__restrict__ x, KspScal *__restrict__ s,
                                                       double *__restrict__ partial, int nchunk, int zc, int tiles_x, int tiles, int remap, FinCtx fin)
@@ -778,7 +786,7 @@ __device__ __forceinline__ void cg_A_body(const GridP &g, const double *__restri
       R.r[m] = ld2<NTL>(r + RO(m) + pl);
       R.p[m] = ld2<NTL>(pold + RO(m) + pl);
     }
-    {
+    if (SQ) {
       // x only exists on owned planes: the two extra trips re-read a cached plane instead of branching
       const int64_t px = (int64_t)min(max(kn_, k0), k1 - 1) * g.sxy;
 #pragma unroll
@@ -799,7 +807,7 @@ __device__ __forceinline__ void cg_A_body(const GridP &g, const double *__restri
   // next plane is fetched as soon as p' and the x-update have consumed the current one (fewer VGPRs, shorter flight).
   // deferred x-update of plane kk:  x += alpha_prev * p_old
   auto xupdate = [&](int kk, int64_t pl, bool pown, const Raw &C, const double2 *xv) {
-    if (!pown) return;
+    if (!SQ || !pown) return;
 #pragma unroll
     for (int m = 0; m < RY; ++m) {
       double2 xn;
@@ -915,7 +923,7 @@ __device__ __forceinline__ void cg_A_body(const GridP &g, const double *__restri
 #pragma unroll
     for (int a = 0; a < NW; ++a) tot[0] += red[a];
   }
-  if (fin.enabled) fused_fin<1, 64 * NW>(1, tot, partial, 0, fin, s, red, &flag);
+  if (fin.enabled) fused_fin<1, 64 * NW>(SQ ? 1 : 3, tot, partial, 0, fin, s, red, &flag);
   else if (tid == 0) partial[blockIdx.x] = tot[0];
 }
 
@@ -940,9 +948,13 @@ __global__ void __launch_bounds__(64 * NW, 2) k_cg_A_probe(FL_CG_A_ARGS)
 // (128 x NW*RY tile marching through a z chunk, three p' planes in LDS, raw planes fetched one trip ahead into a second register
 // set, unconditional loads on clamped addresses, masked stores); q comes out of st7 exactly as in k_cg_A.  The ghost layer of p'
 // is complete: k_cg_A stores p' on every star-ghost cell it forms (rows / columns / planes -1 and n).  Sums as in k_cg_B.
-template <int RY, int NW, bool JAC, int NT>
-__global__ void __launch_bounds__(64 * NW, 2) k_cg_Bq(GridP g, const double *__restrict__ P0, const double *__restrict__ P1, double *__restrict__ r, KspScal *__restrict__ s, double *__restrict__ partial, int stride,
-                                                      int nchunk, int zc, int tiles_x, int tiles, int remap, FinCtx fin)
+// The x-update lives here too (XM): the direction is in registers anyway.  XM == 2 on odd iterations: x += alpha_old p_old + alpha p'
+// (p_old = the other direction buffer, which k_cg_A overwrites only in the NEXT iteration), XM == 0 on even ones: nothing -- x is read
+// and written every second iteration only (12 instead of 16 B/cell/iteration).  XM == 1: x += alpha p' every iteration (A/B runs).
+// The two fma of XM == 2 are the two separate updates in the same order: same x bit for bit.
+template <int RY, int NW, bool JAC, int NT, int XM>
+__device__ __forceinline__ void cg_Bq_body(const GridP &g, const double *__restrict__ P0, const double *__restrict__ P1, double *__restrict__ r, double *__restrict__ x, KspScal *__restrict__ s,
+                                           double *__restrict__ partial, int stride, int nchunk, int zc, int tiles_x, int tiles, int remap, FinCtx fin)
 {
   using T               = TileA<RY, NW>;
   constexpr int TX = T::TX, TY = T::TY, LX = T::LX, LY = T::LY;
@@ -952,7 +964,8 @@ __global__ void __launch_bounds__(64 * NW, 2) k_cg_Bq(GridP g, const double *__r
   __shared__ int                                 flag;
   if (s->reason != 0) return;
   const double *p     = s->cur ? P1 : P0;  // the scalar step after k_cg_A has flipped cur: this is the direction it wrote
-  const double  alpha = s->alpha;
+  const double *pprev = s->cur ? P0 : P1;
+  const double  alpha = s->alpha, alpha_old = s->alpha_old;
 
   const int b     = remap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
   const int chunk = b / tiles, tile = b % tiles;
@@ -998,6 +1011,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_cg_Bq(GridP g, const double *__r
   double zlc = 0., zcc = 0., zhc = 0.;  // z-row of plane kk-1 (the plane whose q is formed)
   struct Raw {
     double2 p[RY], r[RY];  // p' of plane kn, r of plane kn - 1
+    double2 x[XM ? RY : 1], pp[XM == 2 ? RY : 1];  // x (and the direction before) of plane kn - 1
     double  hpA, hpB;
     double  zl, zc, zh;
   };
@@ -1008,6 +1022,8 @@ __global__ void __launch_bounds__(64 * NW, 2) k_cg_Bq(GridP g, const double *__r
     for (int m = 0; m < RY; ++m) {
       R.p[m] = ld2<NTL>(p + RO(m) + pl);
       R.r[m] = ld2<NTL>(r + RO(m) + pr);
+      if (XM) R.x[m] = ld2<NTL>(x + RO(m) + pr);
+      if (XM == 2) R.pp[m] = ld2<NTL>(pprev + RO(m) + pr);
     }
     R.hpA = p[tbase + pl + hAo];
     R.hpB = p[tbase + pl + hBo];
@@ -1043,6 +1059,19 @@ __global__ void __launch_bounds__(64 * NW, 2) k_cg_Bq(GridP g, const double *__r
         if (rown[m]) {
           if (own1) st2<NTS>(r + RO(m) + pc, rn);
           else if (own0) r[RO(m) + pc] = rn.x;
+        }
+        if (XM) {
+          double2 xn = C.x[m];
+          if (XM == 2) {
+            xn.x = fma(alpha_old, C.pp[m].x, xn.x);
+            xn.y = fma(alpha_old, C.pp[m].y, xn.y);
+          }
+          xn.x = fma(alpha, cen.x, xn.x);
+          xn.y = fma(alpha, cen.y, xn.y);
+          if (rown[m]) {
+            if (own1) st2<NTS>(x + RO(m) + pc, xn);
+            else if (own0) x[RO(m) + pc] = xn.x;
+          }
         }
         // selects, not 0/1 factors: outside the block q is inf * 0 (the ghost diagonal is +inf)
         const bool   o0 = rown[m] && own0, o1 = rown[m] && own1;
@@ -1085,11 +1114,24 @@ __global__ void __launch_bounds__(64 * NW, 2) k_cg_Bq(GridP g, const double *__r
 #pragma unroll
       for (int q = 0; q < NW; ++q) tot[a] += red[a * NW + q];
   }
-  if (fin.enabled) fused_fin<5, 64 * NW>(2, tot, partial, stride, fin, s, red, &flag);
+  if (fin.enabled) fused_fin<5, 64 * NW>(XM ? 4 : 2, tot, partial, stride, fin, s, red, &flag);
   else if (tid == 0)
 #pragma unroll
     for (int a = 0; a < 5; ++a) partial[(int64_t)a * stride + blockIdx.x] = tot[a];
 }
+#define FL_CG_BQ_ARGS GridP g, const double *__restrict__ P0, const double *__restrict__ P1, double *__restrict__ r, double *__restrict__ x, KspScal *__restrict__ s, double *__restrict__ partial, int stride, int nchunk, int zc, int tiles_x, int tiles, int remap, FinCtx fin
+template <int RY, int NW, bool JAC, int NT, int XM>
+__global__ void __launch_bounds__(64 * NW, 2) k_cg_Bq(FL_CG_BQ_ARGS)
+{
+  cg_Bq_body<RY, NW, JAC, NT, XM>(g, P0, P1, r, x, s, partial, stride, nchunk, zc, tiles_x, tiles, remap, fin);
+}
+// the placement probe's launches under their own name (see k_cg_A_probe)
+template <int RY, int NW, bool JAC, int NT, int XM>
+__global__ void __launch_bounds__(64 * NW, 2) k_cg_Bq_probe(FL_CG_BQ_ARGS)
+{
+  cg_Bq_body<RY, NW, JAC, NT, XM>(g, P0, P1, r, x, s, partial, stride, nchunk, zc, tiles_x, tiles, remap, fin);
+}
+#undef FL_CG_BQ_ARGS
 
 // ------------------------------------------------------------------------------------------------ unfused CG pieces (variant 1)
 
@@ -1477,16 +1519,25 @@ void launch_cg_B(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const
   }
 }
 
-// k_cg_Bq on the tiling of k_cg_A (plan_cg_A)
-template <int RY, int NW>
-static void launch_cg_Bq_t(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const double *P0, const double *P1, double *r, KspScal *s, double *partial, int stride, const FinCtx &fin)
+// k_cg_Bq on the tiling of k_cg_A (plan_cg_A).  xmode: 0 no x-update, 1 x += alpha p', 2 the two updates owed on odd iterations
+template <int RY, int NW, int XM>
+static void launch_cg_Bq_x(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const double *P0, const double *P1, double *r, double *x, KspScal *s, double *partial, int stride, const FinCtx &fin)
 {
   const int  tiles = p.tiles_x * p.tiles_y;
   const dim3 gr(p.nblocks), bl(64 * NW);
-  if (jac) hipLaunchKernelGGL((k_cg_Bq<RY, NW, true, 2>), gr, bl, 0, st, g, P0, P1, r, s, partial, stride, p.nchunk, p.zc, p.tiles_x, tiles, p.remap, fin);
-  else hipLaunchKernelGGL((k_cg_Bq<RY, NW, false, 2>), gr, bl, 0, st, g, P0, P1, r, s, partial, stride, p.nchunk, p.zc, p.tiles_x, tiles, p.remap, fin);
+  if (p.probe) hipLaunchKernelGGL((k_cg_Bq_probe<RY, NW, true, 2, XM>), gr, bl, 0, st, g, P0, P1, r, x, s, partial, stride, p.nchunk, p.zc, p.tiles_x, tiles, p.remap, fin);
+  else if (jac) hipLaunchKernelGGL((k_cg_Bq<RY, NW, true, 2, XM>), gr, bl, 0, st, g, P0, P1, r, x, s, partial, stride, p.nchunk, p.zc, p.tiles_x, tiles, p.remap, fin);
+  else hipLaunchKernelGGL((k_cg_Bq<RY, NW, false, 2, XM>), gr, bl, 0, st, g, P0, P1, r, x, s, partial, stride, p.nchunk, p.zc, p.tiles_x, tiles, p.remap, fin);
 }
-void launch_cg_Bq(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const double *P0, const double *P1, double *r, KspScal *s, double *partial, int stride, unsigned *counter, double *hist, int nhist, double *sums)
+template <int RY, int NW>
+static void launch_cg_Bq_t(hipStream_t st, const GridP &g, bool jac, const PlanA &p, int xmode, const double *P0, const double *P1, double *r, double *x, KspScal *s, double *partial, int stride, const FinCtx &fin)
+{
+  if (xmode == 2) launch_cg_Bq_x<RY, NW, 2>(st, g, jac, p, P0, P1, r, x, s, partial, stride, fin);
+  else if (xmode == 1) launch_cg_Bq_x<RY, NW, 1>(st, g, jac, p, P0, P1, r, x, s, partial, stride, fin);
+  else launch_cg_Bq_x<RY, NW, 0>(st, g, jac, p, P0, P1, r, x, s, partial, stride, fin);
+}
+void launch_cg_Bq(hipStream_t st, const GridP &g, bool jac, const PlanA &p, int xmode, const double *P0, const double *P1, double *r, double *x, KspScal *s, double *partial, int stride, unsigned *counter, double *hist,
+                  int nhist, double *sums)
 {
   FinCtx fin;
   fin.sums    = sums;
@@ -1495,9 +1546,9 @@ void launch_cg_Bq(hipStream_t st, const GridP &g, bool jac, const PlanA &p, cons
   fin.nhist   = nhist;
   fin.enabled = counter != nullptr;
   switch (p.ry * 10 + p.nw) {
-  case 28: launch_cg_Bq_t<2, 8>(st, g, jac, p, P0, P1, r, s, partial, stride, fin); break;
-  case 24: launch_cg_Bq_t<2, 4>(st, g, jac, p, P0, P1, r, s, partial, stride, fin); break;
-  default: launch_cg_Bq_t<1, 4>(st, g, jac, p, P0, P1, r, s, partial, stride, fin); break;
+  case 28: launch_cg_Bq_t<2, 8>(st, g, jac, p, xmode, P0, P1, r, x, s, partial, stride, fin); break;
+  case 24: launch_cg_Bq_t<2, 4>(st, g, jac, p, xmode, P0, P1, r, x, s, partial, stride, fin); break;
+  default: launch_cg_Bq_t<1, 4>(st, g, jac, p, xmode, P0, P1, r, x, s, partial, stride, fin); break;
   }
 }
 

@@ -170,7 +170,7 @@ class Poisson:
         check(lib.fl_poisson_solve(self.h, _ptr(b), _ptr(x), C.byref(o), C.byref(st)), "fl_poisson_solve")
         self._post()
         info = dict(iters=st.iters, reason=st.reason, rnorm0=st.rnorm0, rnorm=st.rnorm, seconds=st.seconds,
-                    kernel_ms=st.kernel_ms, kernel_launches=st.kernel_launches)
+                    kernel_ms=st.kernel_ms, kernel_launches=st.kernel_launches, kernel2_ms=st.kernel2_ms, kernel2_launches=st.kernel2_launches)
         if history:
             info["history"] = hist[:st.iters + 1].copy()
             o.history = None

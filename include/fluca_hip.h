@@ -102,7 +102,8 @@ typedef struct fl_ksp_opts {
                                BLAS-1/SpMV step (A/B + debugging), 2 = fused kernels with q stored and read back (72 B/cell) */
   int     check_every;      /* host polls the device-side convergence flag every this many iterations (0 = default 16);
                              * < 0 with FL_NORM_NONE (Chebyshev): never -- exactly maxit steps, no statistics (smoother use) */
-  int     profile;          /* 1: bracket the dominant kernel of every iteration with HIP events -> stats.kernel_ms */
+  int     profile;          /* n > 0: bracket the kernels of every n-th pair of CG iterations (every Chebyshev launch) with HIP events ->
+                               stats.kernel_ms (k_cg_A / the Chebyshev kernel), stats.kernel2_ms (k_cg_Bq); 1 = every iteration */
   double *history;          /* optional host array, receives the monitored norm of iterations 0..iters */
   int     nhistory;
   int     mg_levels;        /* FL_PC_MG: number of grid levels, 0 = coarsen as far as possible (-pc_mg_levels) */
@@ -117,6 +118,9 @@ typedef struct fl_ksp_stats {
   double seconds;         /* wall time of the solve measured with HIP events on the handle's stream */
   double kernel_ms;       /* profile=1: mean duration of the dominant kernel (HIP events), else 0 */
   int    kernel_launches; /* number of launches averaged in kernel_ms */
+  double kernel2_ms;      /* profile=1, CG: mean duration of the second kernel of an iteration (k_cg_Bq: r-update, and the x-updates on
+                             every second iteration), else 0 */
+  int    kernel2_launches;
 } fl_ksp_stats;
 
 typedef struct fl_poisson  fl_poisson;
@@ -159,7 +163,7 @@ int fl_vec_maxpy(fl_poisson *h, int64_t n, double *x_dev, const double *alphas, 
  *                test sits between them (KSP_NORM_NONE sweeps, the multigrid smoother) and the grid is large enough to gain;
  *                2 = the same on every grid where it is legal.
  *   "placement"  1 (default) = the first solve on a handle whose padded vectors are >= 256 MiB allocates ONE arena (16 GiB +
- *                8 vectors) and carves the solver vectors out of it where a probe of the CG stencil kernel runs fastest
+ *                8 vectors) and carves the solver vectors out of it where a probe of the CG kernel pair (k_cg_A + the odd-iteration k_cg_Bq) runs fastest
  *                (see fl_poisson_tune_placement); 0 = one plain allocation per vector.
  * Returns FL_ERR_ARG_WRONG for an unknown name.  Process-wide; set before the solve it should affect. */
 int fl_tuning_set(const char *name, int value);
@@ -169,7 +173,7 @@ int fl_tuning_get(const char *name, int *value);
  * when all of them sit in one physically contiguous block of memory (what back-to-back allocations give) than when two or
  * three of them come from a different block (measurements: profiles/r02_placement.md).  This call -- made implicitly by the
  * first solve of a large handle unless the tuning knob "placement" is 0 -- allocates one arena, slides a window of five packed
- * vectors through it with the CG stencil kernel as the probe (about 20 launches) and carves the vectors out where the window
+ * vectors through it with the CG kernel pair as the probe (about 20 positions) and carves the vectors out where the window
  * was fastest.  Deterministic, idempotent, never changes results.  max_tries >= 1 (kept from the earlier interface, unused).
  * probe_ms_out (may be NULL): {probe time with all vectors in one block, probe time at the chosen place}; {0, 0} if the
  * handle is too small to be placed or memory is short. */
