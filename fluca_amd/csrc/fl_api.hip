@@ -284,6 +284,16 @@ extern "C" int fl_poisson_sizes(const fl_poisson *h, int64_t out[4])
 // was fastest; the vectors outside the window come alternately from the arena's two sides.  Done once per handle, by the
 // first fl_ensure_vec of a large handle (tuning knob "placement", default 1) or explicitly by fl_poisson_tune_placement.
 
+// "cg_xbatch" (fl_tuning_set; initial value from FLUCA_CG_XBATCH): 1 (default) k_cg_Bq applies both x-updates of an iteration pair on
+// the odd iteration, 0 one per iteration.  Same x bit for bit.
+int &fl_cg_xbatch_mode()
+{
+  static int m = []() {
+    const char *e = std::getenv("FLUCA_CG_XBATCH");
+    return e ? std::atoi(e) : 1;
+  }();
+  return m;
+}
 int &fl_placement_mode()
 {
   static int m = []() {
@@ -888,10 +898,7 @@ static int solve_cg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts
     const char *e = std::getenv("FLUCA_OVERLAP");  // 0: pack / transfer / unpack after k_cg_B, on the handle's stream (A/B measurements)
     return e ? std::atoi(e) != 0 : true;
   }();
-  static const bool xbatch_env = []() {
-    const char *e = std::getenv("FLUCA_CG_XBATCH");
-    return e ? std::atoi(e) != 0 : true;
-  }();
+  const bool xbatch_env = fl_cg_xbatch_mode() != 0;
   const bool fusedfin = !h->multi && variant != 1 && fusedfin_env;
   // several ranks: the last block of k_cg_A / k_cg_B still reduces the rank's partial sums (no k_reduce launch); the
   // all-reduce and the scalar kernel follow

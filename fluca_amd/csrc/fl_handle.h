@@ -341,6 +341,7 @@ struct ProfEvents {
 int  fl_dev_alloc(fl_poisson *h, void **p, size_t bytes, bool zero);
 int  fl_ensure_vec(fl_poisson *h, double **v);
 int &fl_placement_mode();
+int &fl_cg_xbatch_mode();
 int  fl_ensure_partials(fl_poisson *h, int nblocks);
 int  fl_ensure_hist(fl_poisson *h, int nhist);
 int  fl_zero_vec(fl_poisson *h, double *v);

@@ -698,6 +698,10 @@ extern "C" int fl_tuning_set(const char *name, int value)
     fl_placement_mode() = value;
     return FL_SUCCESS;
   }
+  if (std::strcmp(name, "cg_xbatch") == 0) {
+    fl_cg_xbatch_mode() = value;
+    return FL_SUCCESS;
+  }
   return FL_ERR_ARG_WRONG;
 }
 extern "C" int fl_tuning_get(const char *name, int *value)
@@ -705,6 +709,10 @@ extern "C" int fl_tuning_get(const char *name, int *value)
   if (!name || !value) return FL_ERR_ARG_NULL;
   if (std::strcmp(name, "cheb_fuse") == 0) {
     *value = cheb_fuse_mode();
+    return FL_SUCCESS;
+  }
+  if (std::strcmp(name, "cg_xbatch") == 0) {
+    *value = fl_cg_xbatch_mode();
     return FL_SUCCESS;
   }
   if (std::strcmp(name, "placement") == 0) {

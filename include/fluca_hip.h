@@ -165,6 +165,8 @@ int fl_vec_maxpy(fl_poisson *h, int64_t n, double *x_dev, const double *alphas, 
  *   "placement"  1 (default) = the first solve on a handle whose padded vectors are >= 256 MiB allocates ONE arena (16 GiB +
  *                8 vectors) and carves the solver vectors out of it where a probe of the CG kernel pair (k_cg_A + the odd-iteration k_cg_Bq) runs fastest
  *                (see fl_poisson_tune_placement); 0 = one plain allocation per vector.
+ *   "cg_xbatch"  1 (default) = the CG solver updates x every second iteration (both updates of the pair at once, while the older
+ *                direction is still in its buffer); 0 = one update per iteration.  The same x bit for bit.
  * Returns FL_ERR_ARG_WRONG for an unknown name.  Process-wide; set before the solve it should affect. */
 int fl_tuning_set(const char *name, int value);
 int fl_tuning_get(const char *name, int *value);

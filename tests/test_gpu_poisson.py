@@ -147,6 +147,41 @@ def test_cg_edge_cases():
     P.close()
 
 
+@pytest.mark.parametrize("n,bc", [((17, 9, 11), CAVITY), ((130, 37, 20), CAVITY), ((12, 10, 9), [PER] * 6)])
+def test_cg_x_update_bookkeeping(n, bc):
+    """The CG solver updates x every second iteration (both updates of a pair at once): stopped after ANY number of iterations -- an
+    update still owed or not -- x must be what the textbook sequence gives.  Against the oracle's x after the same number of
+    iterations, against the stored-q kernel pair, and bit for bit against one update per iteration (tuning knob cg_xbatch = 0)."""
+    P, g = make_pair(n, bc, kappa=1e-3)
+    S = g.assemble_S()
+    _, b = mean_free_rhs(S, g.ncell)
+    bd = dev(b)
+    for maxit in (1, 2, 3, 4, 5, 8, 11):
+        kw = dict(rtol=0.0, atol=0.0, maxit=maxit, check_every=3)
+        x0, i0 = P.solve(bd, **kw)
+        assert i0["iters"] == maxit and i0["reason"] == -3
+        xo, io = S.solve(b, rtol=0.0, atol=0.0, maxit=maxit)
+        assert io["iters"] == maxit
+        scale = np.abs(xo).max()
+        assert np.abs(host(x0) - xo).max() <= 1e-10 * scale, maxit
+        x2, _ = P.solve(bd, variant=2, **kw)
+        assert float((x2 - x0).abs().max()) <= 1e-11 * scale, maxit
+        _knob(b"cg_xbatch", 0)
+        try:
+            x1, i1 = P.solve(bd, **kw)
+        finally:
+            _knob(b"cg_xbatch", 1)
+        assert torch.equal(x1, x0) and i1["rnorm"] == i0["rnorm"], maxit
+    # converged runs stop on an even or an odd iteration as it happens: the same test at two tolerances
+    for rtol in (1e-3, 1e-6):
+        x0, i0 = P.solve(bd, rtol=rtol)
+        xo, io = S.solve(b, rtol=rtol)
+        assert i0["reason"] == io["reason"] == 2 and abs(i0["iters"] - io["iters"]) <= 1
+        if i0["iters"] == io["iters"]:
+            assert np.abs(host(x0) - xo).max() <= 1e-9 * np.abs(xo).max()
+    P.close()
+
+
 def test_manufactured_cavity_solution():
     """p = cos(pi x) cos(pi y) cos(2 pi z) on the cavity_flow_3d box: recover it from b = S p."""
     n = (32, 32, 16)
