@@ -15,6 +15,7 @@
 //   k_cg_Bq the same update with q = S p' formed again from the stored direction (k_cg_A<SQ = false> writes no q): the
 //           pair moves 40 + 24 = 64 B/cell/iteration (+ tile rings).  The solver's default since round 2.
 #include "fl_internal.h"
+#include "fl_stencil.h"
 
 namespace fl {
 
@@ -27,28 +28,6 @@ __device__ __forceinline__ double wave_sum(double v)
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
   return v;
-}
-
-typedef double v2d __attribute__((ext_vector_type(2)));
-// 16-B accesses with an optional non-temporal hint (streams that are not re-read before they would be evicted anyway)
-template <int NT>
-__device__ __forceinline__ double2 ld2(const double *p)
-{
-  if (NT) {
-    const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(p));
-    return make_double2(v.x, v.y);
-  }
-  return *reinterpret_cast<const double2 *>(p);
-}
-template <int NT>
-__device__ __forceinline__ void st2(double *p, double2 v)
-{
-  if (NT) {
-    v2d t;
-    t.x = v.x;
-    t.y = v.y;
-    __builtin_nontemporal_store(t, reinterpret_cast<v2d *>(p));
-  } else *reinterpret_cast<double2 *>(p) = v;
 }
 
 // sum over the 256-thread block; result valid in thread 0.  Fixed order -> deterministic.
@@ -104,13 +83,6 @@ __global__ void k_wrap_ghosts(GridP g, double *__restrict__ v, int axis)
     v[pidx(g, a, b, -1)]   = v[pidx(g, a, b, g.nz - 1)];
     v[pidx(g, a, b, g.nz)] = v[pidx(g, a, b, 0)];
   }
-}
-
-// One row of S in a fixed rounding order (explicit fma chain): k_cg_A (for p.q), k_cg_Bq (for r - alpha q) and the boundary-layer
-// pack of the overlapped halo exchange all form q = S p' with it, so the three agree bit for bit.  dc = xc + (yc + zc).
-__device__ __forceinline__ double st7(double dc, double c, double xl, double w, double xh, double e, double yl, double s, double yh, double n, double zl, double b, double zh, double a)
-{
-  return fma(zh, a, fma(zl, b, fma(yh, n, fma(yl, s, fma(xh, e, fma(xl, w, dc * c))))));
 }
 
 // faces <-> contiguous buffers (multi-rank halo exchange).  side 0 = low, 1 = high.  pack reads owned boundary cells,
@@ -679,16 +651,6 @@ __global__ void __launch_bounds__(256) k_cg_finish(GridP g, const double *__rest
 }
 
 // ------------------------------------------------------------------------------------------------ CG: the fused stencil kernel
-
-template <int RY, int NW>
-struct TileA {
-  static constexpr int TX = 128, TY = NW * RY, LX = TX + 4, LY = TY + 2;
-};
-
-// blockIdx -> logical block.  Blocks are dealt round-robin over the 8 XCDs, so physical blocks b, b+8, ... share an L2.
-// Give each XCD a contiguous range of logical blocks (= neighbouring tiles of one z-chunk): the halo rows / columns a
-// tile re-reads were just fetched into the same L2 by its neighbour.  Speed only; any mapping is correct.
-__device__ __forceinline__ int xcd_remap(int b, int nblocks) { return (nblocks & 7) ? b : (b & 7) * (nblocks >> 3) + (b >> 3); }
 
 // RY rows per wave, NW waves per block (tile 128 x NW*RY), PF prefetch mode, NT: 0 plain, 1 non-temporal stores,
 // 2 non-temporal stores and tile loads (halo loads stay plain: they are meant to hit in L2)

@@ -4,6 +4,7 @@
 // scalars in device memory (KspScal), fixed-order partial sums, lazy constant-null-space removal.
 #include "fl_handle.h"
 #include "fl_device.h"
+#include "fl_stencil.h"
 
 namespace fl {
 
@@ -231,6 +232,198 @@ __global__ void __launch_bounds__(256) k_bcgs_pw(GridP g, const double *__restri
     if (threadIdx.x == 0)
 #pragma unroll
       for (int a = 0; a < 3; ++a) partial[(int64_t)a * stride + blockIdx.x] = acc[a];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ BiCGStab without stored products
+// V0 = M S P and T0 = M S S0 are never written to memory: a 7-point row costs nothing next to its traffic, so every kernel that needs
+// a product stages the vector it belongs to (tile + one-cell ring through LDS, the walk of k_cg_A / k_cg_Bq) and forms it again.
+//   MODE 5  P' = R - (omega_old beta)(V0 - vshift) + beta P,  V0 from the OLD P (staged), P' into the other buffer   reads P,R   writes P'   24 B/cell
+//   MODE 1  V0 from P' (staged): sums  0 sum V0, 1 V0.RP                                                          reads P',RP             16
+//   MODE 2  S0 = R - alpha V0, V0 from P' again; sum 0 sum S0                                                     reads P',R  writes S0   24
+//   MODE 3  T0 from S0 (staged): sums  0 sum T0, 2 S0.T0, 3 T0.T0                                                  reads S0                 8
+//   MODE 4  X += alpha P' + omega (S0 - sshift); R = (S0 - sshift) - omega (T0 - tshift), T0 from S0 again;
+//           sums 0 R.R, 1 R.RP, 2 sum R                                                               reads S0,P',X,RP  writes X,R         48
+// = 120 B/cell/iteration against 152 with V0 and T0 stored (k_apply_pc + k_bcgs_pw).  Scalars, lazy null-space shifts and the
+// convergence test are k_bcgs_fin's, unchanged.
+template <int MODE>
+struct BcgsIo {
+  static constexpr int NE = MODE == 4 ? 3 : (MODE == 3 ? 0 : 1);  // extra per-cell input streams (plane of the product)
+};
+template <int RY, int NW, bool JAC, int MODE>
+__global__ void __launch_bounds__(64 * NW, 2) k_bcgs_st(GridP g, const double *__restrict__ stg, const double *e0, const double *e1, const double *e2, double *w0, double *w1 /* MODE 4: e1 == w0 (X) */,
+                                                        const KspScal *__restrict__ s, double *__restrict__ partial, int stride, int nchunk, int zc, int tiles_x, int tiles, int remap)
+{
+  using T               = TileA<RY, NW>;
+  constexpr int TX = T::TX, TY = T::TY, LX = T::LX, LY = T::LY;
+  constexpr int NE = BcgsIo<MODE>::NE;
+  __shared__ __attribute__((aligned(16))) double lds[3][LY][LX];
+  __shared__ double                              red[4 * NW];
+  if (s->reason != 0) return;
+  const double alpha = s->alpha, omega = s->omega, beta = s->beta, ob = s->omega_old * s->beta, vsh = s->vshift, ssh = s->rshift, tsh = s->tshift;
+
+  const int b     = remap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int chunk = b / tiles, tile = b % tiles;
+  const int i0 = (tile % tiles_x) * TX, j0 = (tile / tiles_x) * TY;
+  const int k0 = chunk * zc, k1 = min(k0 + zc, g.nz);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w  = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i  = i0 + 2 * lane;
+  const int jb = j0 + w * RY;
+
+  const bool   own0 = i < g.nx, own1 = i + 1 < g.nx;
+  const int    il  = min(i, g.nx & ~1);
+  const int    ic0 = min(i, g.nx), ic1 = min(i + 1, g.nx);
+  const double xl0 = g.sl[0][ic0], xc0 = g.sc[0][ic0], xh0 = g.sh[0][ic0];
+  const double xl1 = g.sl[0][ic1], xc1 = g.sc[0][ic1], xh1 = g.sh[0][ic1];
+  int64_t rob[RY];
+  bool    rown[RY];
+  double  yl[RY], yc[RY], yh[RY];
+#pragma unroll
+  for (int m = 0; m < RY; ++m) {
+    const int j = jb + m, jc = min(j, g.ny);
+    rown[m]     = j < g.ny;
+    rob[m]      = g.off0 + (int64_t)jc * g.sx;
+    yl[m]       = g.sl[1][jc];
+    yc[m]       = g.sc[1][jc];
+    yh[m]       = g.sh[1][jc];
+  }
+#define RO(m) (rob[m] + il)
+  // ring cells of this thread: rows -1 / TY (A), columns -1 / TX (B), as in k_cg_A
+  constexpr int HB0 = NW > 4 ? 256 : 0;
+  const int     tb  = tid - HB0;
+  const int     hAi = i0 + (tid & 127), hAj = j0 + (tid < 128 ? -1 : TY);
+  const bool    hAok = tid < 256 && hAi < g.nx && hAj <= g.ny;
+  const int     hBi = i0 + ((tb & 1) ? TX : -1), hBj = j0 + (tb >> 1);
+  const bool    hBok = tb >= 0 && tb < 2 * TY && hBj < g.ny && hBi <= g.nx;
+  const int64_t tbase = g.off0 + (int64_t)j0 * g.sx + i0;
+  const int     hAo   = hAok ? (hAj - j0) * g.sx + (hAi - i0) : 0;
+  const int     hBo   = hBok ? (hBj - j0) * g.sx + (hBi - i0) : 0;
+  const int     hAr = hAok ? (tid < 128 ? 0 : TY + 1) : 0, hAc = hAok ? (tid & 127) + 2 : 0;  // (0,0) is a dead corner slot
+  const int     hBr = hBok ? (tb >> 1) + 1 : 0, hBc = hBok ? ((tb & 1) ? TX + 2 : 1) : 0;
+
+  double acc[4] = {0., 0., 0., 0.};
+  double zlc = 0., zcc = 0., zhc = 0.;  // z-row of plane kk-1 (the plane whose product is formed)
+  struct Raw {
+    double2 v[RY];                 // staged vector, plane kn
+    double2 e[NE ? NE : 1][RY];    // per-cell inputs of plane kn - 1
+    double  hA, hB;
+    double  zl, zc, zh;
+  };
+  auto load = [&](int kn_, Raw &R) {
+    const int     kn = min(kn_, k1);
+    const int64_t pl = (int64_t)kn * g.sxy, pr = (int64_t)min(max(kn_ - 1, k0), k1 - 1) * g.sxy;
+#pragma unroll
+    for (int m = 0; m < RY; ++m) {
+      R.v[m] = ld2<1>(stg + RO(m) + pl);
+      if (NE >= 1) R.e[0][m] = ld2<1>(e0 + RO(m) + pr);
+      if (NE >= 2) R.e[1][m] = ld2<1>(e1 + RO(m) + pr);
+      if (NE >= 3) R.e[NE >= 3 ? 2 : 0][m] = ld2<1>(e2 + RO(m) + pr);
+    }
+    R.hA = stg[tbase + pl + hAo];
+    R.hB = stg[tbase + pl + hBo];
+    R.zl = g.sl[2][kn];
+    R.zc = g.sc[2][kn];
+    R.zh = g.sh[2][kn];
+  };
+  auto step = [&](int kk, Raw &C, Raw &N) {
+    load(kk + 1, N);
+    const double nzl = C.zl, nzc = C.zc, nzh = C.zh;
+    const int    buf = (kk + 3) % 3;
+    const int    kc  = kk - 1;
+    if (kc >= k0) {
+      const int     bc = (kc + 3) % 3, bp = (kc + 2) % 3;
+      const int64_t pc = (int64_t)kc * g.sxy;
+      const int     lc = 2 * lane + 2;
+#pragma unroll
+      for (int m = 0; m < RY; ++m) {
+        const int     lr = w * RY + m + 1;
+        const double2 cen   = *reinterpret_cast<const double2 *>(&lds[bc][lr][lc]);
+        const double2 south = *reinterpret_cast<const double2 *>(&lds[bc][lr - 1][lc]);
+        const double2 north = *reinterpret_cast<const double2 *>(&lds[bc][lr + 1][lc]);
+        const double2 below = *reinterpret_cast<const double2 *>(&lds[bp][lr][lc]);
+        const double  west = lds[bc][lr][lc - 1], east = lds[bc][lr][lc + 2];
+        const double  dyc = yc[m] + zcc;
+        double2       y;  // the product M S (staged vector) of this pair of cells
+        y.x = st7(xc0 + dyc, cen.x, xl0, west, xh0, cen.y, yl[m], south.x, yh[m], north.x, zlc, below.x, zhc, C.v[m].x);
+        y.y = st7(xc1 + dyc, cen.y, xl1, cen.x, xh1, east, yl[m], south.y, yh[m], north.y, zlc, below.y, zhc, C.v[m].y);
+        if (JAC) {
+          y.x /= (xc0 + dyc);
+          y.y /= (xc1 + dyc);
+        }
+        // selects, not 0/1 factors: outside the block the product is inf * 0 (the ghost diagonal is +inf)
+        const bool o0 = rown[m] && own0, o1 = rown[m] && own1;
+        auto       put = [&](double *dst, double2 v) {
+          if (o1) st2<1>(dst + RO(m) + pc, v);
+          else if (o0) dst[RO(m) + pc] = v.x;
+        };
+        if (MODE == 1) {
+          const double2 rp = C.e[0][m];
+          acc[0] += (o0 ? y.x : 0.) + (o1 ? y.y : 0.);
+          acc[1] += (o0 ? y.x * rp.x : 0.) + (o1 ? y.y * rp.y : 0.);
+        } else if (MODE == 2) {
+          const double2 R = C.e[0][m];
+          double2       o;
+          o.x = R.x - alpha * y.x;
+          o.y = R.y - alpha * y.y;
+          put(w0, o);
+          acc[0] += (o0 ? o.x : 0.) + (o1 ? o.y : 0.);
+        } else if (MODE == 3) {
+          acc[0] += (o0 ? y.x : 0.) + (o1 ? y.y : 0.);
+          acc[2] += (o0 ? cen.x * y.x : 0.) + (o1 ? cen.y * y.y : 0.);
+          acc[3] += (o0 ? y.x * y.x : 0.) + (o1 ? y.y * y.y : 0.);
+        } else if (MODE == 4) {
+          const double2 P = C.e[0][m], X = C.e[1][m], RP = C.e[NE >= 3 ? 2 : 0][m];
+          const double  s0 = cen.x - ssh, s1 = cen.y - ssh;
+          double2       xs, rn;
+          xs.x = X.x + alpha * P.x + omega * s0;
+          xs.y = X.y + alpha * P.y + omega * s1;
+          rn.x = s0 - omega * (y.x - tsh);
+          rn.y = s1 - omega * (y.y - tsh);
+          put(w0, xs);
+          put(w1, rn);
+          acc[0] += (o0 ? rn.x * rn.x : 0.) + (o1 ? rn.y * rn.y : 0.);
+          acc[1] += (o0 ? rn.x * RP.x : 0.) + (o1 ? rn.y * RP.y : 0.);
+          acc[2] += (o0 ? rn.x : 0.) + (o1 ? rn.y : 0.);
+        } else {  // MODE 5
+          const double2 R = C.e[0][m];
+          double2       o;
+          o.x = R.x - ob * (y.x - vsh) + beta * cen.x;
+          o.y = R.y - ob * (y.y - vsh) + beta * cen.y;
+          put(w0, o);
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < RY; ++m) *reinterpret_cast<double2 *>(&lds[buf][w * RY + m + 1][2 * lane + 2]) = C.v[m];
+    lds[buf][hAr][hAc] = C.hA;
+    lds[buf][hBr][hBc] = C.hB;
+    __syncthreads();
+    zlc = nzl;
+    zcc = nzc;
+    zhc = nzh;
+  };
+  {
+    Raw A, B;
+    load(k0 - 1, A);
+    for (int kk = k0 - 1; kk <= k1; kk += 2) {
+      step(kk, A, B);
+      if (kk + 1 <= k1) step(kk + 1, B, A);
+    }
+  }
+#undef RO
+  if (MODE == 5) return;  // no sums
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    acc[a] = wave_sum(acc[a]);
+    if (lane == 0) red[a * NW + w] = acc[a];
+  }
+  __syncthreads();
+  if (tid < 4) {
+    double t = 0.;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) t += red[tid * NW + q];
+    partial[(int64_t)tid * stride + blockIdx.x] = t;
   }
 }
 
@@ -836,8 +1029,85 @@ int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero)
   return 0;
 }
 
+namespace {
+template <int RY, int NW, int MODE>
+void bcgs_st_t(fl_poisson *h, const PlanA &p, bool jac, const double *stg, const double *e0, const double *e1, const double *e2, double *w0, double *w1)
+{
+  const int  tiles = p.tiles_x * p.tiles_y;
+  const dim3 gr(p.nblocks), bl(64 * NW);
+  if (jac) hipLaunchKernelGGL((k_bcgs_st<RY, NW, true, MODE>), gr, bl, 0, h->stream, h->g, stg, e0, e1, e2, w0, w1, h->scal, h->partial, h->partial_stride, p.nchunk, p.zc, p.tiles_x, tiles, p.remap);
+  else hipLaunchKernelGGL((k_bcgs_st<RY, NW, false, MODE>), gr, bl, 0, h->stream, h->g, stg, e0, e1, e2, w0, w1, h->scal, h->partial, h->partial_stride, p.nchunk, p.zc, p.tiles_x, tiles, p.remap);
+}
+template <int MODE>
+void launch_bcgs_st(fl_poisson *h, const PlanA &p, bool jac, const double *stg, const double *e0, const double *e1, const double *e2, double *w0, double *w1)
+{
+  switch (p.ry * 10 + p.nw) {
+  case 28: bcgs_st_t<2, 8, MODE>(h, p, jac, stg, e0, e1, e2, w0, w1); break;
+  case 24: bcgs_st_t<2, 4, MODE>(h, p, jac, stg, e0, e1, e2, w0, w1); break;
+  default: bcgs_st_t<1, 4, MODE>(h, p, jac, stg, e0, e1, e2, w0, w1); break;
+  }
+}
+}  // namespace
+
 int fl_solve_bcgs(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *o, fl_ksp_stats *st)
 {
+  // variant 0 (default): V0 = M S P and T0 = M S S0 are formed wherever they are needed and never stored (k_bcgs_st, 120 B/cell/iteration);
+  // any other value: the stored products of round 1 (k_apply_pc + k_bcgs_pw, 152 B/cell)
+  static const int variant_env = []() {
+    const char *e = std::getenv("FLUCA_BCGS_VARIANT");
+    return e ? std::atoi(e) : -1;
+  }();
+  const int variant = (o->variant == 0 && variant_env >= 0) ? variant_env : o->variant;
+  if (variant == 0) {
+    const GridP &g   = h->g;
+    const bool   jac = o->pc == FL_PC_JACOBI;
+    // vectors: r=R, P0=RP, P1/q=P (two buffers: a tile reads its neighbours' old P while they write the new one), xp=X, w0=S0
+    for (double **v : {&h->r, &h->P0, &h->P1, &h->q, &h->xp, &h->w0}) FL_CHK(fl_ensure_vec(h, v));
+    const TP    tp = tile_plan(g);
+    const PlanA pa = plan_cg_A(g, 0, 0);
+    FL_CHK(fl_ensure_partials(h, std::max(tp.nblocks, pa.nblocks)));
+    const int nhist = o->maxit + 1;
+    FL_CHK(fl_ensure_hist(h, nhist));
+    hipStream_t s = h->stream;
+    init_scal(h, o);
+    FL_HIP(hipEventRecord(h->ev0, s));
+    FL_HIP(hipMemcpyAsync(h->scal, h->scal_host, sizeof(KspScal), hipMemcpyHostToDevice, s));
+    for (double *v : {h->P1, h->q, h->xp}) FL_CHK(fl_zero_vec(h, v));
+    double *R = h->r, *RP = h->P0, *P = h->P1, *Pn = h->q, *X = h->xp, *S0 = h->w0;
+    auto    fin = [&](int mode) {
+      return [=](const double *partial, int nb, int stride, const double *sums) { hipLaunchKernelGGL(k_bcgs_fin, dim3(1), dim3(256), 0, s, mode, partial, nb, stride, sums, h->scal, h->hist, nhist); };
+    };
+    launch_pw<3>(h, tp, jac, b, nullptr, nullptr, nullptr, R, nullptr);
+    FL_CHK(fin_step(h, tp.nblocks, 3, fin(0)));
+    launch_pw<4>(h, tp, jac, nullptr, nullptr, nullptr, nullptr, R, RP);
+    const bool ghosts = fl_any_ghost_exchange(h);
+    const int  every  = o->check_every > 0 ? o->check_every : 16;
+    int        it = 0;
+    bool       done = false;
+    while (!done) {
+      const int stop = std::min(o->maxit, it + every);
+      for (; it < stop; ++it) {
+        // P' = R - omega_old beta (M S P - vshift) + beta P   (the old P's ghosts are still those filled for the iteration before)
+        launch_bcgs_st<5>(h, pa, jac, P, R, nullptr, nullptr, Pn, nullptr);
+        std::swap(P, Pn);
+        if (ghosts) FL_CHK(fl_fill_ghosts(h, P));
+        launch_bcgs_st<1>(h, pa, jac, P, RP, nullptr, nullptr, nullptr, nullptr);
+        FL_CHK(fin_step(h, pa.nblocks, 4, fin(1)));
+        launch_bcgs_st<2>(h, pa, jac, P, R, nullptr, nullptr, S0, nullptr);
+        FL_CHK(fin_step(h, pa.nblocks, 3, fin(2)));
+        if (ghosts) FL_CHK(fl_fill_ghosts(h, S0));
+        launch_bcgs_st<3>(h, pa, jac, S0, nullptr, nullptr, nullptr, nullptr, nullptr);
+        FL_CHK(fin_step(h, pa.nblocks, 4, fin(3)));
+        launch_bcgs_st<4>(h, pa, jac, S0, P, X, RP, X, R);
+        FL_CHK(fin_step(h, pa.nblocks, 3, fin(4)));
+      }
+      FL_CHK(fl_poll_scal(h));
+      if (h->scal_host->reason != 0 || it >= o->maxit) done = true;
+    }
+    launch_unpad_copy(s, g, X, x, nullptr);
+    return finish_stats(h, o, st);
+  }
+
   const GridP &g   = h->g;
   const bool   jac = o->pc == FL_PC_JACOBI;
   // vectors: r=R, P0=RP, P1=P, q=V0, xp=X, w0=S0, w1=T0

@@ -133,14 +133,25 @@ struct MomLds {
 //    in flight; they are consumed by the register rotation at the end of the iteration.
 template <bool DOT, bool JAC, int OUT>
 __global__ void __launch_bounds__(MOM_NT, FL_MOM_WPE) k_mom_apply(GridP g, MomP m, const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ F, int64_t cs, const double *__restrict__ o,
-                                                                const KspScal *__restrict__ s, double *__restrict__ partial, int pstride, int tiles_x, int nchunk, int zc)
+                                                                const KspScal *__restrict__ s, double *__restrict__ partial, int pstride, int tiles_x, int nchunk, int zc, int order)
 {
   __shared__ MomLds lds[2];
   __shared__ double ltabx[MOM_NTAB][64];  // the x-axis table numbers of this tile's 64 columns (general rows of wall tiles)
   __shared__ double red[4 * MOM_RY];
   if (s && s->reason != 0) return;
   constexpr bool DG = JAC || OUT == 2;
-  const int      b = blockIdx.x, chunk = b % nchunk, tile = b / nchunk;
+  // order 1: chunk-major and XCD-contiguous like k_cg_A (blocks are dealt round-robin over the 8 XCDs: give each XCD a contiguous range of
+  // neighbouring tiles of one z chunk, so that the ring a tile re-reads was just fetched into the same L2 by its neighbour)
+  int b = blockIdx.x, chunk, tile;
+  if (order == 1) {
+    const int nb = gridDim.x, tiles = nb / nchunk;
+    if ((nb & 7) == 0) b = (b & 7) * (nb >> 3) + (b >> 3);
+    chunk = b / tiles;
+    tile  = b % tiles;
+  } else {
+    chunk = b % nchunk;
+    tile  = b / nchunk;
+  }
   const int      lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int      i0 = (tile % tiles_x) * 64, j0 = (tile / tiles_x) * MOM_RY, j = j0 + w;
   const int      i = i0 + lane;
@@ -580,11 +591,20 @@ int mom_ghosts(fl_momentum *m, double *v3)
   return 0;
 }
 
+int mom_order()
+{
+  static const int o = []() {
+    const char *e = std::getenv("FLUCA_MOM_ORDER");
+    return e ? std::atoi(e) : 0;
+  }();
+  return o;
+}
+
 template <bool DOT, bool JAC, int OUT>
 void mom_apply_t(fl_momentum *m, const double *x, double *y, const double *o, const KspScal *s, const MomP *coeffs = nullptr)
 {
   fl_poisson *h = m->p;
-  hipLaunchKernelGGL((k_mom_apply<DOT, JAC, OUT>), dim3(m->ablocks), dim3(MOM_NT), 0, h->stream, h->g, coeffs ? *coeffs : m->mp, x, y, m->F, (int64_t)h->padlen, o, s, h->partial, h->partial_stride, m->tiles_x, m->anchunk, m->azc);
+  hipLaunchKernelGGL((k_mom_apply<DOT, JAC, OUT>), dim3(m->ablocks), dim3(MOM_NT), 0, h->stream, h->g, coeffs ? *coeffs : m->mp, x, y, m->F, (int64_t)h->padlen, o, s, h->partial, h->partial_stride, m->tiles_x, m->anchunk, m->azc, mom_order());
 }
 
 template <int OP>
@@ -661,6 +681,8 @@ int mom_init(fl_momentum *m, fl_poisson *h)
     const int atiles = m->tiles_x * ((g.ny + MOM_RY - 1) / MOM_RY);
     int       nc = std::max(1, (2048 + atiles / 2) / atiles);
     nc         = std::max(1, std::min(std::min(nc, std::max(1, g.nz / 8)), g.nz));
+    if (const char *e = std::getenv("FLUCA_MOM_CHUNKS"))  // experiments: z chunks of k_mom_apply
+      if (std::atoi(e) > 0) nc = std::min(std::atoi(e), g.nz);
     if (atiles * nc > MAX_PARTIAL_BLOCKS) nc = std::max(1, MAX_PARTIAL_BLOCKS / atiles);
     m->azc     = (g.nz + nc - 1) / nc;
     m->anchunk = (g.nz + m->azc - 1) / m->azc;

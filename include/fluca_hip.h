@@ -98,8 +98,10 @@ typedef struct fl_ksp_opts {
   int     maxit;            /* -ksp_max_it   (PETSc default 10000) */
   double  rtol, atol, dtol; /* -ksp_rtol 1e-5, -ksp_atol 1e-50, -ksp_divtol 1e5 */
   double  emin, emax;       /* Chebyshev bounds of the preconditioned operator; 0,0 = Gershgorin bound * (0.1, 1.1) */
-  int     variant;          /* CG: 0 = fused kernels, q = S p formed twice and never stored (default; 64 B/cell/iteration), 1 = one kernel per
-                               BLAS-1/SpMV step (A/B + debugging), 2 = fused kernels with q stored and read back (72 B/cell) */
+  int     variant;          /* CG: 0 = fused kernels, q = S p formed twice and never stored, x updated every second iteration (default;
+                               60 B/cell/iteration), 1 = one kernel per BLAS-1/SpMV step (A/B + debugging), 2 = fused kernels with q stored
+                               and read back (72 B/cell).  BiCGStab: 0 = M S p and M S s formed where they are needed and never stored
+                               (default; 120 B/cell/iteration), other = stored (152 B/cell) */
   int     check_every;      /* host polls the device-side convergence flag every this many iterations (0 = default 16);
                              * < 0 with FL_NORM_NONE (Chebyshev): never -- exactly maxit steps, no statistics (smoother use) */
   int     profile;          /* n > 0: bracket the kernels of every n-th pair of CG iterations (every Chebyshev launch) with HIP events ->
