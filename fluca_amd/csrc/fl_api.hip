@@ -352,14 +352,16 @@ int place_vectors(fl_poisson *h)
           launch_cg_Bq(s, h->g, true, plan, 2, vec(1), vec(2), vec(0), vec(4), sc.p + par, h->partial, h->partial_stride, nullptr, nullptr, 0);
         }
     };
-    run(1);
+    // one untimed pair (TLB / L2 warm-up of the new position), then one timed repetition = two pairs (both direction-buffer parities)
+    launch_cg_A(s, h->g, true, plan, vec(0), vec(1), vec(2), vec(3), vec(4), sc.p, h->partial, nullptr, nullptr, 0);
+    launch_cg_Bq(s, h->g, true, plan, 2, vec(1), vec(2), vec(0), vec(4), sc.p, h->partial, h->partial_stride, nullptr, nullptr, 0);
     FL_HIP(hipEventRecord(h->ev0, s));
-    run(2);
+    run(1);
     FL_HIP(hipEventRecord(h->ev1, s));
     FL_HIP(hipStreamSynchronize(s));
     float ms = 0.f;
     FL_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
-    *ms_out = ms / 4.;
+    *ms_out = ms / 2.;
     return 0;
   };
   // Where the seams of an allocation lie depends on what the device's memory manager handed out before (on most fresh boxes one is
@@ -387,19 +389,27 @@ int place_vectors(fl_poisson *h)
     sc.arenas.push_back(a);
     FL_HIP(hipMemsetAsync(a, 0, w, s));
     const size_t lo = (size_t)PL_SIDE * vecb, hi = w - (size_t)(PL_WIN + PL_SIDE) * vecb;
-    const size_t step = std::max(vecb / 2, (((hi - lo) / 48) >> 21) << 21);  // half a vector, at most ~50 probes
+    // coarse pass in steps of one vector (the fast stretch before a seam is four vectors long), then the two half steps next to the best
+    const size_t step = std::max(vecb, (((hi - lo) / 32) >> 21) << 21);
     size_t       abest = lo;
     double       afirst = 0., abest_ms = 0.;
     int          nprobe = 0;
-    for (size_t b = lo; b <= hi; b += step, ++nprobe) {
+    auto         try_at = [&](size_t b) -> int {
       double ms = 0.;
       FL_CHK(probe(a, b, &ms));
       if (verbose) std::fprintf(stderr, "[fluca placement] arena %d, window at %.2f GiB: %.4f ms\n", attempt, (double)b / (double)((size_t)1 << 30), ms);
-      if (nprobe == 0) afirst = abest_ms = ms;
+      if (nprobe++ == 0) afirst = abest_ms = ms;
       if (ms < abest_ms) {
         abest_ms = ms;
         abest    = b;
       }
+      return 0;
+    };
+    for (size_t b = lo; b <= hi; b += step) FL_CHK(try_at(b));
+    if (abest_ms <= 0.985 * afirst) {
+      const size_t c = abest, half = ((step / 2) >> 21) << 21;
+      if (c >= lo + half) FL_CHK(try_at(c - half));
+      if (c + half <= hi) FL_CHK(try_at(c + half));
     }
     if (attempt == 0) first_ms = afirst;
     if (!arena || abest_ms < best_ms) {
