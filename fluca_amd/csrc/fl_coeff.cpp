@@ -100,6 +100,12 @@ int build_axis(Axis &a, int64_t n, const double *xf, const double *xc, int bc_lo
     a.sc[i] = slot[1];
     a.sh[i] = slot[2];
   }
+  if (a.periodic && n == 1) {
+    // a single cell across a periodic axis is its own neighbour on both sides: an assembled matrix (MatSetValues with ADD_VALUES,
+    // the oracle's CSR) carries the three entries summed on the diagonal, and PCJACOBI divides by that sum -- so do the tables
+    a.sc[0] += a.sl[0] + a.sh[0];
+    a.sl[0] = a.sh[0] = 0.;
+  }
 
   // outlet pressure coefficient of the Gst boundary vector, cnlinearcart3d.c:2643-2646 / :2671-2674
   a.bcc_lo = a.bcc_hi = 0.;

@@ -108,6 +108,36 @@ def test_cg_neumann_matches_oracle(n, bc, variant):
     P.close()
 
 
+@pytest.mark.parametrize("ksp", [fo.KSP_CG, fo.KSP_BCGS])
+@pytest.mark.parametrize("n,bc", [((2, 2, 2), [PER] * 6), ((3, 2, 5), CAVITY), ((129, 3, 2), CAVITY), ((2, 257, 3), [V, V, PER, PER, V, V]),
+                                   ((1, 4, 4), [PER, PER, V, V, V, V]), ((4, 1, 4), [V, V, PER, PER, V, V]), ((4, 4, 1), [V, V, V, V, PER, PER])])
+def test_degenerate_shapes(n, bc, ksp):
+    """Grids thinner than every tile, one plane per chunk, a single cell across a periodic axis (its own neighbour on both sides: the
+    assembled matrix carries the three entries summed on the diagonal, which is what PCJACOBI divides by): the LDS-staged kernels mask
+    and clamp, the answers are the oracle's."""
+    P, g = make_pair(n, bc, kappa=1e-3)
+    S = g.assemble_S()
+    _, b = mean_free_rhs(S, g.ncell)
+    xo, io = S.solve(b, ksp=ksp, rtol=1e-8, maxit=500)
+    xg, ig = P.solve(dev(b), type=ksp, rtol=1e-8, maxit=500, check_every=3, history=True)
+    assert ig["reason"] == io["reason"], (ig, io["reason"])
+    m = min(len(ig["history"]), len(io["history"]), 6)
+    assert np.allclose(ig["history"][:m], io["history"][:m], rtol=1e-9)
+    xg = host(xg)
+    if ksp == fo.KSP_CG:
+        assert abs(ig["iters"] - io["iters"]) <= 2, (ig["iters"], io["iters"])
+        assert np.linalg.norm((xg - xg.mean()) - (xo - xo.mean())) <= 1e-6 * max(np.linalg.norm(xo), 1e-300) + 1e-12
+    else:
+        # these thin grids are 1-D-like and ill conditioned (300 - 400 BiCGStab iterations): round-off moves the stopping iteration by
+        # tens and the answer by 1e-4 (the same for the stored-product kernels, tools/experiments/bcgs_diag2.py); what must hold is
+        # the early history (above) and the true residual at the end
+        assert abs(ig["iters"] - io["iters"]) <= max(3, io["iters"] // 4), (ig["iters"], io["iters"])
+        assert np.linalg.norm(b - S.mult(xg)) <= 5e-8 * np.linalg.norm(b)
+    y = host(P.apply(dev(xo)))
+    assert np.abs(y - S.mult(xo)).max() <= 1e-12 * max(np.abs(y).max(), 1e-300) + 1e-300
+    P.close()
+
+
 @pytest.mark.parametrize("n", [(9, 12, 7), (132, 260, 9)])
 def test_cg_outlet_nonsingular(n):
     """uniform grid + pressure outlet: S symmetric positive definite, no null space (nsbasic.c:214-231)"""
