@@ -423,7 +423,11 @@ bool fl_cheb2_usable(const fl_poisson *h)
 Cheb2Plan fl_cheb2_plan(const GridP &g)
 {
   Cheb2Plan p;
-  p.nw      = g.ny > 8 ? 8 : 4;
+  static const int force_nw = []() {
+    const char *e = std::getenv("FLUCA_CHEB2_NW");  // experiments: 4 = 128 x 8 tiles (two 256-thread blocks per CU), 8 = 128 x 16
+    return e ? std::atoi(e) : 0;
+  }();
+  p.nw      = (force_nw == 4 || force_nw == 8) ? force_nw : (g.ny > 8 ? 8 : 4);
   p.tiles_x = (g.nx + 127) / 128;
   const int ty    = 2 * p.nw;
   const int tiles = p.tiles_x * ((g.ny + ty - 1) / ty);
