@@ -873,6 +873,10 @@ static int solve_cg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts
   FL_CHK(fl_ensure_hist(h, nhist));
   hipStream_t s = h->stream;
 
+  const bool xbatch_env = fl_cg_xbatch_mode() != 0;
+  // q-free pair with batched x-updates: the padded x is not zeroed -- the first pair of updates (iteration 1) writes it without reading
+  // it, and until then KspScal::x_valid = 0 tells k_cg_finish that it stands for 0
+  const bool xlazy = !storeq && xbatch_env;
   KspScal &S = *h->scal_host;
   std::memset(&S, 0, sizeof(S));
   S.rtol         = o->rtol;
@@ -883,6 +887,7 @@ static int solve_cg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts
   S.norm_type    = o->norm_type;
   S.nullspace    = o->remove_nullspace;
   S.rz_old       = 1.;
+  S.x_valid      = xlazy ? 0 : 1;
 
   FL_HIP(hipEventRecord(h->ev0, s));
   FL_HIP(hipMemcpyAsync(h->scal, h->scal_host, sizeof(KspScal), hipMemcpyHostToDevice, s));
@@ -895,7 +900,7 @@ static int solve_cg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts
     FL_CHK(fl_zero_vec(h, h->xp));
     h->poisoned = false;
   }
-  launch_cg_init(s, g, jac, b, h->r, h->xp, h->partial, h->partial_stride, nsb);
+  launch_cg_init(s, g, jac, b, h->r, xlazy ? nullptr : h->xp, h->partial, h->partial_stride, nsb);
   FL_CHK(cg_fin(h, 0, nsb, 5, h->hist, nhist));
   const bool ghosts = fl_any_ghost_exchange(h);
   if (ghosts) FL_CHK(fl_fill_ghosts(h, h->r));
@@ -908,7 +913,6 @@ static int solve_cg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts
     const char *e = std::getenv("FLUCA_OVERLAP");  // 0: pack / transfer / unpack after k_cg_B, on the handle's stream (A/B measurements)
     return e ? std::atoi(e) != 0 : true;
   }();
-  const bool xbatch_env = fl_cg_xbatch_mode() != 0;
   const bool fusedfin = !h->multi && variant != 1 && fusedfin_env;
   // several ranks: the last block of k_cg_A / k_cg_B still reduces the rank's partial sums (no k_reduce launch); the
   // all-reduce and the scalar kernel follow
@@ -954,7 +958,7 @@ static int solve_cg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts
       // several ranks: the boundary layers of the new r leave now (packed as r - alpha q), the transfers overlap k_cg_B
       // q-free pair: k_cg_Bq owns the x-update -- both updates of an iteration pair on the odd one (x is read and written every second
       // iteration only), or one per iteration with FLUCA_CG_XBATCH=0
-      const int  xmode   = xbatch_env ? ((it & 1) ? 2 : 0) : 1;
+      const int  xmode   = xbatch_env ? ((it & 1) ? (it == 1 ? 3 : 2) : 0) : 1;
       const bool overlap = ghosts && variant != 1 && h->multi && overlap_env;
       if (overlap) FL_CHK(fl_exchange_r_begin(h, h->r, storeq ? h->q : nullptr));
       if (prof) FL_HIP(hipEventRecord(pev[pi + 2], s));

@@ -82,6 +82,8 @@ struct KspScal {
   // Chebyshev (lazy constant shifts of x and d)
   double ck, ckm1, mu, omegaprod, scale, xshift, dshift, cheb_rho, cheb_c;
   int    it, maxit, reason, norm_type, nullspace, pending_x, cur;
+  int    x_valid;  // CG, q-free pair: 0 until k_cg_Bq has written x for the first time (the padded x is not zeroed: the first pair of
+                   // updates writes it without reading it)
   int    dcur;  // Chebyshev: which of the two d buffers holds the current d (the fused two-step kernel flips it)
 };
 

@@ -398,6 +398,7 @@ __device__ __forceinline__ void cg_fin_apply(int mode, const double *out, KspSca
     s->beta      = rz / s->rz_old;
     s->it += 1;
     s->pending_x = mode == 4 ? 0 : 1;
+    if (mode == 4) s->x_valid = 1;
   }
   s->dp = dp;
   if (hist && s->it < nhist) hist[s->it] = dp;
@@ -625,6 +626,7 @@ __global__ void __launch_bounds__(256) k_cg_finish(GridP g, const double *__rest
   const double *p     = s->cur ? P1 : P0;
   const double  alpha = s->pending_x ? s->alpha : 0.;
   const bool    upd   = s->pending_x != 0;
+  const bool    xv    = s->x_valid != 0;  // false: x has never been written in this solve (it stands for 0)
   const int     lane  = threadIdx.x & 63;
   const int     nxs   = (g.nx + 127) / 128;
   const int64_t nseg  = (int64_t)nxs * g.ny * g.nz;
@@ -635,7 +637,7 @@ __global__ void __launch_bounds__(256) k_cg_finish(GridP g, const double *__rest
     const int     i = xs * 128 + 2 * lane;
     const int64_t ob = ((int64_t)k * g.ny + j) * g.nx + i, op = pidx(g, i, j, k);
     if (pairs && i + 1 < g.nx) {
-      double2 v = *reinterpret_cast<const double2 *>(x + op);
+      double2 v = xv ? *reinterpret_cast<const double2 *>(x + op) : make_double2(0., 0.);
       if (upd) {
         const double2 pv = *reinterpret_cast<const double2 *>(p + op);
         v.x += alpha * pv.x;
@@ -645,7 +647,10 @@ __global__ void __launch_bounds__(256) k_cg_finish(GridP g, const double *__rest
     } else {
 #pragma unroll
       for (int c = 0; c < 2; ++c)
-        if (i + c < g.nx) xout[ob + c] = upd ? x[op + c] + alpha * p[op + c] : x[op + c];
+        if (i + c < g.nx) {
+          const double xv0 = xv ? x[op + c] : 0.;
+          xout[ob + c]     = upd ? xv0 + alpha * p[op + c] : xv0;
+        }
     }
   }
 }
@@ -912,7 +917,8 @@ __global__ void __launch_bounds__(64 * NW, 2) k_cg_A_probe(FL_CG_A_ARGS)
 // is complete: k_cg_A stores p' on every star-ghost cell it forms (rows / columns / planes -1 and n).  Sums as in k_cg_B.
 // The x-update lives here too (XM): the direction is in registers anyway.  XM == 2 on odd iterations: x += alpha_old p_old + alpha p'
 // (p_old = the other direction buffer, which k_cg_A overwrites only in the NEXT iteration), XM == 0 on even ones: nothing -- x is read
-// and written every second iteration only (12 instead of 16 B/cell/iteration).  XM == 1: x += alpha p' every iteration (A/B runs).
+// and written every second iteration only (12 instead of 16 B/cell/iteration).  XM == 3: the first odd iteration of a solve, as XM == 2
+// with x = 0 not read (the padded x is not zeroed by k_cg_init then).  XM == 1: x += alpha p' every iteration (A/B runs).
 // The two fma of XM == 2 are the two separate updates in the same order: same x bit for bit.
 template <int RY, int NW, bool JAC, int NT, int XM>
 __device__ __forceinline__ void cg_Bq_body(const GridP &g, const double *__restrict__ P0, const double *__restrict__ P1, double *__restrict__ r, double *__restrict__ x, KspScal *__restrict__ s,
@@ -973,7 +979,7 @@ __device__ __forceinline__ void cg_Bq_body(const GridP &g, const double *__restr
   double zlc = 0., zcc = 0., zhc = 0.;  // z-row of plane kk-1 (the plane whose q is formed)
   struct Raw {
     double2 p[RY], r[RY];  // p' of plane kn, r of plane kn - 1
-    double2 x[XM ? RY : 1], pp[XM == 2 ? RY : 1];  // x (and the direction before) of plane kn - 1
+    double2 x[(XM == 1 || XM == 2) ? RY : 1], pp[XM >= 2 ? RY : 1];  // x (and the direction before) of plane kn - 1
     double  hpA, hpB;
     double  zl, zc, zh;
   };
@@ -984,8 +990,8 @@ __device__ __forceinline__ void cg_Bq_body(const GridP &g, const double *__restr
     for (int m = 0; m < RY; ++m) {
       R.p[m] = ld2<NTL>(p + RO(m) + pl);
       R.r[m] = ld2<NTL>(r + RO(m) + pr);
-      if (XM) R.x[m] = ld2<NTL>(x + RO(m) + pr);
-      if (XM == 2) R.pp[m] = ld2<NTL>(pprev + RO(m) + pr);
+      if (XM == 1 || XM == 2) R.x[m] = ld2<NTL>(x + RO(m) + pr);
+      if (XM >= 2) R.pp[m] = ld2<NTL>(pprev + RO(m) + pr);
     }
     R.hpA = p[tbase + pl + hAo];
     R.hpB = p[tbase + pl + hBo];
@@ -1023,8 +1029,8 @@ __device__ __forceinline__ void cg_Bq_body(const GridP &g, const double *__restr
           else if (own0) r[RO(m) + pc] = rn.x;
         }
         if (XM) {
-          double2 xn = C.x[m];
-          if (XM == 2) {
+          double2 xn = XM == 3 ? make_double2(0., 0.) : C.x[m];  // XM == 3: the first pair of updates of a solve, x = 0 is not read
+          if (XM >= 2) {
             xn.x = fma(alpha_old, C.pp[m].x, xn.x);
             xn.y = fma(alpha_old, C.pp[m].y, xn.y);
           }
@@ -1494,7 +1500,8 @@ static void launch_cg_Bq_x(hipStream_t st, const GridP &g, bool jac, const PlanA
 template <int RY, int NW>
 static void launch_cg_Bq_t(hipStream_t st, const GridP &g, bool jac, const PlanA &p, int xmode, const double *P0, const double *P1, double *r, double *x, KspScal *s, double *partial, int stride, const FinCtx &fin)
 {
-  if (xmode == 2) launch_cg_Bq_x<RY, NW, 2>(st, g, jac, p, P0, P1, r, x, s, partial, stride, fin);
+  if (xmode == 3) launch_cg_Bq_x<RY, NW, 3>(st, g, jac, p, P0, P1, r, x, s, partial, stride, fin);
+  else if (xmode == 2) launch_cg_Bq_x<RY, NW, 2>(st, g, jac, p, P0, P1, r, x, s, partial, stride, fin);
   else if (xmode == 1) launch_cg_Bq_x<RY, NW, 1>(st, g, jac, p, P0, P1, r, x, s, partial, stride, fin);
   else launch_cg_Bq_x<RY, NW, 0>(st, g, jac, p, P0, P1, r, x, s, partial, stride, fin);
 }
