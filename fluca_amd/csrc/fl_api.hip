@@ -640,7 +640,7 @@ int fl_fill_ghosts(fl_poisson *h, double *v)
 // fdapply.c:71, cnlinearcart3d.c:893-894).  begin: the boundary layers of r - alpha q are packed on the handle's stream BEFORE
 // k_cg_B forms the new r; a second stream waits for the pack, runs the transfers and writes the ghost layers, which k_cg_B neither
 // reads nor writes.  end: the handle's stream waits for the ghosts (and fills the locally wrapped axes) before k_cg_A needs them.
-int fl_exchange_r_begin(fl_poisson *h, double *r, const double *q)  // q == NULL: q is formed from the current direction (k_cg_Bq's way)
+int fl_exchange_r_begin(fl_poisson *h, double *r, const double *q)  // q: valid on the boundary layers of the block at least (PlanA::qb)
 {
   if (!h->multi) return 0;
   if (h->comm.kind == Comm::NONE) return FL_ERR_ARG_WRONGSTATE;
@@ -652,10 +652,7 @@ int fl_exchange_r_begin(fl_poisson *h, double *r, const double *q)  // q == NULL
   std::vector<Msg> msgs;
   double          *sbuf[6], *rbuf[6];
   FL_CHK(halo_messages(h, msgs, sbuf, rbuf));
-  if (!msgs.empty()) {
-    if (q) launch_pack_faces_rq(h->stream, h->g, r, q, h->scal, sbuf);
-    else launch_pack_faces_rp(h->stream, h->g, r, h->P0, h->P1, h->scal, sbuf);
-  }
+  if (!msgs.empty()) launch_pack_faces_rq(h->stream, h->g, r, q, h->scal, sbuf);
   FL_HIP(hipEventRecord(h->ev_packed, h->stream));
   FL_HIP(hipStreamWaitEvent(h->comm_stream, h->ev_packed, 0));
   FL_CHK(h->comm.exchange(h->comm_stream, msgs));
@@ -861,6 +858,11 @@ static int solve_cg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts
   const bool storeq = variant != 0;  // variants 1 and 2 keep q in memory and update r with k_cg_B
   PlanA       plan = plan_cg_A(g, 0, 0);
   plan.sq          = storeq ? 1 : 0;
+  static const int qb_env = []() {
+    const char *e = std::getenv("FLUCA_CG_QB");  // experiments (only with FLUCA_OVERLAP=0): 0 = k_cg_A stores no q at all
+    return e ? std::atoi(e) : 1;
+  }();
+  plan.qb          = (!storeq && h->multi && qb_env) ? 1 : 0;  // several ranks: q of the boundary layers is kept for the overlapped exchange of r
   static const int bq_chunks_env = []() {
     const char *e = std::getenv("FLUCA_CGBQ_CHUNKS");  // experiments: z chunks of k_cg_Bq (default: those of k_cg_A)
     return e ? std::atoi(e) : 0;
@@ -960,7 +962,7 @@ static int solve_cg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts
       // iteration only), or one per iteration with FLUCA_CG_XBATCH=0
       const int  xmode   = xbatch_env ? ((it & 1) ? (it == 1 ? 3 : 2) : 0) : 1;
       const bool overlap = ghosts && variant != 1 && h->multi && overlap_env;
-      if (overlap) FL_CHK(fl_exchange_r_begin(h, h->r, storeq ? h->q : nullptr));
+      if (overlap) FL_CHK(fl_exchange_r_begin(h, h->r, h->q));
       if (prof) FL_HIP(hipEventRecord(pev[pi + 2], s));
       if (storeq) launch_cg_B(s, g, jac, planB, h->q, h->r, h->scal, h->partial, h->partial_stride, (fusedfin || fusedsum) ? h->tickets + 1 : nullptr, h->hist, nhist, fusedsum ? h->sums : nullptr);
       else launch_cg_Bq(s, g, jac, planB, xmode, h->P0, h->P1, h->r, h->xp, h->scal, h->partial, h->partial_stride, (fusedfin || fusedsum) ? h->tickets + 1 : nullptr, h->hist, nhist, fusedsum ? h->sums : nullptr);

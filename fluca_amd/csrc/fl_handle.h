@@ -30,7 +30,6 @@ void launch_unpack(hipStream_t, const GridP &, double *, const double *, int, in
 void launch_pack_faces(hipStream_t, const GridP &, const double *, double *const bufs[6]);
 void launch_unpack_faces(hipStream_t, const GridP &, double *, double *const bufs[6]);
 void launch_pack_faces_rq(hipStream_t, const GridP &, const double *, const double *, const KspScal *, double *const bufs[6]);
-void launch_pack_faces_rp(hipStream_t, const GridP &, const double *r, const double *P0, const double *P1, const KspScal *, double *const bufs[6]);
 void launch_apply(hipStream_t, const GridP &, const double *, double *, int);
 void launch_diagonal(hipStream_t, const GridP &, double *);
 void launch_rhs(hipStream_t, const GridP &, const double *, const double *, const double *, const double *, const double *, const double *, const double *, double *);
@@ -47,7 +46,7 @@ void launch_cg_init(hipStream_t, const GridP &, bool, const double *, double *, 
 void launch_cg_finish(hipStream_t, const GridP &, const double *, const double *, const double *, double *, const KspScal *, int);
 struct PlanA {
   int ry, nw, tiles_x, tiles_y, nchunk, zc, nblocks, pf, nt, remap, probe;
-  int sq;  // keep in step with the definition in fl_kernels.hip
+  int sq, qb;  // keep in step with the definition in fl_kernels.hip
 };
 PlanA plan_tiles(const GridP &, int ry, int nw, int nchunk_force, int target_blocks, int min_zc = 8);
 PlanA plan_cg_A(const GridP &, int, int);

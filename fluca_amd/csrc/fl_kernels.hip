@@ -146,27 +146,6 @@ __global__ void k_pack_faces_rq(GridP g, const double *__restrict__ r, const dou
   const int64_t p = axis == 0 ? pidx(g, c, a, b) : (axis == 1 ? pidx(g, a, c, b) : pidx(g, a, b, c));
   buf[(int64_t)b * na + a] = s->reason != 0 ? r[p] : fma(-alpha, q[p], r[p]);
 }
-// the same when k_cg_A does not store q (k_cg_Bq): q = S p' of the boundary cell from the direction k_cg_A wrote, through st7 like k_cg_Bq
-__global__ void k_pack_faces_rp(GridP g, const double *__restrict__ r, const double *__restrict__ P0, const double *__restrict__ P1, const KspScal *__restrict__ s, FaceBufs fb)
-{
-  const int bnd = blockIdx.z, axis = bnd / 2, side = bnd % 2;
-  double   *buf = fb.buf[bnd];
-  if (!buf) return;
-  const int a = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y * 4 + threadIdx.y;
-  const int na = axis == 0 ? g.ny : g.nx, nb = axis == 2 ? g.ny : g.nz;
-  if (a >= na || b >= nb) return;
-  const int n = axis == 0 ? g.nx : (axis == 1 ? g.ny : g.nz), c = side ? n - 1 : 0;
-  const int i = axis == 0 ? c : a, j = axis == 0 ? a : (axis == 1 ? c : b), k = axis == 2 ? c : b;
-  const int64_t o = pidx(g, i, j, k);
-  double        v = r[o];
-  if (s->reason == 0) {
-    const double *p  = s->cur ? P1 : P0;
-    const double  q  = st7(g.sc[0][i] + (g.sc[1][j] + g.sc[2][k]), p[o], g.sl[0][i], p[o - 1], g.sh[0][i], p[o + 1], g.sl[1][j], p[o - g.sx], g.sh[1][j], p[o + g.sx], g.sl[2][k], p[o - g.sxy],
-                           g.sh[2][k], p[o + g.sxy]);
-    v = fma(-s->alpha, q, v);
-  }
-  buf[(int64_t)b * na + a] = v;
-}
 __global__ void k_unpack_faces(GridP g, double *__restrict__ v, FaceBufs fb)
 {
   const int     bnd = blockIdx.z, axis = bnd / 2, side = bnd % 2;
@@ -682,7 +661,8 @@ __device__ __forceinline__ void cg_A_body(const GridP &g, const double *__restri
   const double  zs         = s->zshift;
   const double  alpha_prev = s->alpha;  // 0 on the first iteration (and p_old = 0): the deferred x-update is a no-op then
 
-  const int b     = remap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+  const bool qbnd = !SQ && (remap & 2) != 0;  // store q on the block's boundary layers only (PlanA::qb)
+  const int  b    = (remap & 1) ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
   const int chunk = b / tiles, tile = b % tiles;  // chunk-major: consecutive logical blocks are neighbouring tiles
   const int i0 = (tile % tiles_x) * TX, j0 = (tile / tiles_x) * TY;
   const int k0 = chunk * zc, k1 = min(k0 + zc, g.nz);  // plan_tiles guarantees k0 < k1 for every block
@@ -850,6 +830,17 @@ __device__ __forceinline__ void cg_A_body(const GridP &g, const double *__restri
           } else if (own0) {
             if (SQ) q[RO(m) + pc] = qq.x;
             dot += cen.x * qq.x;
+          }
+          if (qbnd) {
+            // the first / last plane and row of the block entirely, of the other rows the first and the last cell
+            const int j = jb + m;
+            if (kc == 0 || kc == g.nz - 1 || j == 0 || j == g.ny - 1) {
+              if (own1) st2<0>(q + RO(m) + pc, qq);
+              else if (own0) q[RO(m) + pc] = qq.x;
+            } else {
+              if (own0 && (i == 0 || i == g.nx - 1)) q[RO(m) + pc] = qq.x;
+              if (own1 && i + 1 == g.nx - 1) q[RO(m) + pc + 1] = qq.y;
+            }
           }
         }
       }
@@ -1260,13 +1251,6 @@ void launch_pack_faces_rq(hipStream_t st, const GridP &g, const double *r, const
   dim3      grid((na + 63) / 64, (nb + 3) / 4, 6);
   hipLaunchKernelGGL(k_pack_faces_rq, grid, dim3(64, 4), 0, st, g, r, q, s, fb);
 }
-void launch_pack_faces_rp(hipStream_t st, const GridP &g, const double *r, const double *P0, const double *P1, const KspScal *s, double *const bufs[6])
-{
-  FaceBufs fb;
-  for (int a = 0; a < 6; ++a) fb.buf[a] = bufs[a];
-  const int na = std::max(g.nx, g.ny), nb = std::max(g.ny, g.nz);
-  hipLaunchKernelGGL(k_pack_faces_rp, dim3((na + 63) / 64, (nb + 3) / 4, 6), dim3(64, 4, 1), 0, st, g, r, P0, P1, s, fb);
-}
 void launch_unpack_faces(hipStream_t st, const GridP &g, double *v, double *const bufs[6])
 {
   FaceBufs fb;
@@ -1337,6 +1321,7 @@ void launch_cg_finish(hipStream_t st, const GridP &g, const double *P0, const do
 struct PlanA {
   int ry, nw, tiles_x, tiles_y, nchunk, zc, nblocks, pf, nt, remap, probe;
   int sq;  // 1: k_cg_A stores q (k_cg_B reads it back); 0: q is formed again by k_cg_Bq (the default of the solver)
+  int qb;  // sq == 0 only: k_cg_A still stores q on the six boundary layers of the block (the overlapped halo exchange packs r - alpha q there)
 };
 // tiling of k_cg_A / k_cg_B (K_B always runs 4-wave blocks: it reuses ry, nchunk, zc with nw = 4)
 PlanA plan_tiles(const GridP &g, int ry, int nw, int nchunk_force, int target_blocks, int min_zc = 8)
@@ -1349,6 +1334,7 @@ PlanA plan_tiles(const GridP &g, int ry, int nw, int nchunk_force, int target_bl
   p.remap   = 1;
   p.probe   = 0;
   p.sq      = 0;
+  p.qb      = 0;
   p.tiles_x = (g.nx + 127) / 128;
   p.tiles_y = (g.ny + nw * ry - 1) / (nw * ry);
   const int tiles = p.tiles_x * p.tiles_y;
@@ -1411,13 +1397,14 @@ template <int RY, int NW, int PF, int NT, bool SQ>
 static void launch_cg_A_q(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const double *r, double *P0, double *P1, double *q, double *x, KspScal *s, double *partial, const FinCtx &fin)
 {
   const int  tiles = p.tiles_x * p.tiles_y;
+  const int  rq    = (p.remap ? 1 : 0) | (p.qb ? 2 : 0);  // bit 0: XCD-contiguous block order, bit 1: q on the boundary layers
   const dim3 gr(p.nblocks), bl(64 * NW);
   if (p.probe) {
-    if (jac) hipLaunchKernelGGL((k_cg_A_probe<RY, NW, true, PF, NT, SQ>), gr, bl, 0, st, g, r, P0, P1, q, x, s, partial, p.nchunk, p.zc, p.tiles_x, tiles, p.remap, fin);
-    else hipLaunchKernelGGL((k_cg_A_probe<RY, NW, false, PF, NT, SQ>), gr, bl, 0, st, g, r, P0, P1, q, x, s, partial, p.nchunk, p.zc, p.tiles_x, tiles, p.remap, fin);
+    if (jac) hipLaunchKernelGGL((k_cg_A_probe<RY, NW, true, PF, NT, SQ>), gr, bl, 0, st, g, r, P0, P1, q, x, s, partial, p.nchunk, p.zc, p.tiles_x, tiles, rq, fin);
+    else hipLaunchKernelGGL((k_cg_A_probe<RY, NW, false, PF, NT, SQ>), gr, bl, 0, st, g, r, P0, P1, q, x, s, partial, p.nchunk, p.zc, p.tiles_x, tiles, rq, fin);
   } else {
-    if (jac) hipLaunchKernelGGL((k_cg_A<RY, NW, true, PF, NT, SQ>), gr, bl, 0, st, g, r, P0, P1, q, x, s, partial, p.nchunk, p.zc, p.tiles_x, tiles, p.remap, fin);
-    else hipLaunchKernelGGL((k_cg_A<RY, NW, false, PF, NT, SQ>), gr, bl, 0, st, g, r, P0, P1, q, x, s, partial, p.nchunk, p.zc, p.tiles_x, tiles, p.remap, fin);
+    if (jac) hipLaunchKernelGGL((k_cg_A<RY, NW, true, PF, NT, SQ>), gr, bl, 0, st, g, r, P0, P1, q, x, s, partial, p.nchunk, p.zc, p.tiles_x, tiles, rq, fin);
+    else hipLaunchKernelGGL((k_cg_A<RY, NW, false, PF, NT, SQ>), gr, bl, 0, st, g, r, P0, P1, q, x, s, partial, p.nchunk, p.zc, p.tiles_x, tiles, rq, fin);
   }
 }
 template <int RY, int NW, int PF, int NT>
