@@ -1011,7 +1011,7 @@ __device__ __forceinline__ void cg_Bq_body(const GridP &g, const double *__restr
         const double  q0 = st7(xc0 + dyc, cen.x, xl0, west, xh0, cen.y, yl[m], south.x, yh[m], north.x, zlc, below.x, zhc, C.p[m].x);
         const double  q1 = st7(xc1 + dyc, cen.y, xl1, cen.x, xh1, east, yl[m], south.y, yh[m], north.y, zlc, below.y, zhc, C.p[m].y);
         double2       rn;
-        rn.x = fma(-alpha, q0, C.r[m].x);  // the same rounding as k_pack_faces_rp
+        rn.x = fma(-alpha, q0, C.r[m].x);  // the same rounding as k_pack_faces_rq
         rn.y = fma(-alpha, q1, C.r[m].y);
         const double z0 = JAC ? rn.x / (xc0 + dyc) : rn.x;
         const double z1 = JAC ? rn.y / (xc1 + dyc) : rn.y;
