@@ -50,6 +50,20 @@ def test_two_ranks_through_the_driver_launch_line():
     assert [r["rank"] for r in d["ranks"]] == [0, 1] and d["transport_ranks"] == 2
 
 
+def test_strong_scaling_option_splits_one_grid():
+    """--scaling strong: ONE --cells^3 grid over the ranks (the other reading of BASELINE.json's '512^3 grid at 1/2/4/8 GPUs')."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--cells", "32", "--skip-cpu", "--transport", "host", "--scaling", "strong"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stdout + out.stderr
+    d = _line(out)
+    assert d["scaling"] == "strong" and d["config"]["cells_per_gpu"] == 32 * 32 * 16 and d["config"]["workload"].startswith("32x32x32")
+    assert d["value"] > 0
+
+
 def test_two_ranks_without_rccl_fail_instead_of_falling_back():
     """One GPU, two ranks, production transport: RCCL cannot give both ranks the device, so the run must exit non-zero and print
     no JSON line (a silently host-staged scaling curve would be worthless)."""
