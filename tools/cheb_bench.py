@@ -19,7 +19,7 @@ x = P.empty()
 ref = None
 for mode in (0, 2, 0, 2):
     capi.check(capi.lib.fl_tuning_set(b"cheb_fuse", mode))
-    kw = dict(type=2, norm_type=3, remove_nullspace=0, maxit=steps, check_every=steps)
+    kw = dict(type=2, norm_type=3, remove_nullspace=0, maxit=steps, check_every=steps, pc=int(os.environ.get("CHEB_PC", "1")))
     P.solve(b, x=x, **{**kw, "maxit": 10})
     torch.cuda.synchronize()
     _, info = P.solve(b, x=x, **kw)
