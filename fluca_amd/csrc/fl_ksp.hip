@@ -248,11 +248,13 @@ __global__ void __launch_bounds__(256) k_bcgs_pw(GridP g, const double *__restri
 // convergence test are k_bcgs_fin's, unchanged.
 template <int MODE>
 struct BcgsIo {
-  static constexpr int NE = MODE == 4 ? 3 : (MODE == 3 ? 0 : 1);  // extra per-cell input streams (plane of the product)
+  static constexpr int NE = MODE == 4 ? 3 : (MODE == 3 ? 0 : (MODE == 6 ? 2 : 1));  // extra per-cell input streams (plane of the product)
 };
+//   MODE 6  (Chebyshev, one step: KSPCHEBYSHEV + PCJACOBI, the recurrence of k_cheb)  z = M (b - S x), x staged; d = rho d + c z (in place);
+//           x' = x + d into the other x buffer; sums 0 sum z, 1 z.z, 2 r.r                              reads x,b,d  writes x',d          40
 template <int RY, int NW, bool JAC, int MODE>
-__global__ void __launch_bounds__(64 * NW, 2) k_bcgs_st(GridP g, const double *__restrict__ stg, const double *e0, const double *e1, const double *e2, double *w0, double *w1 /* MODE 4: e1 == w0 (X) */,
-                                                        const KspScal *__restrict__ s, double *__restrict__ partial, int stride, int nchunk, int zc, int tiles_x, int tiles, int remap)
+__device__ __forceinline__ void st_body(const GridP &g, const double *__restrict__ stg, const double *e0, const double *e1, const double *e2, double *w0, double *w1 /* MODE 4: e1 == w0 (X); MODE 6: e1 == w1 (d) */,
+                                        const KspScal *__restrict__ s, double *__restrict__ partial, int stride, int nchunk, int zc, int tiles_x, int tiles, int remap)
 {
   using T               = TileA<RY, NW>;
   constexpr int TX = T::TX, TY = T::TY, LX = T::LX, LY = T::LY;
@@ -261,6 +263,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_bcgs_st(GridP g, const double *_
   __shared__ double                              red[4 * NW];
   if (s->reason != 0) return;
   const double alpha = s->alpha, omega = s->omega, beta = s->beta, ob = s->omega_old * s->beta, vsh = s->vshift, ssh = s->rshift, tsh = s->tshift;
+  const double crho = s->cheb_rho, cc = s->cheb_c;
 
   const int b     = remap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
   const int chunk = b / tiles, tile = b % tiles;
@@ -347,7 +350,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_bcgs_st(GridP g, const double *_
         double2       y;  // the product M S (staged vector) of this pair of cells
         y.x = st7(xc0 + dyc, cen.x, xl0, west, xh0, cen.y, yl[m], south.x, yh[m], north.x, zlc, below.x, zhc, C.v[m].x);
         y.y = st7(xc1 + dyc, cen.y, xl1, cen.x, xh1, east, yl[m], south.y, yh[m], north.y, zlc, below.y, zhc, C.v[m].y);
-        if (JAC) {
+        if (JAC && MODE != 6) {
           y.x /= (xc0 + dyc);
           y.y /= (xc1 + dyc);
         }
@@ -385,6 +388,20 @@ __global__ void __launch_bounds__(64 * NW, 2) k_bcgs_st(GridP g, const double *_
           acc[0] += (o0 ? rn.x * rn.x : 0.) + (o1 ? rn.y * rn.y : 0.);
           acc[1] += (o0 ? rn.x * RP.x : 0.) + (o1 ? rn.y * RP.y : 0.);
           acc[2] += (o0 ? rn.x : 0.) + (o1 ? rn.y : 0.);
+        } else if (MODE == 6) {
+          const double2 bv = C.e[0][m], dv = C.e[NE >= 2 ? 1 : 0][m];
+          const double  r0 = bv.x - y.x, r1 = bv.y - y.y;  // y = S x here (not preconditioned)
+          const double  z0 = JAC ? r0 / (xc0 + dyc) : r0, z1 = JAC ? r1 / (xc1 + dyc) : r1;
+          double2       dn, xo;
+          dn.x = (crho != 0. ? crho * dv.x : 0.) + cc * z0;  // first step: d is not looked at (it may hold anything)
+          dn.y = (crho != 0. ? crho * dv.y : 0.) + cc * z1;
+          xo.x = cen.x + dn.x;
+          xo.y = cen.y + dn.y;
+          put(w1, dn);
+          put(w0, xo);
+          acc[0] += (o0 ? z0 : 0.) + (o1 ? z1 : 0.);
+          acc[1] += (o0 ? z0 * z0 : 0.) + (o1 ? z1 * z1 : 0.);
+          acc[2] += (o0 ? r0 * r0 : 0.) + (o1 ? r1 * r1 : 0.);
         } else {  // MODE 5
           const double2 R = C.e[0][m];
           double2       o;
@@ -425,6 +442,24 @@ __global__ void __launch_bounds__(64 * NW, 2) k_bcgs_st(GridP g, const double *_
     for (int q = 0; q < NW; ++q) t += red[tid * NW + q];
     partial[(int64_t)tid * stride + blockIdx.x] = t;
   }
+}
+template <int RY, int NW, bool JAC, int MODE>
+__global__ void __launch_bounds__(64 * NW, 2) k_bcgs_st(GridP g, const double *__restrict__ stg, const double *e0, const double *e1, const double *e2, double *w0, double *w1, const KspScal *__restrict__ s,
+                                                        double *__restrict__ partial, int stride, int nchunk, int zc, int tiles_x, int tiles, int remap)
+{
+  st_body<RY, NW, JAC, MODE>(g, stg, e0, e1, e2, w0, w1, s, partial, stride, nchunk, zc, tiles_x, tiles, remap);
+}
+// One Chebyshev(-Jacobi) step on the LDS-staged walk (MODE 6): the buffers are picked on the device like in k_cheb (cur / dcur flip in the
+// scalar kernels, the host enqueues steps without waiting)
+template <int RY, int NW, bool JAC>
+__global__ void __launch_bounds__(64 * NW, 2) k_cheb_st(GridP g, const double *X0, const double *X1, double *X0w, double *X1w, const double *__restrict__ b, double *D0, double *D1, const KspScal *__restrict__ s,
+                                                        double *__restrict__ partial, int stride, int nchunk, int zc, int tiles_x, int tiles, int remap)
+{
+  if (s->reason != 0) return;
+  const double *x  = s->cur ? X1 : X0;
+  double       *xn = s->cur ? X0w : X1w;
+  double       *d  = s->dcur ? D1 : D0;
+  st_body<RY, NW, JAC, 6>(g, x, b, d, nullptr, xn, d, s, partial, stride, nchunk, zc, tiles_x, tiles, remap);
 }
 
 // BiCGStab scalar updates.  mode: 0 init (after OP 3)  1 after V0 = M S P   2 after S0   3 after T0 = M S S0   4 after OP 2
@@ -798,8 +833,37 @@ void cheb_t(fl_poisson *h, const TP &tp, double *X0, double *X1, const double *B
 {
   hipLaunchKernelGGL((k_cheb<RY, JAC>), dim3(tp.nblocks), dim3(256), 0, h->stream, h->g, X0, X1, X0, X1, B, D0, D1, h->scal, h->partial, h->partial_stride, tp.nchunk, tp.zc, tp.tiles_x);
 }
-void launch_cheb(fl_poisson *h, const TP &tp, bool jac, double *X0, double *X1, const double *B, double *D0, double *D1)
+template <int RY, int NW>
+void cheb_st_t(fl_poisson *h, const PlanA &p, bool jac, double *X0, double *X1, const double *B, double *D0, double *D1)
 {
+  const int  tiles = p.tiles_x * p.tiles_y;
+  const dim3 gr(p.nblocks), bl(64 * NW);
+  if (jac) hipLaunchKernelGGL((k_cheb_st<RY, NW, true>), gr, bl, 0, h->stream, h->g, X0, X1, X0, X1, B, D0, D1, h->scal, h->partial, h->partial_stride, p.nchunk, p.zc, p.tiles_x, tiles, p.remap);
+  else hipLaunchKernelGGL((k_cheb_st<RY, NW, false>), gr, bl, 0, h->stream, h->g, X0, X1, X0, X1, B, D0, D1, h->scal, h->partial, h->partial_stride, p.nchunk, p.zc, p.tiles_x, tiles, p.remap);
+}
+// "cheb_staged" (initial value from FLUCA_CHEB_STAGED): 1 (default) the one-step kernel on the LDS-staged walk (k_cheb_st), 0 round 1's k_cheb
+int &cheb_staged_mode()
+{
+  static int m = []() {
+    const char *e = std::getenv("FLUCA_CHEB_STAGED");
+    return e ? std::atoi(e) : 1;
+  }();
+  return m;
+}
+// one Chebyshev step; returns the number of blocks whose partial sums the scalar kernel has to add up
+int launch_cheb(fl_poisson *h, const TP &tp, bool jac, double *X0, double *X1, const double *B, double *D0, double *D1)
+{
+  if (cheb_staged_mode() != 0) {
+    const PlanA pa = plan_cg_A(h->g, 0, 0);
+    if (pa.nblocks <= h->partial_stride) {
+      switch (pa.ry * 10 + pa.nw) {
+      case 28: cheb_st_t<2, 8>(h, pa, jac, X0, X1, B, D0, D1); break;
+      case 24: cheb_st_t<2, 4>(h, pa, jac, X0, X1, B, D0, D1); break;
+      default: cheb_st_t<1, 4>(h, pa, jac, X0, X1, B, D0, D1); break;
+      }
+      return pa.nblocks;
+    }
+  }
   if (jac) {
     if (tp.ry == 2) cheb_t<2, true>(h, tp, X0, X1, B, D0, D1);
     else cheb_t<1, true>(h, tp, X0, X1, B, D0, D1);
@@ -807,6 +871,7 @@ void launch_cheb(fl_poisson *h, const TP &tp, bool jac, double *X0, double *X1, 
     if (tp.ry == 2) cheb_t<2, false>(h, tp, X0, X1, B, D0, D1);
     else cheb_t<1, false>(h, tp, X0, X1, B, D0, D1);
   }
+  return tp.nblocks;
 }
 
 // "cheb_fuse" (fl_tuning_set; initial value from FLUCA_CHEB_FUSE): 0 never use the fused two-step kernel, 1 (default) where it
@@ -895,6 +960,10 @@ extern "C" int fl_tuning_set(const char *name, int value)
     fl_cg_xbatch_mode() = value;
     return FL_SUCCESS;
   }
+  if (std::strcmp(name, "cheb_staged") == 0) {
+    cheb_staged_mode() = value;
+    return FL_SUCCESS;
+  }
   return FL_ERR_ARG_WRONG;
 }
 extern "C" int fl_tuning_get(const char *name, int *value)
@@ -906,6 +975,10 @@ extern "C" int fl_tuning_get(const char *name, int *value)
   }
   if (std::strcmp(name, "cg_xbatch") == 0) {
     *value = fl_cg_xbatch_mode();
+    return FL_SUCCESS;
+  }
+  if (std::strcmp(name, "cheb_staged") == 0) {
+    *value = cheb_staged_mode();
     return FL_SUCCESS;
   }
   if (std::strcmp(name, "placement") == 0) {
@@ -1019,8 +1092,8 @@ int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero)
       j += 2;
     } else {
       if (ghosts) FL_CHK(fl_fill_ghosts(h, cur ? X1 : X0));
-      launch_cheb(h, tp, jac, X0, X1, B, D0, D1);
-      FL_CHK(fin_step(h, tp.nblocks, 3, finl));
+      const int nbc = launch_cheb(h, tp, jac, X0, X1, B, D0, D1);
+      FL_CHK(fin_step(h, nbc, 3, finl));
       j += 1;
     }
     cur ^= 1;
@@ -1241,9 +1314,9 @@ int fl_solve_cheb(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *
         if (ghosts && j > 0) FL_CHK(fl_fill_ghosts(h, hostcur ? X1 : X0));
         const bool pr = !fuse && (size_t)(2 * nprof + 1) < prof.ev.size();
         if (pr) FL_HIP(hipEventRecord(prof.ev[2 * nprof], s));
-        launch_cheb(h, tp, jac, X0, X1, B, D0, D1);
+        const int nbc = launch_cheb(h, tp, jac, X0, X1, B, D0, D1);
         if (pr) FL_HIP(hipEventRecord(prof.ev[2 * nprof++ + 1], s));
-        FL_CHK(fin_step(h, tp.nblocks, 3, finl));
+        FL_CHK(fin_step(h, nbc, 3, finl));
         j += 1;
       }
       hostcur ^= 1;

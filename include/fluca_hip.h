@@ -169,6 +169,7 @@ int fl_vec_maxpy(fl_poisson *h, int64_t n, double *x_dev, const double *alphas, 
  *                (see fl_poisson_tune_placement); 0 = one plain allocation per vector.
  *   "cg_xbatch"  1 (default) = the CG solver updates x every second iteration (both updates of the pair at once, while the older
  *                direction is still in its buffer); 0 = one update per iteration.  The same x bit for bit.
+ *   "cheb_staged" 1 (default) = the one-step Chebyshev kernel walks LDS-staged tiles like the CG kernels (k_cheb_st); 0 = round 1's k_cheb.
  * Returns FL_ERR_ARG_WRONG for an unknown name.  Process-wide; set before the solve it should affect. */
 int fl_tuning_set(const char *name, int value);
 int fl_tuning_get(const char *name, int *value);
