@@ -248,8 +248,9 @@ __global__ void __launch_bounds__(256) k_bcgs_pw(GridP g, const double *__restri
 // convergence test are k_bcgs_fin's, unchanged.
 template <int MODE>
 struct BcgsIo {
-  static constexpr int NE = MODE == 4 ? 3 : (MODE == 3 ? 0 : (MODE == 6 ? 2 : 1));  // extra per-cell input streams (plane of the product)
+  static constexpr int NE = MODE == 4 ? 3 : ((MODE == 3 || MODE == 7) ? 0 : (MODE == 6 ? 2 : 1));  // extra per-cell input streams (plane of the product)
 };
+//   MODE 7  y = S x (padded), sums 0 sum y, 2 x.y, 3 y.y          MODE 8  r = o - S x (padded), no sums          (multigrid cycle, JAC = false)
 //   MODE 6  (Chebyshev, one step: KSPCHEBYSHEV + PCJACOBI, the recurrence of k_cheb)  z = M (b - S x), x staged; d = rho d + c z (in place);
 //           x' = x + d into the other x buffer; sums 0 sum z, 1 z.z, 2 r.r                              reads x,b,d  writes x',d          40
 template <int RY, int NW, bool JAC, int MODE>
@@ -261,9 +262,12 @@ __device__ __forceinline__ void st_body(const GridP &g, const double *__restrict
   constexpr int NE = BcgsIo<MODE>::NE;
   __shared__ __attribute__((aligned(16))) double lds[3][LY][LX];
   __shared__ double                              red[4 * NW];
-  if (s->reason != 0) return;
-  const double alpha = s->alpha, omega = s->omega, beta = s->beta, ob = s->omega_old * s->beta, vsh = s->vshift, ssh = s->rshift, tsh = s->tshift;
-  const double crho = s->cheb_rho, cc = s->cheb_c;
+  double alpha = 0., omega = 0., beta = 0., ob = 0., vsh = 0., ssh = 0., tsh = 0., crho = 0., cc = 0.;
+  if (MODE < 7) {  // MODE 7 / 8 (plain products for the multigrid cycle) run without a scalar block
+    if (s->reason != 0) return;
+    alpha = s->alpha; omega = s->omega; beta = s->beta; ob = s->omega_old * s->beta; vsh = s->vshift; ssh = s->rshift; tsh = s->tshift;
+    crho = s->cheb_rho; cc = s->cheb_c;
+  }
 
   const int b     = remap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
   const int chunk = b / tiles, tile = b % tiles;
@@ -388,6 +392,14 @@ __device__ __forceinline__ void st_body(const GridP &g, const double *__restrict
           acc[0] += (o0 ? rn.x * rn.x : 0.) + (o1 ? rn.y * rn.y : 0.);
           acc[1] += (o0 ? rn.x * RP.x : 0.) + (o1 ? rn.y * RP.y : 0.);
           acc[2] += (o0 ? rn.x : 0.) + (o1 ? rn.y : 0.);
+        } else if (MODE == 7) {
+          put(w0, y);
+          acc[0] += (o0 ? y.x : 0.) + (o1 ? y.y : 0.);
+          acc[2] += (o0 ? cen.x * y.x : 0.) + (o1 ? cen.y * y.y : 0.);
+          acc[3] += (o0 ? y.x * y.x : 0.) + (o1 ? y.y * y.y : 0.);
+        } else if (MODE == 8) {
+          const double2 ov = C.e[0][m];
+          put(w0, make_double2(ov.x - y.x, ov.y - y.y));
         } else if (MODE == 6) {
           const double2 bv = C.e[0][m], dv = C.e[NE >= 2 ? 1 : 0][m];
           const double  r0 = bv.x - y.x, r1 = bv.y - y.y;  // y = S x here (not preconditioned)
@@ -429,7 +441,7 @@ __device__ __forceinline__ void st_body(const GridP &g, const double *__restrict
     }
   }
 #undef RO
-  if (MODE == 5) return;  // no sums
+  if (MODE == 5 || MODE == 8) return;  // no sums
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     acc[a] = wave_sum(acc[a]);
@@ -1006,12 +1018,36 @@ int fl_residual(fl_poisson *h, const double *x, const double *b, double *r)
   return 0;
 }
 
+namespace {
+template <int RY, int NW, int MODE>
+void bcgs_st_t(fl_poisson *h, const PlanA &p, bool jac, const double *stg, const double *e0, const double *e1, const double *e2, double *w0, double *w1)
+{
+  const int  tiles = p.tiles_x * p.tiles_y;
+  const dim3 gr(p.nblocks), bl(64 * NW);
+  if (jac) hipLaunchKernelGGL((k_bcgs_st<RY, NW, true, MODE>), gr, bl, 0, h->stream, h->g, stg, e0, e1, e2, w0, w1, h->scal, h->partial, h->partial_stride, p.nchunk, p.zc, p.tiles_x, tiles, p.remap);
+  else hipLaunchKernelGGL((k_bcgs_st<RY, NW, false, MODE>), gr, bl, 0, h->stream, h->g, stg, e0, e1, e2, w0, w1, h->scal, h->partial, h->partial_stride, p.nchunk, p.zc, p.tiles_x, tiles, p.remap);
+}
+template <int MODE>
+void launch_bcgs_st(fl_poisson *h, const PlanA &p, bool jac, const double *stg, const double *e0, const double *e1, const double *e2, double *w0, double *w1)
+{
+  switch (p.ry * 10 + p.nw) {
+  case 28: bcgs_st_t<2, 8, MODE>(h, p, jac, stg, e0, e1, e2, w0, w1); break;
+  case 24: bcgs_st_t<2, 4, MODE>(h, p, jac, stg, e0, e1, e2, w0, w1); break;
+  default: bcgs_st_t<1, 4, MODE>(h, p, jac, stg, e0, e1, e2, w0, w1); break;
+  }
+}
+}  // namespace
+
 // ---- padded-vector entry points of the multigrid cycle (fl_mg.hip): no pad / unpad copies, no statistics ----------------
 
 // r = b - S x on padded vectors (x's ghosts are filled here)
 int fl_residual_padded(fl_poisson *h, double *xpad, const double *bpad, double *rpad)
 {
   FL_CHK(fl_fill_ghosts(h, xpad));
+  if (cheb_staged_mode() != 0) {
+    launch_bcgs_st<8>(h, plan_cg_A(h->g, 0, 0), false, xpad, bpad, nullptr, nullptr, rpad, nullptr);  // LDS-staged walk
+    return 0;
+  }
   const TP tp = tile_plan(h->g);
   launch_apply_pc(h, tp, false, xpad, rpad, bpad, nullptr, nullptr, 3);
   return 0;
@@ -1021,10 +1057,15 @@ int fl_residual_padded(fl_poisson *h, double *xpad, const double *bpad, double *
 int fl_apply_padded_dot(fl_poisson *h, double *xpad, double *ypad, double *xy)
 {
   FL_CHK(fl_fill_ghosts(h, xpad));
-  const TP tp = tile_plan(h->g);
-  FL_CHK(fl_ensure_partials(h, tp.nblocks));
-  launch_apply_pc(h, tp, false, xpad, ypad, nullptr, nullptr, h->partial, 0);
-  launch_reduce(h->stream, h->partial, tp.nblocks, h->partial_stride, 4, h->sums);
+  const TP    tp = tile_plan(h->g);
+  const PlanA pa = plan_cg_A(h->g, 0, 0);
+  FL_CHK(fl_ensure_partials(h, std::max(tp.nblocks, pa.nblocks)));
+  int nbl = tp.nblocks;
+  if (cheb_staged_mode() != 0) {
+    launch_bcgs_st<7>(h, pa, false, xpad, nullptr, nullptr, nullptr, ypad, nullptr);  // LDS-staged walk
+    nbl = pa.nblocks;
+  } else launch_apply_pc(h, tp, false, xpad, ypad, nullptr, nullptr, h->partial, 0);
+  launch_reduce(h->stream, h->partial, nbl, h->partial_stride, 4, h->sums);
   if (h->multi) FL_CHK(h->comm.allreduce(h->stream, h->sums, NSLOT));
   FL_HIP(hipMemcpyAsync(xy, h->sums + 2, sizeof(double), hipMemcpyDeviceToHost, h->stream));
   FL_HIP(hipStreamSynchronize(h->stream));
@@ -1102,25 +1143,6 @@ int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero)
   return 0;
 }
 
-namespace {
-template <int RY, int NW, int MODE>
-void bcgs_st_t(fl_poisson *h, const PlanA &p, bool jac, const double *stg, const double *e0, const double *e1, const double *e2, double *w0, double *w1)
-{
-  const int  tiles = p.tiles_x * p.tiles_y;
-  const dim3 gr(p.nblocks), bl(64 * NW);
-  if (jac) hipLaunchKernelGGL((k_bcgs_st<RY, NW, true, MODE>), gr, bl, 0, h->stream, h->g, stg, e0, e1, e2, w0, w1, h->scal, h->partial, h->partial_stride, p.nchunk, p.zc, p.tiles_x, tiles, p.remap);
-  else hipLaunchKernelGGL((k_bcgs_st<RY, NW, false, MODE>), gr, bl, 0, h->stream, h->g, stg, e0, e1, e2, w0, w1, h->scal, h->partial, h->partial_stride, p.nchunk, p.zc, p.tiles_x, tiles, p.remap);
-}
-template <int MODE>
-void launch_bcgs_st(fl_poisson *h, const PlanA &p, bool jac, const double *stg, const double *e0, const double *e1, const double *e2, double *w0, double *w1)
-{
-  switch (p.ry * 10 + p.nw) {
-  case 28: bcgs_st_t<2, 8, MODE>(h, p, jac, stg, e0, e1, e2, w0, w1); break;
-  case 24: bcgs_st_t<2, 4, MODE>(h, p, jac, stg, e0, e1, e2, w0, w1); break;
-  default: bcgs_st_t<1, 4, MODE>(h, p, jac, stg, e0, e1, e2, w0, w1); break;
-  }
-}
-}  // namespace
 
 int fl_solve_bcgs(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *o, fl_ksp_stats *st)
 {
