@@ -23,7 +23,8 @@
 namespace fl {
 
 struct MomP {
-  const double *tab[3];  // MOM_NTAB x len, slot-major, LOCAL block of each axis
+  const double *tab[3];   // MOM_NTAB x len, slot-major, LOCAL block of each axis
+  const double *stab[3];  // the same numbers times (cC, cL), cell-major (k_mom_scale_tab): what k_mom2 reads
   int           len[3];
   double        cI, cC, cL;
 };
@@ -396,6 +397,11 @@ __global__ void __launch_bounds__(MOM_NT, FL_MOM_WPE) k_mom_apply(GridP g, MomP 
   }
 }
 
+}  // namespace fl
+#include "fl_stencil.h"
+#include "fl_mom_tile.h"
+namespace fl {
+
 // BiCGStab vector updates on three-component padded vectors (interior cells only).
 // OP 0: P = R - (omega_old beta) V + beta P
 // OP 1: S = R - alpha V
@@ -444,6 +450,160 @@ __global__ void __launch_bounds__(256) k_mom_pw(GridP g, int64_t cs, const doubl
     if (threadIdx.x == 0)
 #pragma unroll
       for (int a = 0; a < 3; ++a) partial[(int64_t)a * pstride + blockIdx.x] = acc[a];
+  }
+}
+
+// The same four updates on 128-cell row segments, two x-adjacent cells per lane (16-byte accesses, non-temporal where a value is not read
+// again before it would be evicted anyway): one wave per segment, grid-stride over the segments of the block.  Padded rows start on
+// a 128-byte boundary (PADX), so every pair is 16-byte aligned; the unpadded b of OP 3 is read in pairs when nx is even (pairs != 0).
+template <int OP>
+__global__ void __launch_bounds__(256) k_mom_pw2(GridP g, int64_t cs, const double *__restrict__ a0, const double *__restrict__ a1, const double *__restrict__ a2, const double *__restrict__ a3, double *__restrict__ w0,
+                                                 double *__restrict__ w1, const KspScal *__restrict__ s, double *__restrict__ partial, int pstride, int pairs)
+{
+  __shared__ double red[3 * 4];
+  if (OP != 3 && s->reason != 0) return;
+  const double  alpha = s->alpha, omega = s->omega, beta = s->beta, ob = s->omega_old * s->beta;
+  const int     lane = threadIdx.x & 63, nxs = (g.nx + 127) / 128;
+  const int64_t nseg = (int64_t)nxs * g.ny * g.nz, ncell = (int64_t)g.nx * g.ny * g.nz;
+  double        acc[3] = {0., 0., 0.};
+  for (int64_t seg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); seg < nseg; seg += (int64_t)gridDim.x * 4) {
+    const int     xs = (int)(seg % nxs);
+    const int64_t R  = seg / nxs;
+    const int     j = (int)(R % g.ny), k = (int)(R / g.ny), i = xs * 128 + 2 * lane;
+    if (i >= g.nx) continue;
+    const bool    two = i + 1 < g.nx;
+    const int64_t idx = g.off0 + (int64_t)k * g.sxy + (int64_t)j * g.sx + i, ub = ((int64_t)k * g.ny + j) * g.nx + i;
+    auto          ldp = [&](const double *p, int64_t q) { return two ? ld2<1>(p + q) : make_double2(p[q], 0.); };
+    auto          ldk = [&](const double *p, int64_t q) { return two ? ld2<0>(p + q) : make_double2(p[q], 0.); };  // read again soon: keep it cached
+    auto          stp = [&](double *p, int64_t q, double2 v) {
+      if (two) st2<0>(p + q, v);
+      else p[q] = v.x;
+    };
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int64_t q = c * cs + idx;
+      if (OP == 0) {
+        const double2 r = ldk(a0, q), v = ldp(a1, q), p = ldp(w0, q);
+        stp(w0, q, make_double2(r.x - ob * v.x + beta * p.x, r.y - ob * v.y + beta * p.y));
+      } else if (OP == 1) {
+        const double2 r = ldp(a0, q), v = ldp(a1, q);
+        stp(w0, q, make_double2(r.x - alpha * v.x, r.y - alpha * v.y));
+      } else if (OP == 2) {
+        const double2 P = ldp(a0, q), S = ldp(a1, q), T = ldp(a2, q), RP = ldk(a3, q), X = ldp(w0, q);
+        const double2 rn = make_double2(S.x - omega * T.x, S.y - omega * T.y);
+        double2       xn = X;
+        xn.x += alpha * P.x + omega * S.x;
+        xn.y += alpha * P.y + omega * S.y;
+        if (two) st2<1>(w0 + q, xn);
+        else w0[q] = xn.x;
+        stp(w1, q, rn);
+        acc[0] += rn.x * rn.x + (two ? rn.y * rn.y : 0.);
+        acc[1] += rn.x * RP.x + (two ? rn.y * RP.y : 0.);
+        acc[2] += rn.x + (two ? rn.y : 0.);
+      } else {
+        const int64_t u = c * ncell + ub;
+        double2       b;
+        if (two && pairs) b = ld2<1>(a0 + u);
+        else b = make_double2(a0[u], two ? a0[u + 1] : 0.);
+        double2 r = b;
+        if (a1) {
+          const double2 d = ldp(a1, q);
+          r.x = b.x / d.x;
+          if (two) r.y = b.y / d.y;
+        }
+        stp(w0, q, r);
+        stp(w1, q, r);
+        acc[0] += r.x + (two ? r.y : 0.);
+        acc[1] += r.x * r.x + (two ? r.y * r.y : 0.);
+      }
+    }
+  }
+  if (OP == 2 || OP == 3) {
+    block_sum<3>(acc, red);
+    if (threadIdx.x == 0)
+#pragma unroll
+      for (int a = 0; a < 3; ++a) partial[(int64_t)a * pstride + blockIdx.x] = acc[a];
+  }
+}
+
+// The tile walk of k_mom2 for the vector updates (experiment FLUCA_MOM_PW=3): a block marches a 128 x 8 tile through a z chunk, blocks in
+// the XCD-contiguous order -- the access pattern at which the stencil kernels move 6 TB/s where the grid-stride form above moves 5.3.
+template <int OP>
+__global__ void __launch_bounds__(512) k_mom_pw3(GridP g, int64_t cs, const double *__restrict__ a0, const double *__restrict__ a1, const double *__restrict__ a2, const double *__restrict__ a3, double *__restrict__ w0,
+                                                 double *__restrict__ w1, const KspScal *__restrict__ s, double *__restrict__ partial, int pstride, int pairs, int tiles_x, int nchunk, int zc)
+{
+  __shared__ double red[3 * 8];
+  if (OP != 3 && s->reason != 0) return;
+  const double alpha = s->alpha, omega = s->omega, beta = s->beta, ob = s->omega_old * s->beta;
+  const int    nb = gridDim.x, tiles = nb / nchunk, b = xcd_remap(blockIdx.x, nb), chunk = b / tiles, tile = b % tiles;
+  const int    lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int    i = (tile % tiles_x) * 128 + 2 * lane, j = (tile / tiles_x) * 8 + w;
+  const int    k0 = chunk * zc, k1 = min(k0 + zc, g.nz);
+  const int64_t ncell = (int64_t)g.nx * g.ny * g.nz;
+  double       acc[3] = {0., 0., 0.};
+  if (i < g.nx && j < g.ny) {
+    const bool two = i + 1 < g.nx;
+    auto       ldp = [&](const double *p, int64_t q) { return two ? ld2<1>(p + q) : make_double2(p[q], 0.); };
+    auto       ldk = [&](const double *p, int64_t q) { return two ? ld2<0>(p + q) : make_double2(p[q], 0.); };
+    auto       stp = [&](double *p, int64_t q, double2 v) {
+      if (two) st2<0>(p + q, v);
+      else p[q] = v.x;
+    };
+    for (int k = k0; k < k1; ++k) {
+      const int64_t idx = g.off0 + (int64_t)k * g.sxy + (int64_t)j * g.sx + i, ub = ((int64_t)k * g.ny + j) * g.nx + i;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int64_t q = c * cs + idx;
+        if (OP == 0) {
+          const double2 r = ldk(a0, q), v = ldp(a1, q), p = ldp(w0, q);
+          stp(w0, q, make_double2(r.x - ob * v.x + beta * p.x, r.y - ob * v.y + beta * p.y));
+        } else if (OP == 1) {
+          const double2 r = ldp(a0, q), v = ldp(a1, q);
+          stp(w0, q, make_double2(r.x - alpha * v.x, r.y - alpha * v.y));
+        } else if (OP == 2) {
+          const double2 P = ldp(a0, q), S = ldp(a1, q), T = ldp(a2, q), RP = ldk(a3, q), X = ldp(w0, q);
+          const double2 rn = make_double2(S.x - omega * T.x, S.y - omega * T.y);
+          double2       xn = X;
+          xn.x += alpha * P.x + omega * S.x;
+          xn.y += alpha * P.y + omega * S.y;
+          if (two) st2<1>(w0 + q, xn);
+          else w0[q] = xn.x;
+          stp(w1, q, rn);
+          acc[0] += rn.x * rn.x + (two ? rn.y * rn.y : 0.);
+          acc[1] += rn.x * RP.x + (two ? rn.y * RP.y : 0.);
+          acc[2] += rn.x + (two ? rn.y : 0.);
+        } else {
+          const int64_t u = c * ncell + ub;
+          double2       bb;
+          if (two && pairs) bb = ld2<1>(a0 + u);
+          else bb = make_double2(a0[u], two ? a0[u + 1] : 0.);
+          double2 r = bb;
+          if (a1) {
+            const double2 d = ldp(a1, q);
+            r.x = bb.x / d.x;
+            if (two) r.y = bb.y / d.y;
+          }
+          stp(w0, q, r);
+          stp(w1, q, r);
+          acc[0] += r.x + (two ? r.y : 0.);
+          acc[1] += r.x * r.x + (two ? r.y * r.y : 0.);
+        }
+      }
+    }
+  }
+  if (OP == 2 || OP == 3) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const double v = wave_sum(acc[a]);
+      if (lane == 0) red[a * 8 + w] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+      double v = 0.;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v += red[threadIdx.x * 8 + q];
+      partial[(int64_t)threadIdx.x * pstride + blockIdx.x] = v;
+    }
   }
 }
 
@@ -559,6 +719,7 @@ struct fl_momentum {
   MomP        mp;
   FaceT       ft;
   void       *tabs[3] = {nullptr, nullptr, nullptr};
+  double     *stabs[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};  // scaled tables: [0] the handle's coefficients, [1] fl_momentum_rhs
   std::vector<void *> ttabs;
   double     *srhs = nullptr;  // Schur right-hand side of fl_abf_apply
   double     *tmpv = nullptr;  // 3*cells scratch of fl_abf_jacobian_mult
@@ -573,6 +734,8 @@ struct fl_momentum {
   bool        have_state = false;
   int         tiles_x = 1, tiles_y = 1, nchunk = 1, zc = 1, nblocks = 1;  // 64 x 4 x zc tiles of the vector-update kernels
   int         anchunk = 1, azc = 1, ablocks = 1;                        // 64 x MOM_RY x azc tiles of k_mom_apply
+  int         t2x = 1, t2chunk = 1, t2zc = 1, t2blocks = 1;             // 128 x 8 x t2zc tiles of k_mom2
+  int         pw2blocks = 1;                                            // k_mom_pw2: grid-stride over 128-cell row segments
 };
 
 namespace {
@@ -600,17 +763,78 @@ int mom_order()
   return o;
 }
 
-template <bool DOT, bool JAC, int OUT>
+int mom_kernel()
+{
+  static const int o = []() {
+    const char *e = std::getenv("FLUCA_MOM_KERNEL");  // 2 (default): k_mom2, two cells per lane on 128 x 8 tiles; 1: round 1/2's k_mom_apply (A/B runs)
+    return e ? std::atoi(e) : 2;
+  }();
+  return o;
+}
+int mom_nt()
+{
+  static const int o = []() {
+    const char *e = std::getenv("FLUCA_MOM_NT");  // non-temporal stores of k_mom2
+    return e ? std::atoi(e) : 1;
+  }();
+  return o;
+}
+
+// DOT: 0 no inner products, 1 sum y and y.o (slots 0, 1), 2 x.y and y.y (slots 2, 3), 3 all four (k_mom_apply always forms all four)
+template <int DOT, bool JAC, int OUT>
 void mom_apply_t(fl_momentum *m, const double *x, double *y, const double *o, const KspScal *s, const MomP *coeffs = nullptr)
 {
   fl_poisson *h = m->p;
-  hipLaunchKernelGGL((k_mom_apply<DOT, JAC, OUT>), dim3(m->ablocks), dim3(MOM_NT), 0, h->stream, h->g, coeffs ? *coeffs : m->mp, x, y, m->F, (int64_t)h->padlen, o, s, h->partial, h->partial_stride, m->tiles_x, m->anchunk, m->azc, mom_order());
+  if (mom_kernel() >= 2) {
+    int flags = mom_order() & 1;
+    if (OUT == 1 && (h->g.nx & 1) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0) flags |= 2;
+    if (mom_nt()) hipLaunchKernelGGL((k_mom2<8, DOT, JAC, OUT, 1>), dim3(m->t2blocks), dim3(512), 0, h->stream, h->g, coeffs ? *coeffs : m->mp, x, y, m->F, (int64_t)h->padlen, o, s, h->partial, h->partial_stride, m->t2x, m->t2chunk, m->t2zc, flags);
+    else hipLaunchKernelGGL((k_mom2<8, DOT, JAC, OUT, 0>), dim3(m->t2blocks), dim3(512), 0, h->stream, h->g, coeffs ? *coeffs : m->mp, x, y, m->F, (int64_t)h->padlen, o, s, h->partial, h->partial_stride, m->t2x, m->t2chunk, m->t2zc, flags);
+    return;
+  }
+  hipLaunchKernelGGL((k_mom_apply<(DOT != 0), JAC, OUT>), dim3(m->ablocks), dim3(MOM_NT), 0, h->stream, h->g, coeffs ? *coeffs : m->mp, x, y, m->F, (int64_t)h->padlen, o, s, h->partial, h->partial_stride, m->tiles_x, m->anchunk, m->azc, mom_order());
 }
+// the scaled, cell-major tables of k_mom2 for the coefficients in p (stream-ordered; slot 0: the handle's own, slot 1: a one-off operator)
+int mom_scale_tables(fl_momentum *m, int slot, MomP &p)
+{
+  fl_poisson *h = m->p;
+  for (int d = 0; d < 3; ++d) {
+    const int len = m->mp.len[d], n = len * MOM_STAB;
+    hipLaunchKernelGGL(k_mom_scale_tab, dim3((n + 255) / 256), dim3(256), 0, h->stream, (const double *)m->tabs[d], len, p.cC, p.cL, m->stabs[slot][d]);
+    p.stab[d] = m->stabs[slot][d];
+  }
+  FL_HIP(hipGetLastError());
+  return 0;
+}
+
+// blocks whose partial sums a DOT launch of the momentum operator leaves behind
+int mom_apply_blocks(const fl_momentum *m) { return mom_kernel() >= 2 ? m->t2blocks : m->ablocks; }
+
+int mom_pw_kernel()
+{
+  static const int o = []() {
+    const char *e = std::getenv("FLUCA_MOM_PW");  // 3 (default): k_mom_pw3, the tile walk; 2: k_mom_pw2, 16-byte row segments; 1: round 1's k_mom_pw (A/B runs)
+    return e ? std::atoi(e) : 3;
+  }();
+  return o;
+}
+// blocks of the vector-update kernels = entries of their partial sums
+int mom_pw_blocks(const fl_momentum *m) { return mom_pw_kernel() >= 3 ? m->t2blocks : (mom_pw_kernel() == 2 ? m->pw2blocks : m->nblocks); }
 
 template <int OP>
 void mom_pw(fl_momentum *m, const double *a0, const double *a1, const double *a2, const double *a3, double *w0, double *w1)
 {
   fl_poisson *h = m->p;
+  if (mom_pw_kernel() >= 3) {
+    const int pairs = (h->g.nx & 1) == 0 && (reinterpret_cast<uintptr_t>(a0) & 15) == 0;
+    hipLaunchKernelGGL((k_mom_pw3<OP>), dim3(m->t2blocks), dim3(512), 0, h->stream, h->g, (int64_t)h->padlen, a0, a1, a2, a3, w0, w1, h->scal, h->partial, h->partial_stride, pairs, m->t2x, m->t2chunk, m->t2zc);
+    return;
+  }
+  if (mom_pw_kernel() >= 2) {
+    const int pairs = (h->g.nx & 1) == 0 && (reinterpret_cast<uintptr_t>(a0) & 15) == 0;
+    hipLaunchKernelGGL((k_mom_pw2<OP>), dim3(m->pw2blocks), dim3(256), 0, h->stream, h->g, (int64_t)h->padlen, a0, a1, a2, a3, w0, w1, h->scal, h->partial, h->partial_stride, pairs);
+    return;
+  }
   hipLaunchKernelGGL((k_mom_pw<OP>), dim3(m->nblocks), dim3(256), 0, h->stream, h->g, (int64_t)h->padlen, a0, a1, a2, a3, w0, w1, h->scal, h->partial, h->partial_stride, m->tiles_x, m->nchunk, m->zc);
 }
 
@@ -632,6 +856,8 @@ int mom_init(fl_momentum *m, fl_poisson *h)
     FL_HIP(hipMemcpy(m->tabs[d], loc.data(), sizeof(double) * loc.size(), hipMemcpyHostToDevice));
     m->mp.tab[d] = (const double *)m->tabs[d];
     m->mp.len[d] = len[d];
+    for (int slot = 0; slot < 2; ++slot) FL_HIP(hipMalloc((void **)&m->stabs[slot][d], sizeof(double) * (size_t)MOM_STAB * len[d]));
+    m->mp.stab[d] = m->stabs[0][d];
     // interpolation rows of the owned faces
     const int nfl = d == 0 ? g.fx : (d == 1 ? g.fy : g.fz);
     for (int kind = 0; kind < 3; ++kind) {
@@ -689,7 +915,29 @@ int mom_init(fl_momentum *m, fl_poisson *h)
     m->ablocks = atiles * m->anchunk;
     if (m->ablocks > MAX_PARTIAL_BLOCKS) return FL_ERR_SUP;
   }
-  FL_CHK(fl_ensure_partials(h, std::max(m->nblocks, m->ablocks)));
+  {
+    // k_mom2: 128 x 8 tiles; about four blocks per CU in all (one is resident at a time: 158 KB of LDS) -- 512^3: 3.35 ms with 4 z chunks,
+    // 3.59 with 2, 3.50 with 8 (profiles/r03_mom_plan.txt)
+    m->t2x          = (g.nx + 127) / 128;
+    const int tiles = m->t2x * ((g.ny + 7) / 8);
+    int       nc    = std::max(1, (1024 + tiles / 2) / tiles);
+    nc              = std::max(1, std::min(std::min(nc, std::max(1, g.nz / 8)), g.nz));
+    if (const char *e = std::getenv("FLUCA_MOM_CHUNKS"))
+      if (std::atoi(e) > 0) nc = std::min(std::atoi(e), g.nz);
+    if (tiles * nc > MAX_PARTIAL_BLOCKS) nc = std::max(1, MAX_PARTIAL_BLOCKS / tiles);
+    m->t2zc     = (g.nz + nc - 1) / nc;
+    m->t2chunk  = (g.nz + m->t2zc - 1) / m->t2zc;
+    m->t2blocks = tiles * m->t2chunk;
+    if (m->t2blocks > MAX_PARTIAL_BLOCKS) return FL_ERR_SUP;
+  }
+  {
+    const int64_t nseg = (int64_t)((g.nx + 127) / 128) * g.ny * g.nz;
+    int           nb   = 2048;  // 8 blocks of 4 waves per CU
+    if (const char *e = std::getenv("FLUCA_MOM_PW_BLOCKS"))
+      if (std::atoi(e) > 0) nb = std::atoi(e);
+    m->pw2blocks = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((nseg + 3) / 4, nb), MAX_PARTIAL_BLOCKS));
+  }
+  FL_CHK(fl_ensure_partials(h, std::max(std::max(m->nblocks, m->ablocks), m->t2blocks)));
   FL_CHK(fl_dev_alloc(h, (void **)&m->F, sizeof(double) * 12 * h->padlen, true));
   FL_CHK(fl_dev_alloc(h, (void **)&m->dg, sizeof(double) * 3 * h->padlen, true));
   return fl_momentum_set_coefficients(m, 1., 0., 0.);  // A = I until the first set_state (also fills diag(A))
@@ -724,6 +972,9 @@ extern "C" int fl_momentum_destroy(fl_momentum *m)
     if (t) (void)hipFree(t);
   for (void *t : m->ttabs)
     if (t) (void)hipFree(t);
+  for (auto &sl : m->stabs)
+    for (double *t : sl)
+      if (t) (void)hipFree(t);
   if (m->srhs) (void)hipFree(m->srhs);
   if (m->tmpv) (void)hipFree(m->tmpv);
   if (m->F) (void)hipFree(m->F);
@@ -748,7 +999,8 @@ extern "C" int fl_momentum_set_coefficients(fl_momentum *m, double cI, double cC
   m->mp.cL = cL;
   fl_poisson *h = m->p;
   FL_HIP(hipSetDevice(h->device));
-  mom_apply_t<false, false, 2>(m, m->F, m->dg, nullptr, nullptr);  // x is not used for the diagonal: any valid padded array
+  FL_CHK(mom_scale_tables(m, 0, m->mp));
+  mom_apply_t<0, false, 2>(m, m->F, m->dg, nullptr, nullptr);  // x is not used for the diagonal: any valid padded array
   FL_HIP(hipGetLastError());
   return FL_SUCCESS;
 }
@@ -789,7 +1041,7 @@ extern "C" int fl_momentum_apply(fl_momentum *m, const double *v_dev, double *y_
   FL_CHK(mom_vec(m, 7));
   for (int c = 0; c < 3; ++c) launch_pad_copy(h->stream, h->g, v_dev + (size_t)c * h->ncell, m->vec[7] + (size_t)c * h->padlen);
   FL_CHK(mom_ghosts(m, m->vec[7]));
-  mom_apply_t<false, false, 1>(m, m->vec[7], y_dev, nullptr, nullptr);
+  mom_apply_t<0, false, 1>(m, m->vec[7], y_dev, nullptr, nullptr);
   FL_HIP(hipGetLastError());
   return FL_SUCCESS;
 }
@@ -800,7 +1052,7 @@ extern "C" int fl_momentum_diagonal(fl_momentum *m, double *d_dev)
   if (!m->have_state && m->mp.cC != 0.) return FL_ERR_ARG_WRONGSTATE;
   fl_poisson *h = m->p;
   FL_HIP(hipSetDevice(h->device));
-  mom_apply_t<false, false, 2>(m, m->F, m->dg, nullptr, nullptr);
+  mom_apply_t<0, false, 2>(m, m->F, m->dg, nullptr, nullptr);
   for (int c = 0; c < 3; ++c) launch_unpad_copy(h->stream, h->g, m->dg + (size_t)c * h->padlen, d_dev + (size_t)c * h->ncell, nullptr);
   FL_HIP(hipGetLastError());
   return FL_SUCCESS;
@@ -827,14 +1079,14 @@ extern "C" int fl_momentum_solve(fl_momentum *m, const double *b_dev, double *x_
   double *R = m->vec[0], *RP = m->vec[1], *P = m->vec[2], *V = m->vec[3], *X = m->vec[4], *S = m->vec[5], *T = m->vec[6];
   const int nhist = opts->maxit + 1;
   FL_CHK(fl_ensure_hist(h, nhist));
-  FL_CHK(fl_ensure_partials(h, std::max(m->nblocks, m->ablocks)));
+  FL_CHK(fl_ensure_partials(h, std::max(std::max(m->nblocks, m->ablocks), m->t2blocks)));
   fl_ksp_opts o = *opts;
   o.remove_nullspace = 0;  // A = I + ... is non-singular
   FL_CHK(fl_ksp_begin(h, &o));
   const size_t bytes = sizeof(double) * 3 * h->padlen;
   for (double *v : {P, V, X}) FL_HIP(hipMemsetAsync(v, 0, bytes, h->stream));
   mom_pw<3>(m, b_dev, jac ? m->dg : nullptr, nullptr, nullptr, R, RP);
-  FL_CHK(fl_bcgs_fin_step(h, 0, m->nblocks, 3, nhist));
+  FL_CHK(fl_bcgs_fin_step(h, 0, mom_pw_blocks(m), 3, nhist));
   const int every = o.check_every > 0 ? o.check_every : 4;
   int       it = 0;
   bool      done = false;
@@ -843,16 +1095,16 @@ extern "C" int fl_momentum_solve(fl_momentum *m, const double *b_dev, double *x_
     for (; it < stop; ++it) {
       mom_pw<0>(m, R, V, nullptr, nullptr, P, nullptr);
       FL_CHK(mom_ghosts(m, P));
-      if (jac) mom_apply_t<true, true, 0>(m, P, V, RP, h->scal);
-      else mom_apply_t<true, false, 0>(m, P, V, RP, h->scal);
-      FL_CHK(fl_bcgs_fin_step(h, 1, m->ablocks, 4, nhist));
+      if (jac) mom_apply_t<1, true, 0>(m, P, V, RP, h->scal);
+      else mom_apply_t<1, false, 0>(m, P, V, RP, h->scal);
+      FL_CHK(fl_bcgs_fin_step(h, 1, mom_apply_blocks(m), 4, nhist));
       mom_pw<1>(m, R, V, nullptr, nullptr, S, nullptr);
       FL_CHK(mom_ghosts(m, S));
-      if (jac) mom_apply_t<true, true, 0>(m, S, T, nullptr, h->scal);
-      else mom_apply_t<true, false, 0>(m, S, T, nullptr, h->scal);
-      FL_CHK(fl_bcgs_fin_step(h, 3, m->ablocks, 4, nhist));
+      if (jac) mom_apply_t<2, true, 0>(m, S, T, nullptr, h->scal);
+      else mom_apply_t<2, false, 0>(m, S, T, nullptr, h->scal);
+      FL_CHK(fl_bcgs_fin_step(h, 3, mom_apply_blocks(m), 4, nhist));
       mom_pw<2>(m, P, S, T, RP, X, R);
-      FL_CHK(fl_bcgs_fin_step(h, 4, m->nblocks, 3, nhist));
+      FL_CHK(fl_bcgs_fin_step(h, 4, mom_pw_blocks(m), 3, nhist));
     }
     FL_CHK(fl_poll_scal(h));
     if (h->scal_host->reason != 0 || it >= o.maxit) done = true;
@@ -915,7 +1167,8 @@ extern "C" int fl_momentum_rhs(fl_momentum *m, double dt, double rho, double mu,
   co.cI   = 1.;
   co.cC   = 0.;
   co.cL   = 0.5 * mu * dt / rho;  // VecAXPBYPCZ(momrhs, 1, mu dt / 2 rho, 0, v0, Lv), :2988
-  mom_apply_t<false, false, 1>(m, m->vec[7], momrhs_dev, nullptr, nullptr, &co);
+  FL_CHK(mom_scale_tables(m, 1, co));
+  mom_apply_t<0, false, 1>(m, m->vec[7], momrhs_dev, nullptr, nullptr, &co);
   if (p_dev) FL_CHK(fl_poisson_project(h, p_dev, momrhs_dev, momrhs_dev + N, momrhs_dev + 2 * N, nullptr, nullptr, nullptr));  // VecAXPY(momrhs, -1, Gp), :2993
   if (vbc_dev) lincomb(h, (int64_t)(3 * N), 1., momrhs_dev, 1., vbc_dev, momrhs_dev);
   FL_HIP(hipGetLastError());
@@ -1334,6 +1587,35 @@ extern "C" int fldbg_mom_stream(fl_momentum *m, int reps, int blocks, double *ms
   return 0;
 }
 
+// the operator kernel alone on padded work vectors (no pad / unpad copies): mode 0 plain, 1 Jacobi, 2 Jacobi + y.o (the first product of a
+// BiCGStab iteration), 3 Jacobi + x.y, y.y (the second)
+extern "C" int fldbg_mom_apply(fl_momentum *m, int mode, int reps, double *ms_out)
+{
+  fl_poisson *h = m->p;
+  FL_HIP(hipSetDevice(h->device));
+  FL_CHK(mom_vec(m, 5));
+  FL_CHK(mom_vec(m, 6));
+  FL_CHK(mom_vec(m, 7));
+  auto go = [&]() {
+    switch (mode & 3) {
+      case 0: mom_apply_t<0, false, 0>(m, m->vec[7], m->vec[6], nullptr, nullptr); break;
+      case 1: mom_apply_t<0, true, 0>(m, m->vec[7], m->vec[6], nullptr, nullptr); break;
+      case 2: mom_apply_t<1, true, 0>(m, m->vec[7], m->vec[6], m->vec[5], nullptr); break;
+      default: mom_apply_t<2, true, 0>(m, m->vec[7], m->vec[6], nullptr, nullptr); break;
+    }
+  };
+  go();
+  FL_HIP(hipEventRecord(h->ev0, h->stream));
+  for (int r = 0; r < reps; ++r) go();
+  FL_HIP(hipEventRecord(h->ev1, h->stream));
+  FL_HIP(hipStreamSynchronize(h->stream));
+  FL_HIP(hipGetLastError());
+  float ms = 0.f;
+  FL_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  *ms_out = ms / reps;
+  return 0;
+}
+
 // KSPGMRES as PETSc runs it by default: restart 30 (-ksp_gmres_restart), classical Gram-Schmidt without refinement, left
 // preconditioning, the preconditioned residual norm from the Givens recurrence as the monitored norm, KSPConvergedDefault, the
 // residual re-formed at every restart.  Host control flow over device vectors: per iteration one operator application, one
@@ -1371,8 +1653,8 @@ static int momentum_gmres(fl_momentum *m, const double *b_dev, double *x_dev, co
   auto apply = [&](const double *xin, double *yout) -> int {
     for (int c = 0; c < 3; ++c) launch_pad_copy(s, h->g, xin + (size_t)c * h->ncell, m->vec[7] + (size_t)c * h->padlen);
     FL_CHK(mom_ghosts(m, m->vec[7]));
-    if (jac) mom_apply_t<false, true, 1>(m, m->vec[7], yout, nullptr, nullptr);
-    else mom_apply_t<false, false, 1>(m, m->vec[7], yout, nullptr, nullptr);
+    if (jac) mom_apply_t<0, true, 1>(m, m->vec[7], yout, nullptr, nullptr);
+    else mom_apply_t<0, false, 1>(m, m->vec[7], yout, nullptr, nullptr);
     return 0;
   };
   // M b, once: b ./ diag(A) (PCJACOBI) or b

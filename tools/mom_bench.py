@@ -21,6 +21,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cells", type=int, default=512)
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--nosolve", action="store_true")
+    ap.add_argument("--modes", type=int, default=4)
     a = ap.parse_args()
     n = (a.cells,) * 3
     P = Poisson.uniform(n, [(0, 1)] * 3, [V, V, V, V, SYM, V], 1e-3)
@@ -44,13 +46,25 @@ def main():
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.reps
     out = dict(cells=a.cells, apply_ms_incl_pad=ms)
-    x, info = M.solve(v, rtol=1e-8, maxit=200)
-    x, info = M.solve(v, rtol=1e-8, maxit=200)
-    out.update(solve_iters=info["iters"], solve_reason=info["reason"], solve_ms=info["seconds"] * 1e3,
+    if not a.nosolve:
+      x, info = M.solve(v, rtol=1e-8, maxit=200)
+      x, info = M.solve(v, rtol=1e-8, maxit=200)
+      out.update(solve_iters=info["iters"], solve_reason=info["reason"], solve_ms=info["seconds"] * 1e3,
                ms_per_iter=info["seconds"] * 1e3 / max(info["iters"], 1))
-    # streaming ceiling of the same access mix (15 reads + 3 writes, flat)
+    out["env"] = {k: v for k, v in os.environ.items() if k.startswith("FLUCA_")}
     import ctypes as C
     from fluca_amd.capi import lib
+    # the operator kernel alone on padded vectors: mode bit 0 Jacobi, bit 1 inner products
+    lib.fldbg_mom_apply.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    for mode in range(a.modes):
+        ms = C.c_double()
+        P._pre()
+        rc = lib.fldbg_mom_apply(M.h, mode, a.reps, C.byref(ms))
+        P._post()
+        assert rc == 0, rc
+        out[f"kernel_ms_mode{mode}"] = ms.value
+    out["kernel"] = os.environ.get("FLUCA_MOM_KERNEL", "2")
+    # streaming ceiling of the same access mix (15 reads + 3 writes, flat)
     lib.fldbg_mom_stream.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
     for blocks in (2048, 8192):
         ms = C.c_double()
