@@ -43,44 +43,72 @@ B_ITER_REAL = {0: 60, 2: 72, 1: 136}
 def cg_roofline(info, ncell, variant, ms_per_iter, traffic=None):
     """roofline object of a CG run: the kernel with the larger share of the iteration is the headline entry ("dominant kernel"), the other
     one and the whole iteration (every kernel, driver-timed) are listed beside it.  Durations: HIP events around each launch inside the
-    timed region (fl_ksp_opts.profile)."""
+    timed region (fl_ksp_opts.profile).
+
+    Two kinds of fraction, never to be confused:
+      achieved / frac          SURVEY 8(d)'s ALGORITHMIC bytes of the textbook steps a kernel replaces / its duration (the contract's
+                               figure; it exceeds 1 once a kernel stops moving bytes the textbook sequence moves -- q is never stored, x is
+                               touched every second iteration);
+      traffic_GBps / traffic_frac   bytes that actually crossed the HBM interface (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE per launch from the
+                               last committed counter pass, profiles/pmc_*.json; the kernel's own moved-byte count x cells where no pass
+                               exists for the workload) / the same duration / 8 TB/s: the PHYSICAL fraction of the roofline, <= 1."""
     ks = []
     for (name, algo, moved), ms, n in zip(CG_KERNELS[variant], (info["kernel_ms"], info["kernel2_ms"]), (info["kernel_launches"], info["kernel2_launches"])):
         ach = algo * ncell / (ms * 1e-3) / 1e9 if ms > 0 else None
+        tr = traffic.get(name.split(" ")[0]) if isinstance(traffic, dict) else None
+        tb, src = (tr, "rocprofv3 PMC pass (profiles/)") if tr else (moved * ncell, "moved bytes per cell x cells (no counter pass for this workload)")
+        tg = tb / (ms * 1e-3) / 1e9 if ms > 0 else None
         ks.append({"kernel": name, "algorithmic_bytes_per_cell": algo, "moved_bytes_per_cell": moved, "avg_launch_ms": ms, "launches_timed": n, "achieved": ach,
-                   "frac": ach / HBM_PEAK_GBS if ach else None, "moved_GBps": moved * ncell / (ms * 1e-3) / 1e9 if ms > 0 else None})
+                   "frac": ach / HBM_PEAK_GBS if ach else None, "moved_GBps": moved * ncell / (ms * 1e-3) / 1e9 if ms > 0 else None,
+                   "traffic": tr, "traffic_bytes_used": tb, "traffic_source": src, "traffic_GBps": tg, "traffic_frac": tg / HBM_PEAK_GBS if tg else None})
     dom = max(ks, key=lambda k: k["avg_launch_ms"] or 0.0)
     it_ach = B_ITER_ALGO * ncell / (ms_per_iter * 1e-3) / 1e9
-    tr = traffic.get(dom["kernel"].split(" ")[0]) if isinstance(traffic, dict) else traffic
-    return {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": tr,
+    it_tb = sum(k["traffic_bytes_used"] for k in ks)
+    it_tg = it_tb / (ms_per_iter * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": dom["traffic"],
+            "traffic_GBps": dom["traffic_GBps"], "traffic_frac": dom["traffic_frac"], "traffic_source": dom["traffic_source"],
+            "frac_note": "frac = algorithmic bytes of the textbook steps this kernel replaces / time / peak (SURVEY 8d; may exceed 1); traffic_frac = bytes that crossed "
+                         "the HBM interface / time / peak: the physical fraction",
             "algorithmic_bytes_per_cell": dom["algorithmic_bytes_per_cell"], "moved_bytes_per_cell": dom["moved_bytes_per_cell"],
             "avg_launch_ms": dom["avg_launch_ms"], "launches_timed": dom["launches_timed"], "moved_GBps": dom["moved_GBps"], "kernels": ks,
             "iteration": {"algorithmic_bytes_per_cell": B_ITER_ALGO, "moved_bytes_per_cell": B_ITER_REAL.get(variant), "ms": ms_per_iter, "achieved": it_ach,
-                          "frac": it_ach / HBM_PEAK_GBS, "note": "all kernels of one iteration, driver-timed (ms_per_step)"}}
+                          "frac": it_ach / HBM_PEAK_GBS, "traffic_bytes": it_tb, "traffic_GBps": it_tg, "traffic_frac": it_tg / HBM_PEAK_GBS,
+                          "note": "all kernels of one iteration, driver-timed (ms_per_step)"}}
 B_CHEB_ALGO = 40               # algorithmic bytes / cell / Chebyshev-Jacobi step: read x, b, d; write x', d'
 IBM_B_PER_MARKER = 1584        # SURVEY 8d: L * (4^3 * 3 * 8 + 6 * 8) bytes per interp or spread of three components
 RANK_GRIDS = {1: (1, 1, 1), 2: (1, 1, 2), 4: (1, 2, 2), 8: (2, 2, 2)}
 
 
-def cpu_baseline(sample_n, iters):
-    """The oracle (CPU restatement: assembled CSR + PETSc-style PCG, OpenMP) timed on this box's host cores."""
+def _host_mem_available_gb():
+    try:
+        with open("/proc/meminfo") as fh:
+            for line in fh:
+                if line.startswith("MemAvailable:"):
+                    return int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    return None
+
+
+def _cpu_leg(n1, iters):
+    """The oracle's assembled-CSR Jacobi-PCG (PETSc-style) on an n1^3 cavity grid, `iters` iterations, timed; then the same right-hand
+    side through the HIP path, compared with what was just timed."""
     from oracle import fluca_oracle as fo
-    # a one-GPU box's CPU share is 16 cores; never spawn more OpenMP threads than that (or than the affinity mask)
-    fo.set_num_threads(min(16, len(os.sched_getaffinity(0)), fo.num_threads()))
     bc = [fo.BC_VELOCITY] * 4 + [fo.BC_SYMMETRY, fo.BC_VELOCITY]
-    n = (sample_n,) * 3
+    n = (n1,) * 3
     g = fo.Grid.uniform(n, [(0, 1), (0, 1), (0, 0.5)], bc, 1e-3)
+    t0 = time.perf_counter()
     S = g.assemble_S()
+    t_asm = time.perf_counter() - t0
     rng = np.random.default_rng(20260313)
     p = rng.uniform(-1, 1, g.ncell)
     p -= p.mean()
     b = S.mult(p)
+    del p
     xc, info = S.solve(b, rtol=0.0, atol=0.0, maxit=iters, history=False)
     its_per_s = info["iters"] / info["seconds"]
-    # the same sample through the HIP path, checked against what was just timed (after the timed regions of both)
     parity = None
     try:
-        import torch
         from fluca_amd import poisson as flp
         Pc = flp.Poisson.uniform(n, [(0, 1), (0, 1), (0, 0.5)], bc, 1e-3)
         xg, ig = Pc.solve(torch.as_tensor(b, device="cuda"), rtol=0.0, atol=0.0, maxit=iters)
@@ -92,22 +120,43 @@ def cpu_baseline(sample_n, iters):
         Pc.close()
     except Exception as e:  # noqa: BLE001  (never lose the bench line over the cross-check)
         parity = {"error": repr(e)}
-    # the CPU leg may run the whole 512^3 grid only where the host has the memory (>= 32 GB free for the 12 GB CSR + vectors)
-    # AND the time: 512^3 costs 8x the sample per iteration (about 1 s each on 16 cores), so the default stays a bounded 256^3 sample
-    mem_avail_gb = None
-    try:
-        with open("/proc/meminfo") as fh:
-            for line in fh:
-                if line.startswith("MemAvailable:"):
-                    mem_avail_gb = int(line.split()[1]) / 1e6
-    except OSError:
-        pass
-    return {"value": its_per_s * (sample_n ** 3) / 512.0 ** 3, "unit": "512^3-equivalent PCG iterations/s", "parity_on_sample": parity,
-            "host_mem_available_GB": mem_avail_gb, "full_grid_possible": bool(mem_avail_gb and mem_avail_gb >= 32.0),
-            "cores": fo.num_threads(), "kind": "port", "petsc_cpu": petsc_cpu(sample_n, iters, fo.num_threads()),
-            "sample": f"{sample_n}^3 cavity grid (1/{(512 // sample_n) ** 3} of the cells), {info['iters']} Jacobi-PCG iterations, "
-                      f"assembled CSR (AIJ cost model), {info['seconds']:.2f} s, raw {its_per_s:.3f} it/s on the sample",
-            "host_GBps_at_104B_per_row": 104.0 * sample_n ** 3 * its_per_s / 1e9}
+    return {"cells_per_axis": n1, "iters": info["iters"], "seconds": info["seconds"], "assemble_seconds": t_asm, "its_per_s": its_per_s, "parity": parity,
+            "host_GBps_at_104B_per_row": 104.0 * n1 ** 3 * its_per_s / 1e9}
+
+
+def cpu_baseline(sample_n, sample_iters, full_n, full_iters):
+    """The oracle (CPU restatement: assembled CSR + PETSc-style PCG, OpenMP) timed on this box's host cores.  Where the
+    host has the memory (>= 32 GB available for the 12 GB CSR + vectors) the headline's OWN grid is run for the headline's own number
+    of iterations -- `value` is then a measurement at the metric's size -- and the bounded 256^3 sample is kept as a second entry;
+    otherwise the sample, scaled by the cell count, is the value and says so."""
+    from oracle import fluca_oracle as fo
+    # a one-GPU box's CPU share is 16 cores; never spawn more OpenMP threads than that (or than the affinity mask)
+    fo.set_num_threads(min(16, len(os.sched_getaffinity(0)), fo.num_threads()))
+    mem = _host_mem_available_gb()
+    full_ok = bool(mem and mem >= 32.0) and full_n is not None
+    sample = _cpu_leg(sample_n, sample_iters)
+    sample_value = sample["its_per_s"] * (sample_n ** 3) / 512.0 ** 3
+    out = {"unit": "512^3-equivalent PCG iterations/s", "cores": fo.num_threads(), "kind": "port", "host_mem_available_GB": mem, "full_grid_possible": full_ok,
+           "petsc_cpu": petsc_cpu(sample_n, sample_iters, fo.num_threads()),
+           "sample_256": {"value": sample_value, "parity_on_sample": sample["parity"], "seconds": sample["seconds"],
+                          "sample": f"{sample_n}^3 cavity grid (1/{(512 // sample_n) ** 3} of the cells), {sample['iters']} Jacobi-PCG iterations, raw {sample['its_per_s']:.3f} it/s"},
+           "parity_on_sample": sample["parity"]}
+    full = None
+    if full_ok:
+        try:
+            full = _cpu_leg(full_n, full_iters)
+        except MemoryError as e:
+            out["full_grid_error"] = repr(e)
+    if full:
+        out.update({"value": full["its_per_s"] * (full_n ** 3) / 512.0 ** 3, "parity_on_full_grid": full["parity"],
+                    "sample": f"the headline's own grid: {full_n}^3 cavity, {full['iters']} Jacobi-PCG iterations on the assembled CSR (AIJ cost model), "
+                              f"{full['seconds']:.2f} s (+ {full['assemble_seconds']:.1f} s assembling S, not timed)",
+                    "host_GBps_at_104B_per_row": full["host_GBps_at_104B_per_row"]})
+    else:
+        out.update({"value": sample_value, "parity_on_full_grid": None,
+                    "sample": out["sample_256"]["sample"] + ", scaled by the cell count (host memory too small for the 512^3 CSR)",
+                    "host_GBps_at_104B_per_row": sample["host_GBps_at_104B_per_row"]})
+    return out
 
 
 def petsc_cpu(sample_n, iters, cores):
@@ -151,6 +200,35 @@ def petsc_cpu(sample_n, iters, cores):
                     "ranks": int(m.group(2)), "sample": f"{sample_n}^3, {its} iterations, {sec:.2f} s"}
     except Exception as e:  # noqa: BLE001
         return f"unavailable ({e!r})"
+
+
+def measured_stream_rates():
+    import ctypes as C
+
+    from fluca_amd import capi
+    from fluca_amd import poisson as flp
+    f = capi.lib.fldbg_bench
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    P = flp.Poisson.uniform((512,) * 3, [(0, 1), (0, 1), (0, 0.5)], [1, 1, 1, 1, 4, 1], 1e-3)
+    src = torch.rand(P.ncell, dtype=torch.float64, device="cuda") - 0.5
+    torch.cuda.synchronize()
+    padded = 544 * 514 * 514
+    res = {}
+    first = True
+    for key, mix in (("measured_copy_GBps", 11), ("measured_3r3w_GBps", 33)):
+        best = None
+        for blocks in (8192, 65536):
+            ms, nbk = C.c_double(), C.c_int()
+            capi.check(f(P.h, 3, mix, 81, blocks, 10, C.c_void_p(src.data_ptr()) if first else None, C.byref(ms), C.byref(nbk)), "fldbg_bench")
+            first = False
+            rate = 8.0 * (mix // 10 + mix % 10) * padded / ms.value / 1e6
+            best = rate if best is None else max(best, rate)
+        res[key] = best
+    res["measured_copy_note"] = "library streaming kernels (16 B per lane, 8-fold unrolled, non-temporal), best of 8192 / 65536 blocks, 10 launches each; 544 x 514 x 514 padded doubles per stream"
+    P.close()
+    del src
+    return res
 
 
 def other_configs(stream):
@@ -212,7 +290,12 @@ def other_configs(stream):
                  "metric": "Chebyshev-Jacobi steps/s", "value": K / dt, "steps": K, "ms_per_step": dt / K * 1e3,
                  "step_algorithmic_GBps": B_CHEB_ALGO * P.ncell * K / dt / 1e9,
                  "roofline": {"bound": "hbm", "kernel": "k_cheb2 (two fused Chebyshev-Jacobi steps per launch)" if fused else "k_cheb", "achieved": ach, "peak": HBM_PEAK_GBS,
-                              "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_cell_per_launch": per_launch / P.ncell,
+                              "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                              "traffic_GBps": (traffic or B_CHEB_ALGO * P.ncell) / (info["kernel_ms"] * 1e-3) / 1e9,
+                              "traffic_frac": (traffic or B_CHEB_ALGO * P.ncell) / (info["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "traffic_source": "rocprofv3 PMC pass (profiles/pmc_k_cheb2.json)" if traffic else "40 B x cells per launch (x, b, d read; x', d' written once)",
+                              "frac_note": "frac counts 40 algorithmic B/cell per STEP, two steps per launch; traffic_frac is the physical fraction",
+                              "algorithmic_bytes_per_cell_per_launch": per_launch / P.ncell,
                               "steps_per_launch": 2 if fused else 1, "avg_launch_ms": info["kernel_ms"], "launches_timed": info["kernel_launches"]}}
     P.close()
     del b, x
@@ -253,6 +336,58 @@ def other_configs(stream):
     capi.lib.fl_ibm_destroy(m)
     P.close()
     del u, f, F, U, dV, X
+
+    # The momentum block (KSPSolve(kspA), abfpc.c:72): matrix-free A = I + dt C - (mu dt / 2 rho) L on the same 512^3 cavity
+    # grid, random face fields (V0, v0interp), the operator kernel alone and the Jacobi-BiCGStab iteration around it
+    try:
+        P = flp.Poisson.uniform((512,) * 3, box, [1, 1, 1, 1, 4, 1], 1e-3)
+        P.set_stream(stream)
+        M = flp.Momentum(P)
+        gen = torch.Generator(device="cuda").manual_seed(11)
+        rnd = lambda m_: torch.rand(m_, dtype=torch.float64, device="cuda", generator=gen) * 2 - 1  # noqa: E731
+        V0 = [rnd(P.nface[d]) for d in range(3)]
+        W = [rnd(P.nface[d]) for c in range(3) for d in range(3)]
+        hh = 1.0 / 512
+        stream.wait_stream(torch.cuda.current_stream())
+        M.set_state(0.5 * hh, 1.0, 0.5 * hh, V0, W)
+        del V0, W
+        v = rnd(3 * P.ncell)
+        stream.wait_stream(torch.cuda.current_stream())
+        fa = capi.lib.fldbg_mom_apply
+        fa.restype = C.c_int
+        fa.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        kms = {}
+        for mode, name in ((0, "plain"), (2, "jacobi_dot_first"), (3, "jacobi_dots_second")):
+            ms = C.c_double()
+            capi.check(fa(M.h, mode, 10, C.byref(ms)), "fldbg_mom_apply")
+            kms[name] = ms.value
+        K = 10
+        M.solve(v, rtol=0.0, atol=0.0, maxit=2)
+        (_, info), dt = timed(lambda: M.solve(v, rtol=0.0, atol=0.0, maxit=K))
+        B_APPLY, B_BCGS = 144, 648   # 3 reads + 3 writes of v + 12 face fields; 2 applies (one also reads the shadow residual) + 3 vector updates
+        tr = None
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_k_mom2.json"))).get("hbm_bytes_per_launch")
+        except Exception:  # noqa: BLE001
+            tr = None
+        ach = B_APPLY * P.ncell / (kms["plain"] * 1e-3) / 1e9
+        tg = (tr or B_APPLY * P.ncell) / (kms["plain"] * 1e-3) / 1e9
+        cfg["momentum"] = {"workload": "512^3 cavity grid, momentum block A = I + dt C - (mu dt / 2 rho) L matrix-free (3 velocity components, 12 face fields), "
+                                       f"Jacobi-BiCGStab (KSPBCGS + PCJACOBI) fixed {K} iterations",
+                           "metric": "momentum BiCGStab iterations/s", "value": info["iters"] / dt, "steps": info["iters"], "ms_per_step": dt / max(info["iters"], 1) * 1e3,
+                           "iteration_algorithmic_GBps": B_BCGS * P.ncell * info["iters"] / dt / 1e9, "kernel_ms": kms,
+                           "roofline": {"bound": "hbm", "kernel": "k_mom2 (MatMult(A): two cells per lane on 128 x 8 tiles)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": ach / HBM_PEAK_GBS, "traffic": tr, "traffic_GBps": tg, "traffic_frac": tg / HBM_PEAK_GBS,
+                                        "traffic_source": "rocprofv3 PMC pass (profiles/pmc_k_mom2.json)" if tr else "144 B x cells",
+                                        "algorithmic_bytes_per_cell": B_APPLY, "avg_launch_ms": kms["plain"], "launches_timed": 10,
+                                        "iteration": {"algorithmic_bytes_per_cell": B_BCGS, "ms": dt / max(info["iters"], 1) * 1e3,
+                                                      "achieved": B_BCGS * P.ncell * info["iters"] / dt / 1e9, "frac": B_BCGS * P.ncell * info["iters"] / dt / 1e9 / HBM_PEAK_GBS}}}
+        M.close()
+        P.close()
+        del v
+        torch.cuda.empty_cache()
+    except Exception as e:  # noqa: BLE001
+        cfg["momentum"] = {"error": repr(e)}
 
     # C5 needs 8 GPUs (1024 x 1024 x 512 over 2 x 2 x 2).  What ONE rank of it does, rehearsed on this GPU without the halo exchange:
     # a 512 x 512 x 256 block with config 5's boundary types, the Jacobi-PCG iteration on it and the IBM kernels on the cylinder
@@ -397,7 +532,8 @@ def main():
 
     if args.warmup > 0:
         run(args.warmup, False)      # the first solve places the vectors (one-off, outside the timed region)
-    probe = P.tune_placement()       # idempotent: the probe times the placement step recorded
+    # placement is opt-in (tuning knob "placement" / fl_poisson_tune_placement): the bench asks for it unless told not to
+    probe = P.tune_placement() if args.placement == "auto" else (0.0, 0.0)
     barrier()
     t0 = time.perf_counter()
     info = run(args.steps, True)
@@ -441,7 +577,8 @@ def main():
         "solve_seconds_device": info["seconds"],
         "ranks": per_rank, "transport_ranks": world if world > 1 else None,
         "placement": {"mode": args.placement, "probe_ms_all_vectors_in_one_block": probe[0], "probe_ms_chosen": probe[1],
-                      "note": "probe = one k_cg_A + one odd-iteration k_cg_Bq; deterministic arena search, see include/fluca_hip.h fl_poisson_tune_placement"},
+                      "note": "probe = one k_cg_A + one odd-iteration k_cg_Bq; the search arena is given back, the handle keeps five vectors (include/fluca_hip.h fl_poisson_tune_placement)"},
+        "hbm_bytes_held": P.vector_bytes(),
         "roofline": cg_roofline(info, P.ncell, args.variant, dt / args.steps * 1e3, traffic),
     }
     if world == 1 and not args.skip_extras:
@@ -489,25 +626,16 @@ def main():
         except Exception as e:  # noqa: BLE001
             out["configs"] = {"error": repr(e)}
     if world == 1 and not args.skip_extras:
-        # the attainable streaming rate on THIS box, reported beside the nominal peak: a plain device copy of a
-        # 512^3 vector (1 GiB read + 1 GiB written per pass)
+        # the attainable streaming rate on THIS box, reported beside the nominal peak: the library's own streaming kernels
+        # (16 B per lane, non-temporal, grid-stride; tools/sbench.py) on 512^3-sized padded vectors -- a copy (1 read + 1 write stream)
+        # and the 3 reads + 3 writes mix of the CG kernels
         try:
-            src = torch.empty(512 ** 3, dtype=torch.float64, device="cuda").normal_()
-            dst = torch.empty_like(src)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            for _ in range(3):
-                dst.copy_(src)
-            e0.record()
-            for _ in range(10):
-                dst.copy_(src)
-            e1.record()
-            torch.cuda.synchronize()
-            out["roofline"]["measured_copy_GBps"] = 10 * 2 * src.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-            del src, dst
+            out["roofline"].update(measured_stream_rates())
         except Exception as e:  # noqa: BLE001
             out["roofline"]["measured_copy_GBps"] = None
+            out["roofline"]["measured_copy_error"] = repr(e)
     if rank == 0 and world == 1 and not args.skip_cpu:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_cells, args.cpu_iters)
+        out["cpu_baseline"] = cpu_baseline(args.cpu_cells, args.cpu_iters, args.cells if args.cells >= 512 else None, args.steps)
     elif rank == 0:
         out["cpu_baseline"] = None
     if P.h:

@@ -20,8 +20,10 @@
  * working -- they are read off abf->kspS and translated into fl_ksp_opts -- plus -pc_abf_hip <bool> (default true).
  *
  * This file is written against PETSc >= 3.23 (fluca/CMakeLists.txt:9-11) and the reference's public headers; PETSc is not
- * installed where libflucahip.so was developed, so it has NOT been compiled there.  Everything it needs from the library is
- * exercised by tests/test_gpu_layout.py (the DMStag orderings) and tests/test_gpu_poisson.py (the three calls).
+ * installed where libflucahip.so was developed, so it has NOT been compiled against PETSc there.  It IS parsed on every build by
+ * tools/check_contrib.sh (gcc -fsyntax-only against the real fluca_hip.h and a declarations-only stand-in for the PETSc names it
+ * uses; the first run found a member access on the opaque NS that a real build would have refused).  Everything it needs from
+ * the library is exercised by tests/test_gpu_layout.py (the DMStag orderings) and tests/test_gpu_poisson.py (the three calls).
  */
 #include <fluca_hip.h>
 #include <petscdmstag.h>
@@ -142,7 +144,11 @@ static PetscErrorCode PCABFHipCreateHandle_Private(PC pc, DM sdm)
 
   /* boundary types: NSBoundaryConditionType and fl_bc share their values (flucansbc.h:5-11); boundary index order
      left, right, down, up, back, front (MeshCartGetBoundaryIndex, cart.c:564-591) */
-  PetscCall(MeshGetNumberBoundaries(hip->ns->mesh, &nb));
+  {
+    Mesh mesh;
+    PetscCall(NSGetMesh(hip->ns, &mesh)); /* borrowed (nsopts.c) */
+    PetscCall(MeshGetNumberBoundaries(mesh, &nb));
+  }
   PetscCheck(nb == 6, comm, PETSC_ERR_SUP, "libflucahip handles 3-D Cartesian meshes");
   for (b = 0; b < 6; ++b) {
     NSBoundaryCondition c;

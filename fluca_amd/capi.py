@@ -94,6 +94,7 @@ PROTOTYPES = {
     "fl_tuning_set": (C.c_int, [C.c_char_p, C.c_int]),
     "fl_tuning_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
     "fl_poisson_tune_placement": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double)]),
+    "fl_poisson_vector_bytes": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "fl_poisson_apply": (C.c_int, [_P, _P, _P]),
     "fl_poisson_diagonal": (C.c_int, [_P, _P]),
     "fl_poisson_solve": (C.c_int, [_P, _P, _P, C.POINTER(fl_ksp_opts), C.POINTER(fl_ksp_stats)]),

@@ -1,5 +1,7 @@
 // fl_api.hip -- C-ABI entry points of libflucahip.so (see include/fluca_hip.h), handle management, the Krylov drivers
 // and the two halo transports (RCCL Send/Recv; host-staged callbacks).
+#include <new>
+
 #include "fl_handle.h"
 
 int fl_dev_alloc(fl_poisson *h, void **p, size_t bytes, bool zero)
@@ -208,6 +210,7 @@ extern "C" int fl_poisson_destroy(fl_poisson *h)
   h->comm.destroy();
   for (void *p : h->tables) (void)hipFree(p);
   for (void *p : h->vec_bases) (void)hipFree(p);
+  fl_vmm_destroy(h);
   for (double *p : {h->partial, h->sums, h->hist})
     if (p) (void)hipFree(p);
   for (int b = 0; b < 6; ++b) {
@@ -298,10 +301,93 @@ int &fl_placement_mode()
 {
   static int m = []() {
     const char *e = std::getenv("FLUCA_PLACEMENT");
-    return e ? std::atoi(e) : 1;
+    return e ? std::atoi(e) : 0;  // opt-in since round 3 (1 - 2 % of the CG rate for a search of ~0.15 s per handle): fl_poisson_tune_placement, or this knob
   }();
   return m;
 }
+// An arena whose physical memory is a row of separately created chunks mapped into one reserved address range (HIP virtual memory
+// management).  The search below slides its window through it like through a plain allocation; afterwards the chunks the chosen window
+// does not touch are unmapped and released, so the handle keeps the window's own physical memory -- the place the probe measured --
+// and nothing else.
+struct VmmArena {
+  char                                      *va = nullptr;
+  size_t                                     size = 0, chunk = 0;
+  std::vector<hipMemGenericAllocationHandle_t> handles;
+  std::vector<char>                          live;
+  size_t bytes_live() const
+  {
+    size_t n = 0;
+    for (char c : live) n += c ? chunk : 0;
+    return n;
+  }
+  void release_outside(size_t lo, size_t hi)  // keeps every chunk that overlaps [lo, hi)
+  {
+    for (size_t c = 0; c < handles.size(); ++c) {
+      const size_t b = c * chunk, e = b + chunk;
+      if (live[c] && (e <= lo || b >= hi)) {
+        (void)hipMemUnmap(va + b, chunk);
+        (void)hipMemRelease(handles[c]);
+        live[c] = 0;
+      }
+    }
+  }
+  ~VmmArena()
+  {
+    if (!va) return;
+    release_outside(0, 0);
+    (void)hipMemAddressFree(va, size);
+  }
+};
+static VmmArena *vmm_arena_create(int device, size_t want, size_t chunk_hint)
+{
+  hipMemAllocationProp prop = {};
+  prop.type                 = hipMemAllocationTypePinned;
+  prop.location.type        = hipMemLocationTypeDevice;
+  prop.location.id          = device;
+  size_t gran = 0;
+  if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  VmmArena *A = new (std::nothrow) VmmArena;
+  if (!A) return nullptr;
+  A->chunk = ((chunk_hint + gran - 1) / gran) * gran;
+  const size_t n = (want + A->chunk - 1) / A->chunk;
+  A->size = n * A->chunk;
+  void *va = nullptr;
+  if (hipMemAddressReserve(&va, A->size, 0, nullptr, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    delete A;
+    return nullptr;
+  }
+  A->va = (char *)va;
+  hipMemAccessDesc acc = {};
+  acc.location         = prop.location;
+  acc.flags            = hipMemAccessFlagsProtReadWrite;
+  for (size_t c = 0; c < n; ++c) {
+    hipMemGenericAllocationHandle_t hd;
+    if (hipMemCreate(&hd, A->chunk, &prop, 0) != hipSuccess) break;
+    if (hipMemMap(A->va + c * A->chunk, A->chunk, 0, hd, 0) != hipSuccess) {
+      (void)hipMemRelease(hd);
+      break;
+    }
+    A->handles.push_back(hd);
+    A->live.push_back(1);
+    if (hipMemSetAccess(A->va + c * A->chunk, A->chunk, &acc, 1) != hipSuccess) break;
+  }
+  if (A->handles.size() != n) {
+    (void)hipGetLastError();
+    delete A;
+    return nullptr;
+  }
+  return A;
+}
+void fl_vmm_destroy(fl_poisson *h)
+{
+  if (h->vmm) delete h->vmm;
+  h->vmm = nullptr;
+}
+
 namespace {
 constexpr size_t PL_MIN_VEC   = (size_t)256 << 20;  // smaller vectors: nothing to gain, plain allocations
 constexpr size_t PL_SEAM      = (size_t)16 << 30;   // where the first seam of a fresh allocation has been found on every box
@@ -320,13 +406,16 @@ int place_vectors(fl_poisson *h)
   plan.probe = 1;  // launches k_cg_A_probe / k_cg_Bq_probe: identical code, separate names in profiles
   FL_CHK(fl_ensure_partials(h, plan.nblocks));
   struct Held {  // two scalar blocks (direction buffer parity 0 and 1) and the arenas: whatever is not handed to the handle is released
-    KspScal            *p = nullptr;
-    std::vector<void *> arenas;
+    KspScal                *p = nullptr;
+    std::vector<void *>     arenas;
+    std::vector<VmmArena *> vmm;  // parallel to arenas: non-null where the arena is chunk-mapped virtual memory
     ~Held()
     {
       if (p) (void)hipFree(p);
-      for (void *a : arenas)
-        if (a) (void)hipFree(a);
+      for (size_t a = 0; a < arenas.size(); ++a) {
+        if (vmm[a]) delete vmm[a];
+        else if (arenas[a]) (void)hipFree(arenas[a]);
+      }
     }
   } sc;
   FL_HIP(hipMalloc((void **)&sc.p, 2 * sizeof(KspScal)));
@@ -368,6 +457,10 @@ int place_vectors(fl_poisson *h)
   // found 16 GiB in; on some the whole arena answers flat).  A flat arena is kept allocated -- so that the next one comes from other
   // physical memory -- and the search repeated, at most PL_ARENAS times; the losers are freed at the end.
   constexpr int PL_ARENAS = 3;
+  static const int use_vmm = []() {
+    const char *e = std::getenv("FLUCA_PLACEMENT_VMM");  // 1 (default): chunk-mapped arenas, everything but the chosen window is released
+    return e ? std::atoi(e) : 1;
+  }();
   void  *arena = nullptr;
   size_t want = 0, best = 0;
   double first_ms = 0., best_ms = 0.;
@@ -381,12 +474,15 @@ int place_vectors(fl_poisson *h)
       w = freeb > reserve + (size_t)nslot * vecb ? ((freeb - reserve) >> 30) << 30 : 0;
     }
     if (w < (size_t)nslot * vecb) break;  // not enough memory for an arena
-    void *a = nullptr;
-    if (hipMalloc(&a, w) != hipSuccess) {
+    void     *a  = nullptr;
+    VmmArena *va = use_vmm ? vmm_arena_create(h->device, w, (size_t)256 << 20) : nullptr;
+    if (va) a = va->va;
+    else if (hipMalloc(&a, w) != hipSuccess) {
       (void)hipGetLastError();
       break;
     }
     sc.arenas.push_back(a);
+    sc.vmm.push_back(va);
     FL_HIP(hipMemsetAsync(a, 0, w, s));
     const size_t lo = (size_t)PL_SIDE * vecb, hi = w - (size_t)(PL_WIN + PL_SIDE) * vecb;
     // coarse pass in steps of one vector (the fast stretch before a seam is four vectors long), then the two half steps next to the best
@@ -425,6 +521,45 @@ int place_vectors(fl_poisson *h)
     if (best_ms <= thresh * first_ms) break;  // a seam was found
   }
   if (!arena) return 0;  // no memory for an arena: plain allocations
+  // A chunk-mapped arena gives back everything but the chunks under the chosen window: the handle keeps five vectors (plus at most two
+  // chunks of 256 MiB of slack), on the very physical memory the probe measured.  (Round 2 kept the whole arena, 16 GiB + 8 vectors;
+  // giving it back and allocating "the same place" again -- a filler of the window's offset, then the window -- was tried and does not
+  // land on the same physical memory: probe 1.729 ms where the search had found 1.636, profiles/r03_placement.txt.)
+  {
+    VmmArena *chosen = nullptr;
+    for (size_t a = 0; a < sc.arenas.size(); ++a)
+      if (sc.arenas[a] == arena) chosen = sc.vmm[a];
+    if (chosen) {
+      const size_t winb = (size_t)PL_WIN * vecb;
+      for (size_t a = 0; a < sc.arenas.size(); ++a)
+        if (sc.vmm[a] == chosen) {
+          sc.vmm[a]    = nullptr;
+          sc.arenas[a] = nullptr;
+        }
+      chosen->release_outside(best, best + winb);
+      FL_HIP(hipMemsetAsync((char *)arena + best, 0, winb, s));
+      double again = 0.;
+      const int prc = probe(arena, best, &again);
+      if (prc != 0) {
+        delete chosen;
+        return prc;
+      }
+      if (verbose) std::fprintf(stderr, "[fluca placement] window at %.2f GiB kept (%.2f GiB live of %.2f), probe again %.4f ms (search %.4f, first %.4f)\n", (double)best / (double)((size_t)1 << 30), (double)chosen->bytes_live() / (double)((size_t)1 << 30), (double)chosen->size / (double)((size_t)1 << 30), again, best_ms, first_ms);
+      FL_HIP(hipMemsetAsync((char *)arena + best, 0, winb, s));
+      FL_HIP(hipStreamSynchronize(s));
+      h->vmm         = chosen;
+      h->arena       = nullptr;  // no side pools: every other vector is a plain allocation
+      h->arena_bytes = chosen->bytes_live();
+      h->vec_bytes += chosen->bytes_live();
+      double **wv[PL_WIN] = {&h->r, &h->P0, &h->P1, &h->q, &h->xp};
+      for (int k = 0; k < PL_WIN; ++k) *wv[k] = (double *)((char *)arena + best + (size_t)k * vecb);
+      h->nvec += PL_WIN;
+      h->placed_ms[0] = first_ms;
+      h->placed_ms[1] = again;
+      h->placed_at    = (double)best / (double)((size_t)1 << 30);
+      return 0;
+    }
+  }
   for (void *&a : sc.arenas)
     if (a == arena) a = nullptr;  // this one goes to the handle
   // the probes wrote into the arena: ghost layers of fresh solver vectors are zero by contract
@@ -433,6 +568,7 @@ int place_vectors(fl_poisson *h)
   h->arena       = arena;
   h->arena_bytes = want;
   h->vec_bases.push_back(arena);
+  h->vec_bytes += want;
   double **win[PL_WIN] = {&h->r, &h->P0, &h->P1, &h->q, &h->xp};
   for (int k = 0; k < PL_WIN; ++k) *win[k] = (double *)((char *)arena + best + (size_t)k * vecb);
   h->pool_next[0] = (char *)arena + best - (size_t)PL_SIDE * vecb;
@@ -477,7 +613,9 @@ extern "C" int fl_poisson_tune_placement(fl_poisson *h, int max_tries, double pr
     // vectors that exist already (a solve ran before this call) are dropped: every solve re-creates what it needs
     fl_mg_destroy(h);
     for (void *p : h->vec_bases) (void)hipFree(p);
+    fl_vmm_destroy(h);
     h->vec_bases.clear();
+    h->vec_bytes = 0;
     h->nvec = 0;
     h->slab = nullptr;
     for (double **v : {&h->r, &h->P0, &h->P1, &h->q, &h->xp, &h->w0, &h->w1, &h->w2, &h->cd1}) *v = nullptr;
@@ -490,6 +628,14 @@ extern "C" int fl_poisson_tune_placement(fl_poisson *h, int max_tries, double pr
   return FL_SUCCESS;
 }
 
+// bytes of device memory the handle holds for its padded solver vectors (placement window or arena included)
+extern "C" int fl_poisson_vector_bytes(fl_poisson *h, int64_t *bytes_out)
+{
+  if (!h || !bytes_out) return FL_ERR_ARG_NULL;
+  *bytes_out = (int64_t)h->vec_bytes;
+  return FL_SUCCESS;
+}
+
 // ------------------------------------------------------------------------------------------------ workspace / ghosts
 
 // Padded solver vectors.  Each one starts at a different offset inside its allocation (multiples of FLUCA_SKEW bytes,
@@ -499,7 +645,12 @@ int fl_ensure_vec(fl_poisson *h, double **v)
 {
   if (*v) return 0;
   if (h->nv_il == 1 && !h->placed && h->nvec == 0 && fl_placement_mode() > 0 && sizeof(double) * h->padlen >= PL_MIN_VEC) {
-    FL_CHK(place_vectors(h));  // carves r, P0, P1, q, xp out of one arena (see "placement" above)
+    // carves r, P0, P1, q, xp out of one allocation (see "placement" above).  A failure in there (memory short, a probe launch refused)
+    // is no reason to fail the caller's solve: whatever the search held is released and the vectors become plain allocations.
+    if (place_vectors(h) != 0) {
+      (void)hipGetLastError();
+      for (double **w : {&h->r, &h->P0, &h->P1, &h->q, &h->xp}) *w = nullptr;
+    }
     if (*v) return 0;
   }
   if (double *p = pool_take(h)) {
@@ -532,6 +683,7 @@ int fl_ensure_vec(fl_poisson *h, double **v)
     void *base = nullptr;
     FL_CHK(fl_dev_alloc(h, &base, slot, true));
     h->vec_bases.push_back(base);
+    h->vec_bytes += slot;
     h->nvec++;
     *v = (double *)base;
     return 0;
@@ -1151,6 +1303,7 @@ extern "C" int fldbg_bench(fl_poisson *h, int kernel, int ry, int pf, int nchunk
     // on different physical memory)
     FL_HIP(hipStreamSynchronize(h->stream));
     h->vec_bases.clear();
+    h->vec_bytes = 0;
     h->nvec = 0;
     h->slab = nullptr;
     for (double **v : {&h->r, &h->P0, &h->P1, &h->q, &h->xp, &h->w0, &h->w1, &h->w2}) *v = nullptr;
@@ -1163,6 +1316,7 @@ extern "C" int fldbg_bench(fl_poisson *h, int kernel, int ry, int pf, int nchunk
     FL_HIP(hipStreamSynchronize(h->stream));
     for (void *p : h->vec_bases) (void)hipFree(p);
     h->vec_bases.clear();
+    h->vec_bytes = 0;
     h->nvec = 0;
     h->slab = nullptr;
     for (double **v : {&h->r, &h->P0, &h->P1, &h->q, &h->xp, &h->w0, &h->w1, &h->w2}) *v = nullptr;

@@ -263,6 +263,8 @@ struct fl_poisson {
   // placement (fl_api.hip): one arena, the five CG vectors in a window found by probing, two side pools for the rest
   void  *arena = nullptr;
   size_t arena_bytes = 0, pool_vec = 0;
+  size_t vec_bytes = 0;  // device memory behind vec_bases
+  struct VmmArena *vmm = nullptr;  // placement window that lives in chunk-mapped virtual memory (fl_api.hip)
   char  *pool_next[2] = {nullptr, nullptr}, *pool_end[2] = {nullptr, nullptr};
   int    pool_flip = 0;
   bool   placed = false;
@@ -340,6 +342,7 @@ struct ProfEvents {
 int  fl_dev_alloc(fl_poisson *h, void **p, size_t bytes, bool zero);
 int  fl_ensure_vec(fl_poisson *h, double **v);
 int &fl_placement_mode();
+void fl_vmm_destroy(fl_poisson *h);
 int &fl_cg_xbatch_mode();
 int  fl_ensure_partials(fl_poisson *h, int nblocks);
 int  fl_ensure_hist(fl_poisson *h, int nhist);

@@ -140,6 +140,12 @@ class Poisson:
         self._post()
         return out[0], out[1]
 
+    def vector_bytes(self):
+        """Device memory behind the handle's padded solver vectors (fl_poisson_vector_bytes)."""
+        out = C.c_int64()
+        check(lib.fl_poisson_vector_bytes(self.h, C.byref(out)), "fl_poisson_vector_bytes")
+        return out.value
+
     # ---- MatMult(S) -------------------------------------------------------------------------------------------
     def apply(self, x, y=None):
         y = self.empty() if y is None else y

@@ -164,9 +164,9 @@ int fl_vec_maxpy(fl_poisson *h, int64_t n, double *x_dev, const double *alphas, 
  *   "cheb_fuse"  0 = one kernel launch per Chebyshev step; 1 (default) = two steps per sweep over memory wherever no convergence
  *                test sits between them (KSP_NORM_NONE sweeps, the multigrid smoother) and the grid is large enough to gain;
  *                2 = the same on every grid where it is legal.
- *   "placement"  1 (default) = the first solve on a handle whose padded vectors are >= 256 MiB allocates ONE arena (16 GiB +
- *                8 vectors) and carves the solver vectors out of it where a probe of the CG kernel pair (k_cg_A + the odd-iteration k_cg_Bq) runs fastest
- *                (see fl_poisson_tune_placement); 0 = one plain allocation per vector.
+ *   "placement"  0 (default since round 3) = one plain allocation per vector; 1 = the first solve on a handle whose padded vectors are
+ *                >= 256 MiB runs the placement search of fl_poisson_tune_placement by itself (about 0.15 s, once per handle; worth
+ *                1 - 2 % of the CG iteration rate at 512^3).  A failure inside the search never fails the solve: plain allocations.
  *   "cg_xbatch"  1 (default) = the CG solver updates x every second iteration (both updates of the pair at once, while the older
  *                direction is still in its buffer); 0 = one update per iteration.  The same x bit for bit.
  *   "cheb_staged" 1 (default) = the one-step Chebyshev kernel walks LDS-staged tiles like the CG kernels (k_cheb_st); 0 = round 1's k_cheb.
@@ -174,15 +174,22 @@ int fl_vec_maxpy(fl_poisson *h, int64_t n, double *x_dev, const double *alphas, 
 int fl_tuning_set(const char *name, int value);
 int fl_tuning_get(const char *name, int *value);
 
-/* Placement of the solver vectors in HBM.  A kernel that streams five gigabyte-sized vectors in lock step runs 13 % slower
- * when all of them sit in one physically contiguous block of memory (what back-to-back allocations give) than when two or
- * three of them come from a different block (measurements: profiles/r02_placement.md).  This call -- made implicitly by the
- * first solve of a large handle unless the tuning knob "placement" is 0 -- allocates one arena, slides a window of five packed
- * vectors through it with the CG kernel pair as the probe (about 20 positions) and carves the vectors out where the window
- * was fastest.  Deterministic, idempotent, never changes results.  max_tries >= 1 (kept from the earlier interface, unused).
- * probe_ms_out (may be NULL): {probe time with all vectors in one block, probe time at the chosen place}; {0, 0} if the
- * handle is too small to be placed or memory is short. */
+/* Placement of the solver vectors in HBM (opt-in).  A kernel that streams five gigabyte-sized vectors in lock step runs up to 13 %
+ * slower when all of them sit in one physically contiguous block of memory (what back-to-back allocations give) than when two or
+ * three of them come from a different block (measurements: profiles/r02_placement.md).  This call -- or the first solve of a large
+ * handle when the tuning knob "placement" is 1 -- builds a scratch arena (16 GiB + 8 vectors) out of 256 MiB chunks of physical
+ * memory mapped into one reserved address range (HIP virtual memory management), slides a window of five packed vectors through
+ * it with the CG kernel pair as the probe (about 20 positions), and then RELEASES every chunk the fastest window does not touch:
+ * the vectors stay on the physical memory that was measured.  MEMORY: the handle afterwards holds five padded vectors plus at most
+ * two chunks of slack (5.8 - 6.3 GB at 512^3; an unplaced handle holds 5.75 GB); the arena (up to three while searching, 25 GiB
+ * each at 512^3) exists only during the call.  Where the address-range calls are not available the arena is one plain allocation and
+ * is kept whole, as in round 2.  Deterministic, idempotent, never changes results.  max_tries >= 1 (kept from the earlier
+ * interface, unused).
+ * probe_ms_out (may be NULL): {probe time with all vectors in one block, probe time of the vectors the handle ended up with};
+ * {0, 0} if the handle is too small to be placed or memory is short. */
 int fl_poisson_tune_placement(fl_poisson *h, int max_tries, double probe_ms_out[2]);
+/* bytes of device memory the handle holds for its padded solver vectors */
+int fl_poisson_vector_bytes(fl_poisson *h, int64_t *bytes_out);
 
 /* ---- operator -------------------------------------------------------------------------------- */
 int fl_poisson_apply(fl_poisson *h, const double *x_dev, double *y_dev);  /* y = S x */

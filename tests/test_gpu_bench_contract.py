@@ -31,6 +31,10 @@ def test_single_gpu_line_has_the_contract_keys():
     assert d["value"] > 0 and abs(d["ms_per_step"] * d["value"] * (512 / 64) ** 3 / 1e3 - 1.0) < 1e-6      # value = 512^3-equivalent iterations/s
     r, c = d["roofline"], d["cpu_baseline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    # the physical fraction (bytes that crossed the HBM interface / time / peak) can never exceed 1, whatever the algorithmic one says
+    assert 0 < r["traffic_frac"] <= 1.0 and 0 < r["iteration"]["traffic_frac"] <= 1.0 and all(0 < k["traffic_frac"] <= 1.0 for k in r["kernels"])
+    assert abs(r["traffic_frac"] - r["traffic_GBps"] / r["peak"]) < 1e-12 and r["measured_copy_GBps"] > 3000.0 and r["measured_3r3w_GBps"] > 3000.0
+    assert d["placement"]["mode"] == "auto" and d["hbm_bytes_held"] > 0
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and "petsc_cpu" in c
     assert c["parity_on_sample"]["iters_gpu"] == c["parity_on_sample"]["iters_cpu"] and c["parity_on_sample"]["rel_max_diff_x"] < 1e-9
     assert "workload" in d["config"] and "model" not in d["config"]

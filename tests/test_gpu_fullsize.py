@@ -1,0 +1,89 @@
+"""-m gpu: the BASELINE configurations bench.py times, checked at their OWN size (512^3, 134 M cells).
+
+C3  512^3 channel [VELOCITY inlet, PRESSURE_OUTLET, walls in y, PERIODIC span], Chebyshev-Jacobi sweeps: the fused two-step kernel
+    (k_cheb2: a periodic seam and an outlet across 4 x 64 tiles, several z chunks) against the one-step kernel on the LDS-staged walk
+    (k_cheb_st) on the same handle -- the same arithmetic per cell, so 1e-13 -- and the damping a sweep must deliver.
+C4  512^3 with the immersed sphere of diameter 64 h (12 868 markers on a Fibonacci lattice): fl_ibm_interp / fl_ibm_spread against the
+    oracle's fo_ibm_interp / fo_ibm_spread.  The host cost is O(markers), not O(cells): the oracle loops over the markers' supports.
+The headline's own configuration (512^3 cavity Jacobi-PCG) is compared with the oracle at full size by bench.py's cpu_baseline leg
+(parity_on_full_grid) and by test_gpu_poisson.py::test_full_size_properties_512.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fluca_oracle as fo
+from tests.gpu_common import CAVITY_BOX, O, PER, V
+from tests.test_gpu_ibm import Ibm, sphere_markers
+
+pytestmark = pytest.mark.gpu
+N512 = (512, 512, 512)
+
+
+def _fuse(mode):
+    from fluca_amd import capi
+    capi.check(capi.lib.fl_tuning_set(b"cheb_fuse", mode), "fl_tuning_set")
+
+
+def test_c3_channel_fused_chebyshev_equals_single_steps_at_512():
+    from fluca_amd.poisson import Poisson
+    bc = [V, O, V, V, PER, PER]
+    P = Poisson.uniform(N512, CAVITY_BOX, bc, 1e-3)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    p = torch.rand(P.ncell, generator=gen, dtype=torch.float64, device="cuda") * 2 - 1
+    b = P.apply(p)
+    kw = dict(type=2, norm_type=3, remove_nullspace=0, check_every=100)
+    out = {}
+    try:
+        for mode in (0, 2):
+            _fuse(mode)
+            x, info = P.solve(b, maxit=20, profile=1, **kw)
+            assert info["iters"] == 20 and info["reason"] == 4
+            # which kernel ran: the fused one needs half as many launches as steps
+            assert info["kernel_launches"] == (10 if mode == 2 else 20), info
+            out[mode] = x
+    finally:
+        _fuse(1)
+    scale = float(out[0].norm())
+    assert scale > 0 and float((out[2] - out[0]).norm()) <= 1e-13 * scale
+    # residual damping: 40 steps leave less than 20, both less than the right-hand side (zero initial guess)
+    r20 = float((b - P.apply(out[2])).norm())
+    x40, _ = P.solve(b, maxit=40, **kw)
+    r40 = float((b - P.apply(x40)).norm())
+    assert r40 < r20 < float(b.norm())
+    P.close()
+
+
+@pytest.mark.parametrize("kind", [fo.DELTA_PESKIN4])
+def test_c4_sphere_ibm_matches_oracle_at_512(kind):
+    from fluca_amd.poisson import Poisson
+    box = [(0.0, 1.0)] * 3
+    bc = [V] * 6
+    P = Poisson.uniform(N512, box, bc, 1e-3)
+    g = fo.Grid.uniform(N512, box, bc, 1e-3)
+    h = 1.0 / 512
+    R = 32 * h
+    L = int(round(4 * np.pi * R * R / (h * h)))
+    assert L == 12868
+    X = sphere_markers(L, (0.5, 0.5, 0.5), R)
+    m = Ibm(P, kind, X)
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    u = torch.rand(3 * P.ncell, generator=gen, dtype=torch.float64, device="cuda") * 2 - 1
+    U = m.interp(u, 3).cpu().numpy().reshape(3, L)
+    uh = u.cpu().numpy()
+    Uo = g.ibm_interp(kind, X, uh)
+    assert np.abs(U - Uo).max() <= 1e-13 * np.abs(Uo).max()
+    rng = np.random.default_rng(5)
+    F = rng.standard_normal((3, L))
+    dV = np.full(L, h ** 3)
+    f = torch.zeros(3 * P.ncell, dtype=torch.float64, device="cuda")
+    m.spread(torch.as_tensor(F.reshape(-1), device="cuda"), torch.as_tensor(dV, device="cuda"), f, 3)
+    fo_ = g.ibm_spread(kind, X, dV, F)
+    fh = f.cpu().numpy().reshape(3, -1)
+    assert np.abs(fh - fo_).max() <= 1e-13 * np.abs(fo_).max()
+    # the invariants of SURVEY 8(c) at this size: spreading conserves the total force; interpolation and spreading are adjoint
+    assert np.allclose(fh.sum(axis=1) * h ** 3, (F * dV).sum(axis=1), rtol=1e-11)
+    lhs, rhs = float((U * F * dV).sum()), float((uh.reshape(3, -1) * fh).sum() * h ** 3)
+    assert abs(lhs - rhs) <= 1e-11 * max(abs(lhs), abs(rhs))
+    m.close()
+    P.close()
