@@ -1176,6 +1176,7 @@ extern "C" int fl_poisson_solve(fl_poisson *h, const double *b_dev, double *x_de
   switch (opts->type) {
   case FL_KSP_CG:
     if (opts->norm_type < 0 || opts->norm_type > FL_NORM_NONE) return FL_ERR_ARG_OUTOFRANGE;
+    if (opts->cg_single_reduction) return fl_solve_cg_sr(h, b_dev, x_dev, opts, stats);  // -ksp_cg_single_reduction
     return solve_cg(h, b_dev, x_dev, opts, stats);
   case FL_KSP_BCGS:
     // KSPBCGS: left preconditioning, preconditioned residual norm only

@@ -359,6 +359,7 @@ int fl_residual_padded(fl_poisson *h, double *xpad, const double *bpad, double *
 int fl_apply_padded_dot(fl_poisson *h, double *xpad, double *ypad, double *xy);
 int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero);
 int fl_solve_bcgs(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *o, fl_ksp_stats *st);
+int fl_solve_cg_sr(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *o, fl_ksp_stats *st);
 int fl_ksp_begin(fl_poisson *h, const fl_ksp_opts *o);
 int fl_bcgs_fin_step(fl_poisson *h, int mode, int nblocks, int nslot, int nhist);
 int fl_ksp_finish(fl_poisson *h, const fl_ksp_opts *o, fl_ksp_stats *st);

@@ -248,8 +248,19 @@ __global__ void __launch_bounds__(256) k_bcgs_pw(GridP g, const double *__restri
 // convergence test are k_bcgs_fin's, unchanged.
 template <int MODE>
 struct BcgsIo {
-  static constexpr int NE = MODE == 4 ? 3 : ((MODE == 3 || MODE == 7) ? 0 : (MODE == 6 ? 2 : 1));  // extra per-cell input streams (plane of the product)
+  static constexpr int NE = (MODE == 4 || MODE == 10) ? 3 : ((MODE == 3 || MODE == 7 || MODE == 9) ? 0 : (MODE == 6 ? 2 : 1));  // extra per-cell input streams (plane of the product)
+  static constexpr int NACC = MODE == 9 ? 7 : 4;                                                                                   // partial-sum slots
+  static constexpr bool ZST = MODE == 9 || MODE == 10;  // the staged vector is z = M r formed while staging r (single-reduction CG)
 };
+// KSPCG with -ksp_cg_single_reduction (the option PETSc offers on the reference's sub-KSP as -ns_abf_schur_ksp_cg_single_reduction,
+// prefix built at abfpc.c:206): every inner product of an iteration in ONE reduction.  With z = M r (staged while r is staged) and
+// S = A z formed by the walk:
+//   MODE 9   sums 0 z.r  1 z.S  2 z.z  3 sum z  4 sum r  5 sum S  6 r.r                                   reads r                  8 B/cell
+//   MODE 10  p = (z - zshift) + b p;  W = S + b W (= A p by recurrence);  x += a p;  r' = r - a W into the OTHER r buffer (a tile reads
+//            its neighbours' old r while they write the new one)                          reads r,p,W,x  writes r',p,W,x         64
+// k_cgsr_fin turns the sums into b = beta'/beta, p.Ap = delta - b^2 (p.Ap)_old, a = beta'/p.Ap, the lazy null-space shift and the
+// convergence test.  72 B/cell/iteration against 60 of the two-reduction pair (k_cg_A + k_cg_Bq): the price of one all-reduce and one
+// scalar kernel less per iteration, worth it where those weigh as much as the kernels (several ranks, small blocks).
 //   MODE 7  y = S x (padded), sums 0 sum y, 2 x.y, 3 y.y          MODE 8  r = o - S x (padded), no sums          (multigrid cycle, JAC = false)
 //   MODE 6  (Chebyshev, one step: KSPCHEBYSHEV + PCJACOBI, the recurrence of k_cheb)  z = M (b - S x), x staged; d = rho d + c z (in place);
 //           x' = x + d into the other x buffer; sums 0 sum z, 1 z.z, 2 r.r                              reads x,b,d  writes x',d          40
@@ -259,14 +270,15 @@ __device__ __forceinline__ void st_body(const GridP &g, const double *__restrict
 {
   using T               = TileA<RY, NW>;
   constexpr int TX = T::TX, TY = T::TY, LX = T::LX, LY = T::LY;
-  constexpr int NE = BcgsIo<MODE>::NE;
+  constexpr int NE = BcgsIo<MODE>::NE, NACC = BcgsIo<MODE>::NACC;
+  constexpr bool ZST = BcgsIo<MODE>::ZST;
   __shared__ __attribute__((aligned(16))) double lds[3][LY][LX];
-  __shared__ double                              red[4 * NW];
-  double alpha = 0., omega = 0., beta = 0., ob = 0., vsh = 0., ssh = 0., tsh = 0., crho = 0., cc = 0.;
-  if (MODE < 7) {  // MODE 7 / 8 (plain products for the multigrid cycle) run without a scalar block
+  __shared__ double                              red[NACC * NW];
+  double alpha = 0., omega = 0., beta = 0., ob = 0., vsh = 0., ssh = 0., tsh = 0., crho = 0., cc = 0., zsh = 0.;
+  if (MODE < 7 || MODE >= 9) {  // MODE 7 / 8 (plain products for the multigrid cycle) run without a scalar block
     if (s->reason != 0) return;
     alpha = s->alpha; omega = s->omega; beta = s->beta; ob = s->omega_old * s->beta; vsh = s->vshift; ssh = s->rshift; tsh = s->tshift;
-    crho = s->cheb_rho; cc = s->cheb_c;
+    crho = s->cheb_rho; cc = s->cheb_c; zsh = s->zshift;
   }
 
   const int b     = remap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
@@ -308,8 +320,14 @@ __device__ __forceinline__ void st_body(const GridP &g, const double *__restrict
   const int     hBo   = hBok ? (hBj - j0) * g.sx + (hBi - i0) : 0;
   const int     hAr = hAok ? (tid < 128 ? 0 : TY + 1) : 0, hAc = hAok ? (tid & 127) + 2 : 0;  // (0,0) is a dead corner slot
   const int     hBr = hBok ? (tb >> 1) + 1 : 0, hBc = hBok ? ((tb & 1) ? TX + 2 : 1) : 0;
+  // ZST: x + y part of the diagonal at this thread's ring cells (the ring of z = r / diag is formed from the ring of r)
+  const double  hAdxy = (ZST && JAC && hAok) ? g.sc[0][hAi] + g.sc[1][hAj] : 1.;
+  const double  hBdxy = (ZST && JAC && hBok) ? g.sc[0][hBi] + g.sc[1][hBj] : 1.;
 
-  double acc[4] = {0., 0., 0., 0.};
+  double  acc[NACC];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) acc[a] = 0.;
+  double2 rprev[ZST ? RY : 1];  // ZST: the raw r of the plane whose product is formed (the staged copy is r / diag)
   double zlc = 0., zcc = 0., zhc = 0.;  // z-row of plane kk-1 (the plane whose product is formed)
   struct Raw {
     double2 v[RY];                 // staged vector, plane kn
@@ -338,6 +356,17 @@ __device__ __forceinline__ void st_body(const GridP &g, const double *__restrict
     const double nzl = C.zl, nzc = C.zc, nzh = C.zh;
     const int    buf = (kk + 3) % 3;
     const int    kc  = kk - 1;
+    // what this step stages (and hands the product of plane kc as its z-high neighbour): the vector itself, or z = M r (ZST) -- every
+    // cell divided by its own diagonal (a wall ghost has diagonal +inf: z = 0 there)
+    double2 sv[RY];
+#pragma unroll
+    for (int m = 0; m < RY; ++m) {
+      sv[m] = C.v[m];
+      if (ZST && JAC) {
+        sv[m].x /= (xc0 + yc[m] + C.zc);
+        sv[m].y /= (xc1 + yc[m] + C.zc);
+      }
+    }
     if (kc >= k0) {
       const int     bc = (kc + 3) % 3, bp = (kc + 2) % 3;
       const int64_t pc = (int64_t)kc * g.sxy;
@@ -352,9 +381,9 @@ __device__ __forceinline__ void st_body(const GridP &g, const double *__restrict
         const double  west = lds[bc][lr][lc - 1], east = lds[bc][lr][lc + 2];
         const double  dyc = yc[m] + zcc;
         double2       y;  // the product M S (staged vector) of this pair of cells
-        y.x = st7(xc0 + dyc, cen.x, xl0, west, xh0, cen.y, yl[m], south.x, yh[m], north.x, zlc, below.x, zhc, C.v[m].x);
-        y.y = st7(xc1 + dyc, cen.y, xl1, cen.x, xh1, east, yl[m], south.y, yh[m], north.y, zlc, below.y, zhc, C.v[m].y);
-        if (JAC && MODE != 6) {
+        y.x = st7(xc0 + dyc, cen.x, xl0, west, xh0, cen.y, yl[m], south.x, yh[m], north.x, zlc, below.x, zhc, sv[m].x);
+        y.y = st7(xc1 + dyc, cen.y, xl1, cen.x, xh1, east, yl[m], south.y, yh[m], north.y, zlc, below.y, zhc, sv[m].y);
+        if (JAC && MODE != 6 && !ZST) {
           y.x /= (xc0 + dyc);
           y.y /= (xc1 + dyc);
         }
@@ -392,6 +421,30 @@ __device__ __forceinline__ void st_body(const GridP &g, const double *__restrict
           acc[0] += (o0 ? rn.x * rn.x : 0.) + (o1 ? rn.y * rn.y : 0.);
           acc[1] += (o0 ? rn.x * RP.x : 0.) + (o1 ? rn.y * RP.y : 0.);
           acc[2] += (o0 ? rn.x : 0.) + (o1 ? rn.y : 0.);
+        } else if (MODE == 9) {
+          const double2 rr = rprev[ZST ? m : 0];
+          acc[0] += (o0 ? cen.x * rr.x : 0.) + (o1 ? cen.y * rr.y : 0.);
+          acc[1] += (o0 ? cen.x * y.x : 0.) + (o1 ? cen.y * y.y : 0.);
+          acc[2] += (o0 ? cen.x * cen.x : 0.) + (o1 ? cen.y * cen.y : 0.);
+          acc[3] += (o0 ? cen.x : 0.) + (o1 ? cen.y : 0.);
+          acc[4] += (o0 ? rr.x : 0.) + (o1 ? rr.y : 0.);
+          acc[5] += (o0 ? y.x : 0.) + (o1 ? y.y : 0.);
+          acc[NACC > 6 ? 6 : 0] += (o0 ? rr.x * rr.x : 0.) + (o1 ? rr.y * rr.y : 0.);
+        } else if (MODE == 10) {
+          const double2 rr = rprev[ZST ? m : 0], P = C.e[0][m], Wv = C.e[NE >= 2 ? 1 : 0][m], X = C.e[NE >= 3 ? 2 : 0][m];
+          double2       pn, wn, xn, rn;
+          pn.x = (cen.x - zsh) + beta * P.x;
+          pn.y = (cen.y - zsh) + beta * P.y;
+          wn.x = y.x + beta * Wv.x;
+          wn.y = y.y + beta * Wv.y;
+          xn.x = fma(alpha, pn.x, X.x);
+          xn.y = fma(alpha, pn.y, X.y);
+          rn.x = fma(-alpha, wn.x, rr.x);
+          rn.y = fma(-alpha, wn.y, rr.y);
+          put(const_cast<double *>(e0), pn);
+          put(const_cast<double *>(e1), wn);
+          put(const_cast<double *>(e2), xn);
+          put(w0, rn);
         } else if (MODE == 7) {
           put(w0, y);
           acc[0] += (o0 ? y.x : 0.) + (o1 ? y.y : 0.);
@@ -424,9 +477,12 @@ __device__ __forceinline__ void st_body(const GridP &g, const double *__restrict
       }
     }
 #pragma unroll
-    for (int m = 0; m < RY; ++m) *reinterpret_cast<double2 *>(&lds[buf][w * RY + m + 1][2 * lane + 2]) = C.v[m];
-    lds[buf][hAr][hAc] = C.hA;
-    lds[buf][hBr][hBc] = C.hB;
+    for (int m = 0; m < RY; ++m) {
+      if (ZST) rprev[m] = C.v[m];
+      *reinterpret_cast<double2 *>(&lds[buf][w * RY + m + 1][2 * lane + 2]) = sv[m];
+    }
+    lds[buf][hAr][hAc] = (ZST && JAC) ? C.hA / (hAdxy + C.zc) : C.hA;
+    lds[buf][hBr][hBc] = (ZST && JAC) ? C.hB / (hBdxy + C.zc) : C.hB;
     __syncthreads();
     zlc = nzl;
     zcc = nzc;
@@ -441,14 +497,14 @@ __device__ __forceinline__ void st_body(const GridP &g, const double *__restrict
     }
   }
 #undef RO
-  if (MODE == 5 || MODE == 8) return;  // no sums
+  if (MODE == 5 || MODE == 8 || MODE == 10) return;  // no sums
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
+  for (int a = 0; a < NACC; ++a) {
     acc[a] = wave_sum(acc[a]);
     if (lane == 0) red[a * NW + w] = acc[a];
   }
   __syncthreads();
-  if (tid < 4) {
+  if (tid < NACC) {
     double t = 0.;
 #pragma unroll
     for (int q = 0; q < NW; ++q) t += red[tid * NW + q];
@@ -552,6 +608,62 @@ __global__ void __launch_bounds__(256) k_bcgs_fin(int mode, const double *__rest
     s->reason = reason;
     s->beta   = (s->rho / s->rho_old) * (s->alpha / s->omega_old);
   }
+}
+
+// Single-reduction CG scalar step.  mode 0: after the first MODE 9 pass (iteration 0), mode 1: after an update + MODE 9 pass.
+// sums: 0 z.r  1 z.S  2 z.z  3 sum z  4 sum r  5 sum S  6 r.r  (z unshifted; the constant null space is taken out here: z' = z - m)
+__global__ void __launch_bounds__(256) k_cgsr_fin(int mode, const double *__restrict__ partial, int nblocks, int stride, const double *__restrict__ sums, KspScal *__restrict__ s, double *__restrict__ hist, int nhist)
+{
+  __shared__ double out[NSLOT], red[NSLOT * 4];
+  if (mode != 0 && s->reason != 0) return;
+  if (nblocks > 0) reduce_partials(partial, nblocks, stride, 7, out, red);
+  else {
+    if (threadIdx.x < NSLOT) out[threadIdx.x] = sums[threadIdx.x];
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  const double N = s->ncell_global;
+  const double m = s->nullspace ? out[3] / N : 0.;
+  const double betan = out[0] - m * out[4];  // (z', r)
+  const double delta = out[1] - m * out[5];  // (z', S), S = A z = A z'
+  double       dp;
+  switch (s->norm_type) {
+  case FL_NORM_PRECONDITIONED: {
+    const double zz = out[2] - N * m * m;
+    dp              = sqrt(zz < 0. ? 0. : zz);
+  } break;
+  case FL_NORM_UNPRECONDITIONED: dp = sqrt(out[6]); break;
+  case FL_NORM_NATURAL: dp = sqrt(fabs(betan)); break;
+  default: dp = 0.;
+  }
+  s->zshift = m;
+  if (mode == 0) {
+    s->it     = 0;
+    s->rnorm0 = dp;
+    s->ttol   = fmax(s->rtol * dp, s->atol);
+  } else s->it += 1;
+  s->dp = dp;
+  if (hist && s->it < nhist) hist[s->it] = dp;
+  int reason = converged_default(s, dp);
+  double b = 0., dpi = delta;
+  if (!reason) {
+    if (s->it >= s->maxit) reason = FL_DIVERGED_ITS;
+    else if (betan < 0.) reason = FL_DIVERGED_INDEFINITE_PC;
+    else {
+      if (mode != 0) {
+        b   = betan / s->rz;
+        dpi = delta - b * b * s->pq;  // (p, A p) for p = z + b p_old: delta - 2 b beta'/a_old + b^2 (p.Ap)_old = delta - b^2 (p.Ap)_old
+      }
+      if (dpi <= 0. || isnan(dpi)) reason = isnan(dpi) ? FL_DIVERGED_NANORINF : FL_DIVERGED_INDEFINITE_MAT;
+    }
+  }
+  s->reason = reason;
+  if (reason) return;  // alpha / beta keep the values of the last update: nothing runs after this
+  s->rz_old = s->rz;
+  s->rz     = betan;
+  s->pq     = dpi;
+  s->beta   = b;
+  s->alpha  = betan / dpi;
 }
 
 // ------------------------------------------------------------------------------------------------ Chebyshev
@@ -1241,6 +1353,52 @@ int fl_solve_bcgs(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *
       FL_CHK(fin_step(h, tp.nblocks, 4, fin(3)));
       launch_pw<2>(h, tp, jac, P, S0, T0, RP, X, R);
       FL_CHK(fin_step(h, tp.nblocks, 3, fin(4)));
+    }
+    FL_CHK(fl_poll_scal(h));
+    if (h->scal_host->reason != 0 || it >= o->maxit) done = true;
+  }
+  launch_unpad_copy(s, g, X, x, nullptr);
+  return finish_stats(h, o, st);
+}
+
+// KSPCG with -ksp_cg_single_reduction (fl_ksp_opts.cg_single_reduction): one reduction point, hence one all-reduce and one scalar
+// kernel per iteration on several ranks (two of each in the default pair).  Vectors: r / q = the two r buffers, P0 = p, P1 = W, xp = x.
+int fl_solve_cg_sr(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *o, fl_ksp_stats *st)
+{
+  const GridP &g   = h->g;
+  const bool   jac = o->pc == FL_PC_JACOBI;
+  for (double **v : {&h->r, &h->P0, &h->P1, &h->q, &h->xp}) FL_CHK(fl_ensure_vec(h, v));
+  const PlanA pa = plan_cg_A(g, 0, 0);
+  FL_CHK(fl_ensure_partials(h, pa.nblocks));
+  const int nhist = o->maxit + 1;
+  FL_CHK(fl_ensure_hist(h, nhist));
+  hipStream_t s = h->stream;
+  init_scal(h, o);
+  FL_HIP(hipEventRecord(h->ev0, s));
+  FL_HIP(hipMemcpyAsync(h->scal, h->scal_host, sizeof(KspScal), hipMemcpyHostToDevice, s));
+  // p, W, x enter the first update with factor b = 0 / as the zero initial guess: they must be finite, so they are cleared; the ghost
+  // layers of both r buffers likewise (a wall ghost is divided by its infinite diagonal, whatever finite value it holds)
+  for (double *v : {h->r, h->q, h->P0, h->P1, h->xp}) FL_CHK(fl_zero_vec(h, v));
+  double *R = h->r, *Rn = h->q, *P = h->P0, *W = h->P1, *X = h->xp;
+  launch_pad_copy(s, g, b, R);
+  const bool ghosts = fl_any_ghost_exchange(h);
+  if (ghosts) FL_CHK(fl_fill_ghosts(h, R));
+  auto fin = [&](int mode) {
+    return [=](const double *partial, int nb, int stride, const double *sums) { hipLaunchKernelGGL(k_cgsr_fin, dim3(1), dim3(256), 0, s, mode, partial, nb, stride, sums, h->scal, h->hist, nhist); };
+  };
+  launch_bcgs_st<9>(h, pa, jac, R, nullptr, nullptr, nullptr, nullptr, nullptr);
+  FL_CHK(fin_step(h, pa.nblocks, 7, fin(0)));
+  const int every = o->check_every > 0 ? o->check_every : 16;
+  int       it = 0;
+  bool      done = false;
+  while (!done) {
+    const int stop = std::min(o->maxit, it + every);
+    for (; it < stop; ++it) {
+      launch_bcgs_st<10>(h, pa, jac, R, P, W, X, Rn, nullptr);
+      std::swap(R, Rn);
+      if (ghosts) FL_CHK(fl_fill_ghosts(h, R));
+      launch_bcgs_st<9>(h, pa, jac, R, nullptr, nullptr, nullptr, nullptr, nullptr);
+      FL_CHK(fin_step(h, pa.nblocks, 7, fin(1)));
     }
     FL_CHK(fl_poll_scal(h));
     if (h->scal_host->reason != 0 || it >= o->maxit) done = true;

@@ -626,6 +626,10 @@ FlErrorCode NSSetFromOptions(NS ns, int argc, char **argv)
   if (opt_real(argc, argv, "-ns_abf_schur_ksp_atol", &v)) ns->schur.atol = v;
   if (opt_real(argc, argv, "-ns_abf_schur_ksp_divtol", &v)) ns->schur.dtol = v;
   if (opt_int64(argc, argv, "-ns_abf_schur_ksp_max_it", &iv)) ns->schur.maxit = (int)iv;
+  if (opt_find(argc, argv, "-ns_abf_schur_ksp_cg_single_reduction")) { /* PetscOptionsBool: present without a value, or with true / 1, means on */
+    const char *sv = opt_find(argc, argv, "-ns_abf_schur_ksp_cg_single_reduction");
+    ns->schur.cg_single_reduction = !(sv[0] == '0' || sv[0] == 'f' || sv[0] == 'F' || sv[0] == 'n' || sv[0] == 'N');
+  }
   if ((s = opt_find(argc, argv, "-ns_abf_schur_ksp_chebyshev_eigenvalues"))) {
     if (sscanf(s, "%lf,%lf", &ns->schur.emin, &ns->schur.emax) != 2) return E_ARG_WRONG;
   }

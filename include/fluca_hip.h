@@ -111,6 +111,10 @@ typedef struct fl_ksp_opts {
   int     mg_levels;        /* FL_PC_MG: number of grid levels, 0 = coarsen as far as possible (-pc_mg_levels) */
   int     mg_smooth_its;    /* FL_PC_MG: Chebyshev-Jacobi steps before and after the coarse correction, 0 = 3 (-mg_levels_ksp_max_it) */
   int     gmres_restart;    /* FL_KSP_GMRES: -ksp_gmres_restart, 0 = 30 (PETSc's default) */
+  int     cg_single_reduction; /* FL_KSP_CG with FL_PC_JACOBI / FL_PC_NONE: -ksp_cg_single_reduction (on the reference's sub-KSP:
+                               -ns_abf_schur_ksp_cg_single_reduction, prefix built at abfpc.c:206): all inner products of an iteration in
+                               ONE reduction -- one all-reduce and one scalar kernel per iteration on several ranks instead of two, for
+                               72 instead of 60 B/cell/iteration (W = A p kept by recurrence).  0 (default) = off, as in PETSc */
 } fl_ksp_opts;
 
 typedef struct fl_ksp_stats {

@@ -536,6 +536,7 @@ typedef struct {
   int    maxit;
   double rtol, atol, dtol;
   double emin, emax; /* Chebyshev bounds of the preconditioned operator; both 0 -> Gershgorin estimate * (0.1, 1.1) */
+  int    cg_single_reduction; /* KSPCG -ksp_cg_single_reduction (reachable in the reference as -ns_abf_schur_ksp_cg_single_reduction, abfpc.c:206) */
 } fo_ksp_opts;
 
 typedef struct {
@@ -704,7 +705,72 @@ int fo_ksp_solve(const fo_csr *A, const double *b, double *x, const fo_ksp_opts 
   vset(n, 0., x);
   t0 = now_seconds();
 
-  if (o->type == FO_KSP_CG) {
+  if (o->type == FO_KSP_CG && o->cg_single_reduction) {
+    /* KSPCG with -ksp_cg_single_reduction, restated from PETSc's published algorithm (KSPCGUseSingleReduction manual page and the
+     * D'Azevedo / Eijkhout / Romine rearrangement it cites; PETSc source not available here: "unverified vs PETSc source" like the
+     * other Krylov restatements).  Besides z = B r it keeps S = A z and W = A p, the latter by the recurrence W = S + b W, so that
+     * beta = (z, r), delta = (z, S) and the monitored norm come out of ONE reduction and
+     *     (p, A p) = delta - b^2 (p, A p)_old      for p = z + b p_old, b = beta / beta_old
+     * needs none of its own.  Same iterates as the two-reduction form in exact arithmetic. */
+    double *r = (double *)malloc(sizeof(double) * n), *z = (double *)malloc(sizeof(double) * n), *S = (double *)malloc(sizeof(double) * n);
+    double *p = (double *)calloc(n, sizeof(double)), *W = (double *)calloc(n, sizeof(double));
+    double  beta, betaold = 1., delta, a, bb, dpi = 0., dpiold;
+    vcopy(n, b, r); /* r = b - A*0 */
+    pc_apply(o, n, dinv, r, z);
+    fo_csr_mult(A, z, S);
+    beta  = vdot(n, z, r);
+    delta = vdot(n, z, S);
+    switch (o->norm_type) {
+    case FO_NORM_PRECONDITIONED: dp = sqrt(vdot(n, z, z)); break;
+    case FO_NORM_UNPRECONDITIONED: dp = sqrt(vdot(n, r, r)); break;
+    case FO_NORM_NATURAL: dp = sqrt(fabs(beta)); break;
+    default: dp = 0.;
+    }
+    if (hist && 0 < nhist) hist[0] = dp;
+    reason = converged_default(o, 0, dp, &rnorm0, &ttol);
+    while (!reason) {
+      if (it >= o->maxit) {
+        reason = FO_DIVERGED_ITS;
+        break;
+      }
+      if (beta < 0.) {
+        reason = FO_DIVERGED_INDEFINITE_PC;
+        break;
+      }
+      dpiold = dpi;
+      if (it == 0) {
+        bb  = 0.;
+        dpi = delta;
+      } else {
+        bb  = beta / betaold;
+        dpi = delta - bb * bb * dpiold;
+      }
+      if (dpi <= 0.) {
+        reason = FO_DIVERGED_INDEFINITE_MAT;
+        break;
+      }
+      vaypx(n, bb, z, p); /* p = z + b p */
+      vaypx(n, bb, S, W); /* W = S + b W  (= A p) */
+      betaold = beta;
+      a       = beta / dpi;
+      vaxpy(n, a, p, x);
+      vaxpy(n, -a, W, r);
+      pc_apply(o, n, dinv, r, z);
+      fo_csr_mult(A, z, S);
+      beta  = vdot(n, z, r);
+      delta = vdot(n, z, S);
+      switch (o->norm_type) {
+      case FO_NORM_PRECONDITIONED: dp = sqrt(vdot(n, z, z)); break;
+      case FO_NORM_UNPRECONDITIONED: dp = sqrt(vdot(n, r, r)); break;
+      case FO_NORM_NATURAL: dp = sqrt(fabs(beta)); break;
+      default: dp = 0.;
+      }
+      ++it;
+      if (hist && it < nhist) hist[it] = dp;
+      reason = converged_default(o, it, dp, &rnorm0, &ttol);
+    }
+    free(r); free(z); free(S); free(p); free(W);
+  } else if (o->type == FO_KSP_CG) {
     /* KSPCG, Hestenes-Stiefel, left preconditioning */
     double *r = (double *)malloc(sizeof(double) * n), *z = (double *)malloc(sizeof(double) * n);
     double *p = (double *)malloc(sizeof(double) * n), *w = (double *)malloc(sizeof(double) * n);

@@ -26,7 +26,7 @@ _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 class KspOpts(C.Structure):
     _fields_ = [("type", C.c_int), ("pc", C.c_int), ("norm_type", C.c_int), ("remove_nullspace", C.c_int),
                 ("maxit", C.c_int), ("rtol", C.c_double), ("atol", C.c_double), ("dtol", C.c_double),
-                ("emin", C.c_double), ("emax", C.c_double)]
+                ("emin", C.c_double), ("emax", C.c_double), ("cg_single_reduction", C.c_int)]
 
 
 class KspStats(C.Structure):
@@ -310,9 +310,10 @@ class Csr:
         return lib().fo_gershgorin_dinvA(self.h, pc)
 
     def solve(self, b, ksp=KSP_CG, pc=PC_JACOBI, norm=NORM_PRECONDITIONED, nullspace=True, rtol=1e-5, atol=1e-50,
-              dtol=1e5, maxit=10000, emin=0.0, emax=0.0, history=True):
-        """KSPSolve(kspS, b, x) with PETSc defaults (rtol 1e-5, atol 1e-50, dtol 1e5, maxit 1e4, zero guess)."""
-        o = KspOpts(ksp, pc, norm, int(nullspace), int(maxit), rtol, atol, dtol, emin, emax)
+              dtol=1e5, maxit=10000, emin=0.0, emax=0.0, history=True, single_reduction=False):
+        """KSPSolve(kspS, b, x) with PETSc defaults (rtol 1e-5, atol 1e-50, dtol 1e5, maxit 1e4, zero guess).
+        single_reduction: KSPCG with -ksp_cg_single_reduction."""
+        o = KspOpts(ksp, pc, norm, int(nullspace), int(maxit), rtol, atol, dtol, emin, emax, int(bool(single_reduction)))
         st = KspStats()
         x = np.empty(self.nrow)
         hist = np.full(int(maxit) + 2, np.nan) if history else None

@@ -53,7 +53,20 @@ def run_ranks(world, fn, *args, timeout=600):
         raise AssertionError("multi-process test failed:\n" + "\n".join(msgs) + f"\nexit codes {[p.exitcode for p in procs]}")
 
 
-from fluca_amd.hostcomm import gloo_allreduce, gloo_exchange  # noqa: E402,F401  (the transport lives in the package)
+from fluca_amd.hostcomm import gloo_exchange  # noqa: E402,F401  (the transport lives in the package)
+from fluca_amd import hostcomm as _hostcomm  # noqa: E402
+
+_ALLREDUCE_CALLS = [0]
+
+
+def gloo_allreduce(vals):
+    """the package's all-reduce callback, counted: tests of the single-reduction CG assert one call per iteration"""
+    _ALLREDUCE_CALLS[0] += 1
+    return _hostcomm.gloo_allreduce(vals)
+
+
+def allreduce_calls():
+    return _ALLREDUCE_CALLS[0]
 
 
 def decomp_of(capi, n, ranks, rank):

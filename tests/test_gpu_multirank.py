@@ -46,15 +46,23 @@ def _worker(rank, world, n, ranks, bc, ksp):
     for a in range(3):
         ref = (Vg[a] - Gst[a]).reshape(fshape[a])[mpc.face_block(d, a, periodic)].ravel()
         assert abs(Vl[a].cpu().numpy() - ref).max() <= 1e-11 * max(1.0, abs(ref).max()), ("project", rank, a)
-    # KSPSolve on the decomposed grid vs the single-domain oracle
+    # KSPSolve on the decomposed grid vs the single-domain oracle (ksp 10: KSPCG with -ksp_cg_single_reduction, ONE all-reduce per iteration)
+    sr = ksp == 10
+    if sr:
+        ksp = 0
     nullspace = 2 not in bc
     # (every iteration is two gloo all-reduces and a host-staged exchange: four processes make that slow, keep it short)
     kw = dict(rtol=1e-6 if world < 4 else 1e-4, maxit=2000)
     if ksp == 2:
         lam = S.gershgorin(fo.PC_JACOBI)
         kw = dict(rtol=1e-3, maxit=40, emin=0.1 * lam, emax=1.1 * lam)
-    xo, io = S.solve(b, ksp=ksp, nullspace=nullspace, **kw)
-    xg, ig = P.solve(dev(b.reshape(shp)[blk]), history=True, type=ksp, remove_nullspace=int(nullspace), check_every=6, **kw)
+    xo, io = S.solve(b, ksp=ksp, nullspace=nullspace, single_reduction=sr, **kw)
+    calls = mpc.allreduce_calls() if sr else 0
+    xg, ig = P.solve(dev(b.reshape(shp)[blk]), history=True, type=ksp, remove_nullspace=int(nullspace), check_every=6, cg_single_reduction=int(sr), **kw)
+    if sr:   # ONE all-reduce per iteration (+ the one of iteration 0; the host enqueues check_every = 6 iterations between two looks at the
+        # convergence flag, so up to five more follow the iteration that converged): the point of the option -- the default pair makes two
+        made = mpc.allreduce_calls() - calls
+        assert ig["iters"] + 1 <= made <= ig["iters"] + 6, (made, ig["iters"])
     assert ig["reason"] == io["reason"], (ig["reason"], io["reason"])
     assert abs(ig["iters"] - io["iters"]) <= (2 if ksp != 1 else max(3, io["iters"] // 10)), (ig["iters"], io["iters"])
     m = min(len(ig["history"]), len(io["history"]), 8)
@@ -78,6 +86,9 @@ CASES = [
     (4, (140, 36, 12), (2, 2, 1), [1, 2, 1, 1, 3, 3], 0),      # outlet (no null space), >1 tile in x per rank
     (2, (24, 20, 16), (1, 2, 1), [1, 1, 1, 1, 4, 1], 1),       # BiCGStab
     (2, (24, 20, 16), (1, 1, 2), [1, 1, 3, 3, 4, 1], 2),       # Chebyshev-Jacobi
+    (2, (24, 20, 16), (1, 1, 2), [1, 1, 1, 1, 4, 1], 10),      # single-reduction CG: cavity, z split
+    (2, (24, 20, 16), (2, 1, 1), [3, 3, 1, 1, 3, 3], 10),      # ... across a periodic axis
+    (4, (140, 36, 12), (2, 2, 1), [1, 1, 1, 1, 3, 3], 10),     # ... four ranks, > 1 tile in x per rank
 ]
 
 

@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 V, PER = 1, 3
 
 
-def run(cells, axes, loopback, iters=200):
+def run(cells, axes, loopback, iters=200, sr=0):
     os.environ["FLUCA_COMM_LOOPBACK"] = "1" if loopback else "0"
     from fluca_amd import poisson as flp
     bc = []
@@ -28,8 +28,8 @@ def run(cells, axes, loopback, iters=200):
     p = torch.rand(P.ncell, dtype=torch.float64, device="cuda", generator=g) * 2 - 1
     b = P.apply(p)
     x = P.empty()
-    P.solve(b, x=x, rtol=0.0, atol=0.0, maxit=20, check_every=64)
-    _, info = P.solve(b, x=x, rtol=0.0, atol=0.0, maxit=iters, check_every=64)
+    P.solve(b, x=x, rtol=0.0, atol=0.0, maxit=20, check_every=64, cg_single_reduction=sr)
+    _, info = P.solve(b, x=x, rtol=0.0, atol=0.0, maxit=iters, check_every=64, cg_single_reduction=sr)
     P.close()
     return info["seconds"] / iters * 1e3
 
@@ -38,10 +38,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cells", type=int, default=512)
     ap.add_argument("--axes", type=int, default=3, help="number of periodic axes (= neighbours pairs exchanged)")
+    ap.add_argument("--single-reduction", type=int, default=0, help="1: KSPCG with -ksp_cg_single_reduction (fl_ksp_opts.cg_single_reduction)")
     a = ap.parse_args()
-    local = run(a.cells, a.axes, False)
-    loop = run(a.cells, a.axes, True)
-    print(json.dumps(dict(cells=a.cells, periodic_axes=a.axes, ms_per_iter_local_wrap=local, ms_per_iter_rccl_loopback=loop,
+    local = run(a.cells, a.axes, False, sr=a.single_reduction)
+    loop = run(a.cells, a.axes, True, sr=a.single_reduction)
+    print(json.dumps(dict(cells=a.cells, periodic_axes=a.axes, single_reduction=a.single_reduction, ms_per_iter_local_wrap=local, ms_per_iter_rccl_loopback=loop,
                           overhead_ms=loop - local, efficiency_bound=local / loop)))
 
 
