@@ -30,6 +30,8 @@ for k in sorted(dur):
     if pat not in k:
         continue
     big = [d for d in dur[k] if d >= max(min_ms, 0.5 * max(dur[k]))]
+    if not big:
+        continue
     e = {"launches": len(big), "mean_ms": round(statistics.mean(big), 4), "median_ms": round(statistics.median(big), 4)}
     for c, v in cnt.get(k, {}).items():
         top = [x for x in v if x >= 0.5 * max(v)] if max(v) > 0 else v
