@@ -1252,6 +1252,7 @@ int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero)
     cur ^= 1;
   }
   if (cur) std::swap(h->xp, h->P0);
+  h->poisoned = true;  // no norm is monitored in here: see fl_solve_cheb
   return 0;
 }
 
@@ -1507,6 +1508,9 @@ int fl_solve_cheb(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *
       if (h->scal_host->reason != 0 || j >= total) done = true;
     }
   }
+  // without a monitored norm nothing tells whether NaN / Inf went through the work vectors CG shares with this solver (P0 = X1, q = d,
+  // xp = X0): the next CG solve on the handle clears its direction buffers instead of relying on "beta = 0 times something finite"
+  if (o->norm_type == FL_NORM_NONE) h->poisoned = true;
   if (nopoll) {
     launch_unpad_copy(s, g, hostcur ? X1 : X0, x, S.nullspace ? &h->scal->xshift : nullptr);
     st->iters  = total;

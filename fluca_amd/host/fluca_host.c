@@ -26,6 +26,25 @@ enum { E_MEM = 55, E_SUP = 56, E_ARG_WRONG = 62, E_ARG_OUTOFRANGE = 63, E_ARG_WR
     if (r_) return -r_;         \
   } while (0)
 
+/* the same inside a roctx range (trace_begin .. trace_end): the range is closed on the error path too */
+#define FLABI_T(call)           \
+  do {                          \
+    int r_ = (call);            \
+    if (r_) {                   \
+      trace_end();              \
+      return -r_;               \
+    }                           \
+  } while (0)
+#define FLCHK_T(call)           \
+  do {                          \
+    FlErrorCode e_ = (call);    \
+    if (e_) {                   \
+      trace_end();              \
+      return e_;                \
+    }                           \
+  } while (0)
+static void trace_end(void);
+
 /* ------------------------------------------------------------------------------------------------ registries */
 
 #define MAXTYPES 16
@@ -1477,10 +1496,10 @@ static FlErrorCode NSStep_CNLinear(NS ns)
 
   trace_begin("NSFormFunction"); /* the right-hand side of the step: PetscLogEvent NS_FormFunction (nsbasic.c:131) */
   /* v0interp = B v0 + vbc(t), cnlinearcart3d.c:2826-2829; vbc: :1749-1932 */
-  FLABI(fl_momentum_interp_faces(ns->momentum, c->sol0_v, NULL, c->W));
+  FLABI_T(fl_momentum_interp_faces(ns->momentum, c->sol0_v, NULL, c->W));
   /* momrhs = v0 + cv L v0 - kappa G p, :2976-2993 (p0 on the first step, phalf afterwards) */
-  FLABI(fl_momentum_rhs(ns->momentum, dt, ns->rho, ns->mu, c->sol0_v, ns->step == 0 ? c->sol0_p : c->phalf, NULL, c->f_v));
-  for (int d = 0; d < 3; ++d) FLABI(fl_vec_lincomb(h, c->sz[1 + d], 0., c->f_V[d], 0., NULL, c->f_V[d])); /* interprhs = 0 */
+  FLABI_T(fl_momentum_rhs(ns->momentum, dt, ns->rho, ns->mu, c->sol0_v, ns->step == 0 ? c->sol0_p : c->phalf, NULL, c->f_v));
+  for (int d = 0; d < 3; ++d) FLABI_T(fl_vec_lincomb(h, c->sz[1 + d], 0., c->f_V[d], 0., NULL, c->f_V[d])); /* interprhs = 0 */
   for (int b = 0; b < 6; ++b) {
     if (ns->bcs[b].type != NS_BC_VELOCITY || !cnl_touches(ns, b)) continue;
     const int        ax = b / 2, side = b % 2, a1 = ax == 0 ? 1 : 0, a2 = ax == 2 ? 1 : 2;
@@ -1488,11 +1507,14 @@ static FlErrorCode NSStep_CNLinear(NS ns)
     const int64_t    np = D->len[a1] * D->len[a2], n = cart->N[ax];
     const double    *xf = cart->xf[ax], *xc = cart->xc[ax];
     double          *vb0[3] = {c->plane_host[0], c->plane_host[1], c->plane_host[2]}, *vb1[3] = {c->plane_host[3], c->plane_host[4], c->plane_host[5]};
-    FLCHK(cnl_eval_velocity(ns, b, t, vb0));
-    FLCHK(cnl_eval_velocity(ns, b, t + dt, vb1));
+    FLCHK_T(cnl_eval_velocity(ns, b, t, vb0));
+    FLCHK_T(cnl_eval_velocity(ns, b, t + dt, vb1));
     /* coefficient of the wall value in the one-sided second-derivative row, :698-701 / :726-729 */
     double h1, h2, h3, hcell;
-    if (n < 3) return E_SUP;
+    if (n < 3) {
+      trace_end();
+      return E_SUP;
+    }
     if (!side) {
       h1 = xc[0] - xf[0]; h2 = xc[1] - xc[0]; h3 = xc[2] - xc[0]; hcell = xf[1] - xf[0];
     } else {
@@ -1502,22 +1524,22 @@ static FlErrorCode NSStep_CNLinear(NS ns)
     double      *tmp = c->plane_host[6];
     for (int q = 0; q < 3; ++q) {
       /* v0interp on the wall faces = the wall velocity at t (INSERT), :1788 */
-      FLCHK(cnl_upload(ns, vb0[q], np));
-      FLABI(fl_boundary_set_faces(h, b, 1., c->plane_dev, c->W[q * 3 + ax]));
+      FLCHK_T(cnl_upload(ns, vb0[q], np));
+      FLABI_T(fl_boundary_set_faces(h, b, 1., c->plane_dev, c->W[q * 3 + ax]));
       /* momrhs += cv (vbcL(t) + vbcL(t+dt)) - dt vbcC(t, t+dt), :2985-2998 with :698-701 and :1338 */
       for (int64_t a = 0; a < np; ++a) tmp[a] = cv * cl * (vb0[q][a] + vb1[q][a]) - dt * sgn * (vb1[q][a] * vb0[ax][a] + vb0[q][a] * vb1[ax][a]) / hcell;
-      FLCHK(cnl_upload(ns, tmp, np));
-      FLABI(fl_boundary_add_cells(h, b, 1., c->plane_dev, c->f_v + q * N));
+      FLCHK_T(cnl_upload(ns, tmp, np));
+      FLABI_T(fl_boundary_add_cells(h, b, 1., c->plane_dev, c->f_v + q * N));
     }
     /* interprhs on the wall faces = the wall-normal velocity at t + dt, :3003-3005 with :2178 */
-    FLCHK(cnl_upload(ns, vb1[ax], np));
-    FLABI(fl_boundary_set_faces(h, b, 1., c->plane_dev, c->f_V[ax]));
+    FLCHK_T(cnl_upload(ns, vb1[ax], np));
+    FLABI_T(fl_boundary_set_faces(h, b, 1., c->plane_dev, c->f_V[ax]));
   }
   /* immersed boundary: momrhs += spread(U_target - interp(v0)) */
   if (ns->ibm) {
-    FLABI(fl_ibm_interp(ns->ibm, 3, c->sol0_v, ns->ibm_U));
-    FLABI(fl_vec_lincomb(h, 3 * ns->ibm_L, -1., ns->ibm_U, 1., ns->ibm_Ut, ns->ibm_U)); /* U_target - U (z = NULL: target 0) */
-    FLABI(fl_ibm_spread(ns->ibm, 3, ns->ibm_U, ns->ibm_dV, c->f_v));
+    FLABI_T(fl_ibm_interp(ns->ibm, 3, c->sol0_v, ns->ibm_U));
+    FLABI_T(fl_vec_lincomb(h, 3 * ns->ibm_L, -1., ns->ibm_U, 1., ns->ibm_Ut, ns->ibm_U)); /* U_target - U (z = NULL: target 0) */
+    FLABI_T(fl_ibm_spread(ns->ibm, 3, ns->ibm_U, ns->ibm_dV, c->f_v));
   }
   /* PRESSURE_OUTLET: the boundary-condition vector of G in momrhs (:2976-2984, :219-423) and the Rhie-Chow boundary terms
    * of interprhs (:3013-3044).  As written in the reference, the G vector is NOT scaled by dt/rho in momrhs. */
@@ -1531,8 +1553,10 @@ static FlErrorCode NSStep_CNLinear(NS ns)
       const fl_decomp *D = &ns->mesh->decomp;
       const int64_t    n1 = D->len[a1], n2 = D->len[a2], np = n1 * n2, n = cart->N[ax];
       const double    *xf = cart->xf[ax], *xc = cart->xc[ax];
-      if (!ns->bcs[b].pressure) return E_ARG_WRONGSTATE;
-      if (n < 2) return E_SUP;
+      if (!ns->bcs[b].pressure || n < 2) {
+        trace_end();
+        return !ns->bcs[b].pressure ? E_ARG_WRONGSTATE : E_SUP;
+      }
       double *pq = c->plane_host[0], *pp = c->plane_host[1], *tmp = c->plane_host[2];
       int     differs = 0;
       for (int64_t j = 0; j < n2; ++j)
@@ -1541,8 +1565,8 @@ static FlErrorCode NSStep_CNLinear(NS ns)
           xb[ax] = xf[side ? n : 0];
           xb[a1] = cart->xc[a1][D->lo[a1] + i];
           xb[a2] = cart->xc[a2][D->lo[a2] + j];
-          FLCHK(ns->bcs[b].pressure(3, tq, xb, &vq, ns->bcs[b].ctx_pressure));
-          FLCHK(ns->bcs[b].pressure(3, tp, xb, &vp, ns->bcs[b].ctx_pressure));
+          FLCHK_T(ns->bcs[b].pressure(3, tq, xb, &vq, ns->bcs[b].ctx_pressure));
+          FLCHK_T(ns->bcs[b].pressure(3, tp, xb, &vp, ns->bcs[b].ctx_pressure));
           pq[j * n1 + i] = vq;
           pp[j * n1 + i] = vp;
           differs |= vq != vp;
@@ -1550,24 +1574,24 @@ static FlErrorCode NSStep_CNLinear(NS ns)
       /* G: one-sided first derivative through the boundary value, :257-259 / :285-287 */
       const double h1 = side ? xf[n] - xc[n - 1] : xc[0] - xf[0], h2 = side ? xc[n - 1] - xc[n - 2] : xc[1] - xc[0];
       const double cg = (side ? 1. : -1.) * h2 / (h1 * (h1 + h2));
-      FLCHK(cnl_upload(ns, pq, np));
-      FLABI(fl_boundary_add_cells(h, b, -cg, c->plane_dev, c->f_v + ax * N)); /* VecAXPY(momrhs, -1, Gp), Gp = kappa G p + vbcG(tq) */
+      FLCHK_T(cnl_upload(ns, pq, np));
+      FLABI_T(fl_boundary_add_cells(h, b, -cg, c->plane_dev, c->f_v + ax * N)); /* VecAXPY(momrhs, -1, Gp), Gp = kappa G p + vbcG(tq) */
       if (differs) {
         /* Gst: :2641-2647 / :2669-2675 */
         const double g1 = side ? xf[n] - xc[n - 1] : xc[0] - xf[0], g2 = side ? xf[n] - xc[n - 2] : xc[1] - xf[0];
         const double cgst = (side ? 1. : -1.) * (g1 + g2) / (g1 * g2);
-        if (!rhiechow) FLABI(fl_vec_lincomb(h, 3 * N, 0., w, 0., NULL, w));
+        if (!rhiechow) FLABI_T(fl_vec_lincomb(h, 3 * N, 0., w, 0., NULL, w));
         rhiechow = 1;
         for (int64_t a = 0; a < np; ++a) tmp[a] = pq[a] - pp[a];
-        FLCHK(cnl_upload(ns, tmp, np));
-        FLABI(fl_boundary_add_cells(h, b, kappa * cg, c->plane_dev, w + ax * N));     /* kappa (vbcGq - vbcGp), :3031-3032 */
-        FLABI(fl_boundary_add_faces(h, b, kappa * cgst, c->plane_dev, c->f_V[ax]));   /* + kappa (vbcGstq - vbcGstp), :3034-3035 */
+        FLCHK_T(cnl_upload(ns, tmp, np));
+        FLABI_T(fl_boundary_add_cells(h, b, kappa * cg, c->plane_dev, w + ax * N));     /* kappa (vbcGq - vbcGp), :3031-3032 */
+        FLABI_T(fl_boundary_add_faces(h, b, kappa * cgst, c->plane_dev, c->f_V[ax]));   /* + kappa (vbcGstq - vbcGstp), :3034-3035 */
       }
     }
     if (rhiechow) {
       /* interprhs += (-T) w, :3033 */
       const double *rhs[3] = {c->f_V[0], c->f_V[1], c->f_V[2]};
-      FLABI(fl_momentum_face_interp_scaled(ns->momentum, -1., w, rhs, c->f_V));
+      FLABI_T(fl_momentum_face_interp_scaled(ns->momentum, -1., w, rhs, c->f_V));
     }
   }
   trace_end(); /* NSFormFunction */
@@ -1577,7 +1601,7 @@ static FlErrorCode NSStep_CNLinear(NS ns)
     const double *W[9];
     for (int q = 0; q < 9; ++q) W[q] = c->W[q];
     trace_begin("NSFormJacobian"); /* PetscLogEvent NS_FormJacobian (nsbasic.c:118) */
-    FLABI(fl_momentum_set_state(ns->momentum, dt, ns->rho, ns->mu, V0, W));
+    FLABI_T(fl_momentum_set_state(ns->momentum, dt, ns->rho, ns->mu, V0, W));
     trace_end();
   }
   /* KSPSolve(J, f, x) with PC_ABF */

@@ -97,6 +97,42 @@ def test_decomposed_solve_matches_single_domain_oracle(world, n, ranks, bc, ksp)
     mpc.run_ranks(world, _worker, n, ranks, bc, ksp)
 
 
+def _overlap_worker(rank, world, n, ranks, bc, overlap, outdir):
+    """One CG solve on the decomposed grid with the halo exchange of r overlapped with k_cg_Bq (FLUCA_OVERLAP=1, the default) or run
+    after it (0); the residual history and the block of x go to a file for the comparison."""
+    import os
+    os.environ["FLUCA_OVERLAP"] = str(overlap)      # read once per process, before the first solve
+    import torch
+    from fluca_amd import capi
+    from fluca_amd.poisson import Poisson
+    from oracle import fluca_oracle as fo
+    d = mpc.decomp_of(capi, n, ranks, rank)
+    box = [(0.0, 1.0), (0.0, 1.0), (0.0, 0.5)]
+    P = Poisson.uniform(n, box, bc, 1e-3, decomp=d)
+    P.comm_init_host(mpc.gloo_exchange, mpc.gloo_allreduce, rank, world)
+    g = fo.Grid.uniform(n, box, bc, 1e-3)
+    rng = np.random.default_rng(20260313)
+    p = rng.uniform(-1, 1, g.ncell)
+    p -= p.mean()
+    b = g.assemble_S().mult(p)
+    shp = (n[2], n[1], n[0])
+    xg, ig = P.solve(torch.as_tensor(np.ascontiguousarray(b.reshape(shp)[mpc.block(d)]).ravel(), device="cuda"), history=True, rtol=1e-7, maxit=400, check_every=6)
+    np.savez(os.path.join(outdir, f"ov{overlap}_r{rank}.npz"), hist=ig["history"], x=xg.cpu().numpy(), iters=ig["iters"], reason=ig["reason"])
+    P.close()
+
+
+@pytest.mark.parametrize("world,n,ranks,bc", [(2, (24, 20, 16), (1, 1, 2), [1, 1, 1, 1, 4, 1]), (2, (136, 20, 12), (2, 1, 1), [3, 3, 1, 1, 3, 3])])
+def test_overlapped_exchange_changes_nothing(tmp_path, world, n, ranks, bc):
+    """The exchange of r hidden behind k_cg_Bq (the neighbour's ghost = this rank's boundary cell, formed by the same fma from the q that
+    k_cg_A kept on the boundary layers) against the sequential order: the same history and the same x, bit for bit, on every rank."""
+    for ov in (1, 0):
+        mpc.run_ranks(world, _overlap_worker, n, ranks, bc, ov, str(tmp_path))
+    for r in range(world):
+        a, b_ = np.load(tmp_path / f"ov1_r{r}.npz"), np.load(tmp_path / f"ov0_r{r}.npz")
+        assert int(a["iters"]) == int(b_["iters"]) and int(a["reason"]) == int(b_["reason"]) == 2
+        assert np.array_equal(a["hist"], b_["hist"]) and np.array_equal(a["x"], b_["x"])
+
+
 def _ibm_worker(rank, world, n, ranks, bc, kind):
     """Markers replicated on every rank; interp = all-reduced sum over the owners of the support cells, spread = each rank
     adds to the cells it owns.  Against the single-domain oracle, including supports that straddle block faces and the
