@@ -216,6 +216,8 @@ extern "C" int fl_poisson_destroy(fl_poisson *h)
   for (int b = 0; b < 6; ++b) {
     if (h->fsend[b]) (void)hipFree(h->fsend[b]);
     if (h->frecv[b]) (void)hipFree(h->frecv[b]);
+    if (h->xsend[b]) (void)hipFree(h->xsend[b]);
+    if (h->xrecv[b]) (void)hipFree(h->xrecv[b]);
   }
   for (int d = 0; d < 3; ++d) {
     if (h->hiface[d]) (void)hipFree(h->hiface[d]);
@@ -785,6 +787,54 @@ int fl_fill_ghosts(fl_poisson *h, double *v)
   if (!msgs.empty()) launch_pack_faces(h->stream, g, v, sbuf);    // all boundary layers in one launch
   FL_CHK(h->comm.exchange(h->stream, msgs));
   if (!msgs.empty()) launch_unpack_faces(h->stream, g, v, rbuf);  // all ghost layers in one launch
+  return 0;
+}
+
+// Ghost layers INCLUDING the edge and corner cells (what a 27-point footprint reads: the tri-linear prolongation of the multigrid cycle):
+// the axes are handled one after the other, and the face exchanged / wrapped along axis d spans the ghost layers the axes before it
+// have already filled, so that an edge cell arrives in two hops and a corner cell in three -- the reference's DMStag would do the same
+// with DMSTAG_STENCIL_BOX.  Three exchanges instead of one; used on coarse correction vectors only.
+int fl_fill_ghosts_full(fl_poisson *h, double *v)
+{
+  const GridP &g = h->g;
+  if (h->multi && h->comm.kind == Comm::NONE) return FL_ERR_ARG_WRONGSTATE;
+  int periodic[3];
+  for (int d = 0; d < 3; ++d) periodic[d] = h->ax[d].periodic;
+  fl_halo_msg plan[12];
+  int         np = h->multi ? fl_halo_plan(&h->dec, periodic, plan) : 0;
+  if (h->multi && h->loopback)
+    for (int ax = 0; ax < 3; ++ax)
+      if (periodic[ax]) {
+        plan[np++] = {0, 2 * ax + 1, 2 * ax, 2 * ax + 1, 2 * ax + 1};
+        plan[np++] = {0, 2 * ax, 2 * ax + 1, 2 * ax, 2 * ax};
+      }
+  for (int d = 0; d < 3; ++d) {
+    const int ea = d >= 1 ? 1 : 0, eb = d >= 2 ? 1 : 0;  // in-face directions: (y, z), (x, z), (x, y)
+    if (h->wrap_local[d]) {
+      launch_face_ext(h->stream, g, v, nullptr, d, 0, ea, eb, 0);
+      continue;
+    }
+    if (!h->multi) continue;
+    const int64_t    cnt = (int64_t)((d == 0 ? g.ny : g.nx) + 2 * ea) * ((d == 2 ? g.ny : g.nz) + 2 * eb);
+    std::vector<Msg> msgs;
+    bool             recv_side[2] = {false, false};
+    for (int a = 0; a < np; ++a) {
+      const int sb = plan[a].send_boundary, rb = plan[a].recv_boundary;
+      if (sb / 2 != d) continue;
+      for (int bnd : {sb, rb}) {
+        if (h->xsend[bnd]) continue;
+        const size_t cap = (size_t)(std::max(g.nx, g.ny) + 2) * (size_t)(std::max(g.ny, g.nz) + 2);
+        FL_CHK(fl_dev_alloc(h, (void **)&h->xsend[bnd], sizeof(double) * cap, true));
+        FL_CHK(fl_dev_alloc(h, (void **)&h->xrecv[bnd], sizeof(double) * cap, true));
+      }
+      launch_face_ext(h->stream, g, v, h->xsend[sb], d, sb % 2, ea, eb, 1);
+      msgs.push_back({plan[a].peer, h->xsend[sb], h->xrecv[rb], cnt, plan[a].sendtag + 64, plan[a].recvtag + 64});
+      recv_side[rb % 2] = true;
+    }
+    FL_CHK(h->comm.exchange(h->stream, msgs));
+    for (int side = 0; side < 2; ++side)
+      if (recv_side[side]) launch_face_ext(h->stream, g, v, h->xrecv[2 * d + side], d, side, ea, eb, 2);
+  }
   return 0;
 }
 

@@ -25,6 +25,7 @@ namespace fl {
 void launch_pad_copy(hipStream_t, const GridP &, const double *, double *);
 void launch_unpad_copy(hipStream_t, const GridP &, const double *, double *, const double *);
 void launch_wrap(hipStream_t, const GridP &, double *, int);
+void launch_face_ext(hipStream_t, const GridP &, double *v, double *buf, int axis, int side, int ea, int eb, int mode);
 void launch_pack(hipStream_t, const GridP &, const double *, double *, int, int);
 void launch_unpack(hipStream_t, const GridP &, double *, const double *, int, int);
 void launch_pack_faces(hipStream_t, const GridP &, const double *, double *const bufs[6]);
@@ -280,6 +281,7 @@ struct fl_poisson {
   int      hist_cap = 0;
   double  *fsend[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, *frecv[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   double  *hiface[3] = {nullptr, nullptr, nullptr}, *loface_send[3] = {nullptr, nullptr, nullptr};
+  double  *xsend[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, *xrecv[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // extended faces of fl_fill_ghosts_full
   Comm     comm;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // halo exchange overlapped with k_cg_B (fl_exchange_r_begin / _end): its own stream and the two events that order it
@@ -344,10 +346,12 @@ int  fl_ensure_vec(fl_poisson *h, double **v);
 int &fl_placement_mode();
 void fl_vmm_destroy(fl_poisson *h);
 int &fl_cg_xbatch_mode();
+int &fl_mg_prolong_mode();  // fl_mg.hip: 0 piecewise constant, 1 tri-linear
 int  fl_ensure_partials(fl_poisson *h, int nblocks);
 int  fl_ensure_hist(fl_poisson *h, int nhist);
 int  fl_zero_vec(fl_poisson *h, double *v);
 int  fl_fill_ghosts(fl_poisson *h, double *v);
+int  fl_fill_ghosts_full(fl_poisson *h, double *v);  // edges and corners too (dimension by dimension)
 int  fl_exchange_r_begin(fl_poisson *h, double *r, const double *q);
 int  fl_exchange_r_end(fl_poisson *h, double *r);
 bool fl_any_ghost_exchange(const fl_poisson *h);

@@ -85,6 +85,24 @@ __global__ void k_wrap_ghosts(GridP g, double *__restrict__ v, int axis)
   }
 }
 
+// Dimension-by-dimension ghost fill (edges and corners included): axis d is handled AFTER the axes before it, over a face that is
+// wider by the ghost layers those axes have just received -- ea / eb = 1 extends the first / second in-face direction by one cell on
+// either side.  mode 0: periodic wrap inside the block, 1: pack the owned boundary layer `side`, 2: unpack into the ghost layer `side`.
+__global__ void k_face_ext(GridP g, double *__restrict__ v, double *__restrict__ buf, int axis, int side, int ea, int eb, int mode)
+{
+  const int na = (axis == 0 ? g.ny : g.nx) + 2 * ea, nb = (axis == 2 ? g.ny : g.nz) + 2 * eb;
+  const int ta = blockIdx.x * 64 + threadIdx.x, tb = blockIdx.y * 4 + threadIdx.y;
+  if (ta >= na || tb >= nb) return;
+  const int a = ta - ea, b = tb - eb;
+  const int n = axis == 0 ? g.nx : (axis == 1 ? g.ny : g.nz);
+  auto      at = [&](int c) { return axis == 0 ? pidx(g, c, a, b) : (axis == 1 ? pidx(g, a, c, b) : pidx(g, a, b, c)); };
+  if (mode == 0) {
+    v[at(-1)] = v[at(n - 1)];
+    v[at(n)]  = v[at(0)];
+  } else if (mode == 1) buf[(int64_t)tb * na + ta] = v[at(side ? n - 1 : 0)];
+  else v[at(side ? n : -1)] = buf[(int64_t)tb * na + ta];
+}
+
 // faces <-> contiguous buffers (multi-rank halo exchange).  side 0 = low, 1 = high.  pack reads owned boundary cells,
 // unpack writes the ghost layer.
 __global__ void k_pack_face(GridP g, const double *__restrict__ v, double *__restrict__ buf, int axis, int side)
@@ -1223,6 +1241,11 @@ void launch_wrap(hipStream_t st, const GridP &g, double *v, int axis)
 {
   const int na = axis == 0 ? g.ny : g.nx, nb = axis == 2 ? g.ny : g.nz;
   hipLaunchKernelGGL(k_wrap_ghosts, grid3(na, nb, 1), blk3(), 0, st, g, v, axis);
+}
+void launch_face_ext(hipStream_t st, const GridP &g, double *v, double *buf, int axis, int side, int ea, int eb, int mode)
+{
+  const int na = (axis == 0 ? g.ny : g.nx) + 2 * ea, nb = (axis == 2 ? g.ny : g.nz) + 2 * eb;
+  hipLaunchKernelGGL(k_face_ext, grid3(na, nb, 1), blk3(), 0, st, g, v, buf, axis, side, ea, eb, mode);
 }
 void launch_pack(hipStream_t st, const GridP &g, const double *v, double *buf, int axis, int side)
 {

@@ -1088,6 +1088,10 @@ extern "C" int fl_tuning_set(const char *name, int value)
     cheb_staged_mode() = value;
     return FL_SUCCESS;
   }
+  if (std::strcmp(name, "mg_prolong") == 0) {
+    fl_mg_prolong_mode() = value;
+    return FL_SUCCESS;
+  }
   return FL_ERR_ARG_WRONG;
 }
 extern "C" int fl_tuning_get(const char *name, int *value)
@@ -1107,6 +1111,10 @@ extern "C" int fl_tuning_get(const char *name, int *value)
   }
   if (std::strcmp(name, "placement") == 0) {
     *value = fl_placement_mode();
+    return FL_SUCCESS;
+  }
+  if (std::strcmp(name, "mg_prolong") == 0) {
+    *value = fl_mg_prolong_mode();
     return FL_SUCCESS;
   }
   return FL_ERR_ARG_WRONG;

@@ -8,7 +8,8 @@
 //                from fl_coeff.cpp on the coarse coordinates, same boundary conditions) -- no Galerkin product
 //   smoother   : nu steps of Chebyshev over [0.1, 1.1] x (Gershgorin bound of D^-1 S), Jacobi inside, zero initial guess
 //                (KSPCHEBYSHEV + PCJACOBI as in fl_ksp.hip; -mg_levels_ksp_type chebyshev -mg_levels_pc_type jacobi)
-//   restriction: volume-weighted average of the children's residuals;  prolongation: piecewise constant (child += parent)
+//   restriction: volume-weighted average of the children's residuals;  prolongation: tri-linear between the parent and its neighbours on
+//                the child's side (tuning knob "mg_prolong" = 1, the default; 0 = piecewise constant, child += parent)
 //   cycle      : V(nu, nu):  x = smooth(b); r = b - S x; e = V(R r); x += P e; r = b - S x; x += smooth(r)
 //   coarsest   : Jacobi-PCG to rtol 1e-2 (at most 200 iterations)
 //   outer      : KSPCG, left preconditioning, preconditioned norm ||z||, KSPConvergedDefault, constant null space
@@ -101,6 +102,50 @@ __global__ void __launch_bounds__(256) k_mg_prolong_add(GridP gf, GridP gc, int 
   }
 }
 
+// fine(child) += tensor-product linear interpolation of the coarse correction between the parent and, along every coarsened axis, the
+// neighbour of the parent on the child's side: per axis  (1 - w) coarse(parent) + w coarse(parent + o),  o = -1 / +1, w from the cell
+// centres (1/4 on a uniform axis); w = 0 where there is no such neighbour (behind a wall: the correction is continued as a constant,
+// which is what a zero normal derivative asks for) and on axes that are not coarsened.  The coarse vector needs its edge and corner
+// ghosts (fl_fill_ghosts_full).  pn / pw: per fine cell of this rank's block and axis.
+struct MgLin {
+  const int    *pn[3];
+  const double *pw[3];
+};
+__global__ void __launch_bounds__(256) k_mg_prolong_lin_add(GridP gf, GridP gc, int rx, int ry, int rz, MgLin t, const double *__restrict__ coarse, double *__restrict__ fine)
+{
+  // branch-free: where a cell has no neighbour to interpolate with its offset is 0 and its weight 0, so the "neighbour" read is the
+  // parent itself.  The two cells of a pair share their four (J, K) lines of the coarse grid.
+  const Owned o = owned_of(gf);
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < o.npairs; q += (int64_t)gridDim.x * blockDim.x) {
+    const int     ip = (int)(q % o.npair_row);
+    const int64_t row = q / o.npair_row;
+    const int     j = (int)(row % gf.ny), k = (int)(row / gf.ny), i = 2 * ip;
+    const bool    two = i + 1 < gf.nx;
+    const int     i1 = two ? i + 1 : i;
+    const int64_t fo = gf.off0 + (int64_t)k * gf.sxy + (int64_t)j * gf.sx + i;
+    const int64_t cjk = gc.off0 + (int64_t)(k / rz) * gc.sxy + (int64_t)(j / ry) * gc.sx;
+    const double  wy = t.pw[1][j], wz = t.pw[2][k];
+    const int64_t oy = (int64_t)t.pn[1][j] * gc.sx, oz = (int64_t)t.pn[2][k] * gc.sxy;
+    const int64_t c0 = cjk + i / rx, c1 = cjk + i1 / rx;
+    const int     ox0 = t.pn[0][i], ox1 = t.pn[0][i1];
+    const double  wx0 = t.pw[0][i], wx1 = t.pw[0][i1];
+    double        v0[4], v1[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int64_t sh = ((a & 1) ? oy : 0) + ((a & 2) ? oz : 0);
+      const double  p0 = coarse[c0 + sh], p1 = coarse[c1 + sh];
+      v0[a] = fma(wx0, coarse[c0 + sh + ox0] - p0, p0);
+      v1[a] = fma(wx1, coarse[c1 + sh + ox1] - p1, p1);
+    }
+    const double a0 = fma(wy, v0[1] - v0[0], v0[0]), b0 = fma(wy, v0[3] - v0[2], v0[2]);
+    const double a1 = fma(wy, v1[1] - v1[0], v1[0]), b1 = fma(wy, v1[3] - v1[2], v1[2]);
+    double2      f = ldp(fine, fo, two);
+    f.x += fma(wz, b0 - a0, a0);
+    if (two) f.y += fma(wz, b1 - a1, a1);
+    stp(fine, fo, two, f);
+  }
+}
+
 // slots: 0 sum z   1 z.z   2 r.z   3 sum r   4 r.r      (owned cells only)
 __global__ void __launch_bounds__(256) k_mg_dots(GridP g, const double *__restrict__ z, const double *__restrict__ r, double *__restrict__ partial, int stride)
 {
@@ -155,6 +200,8 @@ struct MgLevel {
   fl_poisson *h = nullptr;  // level 0: the caller's handle (not owned)
   int         r[3] = {1, 1, 1};  // refinement ratio to the NEXT (coarser) level
   double     *w[3] = {nullptr, nullptr, nullptr};  // restriction weights of this level's cells along each axis
+  int        *pn[3] = {nullptr, nullptr, nullptr};  // tri-linear prolongation onto this level: neighbour offset (-1 / +1 / 0) ...
+  double     *pw[3] = {nullptr, nullptr, nullptr};  // ... and its weight, per cell of this rank's block
   double     *x = nullptr, *b = nullptr;  // unpadded cell arrays: the coarsest level's solve goes through the public entry point
 };
 
@@ -163,6 +210,18 @@ struct fl_mg {
 };
 
 void fl_mg_destroy(fl_poisson *h);
+
+// "mg_prolong" (fl_tuning_set; initial value from FLUCA_MG_PROLONG): 1 (default since round 3) tri-linear prolongation, 0 piecewise
+// constant.  512^3 cavity, rtol 1e-8, nu = 3: 7 iterations / 0.078 - 0.080 s against 8 / 0.082 - 0.083 s on the same box; nu = 2: 10 against 22
+// iterations, nu = 1: 20 against 132 (profiles/r03_mg_bench.txt)
+int &fl_mg_prolong_mode()
+{
+  static int m = []() {
+    const char *e = std::getenv("FLUCA_MG_PROLONG");
+    return e ? std::atoi(e) : 1;
+  }();
+  return m;
+}
 
 namespace {
 
@@ -259,6 +318,29 @@ int mg_build_levels(fl_poisson *h, fl_mg *mg, int max_levels)
       }
       FL_HIP(hipMalloc((void **)&mg->lv[l].w[d], sizeof(double) * w.size()));
       FL_HIP(hipMemcpy(mg->lv[l].w[d], w.data(), sizeof(double) * w.size(), hipMemcpyHostToDevice));
+      // tri-linear prolongation: the parent's neighbour on the child's side and its weight, from the cell centres
+      std::vector<int>    pn((size_t)hf->dec.len[d], 0);
+      std::vector<double> pw((size_t)hf->dec.len[d], 0.);
+      if (r[d] == 2) {
+        const int64_t nc = hf->ax[d].n / 2;
+        const double  L = xf[d][(size_t)nc] - xf[d][0];
+        auto          Xc = [&](int64_t I) {  // coarse cell centre, periodic images included
+          if (I < 0) return 0.5 * (xf[d][(size_t)(I + nc)] + xf[d][(size_t)(I + nc) + 1]) - L;
+          if (I >= nc) return 0.5 * (xf[d][(size_t)(I - nc)] + xf[d][(size_t)(I - nc) + 1]) + L;
+          return 0.5 * (xf[d][(size_t)I] + xf[d][(size_t)I + 1]);
+        };
+        for (int64_t il = 0; il < hf->dec.len[d]; ++il) {
+          const int64_t i = hf->dec.lo[d] + il, I = i / 2, In = (i % 2) ? I + 1 : I - 1;
+          if (!hf->ax[d].periodic && (In < 0 || In >= nc)) continue;  // no neighbour behind a wall: constant continuation
+          const double xc = 0.5 * (hf->ax[d].xf[(size_t)i] + hf->ax[d].xf[(size_t)i + 1]);
+          pn[(size_t)il] = (i % 2) ? 1 : -1;
+          pw[(size_t)il] = (xc - Xc(I)) / (Xc(In) - Xc(I));
+        }
+      }
+      FL_HIP(hipMalloc((void **)&mg->lv[l].pn[d], sizeof(int) * std::max<size_t>(pn.size(), 1)));
+      FL_HIP(hipMalloc((void **)&mg->lv[l].pw[d], sizeof(double) * std::max<size_t>(pw.size(), 1)));
+      FL_HIP(hipMemcpy(mg->lv[l].pn[d], pn.data(), sizeof(int) * pn.size(), hipMemcpyHostToDevice));
+      FL_HIP(hipMemcpy(mg->lv[l].pw[d], pw.data(), sizeof(double) * pw.size(), hipMemcpyHostToDevice));
     }
   }
   for (size_t l = 0; l < mg->lv.size(); ++l) {
@@ -309,7 +391,15 @@ int vcycle(fl_mg *mg, size_t l, const fl_ksp_opts *o)
   FL_CHK(fl_residual_padded(h, h->xp, h->r, h->q));                                  // q = b - S x   (q: the smoother's scratch)
   hipLaunchKernelGGL(k_mg_restrict, dim3(nblk(C.h->ncell)), dim3(256), 0, h->stream, C.h->g, h->g, L.r[0], L.r[1], L.r[2], L.w[0], L.w[1], L.w[2], h->q, C.h->r);
   FL_CHK(vcycle(mg, l + 1, o));                                                      // e_c = V(R r)
-  hipLaunchKernelGGL(k_mg_prolong_add, dim3(nblk_pairs(h->g)), dim3(256), 0, h->stream, h->g, C.h->g, L.r[0], L.r[1], L.r[2], C.h->xp, h->xp);  // x += P e_c
+  if (fl_mg_prolong_mode() == 1) {  // x += P e_c, tri-linear: the coarse correction with its edge and corner ghosts
+    FL_CHK(fl_fill_ghosts_full(C.h, C.h->xp));
+    MgLin t;
+    for (int d = 0; d < 3; ++d) {
+      t.pn[d] = L.pn[d];
+      t.pw[d] = L.pw[d];
+    }
+    hipLaunchKernelGGL(k_mg_prolong_lin_add, dim3(nblk_pairs(h->g)), dim3(256), 0, h->stream, h->g, C.h->g, L.r[0], L.r[1], L.r[2], t, (const double *)C.h->xp, h->xp);
+  } else hipLaunchKernelGGL(k_mg_prolong_add, dim3(nblk_pairs(h->g)), dim3(256), 0, h->stream, h->g, C.h->g, L.r[0], L.r[1], L.r[2], C.h->xp, h->xp);  // x += P e_c
   FL_CHK(fl_cheb_smooth_padded(h, nu, true, false));                                 // nu more steps from x
   return 0;
 }
@@ -322,7 +412,9 @@ void fl_mg_destroy(fl_poisson *h)
   if (!mg) return;
   for (size_t l = 0; l < mg->lv.size(); ++l) {
     MgLevel &L = mg->lv[l];
-    for (double *p : {L.x, L.b, L.w[0], L.w[1], L.w[2]})
+    for (double *p : {L.x, L.b, L.w[0], L.w[1], L.w[2], L.pw[0], L.pw[1], L.pw[2]})
+      if (p) (void)hipFree(p);
+    for (int *p : L.pn)
       if (p) (void)hipFree(p);
     if (l > 0 && L.h) fl_poisson_destroy(L.h);
   }

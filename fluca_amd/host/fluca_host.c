@@ -94,6 +94,7 @@ typedef struct {
   int                  nRanks[3];
   int64_t             *l[3]; /* ownership ranges */
   MeshCartBoundaryType bndTypes[3];
+  int64_t              refineFactor[3]; /* -cart_refine_{x,y,z}, default 2 (cart.c:276) */
   double              *xf[3], *xc[3]; /* global coordinates, set by MeshSetUp / SetUniformCoordinates */
 } Mesh_Cart; /* = fluca/include/fluca/private/meshcartimpl.h:8-17 */
 
@@ -168,7 +169,45 @@ static FlErrorCode MeshSetFromOptions_Cart(Mesh mesh, int argc, char **argv)
       else if (!strcasecmp(s, "periodic")) cart->bndTypes[d] = MESHCART_BOUNDARY_PERIODIC;
       else return E_ARG_WRONG;
     }
+    snprintf(opt, sizeof(opt), "-cart_refine_%c", 'x' + d); /* cart.c:37-41 */
+    if (opt_int64(argc, argv, opt, &v)) {
+      if (v < 1) return E_ARG_OUTOFRANGE;
+      cart->refineFactor[d] = v;
+    }
   }
+  /* -cart_refine n: "Refine grid one or more times" (cart.c:42-52): the global sizes and any ownership ranges grow by
+     refineFactor^n before the mesh is set up -- the reference's hook for a hierarchy of grids */
+  int64_t nRefine = 0;
+  if (opt_int64(argc, argv, "-cart_refine", &nRefine)) {
+    if (nRefine < 0) return E_ARG_OUTOFRANGE;
+    for (int d = 0; d < 3; ++d) {
+      int64_t total = 1;
+      for (int64_t i = 0; i < nRefine; ++i) total *= cart->refineFactor[d];
+      cart->N[d] *= total;
+      if (cart->l[d])
+        for (int i = 0; i < cart->nRanks[d]; ++i) cart->l[d][i] *= total;
+    }
+  }
+  return 0;
+}
+
+FlErrorCode MeshCartSetRefinementFactor(Mesh mesh, int64_t refine_x, int64_t refine_y, int64_t refine_z) /* cart.c:432-444 */
+{
+  if (!mesh) return E_ARG_NULL;
+  if (mesh->setupcalled) return E_ARG_WRONGSTATE;
+  Mesh_Cart *cart = (Mesh_Cart *)mesh->data;
+  if (refine_x > 0) cart->refineFactor[0] = refine_x;
+  if (refine_y > 0) cart->refineFactor[1] = refine_y;
+  if (refine_z > 0) cart->refineFactor[2] = refine_z;
+  return 0;
+}
+FlErrorCode MeshCartGetRefinementFactor(Mesh mesh, int64_t *refine_x, int64_t *refine_y, int64_t *refine_z) /* cart.c:446-456 */
+{
+  if (!mesh) return E_ARG_NULL;
+  Mesh_Cart *cart = (Mesh_Cart *)mesh->data;
+  if (refine_x) *refine_x = cart->refineFactor[0];
+  if (refine_y) *refine_y = cart->refineFactor[1];
+  if (refine_z) *refine_z = cart->refineFactor[2];
   return 0;
 }
 
@@ -259,8 +298,9 @@ static FlErrorCode MeshCreate_Cart(Mesh mesh) /* cart.c:262-288 */
   Mesh_Cart *cart = (Mesh_Cart *)calloc(1, sizeof(*cart));
   if (!cart) return E_MEM;
   for (int d = 0; d < 3; ++d) {
-    cart->N[d]      = -1;
-    cart->nRanks[d] = FL_DECIDE;
+    cart->N[d]            = -1;
+    cart->nRanks[d]       = FL_DECIDE;
+    cart->refineFactor[d] = 2; /* cart.c:276 */
   }
   mesh->data                     = cart;
   mesh->ops->setfromoptions      = MeshSetFromOptions_Cart;

@@ -34,6 +34,7 @@ PROTOTYPES = {
     "MeshSetFromOptions": [_P, C.c_int, _argv], "MeshSetUp": [_P],
     "MeshCartSetUniformCoordinates": [_P] + [C.c_double] * 6, "MeshCartSetCoordinates": [_P, _P, _P, _P],
     "MeshCartGetGlobalSizes": [_P, _i64p, _i64p, _i64p], "MeshCartGetNumRanks": [_P, _ip, _ip, _ip],
+    "MeshCartSetRefinementFactor": [_P, C.c_int64, C.c_int64, C.c_int64], "MeshCartGetRefinementFactor": [_P, _i64p, _i64p, _i64p],
     "MeshCartGetCorners": [_P] + [_i64p] * 6, "MeshCartGetIsFirstRank": [_P, _ip, _ip, _ip], "MeshCartGetIsLastRank": [_P, _ip, _ip, _ip],
     "MeshCartGetBoundaryIndex": [_P, C.c_int, _ip], "MeshGetNumberBoundaries": [_P, _ip], "MeshDestroy": [C.POINTER(_P)],
     "NSCreate": [C.POINTER(_P)], "NSSetType": [_P, C.c_char_p], "NSGetType": [_P, C.POINTER(C.c_char_p)], "NSSetMesh": [_P, _P],

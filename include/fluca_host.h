@@ -61,6 +61,9 @@ FlErrorCode MeshSetUp(Mesh mesh);
 FlErrorCode MeshCartSetUniformCoordinates(Mesh mesh, double xmin, double xmax, double ymin, double ymax, double zmin, double zmax);
 FlErrorCode MeshCartSetCoordinates(Mesh mesh, const double *xf, const double *yf, const double *zf); /* = the coordLoaded path, cart.c:131-140 */
 FlErrorCode MeshCartGetGlobalSizes(Mesh mesh, int64_t *M, int64_t *N, int64_t *P);
+/* cart.c:432-456; MeshSetFromOptions honours -cart_refine_{x,y,z} <factor> and -cart_refine <n> (cart.c:37-52: sizes and ownership ranges times factor^n) */
+FlErrorCode MeshCartSetRefinementFactor(Mesh mesh, int64_t refine_x, int64_t refine_y, int64_t refine_z);
+FlErrorCode MeshCartGetRefinementFactor(Mesh mesh, int64_t *refine_x, int64_t *refine_y, int64_t *refine_z);
 FlErrorCode MeshCartGetNumRanks(Mesh mesh, int *m, int *n, int *p);
 FlErrorCode MeshCartGetCorners(Mesh mesh, int64_t *x, int64_t *y, int64_t *z, int64_t *m, int64_t *n, int64_t *p);
 FlErrorCode MeshCartGetIsFirstRank(Mesh mesh, int *fx, int *fy, int *fz);

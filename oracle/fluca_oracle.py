@@ -417,8 +417,8 @@ class MgOracle:
     V(nu,nu) cycle as left preconditioner.  `bounds[l]` = the eigenvalue bound of D^-1 S the product uses on level l
     (fl_poisson_gershgorin); None = the row-wise Gershgorin bound of the assembled matrix."""
 
-    def __init__(self, g, max_levels=0, nu=3, nullspace=True, bounds=None):
-        self.nu, self.nullspace = int(nu), bool(nullspace)
+    def __init__(self, g, max_levels=0, nu=3, nullspace=True, bounds=None, prolong="constant"):
+        self.nu, self.nullspace, self.prolong = int(nu), bool(nullspace), prolong
         self.grids, self.S, self.ratio = [g], [g.assemble_S()], []
         while max_levels <= 0 or len(self.grids) < max_levels:
             gf = self.grids[-1]
@@ -446,10 +446,30 @@ class MgOracle:
         return a.sum(axis=(1, 3, 5)).ravel()
 
     def _prolong(self, l, e):
-        gc, rr = self.grids[l + 1], self.ratio[l]
+        gf, gc, rr = self.grids[l], self.grids[l + 1], self.ratio[l]
         a = e.reshape(gc.n[2], gc.n[1], gc.n[0])
-        for ax, k in ((0, rr[2]), (1, rr[1]), (2, rr[0])):
-            a = np.repeat(a, k, axis=ax)
+        if self.prolong == "constant":
+            for ax, k in ((0, rr[2]), (1, rr[1]), (2, rr[0])):
+                a = np.repeat(a, k, axis=ax)
+            return a.ravel()
+        # tri-linear (tuning knob "mg_prolong" = 1): along every coarsened axis a child takes (1 - w) parent + w (the parent's neighbour on
+        # the child's side), w from the cell centres (1/4 on a uniform axis), periodic images included; no neighbour behind a wall: w = 0
+        for d, ax in ((0, 2), (1, 1), (2, 0)):
+            if rr[d] != 2:
+                continue
+            nc, per = gc.n[d], gf.bc[2 * d] == BC_PERIODIC
+            Xc = 0.5 * (np.asarray(gc.xf[d])[:-1] + np.asarray(gc.xf[d])[1:])
+            xc = 0.5 * (np.asarray(gf.xf[d])[:-1] + np.asarray(gf.xf[d])[1:])
+            L = gc.xf[d][-1] - gc.xf[d][0]
+            i = np.arange(gf.n[d])
+            I = i // 2
+            In = np.where(i % 2 == 1, I + 1, I - 1)
+            ok = np.full(i.shape, True) if per else (In >= 0) & (In < nc)
+            Xn = Xc[In % nc] + np.where(In < 0, -L, 0.0) + np.where(In >= nc, L, 0.0)
+            w = np.where(ok, (xc - Xc[I]) / np.where(ok, Xn - Xc[I], 1.0), 0.0)
+            shape = [1, 1, 1]
+            shape[ax] = -1
+            a = (1.0 - w).reshape(shape) * np.take(a, I, axis=ax) + w.reshape(shape) * np.take(a, In % nc, axis=ax)
         return a.ravel()
 
     def _smooth(self, l, b):

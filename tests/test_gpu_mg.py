@@ -31,7 +31,17 @@ def _bounds(mg):
     ((24, 20, 16), [V, O, V, V, PER, PER], False, False),       # 20 -> 10 -> stops (10 = 2*5 but 5 is odd): semi-coarsening
     ((32, 24, 16), CAVITY, True, True),
 ])
-def test_mg_pcg_matches_oracle(n, bc, nonuni, nullspace):
+@pytest.mark.parametrize("prolong", ["constant", "linear"])
+def test_mg_pcg_matches_oracle(n, bc, nonuni, nullspace, prolong):
+    from fluca_amd import capi
+    capi.check(capi.lib.fl_tuning_set(b"mg_prolong", 1 if prolong == "linear" else 0))
+    try:
+        _mg_pcg_matches_oracle(n, bc, nonuni, nullspace, prolong)
+    finally:
+        capi.check(capi.lib.fl_tuning_set(b"mg_prolong", 1))   # the default
+
+
+def _mg_pcg_matches_oracle(n, bc, nonuni, nullspace, prolong):
     P, g = make_pair(n, bc, kappa=1e-3, nonuniform=nonuni)
     S = g.assemble_S()
     rng = np.random.default_rng(3)
@@ -40,7 +50,7 @@ def test_mg_pcg_matches_oracle(n, bc, nonuni, nullspace):
         p -= p.mean()
     b = S.mult(p)
     mg = fo.MgOracle(g, nullspace=nullspace)
-    mg = fo.MgOracle(g, nullspace=nullspace, bounds=_bounds(mg))
+    mg = fo.MgOracle(g, nullspace=nullspace, bounds=_bounds(mg), prolong=prolong)
     xo, io = mg.pcg(b, rtol=1e-8, maxit=50)
     xg, ig = P.solve(dev(b), history=True, type=0, pc=2, remove_nullspace=int(nullspace), rtol=1e-8, maxit=50)
     assert ig["reason"] == io["reason"] == 2

@@ -259,12 +259,14 @@ def test_decomposed_momentum_matches_single_domain_oracle(world, n, ranks, bc):
     mpc.run_ranks(world, _momentum_worker, n, ranks, bc)
 
 
-def _mg_worker(rank, world, n, ranks, bc, levels):
+def _mg_worker(rank, world, n, ranks, bc, levels, prolong="constant"):
     """Multigrid-preconditioned CG on a decomposed grid (coarse levels keep the fine decomposition and borrow its
-    communicator) vs the single-domain CPU restatement with the same number of levels."""
+    communicator) vs the single-domain CPU restatement with the same number of levels.  prolong = "linear": the tri-linear
+    prolongation, whose coarse correction needs its edge and corner ghosts from the neighbour ranks (fl_fill_ghosts_full)."""
     import ctypes as C
     import torch
     from fluca_amd import capi
+    capi.check(capi.lib.fl_tuning_set(b"mg_prolong", 1 if prolong == "linear" else 0))
     from fluca_amd.poisson import Poisson
     from oracle import fluca_oracle as fo
     d = mpc.decomp_of(capi, n, ranks, rank)
@@ -289,7 +291,7 @@ def _mg_worker(rank, world, n, ranks, bc, levels):
         capi.check(capi.lib.fl_poisson_gershgorin(Q.h, capi.PC_JACOBI, C.byref(lam)))
         bounds.append(lam.value)
         Q.close()
-    mg = fo.MgOracle(g, max_levels=levels, nullspace=nullspace, bounds=bounds)
+    mg = fo.MgOracle(g, max_levels=levels, nullspace=nullspace, bounds=bounds, prolong=prolong)
     xo, io = mg.pcg(b, rtol=1e-4, maxit=50)
     shp = (n[2], n[1], n[0])
     blk = mpc.block(d)
@@ -312,6 +314,15 @@ def _mg_worker(rank, world, n, ranks, bc, levels):
 ])
 def test_decomposed_multigrid_matches_single_domain_oracle(world, n, ranks, bc, levels):
     mpc.run_ranks(world, _mg_worker, n, ranks, bc, levels)
+
+
+@pytest.mark.parametrize("world,n,ranks,bc,levels", [
+    (2, (16, 16, 32), (1, 1, 2), [1, 1, 1, 1, 4, 1], 2),       # walls everywhere: only face ghosts across the split
+    (2, (32, 16, 16), (2, 1, 1), [3, 3, 3, 3, 1, 1], 2),       # two periodic axes, one of them split: edge ghosts travel in two hops
+    (4, (32, 32, 16), (2, 2, 1), [3, 3, 3, 3, 3, 3], 2),       # 2 x 2 ranks, all periodic: corner ghosts in three
+])
+def test_decomposed_multigrid_with_trilinear_prolongation(world, n, ranks, bc, levels):
+    mpc.run_ranks(world, _mg_worker, n, ranks, bc, levels, "linear")
 
 
 def _nsstep_worker(rank, world, n, ranks, opts, dump_dir=None):

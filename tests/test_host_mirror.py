@@ -60,6 +60,37 @@ def test_mesh_options_and_decomposition(H):
     assert H.lib.MeshDestroy(C.byref(mesh)) == 0 and not mesh.value
 
 
+def test_cart_refine_options(H):
+    """-cart_refine n / -cart_refine_{x,y,z} f (fluca/src/mesh/impl/cart/cart.c:37-52): global sizes (and ownership ranges) times f^n, default factor 2"""
+    mesh = cavity_mesh(H, ("-cart_grid_x", 10, "-cart_grid_y", 7, "-cart_grid_z", 5, "-cart_refine", 2, "-cart_refine_y", 3))
+    M, N, Pz = C.c_int64(), C.c_int64(), C.c_int64()
+    assert H.lib.MeshCartGetGlobalSizes(mesh, C.byref(M), C.byref(N), C.byref(Pz)) == 0
+    assert (M.value, N.value, Pz.value) == (40, 63, 20)
+    r = [C.c_int64() for _ in range(3)]
+    assert H.lib.MeshCartGetRefinementFactor(mesh, *[C.byref(v) for v in r]) == 0 and [v.value for v in r] == [2, 3, 2]
+    assert H.lib.MeshDestroy(C.byref(mesh)) == 0
+    # ownership ranges grow with the sizes: 2 ranks in x owning 6 + 4 cells -> 12 + 8 after one refinement
+    mesh = P()
+    lx = (C.c_int64 * 2)(6, 4)
+    assert H.lib.MeshCartCreate3d(0, 0, 0, 10, 8, 8, 2, 1, 1, lx, None, None, C.byref(mesh)) == 0
+    assert H.lib.MeshSetRank(mesh, 1, 2) == 0
+    argc, av = H.argv("-cart_refine", 1)
+    assert H.lib.MeshSetFromOptions(mesh, argc, av) == 0 and H.lib.MeshSetUp(mesh) == 0
+    c = [C.c_int64() for _ in range(6)]
+    assert H.lib.MeshCartGetCorners(mesh, *[C.byref(v) for v in c]) == 0
+    assert [v.value for v in c] == [12, 0, 0, 8, 16, 16]
+    assert H.lib.MeshDestroy(C.byref(mesh)) == 0
+    # the setter is refused once the mesh is set up, a factor < 1 in the options is out of range
+    mesh = cavity_mesh(H)
+    assert H.lib.MeshCartSetRefinementFactor(mesh, 2, 2, 2) == H.ERR_ARG_WRONGSTATE
+    H.lib.MeshDestroy(C.byref(mesh))
+    mesh = P()
+    H.lib.MeshCartCreate3d(0, 0, 0, 8, 8, 8, H.FL_DECIDE, H.FL_DECIDE, H.FL_DECIDE, None, None, None, C.byref(mesh))
+    argc, av = H.argv("-cart_refine_x", 0)
+    assert H.lib.MeshSetFromOptions(mesh, argc, av) == H.ERR_ARG_OUTOFRANGE
+    H.lib.MeshDestroy(C.byref(mesh))
+
+
 def test_mesh_errors_match_reference_behaviour(H):
     mesh = P()
     H.lib.MeshCartCreate3d(0, 0, 0, 8, 8, 8, -1, -1, -1, None, None, None, C.byref(mesh))
