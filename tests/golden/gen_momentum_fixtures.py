@@ -54,8 +54,10 @@ def main():
         Z, Y, X = np.meshgrid(xc[2], xc[1], xc[0], indexing="ij")
         p = (np.cos(np.pi * X) * np.cos(np.pi * Y) * np.cos(2 * np.pi * Z)).ravel()
         p -= p.mean()
-        mg = fo.MgOracle(g)
+        mg = fo.MgOracle(g)                      # piecewise-constant prolongation (the round-2 cycle)
         xm, im = mg.pcg(S.mult(p), rtol=1e-8, maxit=50)
+        mgl = fo.MgOracle(g, prolong="linear")   # tri-linear prolongation (the library's default since round 3)
+        xl, il = mgl.pcg(S.mult(p), rtol=1e-8, maxit=50)
         out.append(dict(n=list(n), dt=DT, rho=RHO, mu=MU, bc=CAVITY,
                         apply=dict(norm2=float(np.linalg.norm(y)), sum=float(y.sum()), absmax=float(np.abs(y).max()),
                                    samples=[float(y[i]) for i in (0, 7, len(y) // 3, len(y) // 2 + 5, len(y) - 1)]),
@@ -63,7 +65,9 @@ def main():
                         bcgs=dict(iters=info["iters"], reason=info["reason"], history=[float(h) for h in info["history"]],
                                   x_norm2=float(np.linalg.norm(x))),
                         mg=dict(levels=mg.nlevels, bounds=[float(v) for v in mg.bounds], iters=im["iters"], reason=im["reason"],
-                                history=[float(h) for h in im["history"]], err_inf=float(np.abs(xm - p).max()))))
+                                history=[float(h) for h in im["history"]], err_inf=float(np.abs(xm - p).max())),
+                        mg_linear=dict(iters=il["iters"], reason=il["reason"], history=[float(h) for h in il["history"]],
+                                       err_inf=float(np.abs(xl - p).max()))))
         print(n, info["iters"], im["iters"], out[-1]["mg"]["err_inf"])
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "momentum_fixtures.json"), "w") as fh:
         json.dump(out, fh, indent=0)

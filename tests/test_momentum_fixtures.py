@@ -70,12 +70,17 @@ def test_hip_path_hits_momentum_fixture(fx):
     p = (np.cos(np.pi * X) * np.cos(np.pi * Y) * np.cos(2 * np.pi * Z)).ravel()
     p -= p.mean()
     bs = P.apply(dev(p))
-    xm, im = P.solve(bs, history=True, type=0, pc=2, rtol=1e-8, maxit=50)
-    assert im["reason"] == fx["mg"]["reason"] and abs(im["iters"] - fx["mg"]["iters"]) <= 1
-    m = min(len(im["history"]), len(fx["mg"]["history"]))
-    assert np.allclose(im["history"][:3], fx["mg"]["history"][:3], rtol=1e-6)
-    assert np.allclose(im["history"][:m], fx["mg"]["history"][:m], rtol=5e-2)
-    xm = xm.cpu().numpy()
-    assert np.abs((xm - xm.mean()) - p).max() <= 10 * fx["mg"]["err_inf"] + 1e-9
+    try:
+        for knob, key in ((0, "mg"), (1, "mg_linear")):       # piecewise-constant, then the default tri-linear prolongation
+            capi.check(capi.lib.fl_tuning_set(b"mg_prolong", knob))
+            xm, im = P.solve(bs, history=True, type=0, pc=2, rtol=1e-8, maxit=50)
+            assert im["reason"] == fx[key]["reason"] and abs(im["iters"] - fx[key]["iters"]) <= 1
+            m = min(len(im["history"]), len(fx[key]["history"]))
+            assert np.allclose(im["history"][:3], fx[key]["history"][:3], rtol=1e-6)
+            assert np.allclose(im["history"][:m], fx[key]["history"][:m], rtol=5e-2)
+            xm = xm.cpu().numpy()
+            assert np.abs((xm - xm.mean()) - p).max() <= 10 * fx[key]["err_inf"] + 1e-9
+    finally:
+        capi.check(capi.lib.fl_tuning_set(b"mg_prolong", 1))
     M.close()
     P.close()
