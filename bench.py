@@ -338,7 +338,8 @@ def other_configs(stream):
     del u, f, F, U, dV, X
 
     # The momentum block (KSPSolve(kspA), abfpc.c:72): matrix-free A = I + dt C - (mu dt / 2 rho) L on the same 512^3 cavity
-    # grid, random face fields (V0, v0interp), the operator kernel alone and the Jacobi-BiCGStab iteration around it
+    # grid, random V0 and v0, v0interp = B v0 (fl_momentum_interp_faces) handed over with v0 (fl_momentum_set_state_v0: the operator forms the inner
+    # face values itself), the operator kernel alone and the Jacobi-BiCGStab iteration around it
     try:
         P = flp.Poisson.uniform((512,) * 3, box, [1, 1, 1, 1, 4, 1], 1e-3)
         P.set_stream(stream)
@@ -346,11 +347,12 @@ def other_configs(stream):
         gen = torch.Generator(device="cuda").manual_seed(11)
         rnd = lambda m_: torch.rand(m_, dtype=torch.float64, device="cuda", generator=gen) * 2 - 1  # noqa: E731
         V0 = [rnd(P.nface[d]) for d in range(3)]
-        W = [rnd(P.nface[d]) for c in range(3) for d in range(3)]
+        v0 = rnd(3 * P.ncell)
         hh = 1.0 / 512
         stream.wait_stream(torch.cuda.current_stream())
-        M.set_state(0.5 * hh, 1.0, 0.5 * hh, V0, W)
-        del V0, W
+        W = M.interp_faces(v0)
+        M.set_state(0.5 * hh, 1.0, 0.5 * hh, V0, W, v0=v0)
+        del V0, W, v0
         v = rnd(3 * P.ncell)
         stream.wait_stream(torch.cuda.current_stream())
         fa = capi.lib.fldbg_mom_apply
@@ -364,21 +366,23 @@ def other_configs(stream):
         K = 10
         M.solve(v, rtol=0.0, atol=0.0, maxit=2)
         (_, info), dt = timed(lambda: M.solve(v, rtol=0.0, atol=0.0, maxit=K))
-        B_APPLY, B_BCGS = 144, 648   # 3 reads + 3 writes of v + 12 face fields; 2 applies (one also reads the shadow residual) + 3 vector updates
+        # per cell: x 24 + y 24 + v0 24 + V0 24 (k_mom3; the nine stored v0interp fields, 72 B more, are read by k_mom2 only); a BiCGStab iteration = 2 products
+        # (one also reads the shadow residual) + 3 vector updates
+        B_APPLY, B_BCGS = 96, 552
         tr = None
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_k_mom2.json"))).get("hbm_bytes_per_launch")
+            tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_k_mom3.json"))).get("hbm_bytes_per_launch")
         except Exception:  # noqa: BLE001
             tr = None
         ach = B_APPLY * P.ncell / (kms["plain"] * 1e-3) / 1e9
         tg = (tr or B_APPLY * P.ncell) / (kms["plain"] * 1e-3) / 1e9
-        cfg["momentum"] = {"workload": "512^3 cavity grid, momentum block A = I + dt C - (mu dt / 2 rho) L matrix-free (3 velocity components, 12 face fields), "
+        cfg["momentum"] = {"workload": "512^3 cavity grid, momentum block A = I + dt C - (mu dt / 2 rho) L matrix-free (3 velocity components; V0 on faces, v0interp = B v0 formed in the kernel), "
                                        f"Jacobi-BiCGStab (KSPBCGS + PCJACOBI) fixed {K} iterations",
                            "metric": "momentum BiCGStab iterations/s", "value": info["iters"] / dt, "steps": info["iters"], "ms_per_step": dt / max(info["iters"], 1) * 1e3,
                            "iteration_algorithmic_GBps": B_BCGS * P.ncell * info["iters"] / dt / 1e9, "kernel_ms": kms,
-                           "roofline": {"bound": "hbm", "kernel": "k_mom2 (MatMult(A): two cells per lane on 128 x 8 tiles)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "roofline": {"bound": "hbm", "kernel": "k_mom3 (MatMult(A): two cells per lane on 128 x 8 tiles, v0interp formed from v0 in the kernel)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": ach / HBM_PEAK_GBS, "traffic": tr, "traffic_GBps": tg, "traffic_frac": tg / HBM_PEAK_GBS,
-                                        "traffic_source": "rocprofv3 PMC pass (profiles/pmc_k_mom2.json)" if tr else "144 B x cells",
+                                        "traffic_source": "rocprofv3 PMC pass (profiles/pmc_k_mom3.json)" if tr else "96 B x cells",
                                         "algorithmic_bytes_per_cell": B_APPLY, "avg_launch_ms": kms["plain"], "launches_timed": 10,
                                         "iteration": {"algorithmic_bytes_per_cell": B_BCGS, "ms": dt / max(info["iters"], 1) * 1e3,
                                                       "achieved": B_BCGS * P.ncell * info["iters"] / dt / 1e9, "frac": B_BCGS * P.ncell * info["iters"] / dt / 1e9 / HBM_PEAK_GBS}}}

@@ -116,6 +116,7 @@ PROTOTYPES = {
     "fl_momentum_create": (C.c_int, [_P, C.POINTER(_P)]),
     "fl_momentum_destroy": (C.c_int, [_P]),
     "fl_momentum_set_state": (C.c_int, [_P, C.c_double, C.c_double, C.c_double, _P, _P]),
+    "fl_momentum_set_state_v0": (C.c_int, [_P, C.c_double, C.c_double, C.c_double, _P, _P, _P]),
     "fl_momentum_set_coefficients": (C.c_int, [_P, C.c_double, C.c_double, C.c_double]),
     "fl_momentum_apply": (C.c_int, [_P, _P, _P]),
     "fl_momentum_diagonal": (C.c_int, [_P, _P]),

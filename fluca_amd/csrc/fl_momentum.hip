@@ -25,6 +25,7 @@ namespace fl {
 struct MomP {
   const double *tab[3];   // MOM_NTAB x len, slot-major, LOCAL block of each axis
   const double *stab[3];  // the same numbers times (cC, cL), cell-major (k_mom_scale_tab): what k_mom2 reads
+  const double *bw[3];    // rows of B (build_axis_faceinterp) per LOCAL face, face-major: w0, w1 of the normal rule, w0, w1 of the tangential rule (k_mom3)
   int           len[3];
   double        cI, cC, cL;
 };
@@ -400,6 +401,7 @@ __global__ void __launch_bounds__(MOM_NT, FL_MOM_WPE) k_mom_apply(GridP g, MomP 
 }  // namespace fl
 #include "fl_stencil.h"
 #include "fl_mom_tile.h"
+#include "fl_mom_tile3.h"
 namespace fl {
 
 // BiCGStab vector updates on three-component padded vectors (interior cells only).
@@ -719,12 +721,15 @@ struct fl_momentum {
   MomP        mp;
   FaceT       ft;
   void       *tabs[3] = {nullptr, nullptr, nullptr};
+  double     *bws[3] = {nullptr, nullptr, nullptr};
   double     *stabs[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};  // scaled tables: [0] the handle's coefficients, [1] fl_momentum_rhs
   std::vector<void *> ttabs;
   double     *srhs = nullptr;  // Schur right-hand side of fl_abf_apply
   double     *tmpv = nullptr;  // 3*cells scratch of fl_abf_jacobian_mult
   double     *F = nullptr;   // 12 padded face fields: V0[0..2], v0interp[c*3+d] at 3 + c*3 + d
   double     *dg = nullptr;  // diag(A), 3 padded components (valid after set_state)
+  double     *v0p = nullptr; // v0 (3 padded components with valid ghosts) when the state came through fl_momentum_set_state_v0
+  bool        fly = false;   // k_mom3: v0interp on inner faces is interpolated from v0p inside the kernel
   double     *vec[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   // PCABF with schurainv / upperainv != ID (abfpc.c:81-94, 151-171): 1 / diag(A) or 1 / rowsum(A), scratch, FGMRES basis
   int                   schur_ainv = FL_ABF_AINV_ID, upper_ainv = FL_ABF_AINV_ID;
@@ -766,8 +771,10 @@ int mom_order()
 int mom_kernel()
 {
   static const int o = []() {
-    const char *e = std::getenv("FLUCA_MOM_KERNEL");  // 2 (default): k_mom2, two cells per lane on 128 x 8 tiles; 1: round 1/2's k_mom_apply (A/B runs)
-    return e ? std::atoi(e) : 2;
+    // 3 (default): k_mom3 (v0interp formed in the kernel) when the state came with v0 (fl_momentum_set_state_v0), else k_mom2;
+    // 2: always k_mom2, two cells per lane on 128 x 8 tiles, all twelve face fields read; 1: round 1/2's k_mom_apply (A/B runs)
+    const char *e = std::getenv("FLUCA_MOM_KERNEL");
+    return e ? std::atoi(e) : 3;
   }();
   return o;
 }
@@ -788,6 +795,11 @@ void mom_apply_t(fl_momentum *m, const double *x, double *y, const double *o, co
   if (mom_kernel() >= 2) {
     int flags = mom_order() & 1;
     if (OUT == 1 && (h->g.nx & 1) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0) flags |= 2;
+    if (mom_kernel() >= 3 && m->fly && h->g.ny > 8) {  // ny > 8: no 128 x 8 tile holds both ends of the y axis (k_mom3 stages one block-end row)
+      hipLaunchKernelGGL((k_mom3<8, DOT, JAC, OUT, 1>), dim3(m->t2blocks), dim3(512), 0, h->stream, h->g, coeffs ? *coeffs : m->mp, x, y, m->F, (const double *)m->v0p, (int64_t)h->padlen, o, s, h->partial,
+                         h->partial_stride, m->t2x, m->t2chunk, m->t2zc, flags);
+      return;
+    }
     if (mom_nt()) hipLaunchKernelGGL((k_mom2<8, DOT, JAC, OUT, 1>), dim3(m->t2blocks), dim3(512), 0, h->stream, h->g, coeffs ? *coeffs : m->mp, x, y, m->F, (int64_t)h->padlen, o, s, h->partial, h->partial_stride, m->t2x, m->t2chunk, m->t2zc, flags);
     else hipLaunchKernelGGL((k_mom2<8, DOT, JAC, OUT, 0>), dim3(m->t2blocks), dim3(512), 0, h->stream, h->g, coeffs ? *coeffs : m->mp, x, y, m->F, (int64_t)h->padlen, o, s, h->partial, h->partial_stride, m->t2x, m->t2chunk, m->t2zc, flags);
     return;
@@ -860,6 +872,7 @@ int mom_init(fl_momentum *m, fl_poisson *h)
     m->mp.stab[d] = m->stabs[0][d];
     // interpolation rows of the owned faces
     const int nfl = d == 0 ? g.fx : (d == 1 ? g.fy : g.fz);
+    std::vector<double> bw((size_t)4 * nfl, 0.);
     for (int kind = 0; kind < 3; ++kind) {
       std::vector<double> w0, w1;
       std::vector<int>    c0;
@@ -870,6 +883,10 @@ int mom_init(fl_momentum *m, fl_poisson *h)
         l0[f] = w0[(size_t)(lo[d] + f)];
         l1[f] = w1[(size_t)(lo[d] + f)];
         lc[f] = (int)(c0[(size_t)(lo[d] + f)] - lo[d]);
+        if (kind >= 1) {
+          bw[(size_t)4 * f + 2 * (kind - 1)]     = l0[f];
+          bw[(size_t)4 * f + 2 * (kind - 1) + 1] = l1[f];
+        }
       }
       const void  *src[3] = {l0.data(), l1.data(), lc.data()};
       const size_t by[3] = {sizeof(double) * nfl, sizeof(double) * nfl, sizeof(int) * nfl};
@@ -883,6 +900,9 @@ int mom_init(fl_momentum *m, fl_poisson *h)
       m->ft.w1[kind][d] = (const double *)dv[1];
       m->ft.c0[kind][d] = (const int *)dv[2];
     }
+    FL_HIP(hipMalloc((void **)&m->bws[d], sizeof(double) * std::max<size_t>(bw.size(), 4)));
+    FL_HIP(hipMemcpy(m->bws[d], bw.data(), sizeof(double) * bw.size(), hipMemcpyHostToDevice));
+    m->mp.bw[d] = m->bws[d];
   }
   m->mp.cI = 1.;
   m->mp.cC = 0.;
@@ -972,6 +992,8 @@ extern "C" int fl_momentum_destroy(fl_momentum *m)
     if (t) (void)hipFree(t);
   for (void *t : m->ttabs)
     if (t) (void)hipFree(t);
+  for (double *t : m->bws)
+    if (t) (void)hipFree(t);
   for (auto &sl : m->stabs)
     for (double *t : sl)
       if (t) (void)hipFree(t);
@@ -979,6 +1001,7 @@ extern "C" int fl_momentum_destroy(fl_momentum *m)
   if (m->tmpv) (void)hipFree(m->tmpv);
   if (m->F) (void)hipFree(m->F);
   if (m->dg) (void)hipFree(m->dg);
+  if (m->v0p) (void)hipFree(m->v0p);
   for (double *v : m->vec)
     if (v) (void)hipFree(v);
   for (double *v : {m->ainv[0], m->ainv[1], m->zV[0], m->zV[1], m->zV[2], m->gv})
@@ -1005,7 +1028,8 @@ extern "C" int fl_momentum_set_coefficients(fl_momentum *m, double cI, double cC
   return FL_SUCCESS;
 }
 
-extern "C" int fl_momentum_set_state(fl_momentum *m, double dt, double rho, double mu, const double *const V0_dev[3], const double *const v0interp_dev[9])
+namespace {
+int mom_set_state(fl_momentum *m, double dt, double rho, double mu, const double *const V0_dev[3], const double *const v0interp_dev[9], const double *v0_dev)
 {
   if (!m || !V0_dev || !v0interp_dev) return FL_ERR_ARG_NULL;
   if (!(rho > 0.)) return FL_ERR_ARG_OUTOFRANGE;
@@ -1028,8 +1052,30 @@ extern "C" int fl_momentum_set_state(fl_momentum *m, double dt, double rho, doub
     // high face of the last owned cell: periodic image or the neighbour's first face (the physical last face came with the copy)
     if (fl_any_ghost_exchange(h)) FL_CHK(fl_fill_ghosts(h, dst));
   }
+  m->fly = false;
+  if (v0_dev) {
+    if (!m->v0p) FL_CHK(fl_dev_alloc(h, (void **)&m->v0p, sizeof(double) * 3 * h->padlen, true));
+    for (int c = 0; c < 3; ++c) launch_pad_copy(h->stream, g, v0_dev + (size_t)c * h->ncell, m->v0p + (size_t)c * h->padlen);
+    FL_CHK(mom_ghosts(m, m->v0p));
+    m->fly = true;
+  }
   m->have_state = true;
   return fl_momentum_set_coefficients(m, 1., dt, -0.5 * mu * dt / rho);  // MatScale(A, dt); MatAXPY(A, -mu dt / 2 rho, L); MatShift(A, 1)
+}
+}  // namespace
+
+extern "C" int fl_momentum_set_state(fl_momentum *m, double dt, double rho, double mu, const double *const V0_dev[3], const double *const v0interp_dev[9])
+{
+  return mom_set_state(m, dt, rho, mu, V0_dev, v0interp_dev, nullptr);
+}
+
+// The same state, with the cell-centred v0 that v0interp was interpolated from (v0interp = B v0 + vbc, cnlinearcart3d.c:2826-2829; vbc
+// lives on boundary faces only): the operator then reads v0interp only on the faces at the ends of this rank's block and forms the
+// inner ones from v0 (k_mom3: 96 B/cell per product instead of 144).
+extern "C" int fl_momentum_set_state_v0(fl_momentum *m, double dt, double rho, double mu, const double *const V0_dev[3], const double *const v0interp_dev[9], const double *v0_dev)
+{
+  if (!v0_dev) return FL_ERR_ARG_NULL;
+  return mom_set_state(m, dt, rho, mu, V0_dev, v0interp_dev, v0_dev);
 }
 
 extern "C" int fl_momentum_apply(fl_momentum *m, const double *v_dev, double *y_dev)

@@ -1641,7 +1641,8 @@ static FlErrorCode NSStep_CNLinear(NS ns)
     const double *W[9];
     for (int q = 0; q < 9; ++q) W[q] = c->W[q];
     trace_begin("NSFormJacobian"); /* PetscLogEvent NS_FormJacobian (nsbasic.c:118) */
-    FLABI_T(fl_momentum_set_state(ns->momentum, dt, ns->rho, ns->mu, V0, W));
+    /* W = B v0 with the boundary values set on boundary faces only (fl_boundary_set_faces above): the operator may form the inner ones from v0 */
+    FLABI_T(fl_momentum_set_state_v0(ns->momentum, dt, ns->rho, ns->mu, V0, W, c->sol0_v));
     trace_end();
   }
   /* KSPSolve(J, f, x) with PC_ABF */

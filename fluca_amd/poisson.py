@@ -279,8 +279,9 @@ class Momentum:
         except Exception:
             pass
 
-    def set_state(self, dt, rho, mu, V0, W):
-        """V0: 3 face tensors (face-normal velocity of the previous step); W: 9 face tensors, W[c*3+d] = v0interp_c on d-faces."""
+    def set_state(self, dt, rho, mu, V0, W, v0=None):
+        """V0: 3 face tensors (face-normal velocity of the previous step); W: 9 face tensors, W[c*3+d] = v0interp_c on d-faces.
+        v0 (3 * cells, optional): the cell-centred velocity W was interpolated from (W = B v0 + vbc) -- fl_momentum_set_state_v0."""
         assert len(V0) == 3 and len(W) == 9
         for d in range(3):
             assert V0[d].numel() == self.p.nface[d]
@@ -291,7 +292,11 @@ class Momentum:
         for t in list(V0) + list(W):
             _ptr(t)
         self.p._pre()
-        check(lib.fl_momentum_set_state(self.h, float(dt), float(rho), float(mu), a, b), "fl_momentum_set_state")
+        if v0 is None:
+            check(lib.fl_momentum_set_state(self.h, float(dt), float(rho), float(mu), a, b), "fl_momentum_set_state")
+        else:
+            assert v0.numel() == 3 * self.p.ncell
+            check(lib.fl_momentum_set_state_v0(self.h, float(dt), float(rho), float(mu), a, b, _ptr(v0)), "fl_momentum_set_state_v0")
         self.p._post()
 
     def set_coefficients(self, cI, cC, cL):

@@ -285,6 +285,12 @@ int fl_momentum_destroy(fl_momentum *m);
  * v0interp_dev[c*3+d]: component c of cnl->v0interp on the d-faces.  Face layouts as at the top of this file.
  * Copies the twelve fields (the caller may reuse its buffers) and sets cI = 1, cC = dt, cL = -mu dt / (2 rho). */
 int fl_momentum_set_state(fl_momentum *m, double dt, double rho, double mu, const double *const V0_dev[3], const double *const v0interp_dev[9]);
+/* The same state, handed over together with the cell-centred velocity it was interpolated from: v0_dev = sol0's NS_FIELD_VELOCITY
+ * (3 * cells, component-major), v0interp = B v0 + vbc (cnlinearcart3d.c:2826-2829; vbc is non-zero on boundary faces only, :1749-1932).
+ * The operator then forms v0interp on the inner faces from v0 inside its kernel (bit-identical to fl_momentum_interp_faces) and reads the
+ * nine stored fields only on the faces at the ends of this rank's block: 96 B per cell and product instead of 144.  A v0interp that is
+ * NOT B v0 on inner faces gives a different operator than fl_momentum_set_state -- use that entry point then. */
+int fl_momentum_set_state_v0(fl_momentum *m, double dt, double rho, double mu, const double *const V0_dev[3], const double *const v0interp_dev[9], const double *v0_dev);
 /* A = cI I + cC C + cL L with explicit coefficients (other time integrators; L or C alone in the parity tests) */
 int fl_momentum_set_coefficients(fl_momentum *m, double cI, double cC, double cL);
 int fl_momentum_apply(fl_momentum *m, const double *v_dev, double *y_dev); /* y = A v      (MatMult) */

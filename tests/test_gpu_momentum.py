@@ -354,6 +354,65 @@ def test_face_velocity_interpolation_B_matches_oracle(n, bc, nonuni):
     P.close()
 
 
+def _boundary_vbc(g, rng):
+    """vbc of cnlinearcart3d.c:1749-1932: values on the faces at the ends of a non-periodic axis, zero on every inner face"""
+    out = []
+    for c in range(3):
+        for d in range(3):
+            shape = [g.n[2], g.n[1], g.n[0]]
+            shape[2 - d] = g.nf[d]
+            a = np.zeros(shape)
+            if not g.periodic[d]:
+                ends = [slice(None)] * 3
+                for f in (0, g.n[d]):
+                    ends[2 - d] = f
+                    a[tuple(ends)] = rng.standard_normal(a[tuple(ends)].shape)
+            out.append(a.ravel())
+    return out
+
+
+@pytest.mark.parametrize("n,bc,nonuni", CASES + [((256, 21, 6), [O, V, V, SYM, PER, PER], True), ((129, 16, 9), [PER] * 6, False), ((3, 9, 4), CAVITY, False)])
+def test_state_with_v0_forms_the_same_operator(n, bc, nonuni):
+    """fl_momentum_set_state_v0 (v0interp on inner faces formed inside k_mom3 from v0) against the oracle's rows built from the stored
+    v0interp = B v0 + vbc, against the stored-path kernel, and through a BiCGStab solve"""
+    P, M, g = _pair(n, bc, nonuni)
+    rng = np.random.default_rng(23)
+    V0 = [rng.standard_normal(g.nface[d]) for d in range(3)]
+    v0 = rng.standard_normal(3 * g.ncell)
+    vbc = _boundary_vbc(g, rng)
+    W = [b + c for b, c in zip(g.apply_B(v0), vbc)]
+    hmin = min(np.diff(g.xf[d]).min() for d in range(3))
+    dt, rho, mu = 0.5 * hmin, 1.3, 0.5 * hmin
+    v = rng.standard_normal(3 * g.ncell)
+    A = g.assemble_momentum(1.0, dt, -0.5 * mu * dt / rho, V0, W)
+    Wd = M.interp_faces(dev(v0), [dev(a) for a in vbc])
+    for q in range(9):
+        assert np.abs(host(Wd[q]) - W[q]).max() <= 2e-13 * max(1.0, np.abs(W[q]).max())
+    M.set_state(dt, rho, mu, [dev(a) for a in V0], Wd)
+    y_stored, d_stored = host(M.apply(dev(v))), host(M.diagonal())
+    M.set_state(dt, rho, mu, [dev(a) for a in V0], Wd, v0=dev(v0))
+    y_fly, d_fly = host(M.apply(dev(v))), host(M.diagonal())
+    _close(y_fly, A.mult(v))
+    _close(d_fly, A.diag())
+    # same table numbers, same two products per face value in the same order: the two kernels agree to the last rounding of the sums
+    assert np.abs(y_fly - y_stored).max() <= 4e-15 * np.abs(y_stored).max()
+    assert np.abs(d_fly - d_stored).max() <= 4e-15 * np.abs(d_stored).max()
+    b = rng.standard_normal(3 * g.ncell)
+    for pc in (fo.PC_JACOBI, fo.PC_NONE):
+        xo, io = A.solve(b, ksp=fo.KSP_BCGS, pc=pc, nullspace=False, rtol=1e-8, maxit=500)
+        xg, ig = M.solve(dev(b), history=True, pc=pc, rtol=1e-8, maxit=500)
+        assert io["reason"] > 0 and ig["reason"] == io["reason"]
+        assert np.allclose(ig["history"][:3], io["history"][:3], rtol=1e-9)
+        assert abs(ig["iters"] - io["iters"]) <= max(2, io["iters"] // 6)
+        assert np.linalg.norm(host(xg) - xo) <= 1e-5 * np.linalg.norm(xo)
+    # a state without v0 afterwards goes back to the stored fields
+    Wr = [rng.standard_normal(g.nface[d]) for c in range(3) for d in range(3)]
+    M.set_state(dt, rho, mu, [dev(a) for a in V0], [dev(a) for a in Wr])
+    _close(host(M.apply(dev(v))), g.assemble_momentum(1.0, dt, -0.5 * mu * dt / rho, V0, Wr).mult(v))
+    M.close()
+    P.close()
+
+
 def test_momentum_and_multigrid_full_size_properties_512():
     """BASELINE size (512^3: 134 M cells, 403 M velocity unknowns): size-independent properties of the widened rows.
     Linearity of A, A with zero advecting fields and zero viscosity is the identity, diag(A) = A e summed the cheap way on

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--nosolve", action="store_true")
     ap.add_argument("--modes", type=int, default=4)
+    ap.add_argument("--fly", type=int, default=1, help="1: v0interp = B v0, state handed over with v0 (k_mom3); 0: random v0interp fields, stored path (k_mom2)")
     a = ap.parse_args()
     n = (a.cells,) * 3
     P = Poisson.uniform(n, [(0, 1)] * 3, [V, V, V, V, SYM, V], 1e-3)
@@ -30,9 +31,15 @@ def main():
     g = torch.Generator(device="cuda").manual_seed(1)
     rnd = lambda m: torch.rand(m, dtype=torch.float64, device="cuda", generator=g) * 2 - 1
     V0 = [rnd(P.nface[d]) for d in range(3)]
-    W = [rnd(P.nface[d]) for c in range(3) for d in range(3)]
     h = 1.0 / a.cells
-    M.set_state(0.5 * h, 1.0, 0.5 * h, V0, W)
+    if a.fly:
+        v0 = rnd(3 * P.ncell)
+        W = M.interp_faces(v0)
+        M.set_state(0.5 * h, 1.0, 0.5 * h, V0, W, v0=v0)
+        del v0
+    else:
+        W = [rnd(P.nface[d]) for c in range(3) for d in range(3)]
+        M.set_state(0.5 * h, 1.0, 0.5 * h, V0, W)
     del V0, W
     v = rnd(3 * P.ncell)
     y = torch.empty_like(v)
@@ -63,7 +70,7 @@ def main():
         P._post()
         assert rc == 0, rc
         out[f"kernel_ms_mode{mode}"] = ms.value
-    out["kernel"] = os.environ.get("FLUCA_MOM_KERNEL", "2")
+    out["kernel"] = os.environ.get("FLUCA_MOM_KERNEL", "3" if a.fly else "2")
     # streaming ceiling of the same access mix (15 reads + 3 writes, flat)
     lib.fldbg_mom_stream.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
     for blocks in (2048, 8192):
