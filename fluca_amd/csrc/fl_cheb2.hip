@@ -71,7 +71,9 @@ __device__ __forceinline__ int c2_wrap(int gi, int n, int per, bool &in)
 __device__ __forceinline__ int c2_xcd_remap(int b, int nblocks) { return (nblocks & 7) ? b : (b & 7) * (nblocks >> 3) + (b >> 3); }
 
 // sums: 0 sum z  1 z.z  2 r.r of step 1;  3..5 the same of step 2
-template <int RY, int NW, bool JAC, int NT>
+// MGD (the last smoothing sweep of a multigrid cycle inside PCG): instead, the five sums the outer iteration wants of the sweep's result
+// x'' and its right-hand side b -- 0 sum x''  1 x''.x''  2 b.x''  3 sum b  4 b.b (slot 5 is 0) -- which saves a pass over both vectors
+template <int RY, int NW, bool JAC, int NT, bool MGD = false>
 __global__ void __launch_bounds__(64 * NW) k_cheb2(GridP g, int perx, int pery, int perz, const double *X0, const double *X1, double *X0w, double *X1w, const double *__restrict__ b, const double *D0, const double *D1, double *D0w,
                                                   double *D1w, const KspScal *__restrict__ s, double *__restrict__ partial, int stride, int zc, int tiles_x, int tiles, int remap)
 {
@@ -259,12 +261,12 @@ __global__ void __launch_bounds__(64 * NW) k_cheb2(GridP g, int perx, int pery, 
         d1v[m].y = e1;
         x1v[m].x = ok0 ? cen.x + e0 : 0.;
         x1v[m].y = ok1 ? cen.y + e1 : 0.;
-        if (own && ok0) {
+        if (!MGD && own && ok0) {
           acc[0] += z0;
           acc[1] += z0 * z0;
           acc[2] += r0 * r0;
         }
-        if (own && ok1) {
+        if (!MGD && own && ok1) {
           acc[0] += z1;
           acc[1] += z1 * z1;
           acc[2] += r1 * r1;
@@ -312,15 +314,31 @@ __global__ void __launch_bounds__(64 * NW) k_cheb2(GridP g, int perx, int pery, 
           if (in1) {
             c2_ST2<NTS>(dn + rob[m] + p2, lo, e);
             c2_ST2<NTS>(xn + rob[m] + p2, lo, xo);
-            acc[3] += z0 + z1;
-            acc[4] += z0 * z0 + z1 * z1;
-            acc[5] += r0 * r0 + r1 * r1;
+            if (MGD) {
+              acc[0] += xo.x + xo.y;
+              acc[1] += xo.x * xo.x + xo.y * xo.y;
+              acc[2] += sb2[m].x * xo.x + sb2[m].y * xo.y;
+              acc[3] += sb2[m].x + sb2[m].y;
+              acc[4] += sb2[m].x * sb2[m].x + sb2[m].y * sb2[m].y;
+            } else {
+              acc[3] += z0 + z1;
+              acc[4] += z0 * z0 + z1 * z1;
+              acc[5] += r0 * r0 + r1 * r1;
+            }
           } else {
             c2_ST1(dn + rob[m] + p2, lo, e.x);
             c2_ST1(xn + rob[m] + p2, lo, xo.x);
-            acc[3] += z0;
-            acc[4] += z0 * z0;
-            acc[5] += r0 * r0;
+            if (MGD) {
+              acc[0] += xo.x;
+              acc[1] += xo.x * xo.x;
+              acc[2] += sb2[m].x * xo.x;
+              acc[3] += sb2[m].x;
+              acc[4] += sb2[m].x * sb2[m].x;
+            } else {
+              acc[3] += z0;
+              acc[4] += z0 * z0;
+              acc[5] += r0 * r0;
+            }
           }
         }
       }
@@ -447,15 +465,20 @@ Cheb2Plan fl_cheb2_plan(const GridP &g)
   return p;
 }
 
-template <int NW, bool JAC>
+template <int NW, bool JAC, bool MGD = false>
 static void cheb2_t(fl_poisson *h, const Cheb2Plan &p, double *X0, double *X1, const double *B, double *D0, double *D1)
 {
   const int per[3] = {h->ax[0].periodic, h->ax[1].periodic, h->ax[2].periodic};
-  hipLaunchKernelGGL((k_cheb2<2, NW, JAC, 2>), dim3(p.nblocks), dim3(64 * NW), 0, h->stream, h->g, per[0], per[1], per[2], X0, X1, X0, X1, B, D0, D1, D0, D1, h->scal, h->partial, h->partial_stride, p.zc, p.tiles_x, p.tiles, 1);
+  hipLaunchKernelGGL((k_cheb2<2, NW, JAC, 2, MGD>), dim3(p.nblocks), dim3(64 * NW), 0, h->stream, h->g, per[0], per[1], per[2], X0, X1, X0, X1, B, D0, D1, D0, D1, h->scal, h->partial, h->partial_stride, p.zc, p.tiles_x, p.tiles, 1);
 }
 
-void fl_launch_cheb2(fl_poisson *h, const Cheb2Plan &p, bool jac, double *X0, double *X1, const double *B, double *D0, double *D1)
+void fl_launch_cheb2(fl_poisson *h, const Cheb2Plan &p, bool jac, double *X0, double *X1, const double *B, double *D0, double *D1, bool mgdots)
 {
+  if (mgdots) {  // the multigrid smoother is the Jacobi one
+    if (p.nw == 8) cheb2_t<8, true, true>(h, p, X0, X1, B, D0, D1);
+    else cheb2_t<4, true, true>(h, p, X0, X1, B, D0, D1);
+    return;
+  }
   if (p.nw == 8) {
     if (jac) cheb2_t<8, true>(h, p, X0, X1, B, D0, D1);
     else cheb2_t<8, false>(h, p, X0, X1, B, D0, D1);

@@ -361,7 +361,7 @@ int fl_apply_tiled(fl_poisson *h, const double *xpad, double *y, int unpadded_y)
 int fl_residual(fl_poisson *h, const double *x, const double *b, double *r);
 int fl_residual_padded(fl_poisson *h, double *xpad, const double *bpad, double *rpad);
 int fl_apply_padded_dot(fl_poisson *h, double *xpad, double *ypad, double *xy);
-int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero);
+int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero, bool *mgdots = nullptr, const double *subq = nullptr, double suba = 0.);
 int fl_solve_bcgs(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *o, fl_ksp_stats *st);
 int fl_solve_cg_sr(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *o, fl_ksp_stats *st);
 int fl_ksp_begin(fl_poisson *h, const fl_ksp_opts *o);
@@ -375,7 +375,7 @@ struct Cheb2Plan {
 };
 bool      fl_cheb2_usable(const fl_poisson *h);
 Cheb2Plan fl_cheb2_plan(const GridP &g);
-void      fl_launch_cheb2(fl_poisson *h, const Cheb2Plan &p, bool jac, double *X0, double *X1, const double *B, double *D0, double *D1);
+void      fl_launch_cheb2(fl_poisson *h, const Cheb2Plan &p, bool jac, double *X0, double *X1, const double *B, double *D0, double *D1, bool mgdots = false);
 // fl_mg.hip
 int  fl_solve_cg_mg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *o, fl_ksp_stats *st);
 void fl_mg_destroy(fl_poisson *h);

@@ -784,8 +784,10 @@ __global__ void __launch_bounds__(256) k_cheb(GridP g, const double *X0, const d
 // The first step from a zero initial guess (rho = 0, x = 0): z = M b ; d = c z ; x' = d.  The same numbers k_cheb produces
 // from a zeroed x (S 0 = +0, b - 0 = b, 0 + d = d), without zeroing x, reading it and d, or the stencil: 8 B/cell read and
 // 16 written instead of 8 (memset) + 24 + 16.  No sums: only for the smoother call (KSP_NORM_NONE, no null space).
-template <bool JAC>
-__global__ void __launch_bounds__(256) k_cheb_first(GridP g, double *X0w, double *X1w, const double *__restrict__ b, double *D0, double *D1, const KspScal *__restrict__ s)
+// SUB: the right-hand side is updated on the way, b -= suba * subq (the outer CG's r -= alpha q in front of a multigrid cycle)
+template <bool JAC, bool SUB = false>
+__global__ void __launch_bounds__(256) k_cheb_first(GridP g, double *X0w, double *X1w, double *__restrict__ b, double *D0, double *D1, const KspScal *__restrict__ s, const double *__restrict__ subq = nullptr,
+                                                    double suba = 0.)
 {
   if (s->reason != 0) return;
   double       *xn = s->cur ? X0w : X1w;
@@ -802,6 +804,16 @@ __global__ void __launch_bounds__(256) k_cheb_first(GridP g, double *X0w, double
     double2       bv;
     if (two) bv = *reinterpret_cast<const double2 *>(b + off);
     else bv = make_double2(b[off], 0.);
+    if (SUB) {
+      if (two) {
+        const double2 qv = *reinterpret_cast<const double2 *>(subq + off);
+        bv = make_double2(bv.x - suba * qv.x, bv.y - suba * qv.y);
+        *reinterpret_cast<double2 *>(b + off) = bv;
+      } else {
+        bv.x -= suba * subq[off];
+        b[off] = bv.x;
+      }
+    }
     const double  z0 = JAC ? bv.x / (g.sc[0][i] + dyz) : bv.x, z1 = two ? (JAC ? bv.y / (g.sc[0][i + 1] + dyz) : bv.y) : 0.;
     const double2 dn = make_double2(0. + cc * z0, 0. + cc * z1);
     if (two) {
@@ -1196,8 +1208,14 @@ int fl_apply_padded_dot(fl_poisson *h, double *xpad, double *ypad, double *xy)
 // zero when guess_zero), the result is left in h->xp (the two x buffers h->xp / h->P0 swap roles as needed).  No convergence
 // test, no null-space bookkeeping (a constant in x never reaches a residual: the caller projects once at the end), the host
 // never waits.  Spectrum bounds as in fl_solve_cheb.
-int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero)
+// mgdots (in: the caller wants the five sums of k_mg_dots over the result and the right-hand side; out: whether h->sums holds them -- only
+// when the last sweep is the fused Jacobi kernel, which forms them on its way, fl_cheb2.hip)
+// subq / suba: the right-hand side h->r is first updated in place, r -= suba * subq (padded), on the first step's pass (guess_zero only)
+int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero, bool *mgdots, const double *subq, double suba)
 {
+  if (subq && !(guess_zero && nu > 0)) return FL_ERR_ARG_WRONGSTATE;
+  const bool want = mgdots && *mgdots;
+  if (mgdots) *mgdots = false;
   for (double **v : {&h->r, &h->P0, &h->q, &h->xp}) FL_CHK(fl_ensure_vec(h, v));
   if (nu <= 0) {
     if (guess_zero) FL_CHK(fl_zero_vec(h, h->xp));
@@ -1242,14 +1260,22 @@ int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero)
       // the sums k_cheb_fin would look at are not used without a norm and a null space: it only advances the recurrence
       const int64_t pairs = (int64_t)((h->g.nx + 1) / 2) * h->g.ny * h->g.nz;
       const int     nb    = (int)std::max<int64_t>(1, std::min<int64_t>((pairs + 255) / 256, 8192));
-      if (jac) hipLaunchKernelGGL((k_cheb_first<true>), dim3(nb), dim3(256), 0, s, h->g, X0, X1, B, D0, D1, h->scal);
-      else hipLaunchKernelGGL((k_cheb_first<false>), dim3(nb), dim3(256), 0, s, h->g, X0, X1, B, D0, D1, h->scal);
+      if (subq) {
+        if (jac) hipLaunchKernelGGL((k_cheb_first<true, true>), dim3(nb), dim3(256), 0, s, h->g, X0, X1, B, D0, D1, h->scal, subq, suba);
+        else hipLaunchKernelGGL((k_cheb_first<false, true>), dim3(nb), dim3(256), 0, s, h->g, X0, X1, B, D0, D1, h->scal, subq, suba);
+      } else if (jac) hipLaunchKernelGGL((k_cheb_first<true>), dim3(nb), dim3(256), 0, s, h->g, X0, X1, B, D0, D1, h->scal, (const double *)nullptr, 0.);
+      else hipLaunchKernelGGL((k_cheb_first<false>), dim3(nb), dim3(256), 0, s, h->g, X0, X1, B, D0, D1, h->scal, (const double *)nullptr, 0.);
       FL_CHK(fin_step(h, tp.nblocks, 3, finl));
       j += 1;
-    } else if (fuse && j + 2 <= nu) {
+    } else if (fuse && j + 2 <= nu && !(want && jac && !h->multi && ((nu - j) & 1))) {  // (asked for the sums: an odd step count takes its single step first, so that a fused sweep ends the call)
       // two steps in one sweep; reads no ghost layer (fl_cheb2.hip)
-      fl_launch_cheb2(h, cp, jac, X0, X1, B, D0, D1);
-      FL_CHK(fin_step(h, cp.nblocks, 6, fin2));
+      const bool md = want && jac && j + 2 == nu && !h->multi;
+      fl_launch_cheb2(h, cp, jac, X0, X1, B, D0, D1, md);
+      FL_CHK(fin_step(h, cp.nblocks, 6, fin2));  // without a norm and a null space the sums only advance the recurrence
+      if (md) {
+        launch_reduce(s, h->partial, cp.nblocks, h->partial_stride, 5, h->sums);
+        *mgdots = true;
+      }
       j += 2;
     } else {
       if (ghosts) FL_CHK(fl_fill_ghosts(h, cur ? X1 : X0));

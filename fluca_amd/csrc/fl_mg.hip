@@ -146,6 +146,130 @@ __global__ void __launch_bounds__(256) k_mg_prolong_lin_add(GridP gf, GridP gc, 
   }
 }
 
+// The same arithmetic on a tile walk: block = 4 rows x 128 cells (a lane owns a pair) marching through ZC planes, so that row and plane
+// numbers are wave-uniform (their table entries arrive by scalar loads, no 64-bit division per pair as in the grid-stride form above) and
+// the coarse lines of two consecutive planes / rows are the same lines (L1 / L2 hits).  R2: every axis is coarsened by two (shifts).
+// 512^3: 1.1 ms -> see profiles/r03_mg_bench.txt (the fine level moves 17 B/cell: 0.38 ms at 6 TB/s).
+template <bool R2>
+__global__ void __launch_bounds__(256) k_mg_prolong_lin_tile(GridP gf, GridP gc, int rx, int ry, int rz, MgLin t, const double *__restrict__ coarse, double *__restrict__ fine, int zc)
+{
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = ((int)blockIdx.x * 64 + lane) * 2, j = (int)blockIdx.y * 4 + w;
+  if (j >= gf.ny || i >= gf.nx) return;
+  const int     k0 = (int)blockIdx.z * zc, k1 = min(k0 + zc, gf.nz);
+  const bool    two = i + 1 < gf.nx;
+  const int     i1 = two ? i + 1 : i;
+  const int     I0 = R2 ? i >> 1 : i / rx, I1 = R2 ? i1 >> 1 : i1 / rx, J = R2 ? j >> 1 : j / ry;
+  const int     ox0 = t.pn[0][i], ox1 = t.pn[0][i1];
+  const double  wx0 = t.pw[0][i], wx1 = t.pw[0][i1];
+  const double  wy = t.pw[1][j];
+  const int64_t oy = (int64_t)t.pn[1][j] * gc.sx;
+  const double *cj = coarse + gc.off0 + (int64_t)J * gc.sx;
+  double       *fj = fine + gf.off0 + (int64_t)j * gf.sx + i;
+  for (int k = k0; k < k1; ++k) {
+    const int     K = R2 ? k >> 1 : k / rz;
+    const double  wz = t.pw[2][k];
+    const int64_t oz = (int64_t)t.pn[2][k] * gc.sxy;
+    const double *ck = cj + (int64_t)K * gc.sxy;
+    double        v0[4], v1[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const double *line = ck + ((a & 1) ? oy : 0) + ((a & 2) ? oz : 0);
+      const double  p0 = line[I0], p1 = line[I1];
+      v0[a] = fma(wx0, line[I0 + ox0] - p0, p0);
+      v1[a] = fma(wx1, line[I1 + ox1] - p1, p1);
+    }
+    const double a0 = fma(wy, v0[1] - v0[0], v0[0]), b0 = fma(wy, v0[3] - v0[2], v0[2]);
+    const double a1 = fma(wy, v1[1] - v1[0], v1[0]), b1 = fma(wy, v1[3] - v1[2], v1[2]);
+    const int64_t fo = (int64_t)k * gf.sxy;
+    double2       f = ldp(fj, fo, two);
+    f.x += fma(wz, b0 - a0, a0);
+    if (two) f.y += fma(wz, b1 - a1, a1);
+    stp(fj, fo, two, f);
+  }
+}
+
+// The same arithmetic once more, parent-centred, for the usual case that every axis is coarsened by two: a lane owns ONE coarse cell and
+// writes its eight children; a wave owns a coarse row (lanes 0 and 63 only carry the x-neighbours of lanes 1 and 62), a block four rows,
+// marching through KC coarse planes.  Per coarse cell and plane step: three 8-byte reads of the coarse vector (rows J-1, J, J+1 of the
+// plane ahead; x-neighbours by DPP) where the fine-cell-centred kernels issue 64, plus the four 16-byte read-modify-writes of the children.
+// The x interpolation is done as a plane arrives (two values per row: one per x-child), so three planes of 3 x 2 values ride in registers.
+template <int CTRL>
+__device__ __forceinline__ double mg_lane_shift(double v)
+{
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__global__ void __launch_bounds__(256) k_mg_prolong_lin_cc(GridP gf, GridP gc, MgLin t, const double *__restrict__ coarse, double *__restrict__ fine, int kc)
+{
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int J = (int)blockIdx.y * 4 + w;
+  if (J >= gc.ny) return;
+  const int  I = (int)blockIdx.x * 62 - 1 + lane, Ic = min(I, gc.nx);  // lane 0 of the first block: the low ghost column
+  const bool act = lane >= 1 && lane <= 62 && I < gc.nx;
+  const int  K0 = (int)blockIdx.z * kc, K1 = min(K0 + kc, gc.nz);
+  const int  ia = act ? 2 * I : 0;
+  const int    ox[2] = {t.pn[0][ia], t.pn[0][ia + 1]};
+  const double wx[2] = {t.pw[0][ia], t.pw[0][ia + 1]};
+  const int    oy[2] = {t.pn[1][2 * J], t.pn[1][2 * J + 1]};
+  const double wy[2] = {t.pw[1][2 * J], t.pw[1][2 * J + 1]};
+  const double *cb = coarse + gc.off0 + (int64_t)J * gc.sx + Ic;
+  // x-interpolated values of the three rows of coarse plane K: X[jj + 1][a] for the x-child a
+  auto plane = [&](int K, double (&X)[3][2]) {
+    const double *cp = cb + (int64_t)K * gc.sxy;
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) {
+      const double C = cp[(int64_t)(jj - 1) * gc.sx];
+      const double L = mg_lane_shift<0x138>(C), R = mg_lane_shift<0x130>(C);  // lane - 1, lane + 1
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const double N = ox[a] < 0 ? L : (ox[a] > 0 ? R : C);
+        X[jj][a] = fma(wx[a], N - C, C);
+      }
+    }
+  };
+  double Xm[3][2], Xc[3][2], Xp[3][2];
+  plane(K0 - 1, Xm);
+  plane(K0, Xc);
+  for (int K = K0; K < K1; ++K) {
+    plane(K + 1, Xp);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int    k = 2 * K + c, oz = t.pn[2][k];
+      const double wz = t.pw[2][k];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        double2 add;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          // the four lines of k_mg_prolong_lin_add: (0,0), (oy,0), (0,oz), (oy,oz)
+          const double v0 = Xc[1][a], v1 = oy[b] < 0 ? Xc[0][a] : (oy[b] > 0 ? Xc[2][a] : Xc[1][a]);
+          const double z0 = oz < 0 ? Xm[1][a] : (oz > 0 ? Xp[1][a] : Xc[1][a]);
+          const double z1 = oz < 0 ? (oy[b] < 0 ? Xm[0][a] : (oy[b] > 0 ? Xm[2][a] : Xm[1][a]))
+                                   : (oz > 0 ? (oy[b] < 0 ? Xp[0][a] : (oy[b] > 0 ? Xp[2][a] : Xp[1][a])) : v1);
+          const double A = fma(wy[b], v1 - v0, v0), B = fma(wy[b], z1 - z0, z0);
+          (a ? add.y : add.x) = fma(wz, B - A, A);
+        }
+        if (act) {
+          double2 *f = reinterpret_cast<double2 *>(fine + gf.off0 + (int64_t)k * gf.sxy + (int64_t)(2 * J + b) * gf.sx + 2 * I);
+          double2  v = *f;
+          v.x += add.x;
+          v.y += add.y;
+          *f = v;
+        }
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj)
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        Xm[jj][a] = Xc[jj][a];
+        Xc[jj][a] = Xp[jj][a];
+      }
+  }
+}
+
 // slots: 0 sum z   1 z.z   2 r.z   3 sum r   4 r.r      (owned cells only)
 __global__ void __launch_bounds__(256) k_mg_dots(GridP g, const double *__restrict__ z, const double *__restrict__ r, double *__restrict__ partial, int stride)
 {
@@ -171,6 +295,10 @@ __global__ void __launch_bounds__(256) k_mg_dots(GridP g, const double *__restri
 // OP 0:  y0 = a x0 + b (y0 - c)                (p = (z - m) + beta p  as  y0 = p, x0 = z: y0 = 1*(x0 - c) + b y0, see launch)
 // OP 1:  y0 += a x0 ;  y1 -= a x1              (x += alpha p ; r -= alpha q)
 // OP 2:  y0 = x0 - c                           (p = z - m)
+// OP 3:  y0 += a x0                            (x += alpha p, the update still owed when the iteration stops)
+// OP 4:  y1 += a y0 ;  y0 = (x0 - c) + b y0    (x += alpha p with the OLD p, then p = (z - m) + beta p: the x-update rides on the pass that
+//                                               rewrites p anyway; r -= alpha q rides on the cycle's first smoothing step, k_cheb_first)
+// OP 5:  y1 -= a x1                            (r -= alpha q alone: hierarchies whose level 0 has no smoother)
 template <int OP>
 __global__ void __launch_bounds__(256) k_mg_pw(GridP g, double a, double b, double c, const double *__restrict__ x0, const double *__restrict__ x1, double *__restrict__ y0, double *__restrict__ y1)
 {
@@ -184,6 +312,16 @@ __global__ void __launch_bounds__(256) k_mg_pw(GridP g, double a, double b, doub
     } else if (OP == 1) {
       const double2 pv = ldp(x0, off, two), qv = ldp(x1, off, two), xv = ldp(y0, off, two), rv = ldp(y1, off, two);
       stp(y0, off, two, make_double2(xv.x + a * pv.x, xv.y + a * pv.y));
+      stp(y1, off, two, make_double2(rv.x - a * qv.x, rv.y - a * qv.y));
+    } else if (OP == 3) {
+      const double2 pv = ldp(x0, off, two), xv = ldp(y0, off, two);
+      stp(y0, off, two, make_double2(xv.x + a * pv.x, xv.y + a * pv.y));
+    } else if (OP == 4) {
+      const double2 zv = ldp(x0, off, two), pv = ldp(y0, off, two), xv = ldp(y1, off, two);
+      stp(y1, off, two, make_double2(xv.x + a * pv.x, xv.y + a * pv.y));
+      stp(y0, off, two, make_double2((zv.x - c) + b * pv.x, (zv.y - c) + b * pv.y));
+    } else if (OP == 5) {
+      const double2 qv = ldp(x1, off, two), rv = ldp(y1, off, two);
       stp(y1, off, two, make_double2(rv.x - a * qv.x, rv.y - a * qv.y));
     } else {
       const double2 xv = ldp(x0, off, two);
@@ -359,8 +497,12 @@ int mg_build_levels(fl_poisson *h, fl_mg *mg, int max_levels)
 }
 
 // V-cycle on level l: right-hand side in the level handle's h->r, answer (zero initial guess) in its h->xp -- both padded
-int vcycle(fl_mg *mg, size_t l, const fl_ksp_opts *o)
+// sums (level 0 only; in: asked for, out: delivered): the five sums of k_mg_dots over (answer, right-hand side) left in h->sums by the last sweep
+// subq / suba (level 0 only): the right-hand side is first updated in place, b -= suba * subq, on the first smoothing step's pass over it
+int vcycle(fl_mg *mg, size_t l, const fl_ksp_opts *o, bool *sums = nullptr, const double *subq = nullptr, double suba = 0.)
 {
+  const bool want = sums && *sums;
+  if (sums) *sums = false;
   MgLevel    &L = mg->lv[l];
   fl_poisson *h = L.h;
   if (l + 1 == mg->lv.size()) {
@@ -373,6 +515,7 @@ int vcycle(fl_mg *mg, size_t l, const fl_ksp_opts *o)
     so.pc    = FL_PC_JACOBI;
     so.rtol  = 1e-2;
     so.maxit = 200;
+    if (subq) hipLaunchKernelGGL(k_mg_pw<5>, dim3(nblk_pairs(h->g)), dim3(256), 0, h->stream, h->g, suba, 0., 0., (const double *)nullptr, subq, (double *)nullptr, h->r);
     launch_unpad_copy(h->stream, h->g, h->r, L.b, nullptr);
     // a one-level hierarchy runs this solve on the OUTER handle, whose h->r is the outer residual and is the inner
     // solve's work vector as well: keep it aside
@@ -387,7 +530,7 @@ int vcycle(fl_mg *mg, size_t l, const fl_ksp_opts *o)
   }
   const int nu = o->mg_smooth_its > 0 ? o->mg_smooth_its : 3;
   MgLevel  &C  = mg->lv[l + 1];
-  FL_CHK(fl_cheb_smooth_padded(h, nu, true, true));                                  // x = smooth(b), zero initial guess
+  FL_CHK(fl_cheb_smooth_padded(h, nu, true, true, nullptr, subq, suba));             // x = smooth(b), zero initial guess
   FL_CHK(fl_residual_padded(h, h->xp, h->r, h->q));                                  // q = b - S x   (q: the smoother's scratch)
   hipLaunchKernelGGL(k_mg_restrict, dim3(nblk(C.h->ncell)), dim3(256), 0, h->stream, C.h->g, h->g, L.r[0], L.r[1], L.r[2], L.w[0], L.w[1], L.w[2], h->q, C.h->r);
   FL_CHK(vcycle(mg, l + 1, o));                                                      // e_c = V(R r)
@@ -398,9 +541,24 @@ int vcycle(fl_mg *mg, size_t l, const fl_ksp_opts *o)
       t.pn[d] = L.pn[d];
       t.pw[d] = L.pw[d];
     }
-    hipLaunchKernelGGL(k_mg_prolong_lin_add, dim3(nblk_pairs(h->g)), dim3(256), 0, h->stream, h->g, C.h->g, L.r[0], L.r[1], L.r[2], t, (const double *)C.h->xp, h->xp);
+    static const int tiled = []() {
+      const char *e = std::getenv("FLUCA_MG_PROLONG_TILE");  // 2 (default): parent-centred where every axis is halved, else 1: the tile walk; 0: the grid-stride kernel
+      return e ? std::atoi(e) : 2;
+    }();
+    if (tiled >= 2 && L.r[0] == 2 && L.r[1] == 2 && L.r[2] == 2) {
+      const int  kc = 4;
+      const GridP &gcs = C.h->g;
+      hipLaunchKernelGGL(k_mg_prolong_lin_cc, dim3((gcs.nx + 61) / 62, (gcs.ny + 3) / 4, (gcs.nz + kc - 1) / kc), dim3(256), 0, h->stream, h->g, gcs, t, (const double *)C.h->xp, h->xp, kc);
+    } else if (tiled) {
+      const int  zc = 8;
+      const dim3 grid((h->g.nx + 127) / 128, (h->g.ny + 3) / 4, (h->g.nz + zc - 1) / zc);
+      if (L.r[0] == 2 && L.r[1] == 2 && L.r[2] == 2) hipLaunchKernelGGL((k_mg_prolong_lin_tile<true>), grid, dim3(256), 0, h->stream, h->g, C.h->g, L.r[0], L.r[1], L.r[2], t, (const double *)C.h->xp, h->xp, zc);
+      else hipLaunchKernelGGL((k_mg_prolong_lin_tile<false>), grid, dim3(256), 0, h->stream, h->g, C.h->g, L.r[0], L.r[1], L.r[2], t, (const double *)C.h->xp, h->xp, zc);
+    } else hipLaunchKernelGGL(k_mg_prolong_lin_add, dim3(nblk_pairs(h->g)), dim3(256), 0, h->stream, h->g, C.h->g, L.r[0], L.r[1], L.r[2], t, (const double *)C.h->xp, h->xp);
   } else hipLaunchKernelGGL(k_mg_prolong_add, dim3(nblk_pairs(h->g)), dim3(256), 0, h->stream, h->g, C.h->g, L.r[0], L.r[1], L.r[2], C.h->xp, h->xp);  // x += P e_c
-  FL_CHK(fl_cheb_smooth_padded(h, nu, true, false));                                 // nu more steps from x
+  bool got = want;
+  FL_CHK(fl_cheb_smooth_padded(h, nu, true, false, &got));                           // nu more steps from x
+  if (sums) *sums = got;
   return 0;
 }
 
@@ -461,9 +619,19 @@ int fl_solve_cg_mg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts 
   double  d[5], rz = 0., rz_old = 1., dp = 0., pq = 0., m = 0.;
   std::vector<double> hist;
   // z' = z - m 1 with m = mean(z):  z'.z' = z.z - N m^2,  r.z' = r.z - m sum r
+  static const bool fused_dots = []() {
+    const char *e = std::getenv("FLUCA_MG_FUSED_DOTS");  // 0: always the separate k_mg_dots pass (A/B runs)
+    return e ? std::atoi(e) != 0 : true;
+  }();
+  const double *subq = nullptr;  // r -= suba * subq is owed (taken care of inside the next cycle)
+  double        suba = 0.;
   auto cycle_and_sums = [&]() -> int {
-    FL_CHK(vcycle(mg, 0, o));                                              // z = M^-1 r
-    FL_CHK(dots(h, h->xp, h->r, d));
+    bool got = fused_dots;
+    FL_CHK(vcycle(mg, 0, o, &got, subq, suba));                            // [r -= alpha q ;] z = M^-1 r
+    if (got) {  // the cycle's last smoothing sweep formed the sums on its way
+      FL_HIP(hipMemcpyAsync(d, h->sums, sizeof(double) * 5, hipMemcpyDeviceToHost, h->stream));
+      FL_HIP(hipStreamSynchronize(h->stream));
+    } else FL_CHK(dots(h, h->xp, h->r, d));
     m = ns ? d[0] / N : 0.;
     const double zz = d[1] - N * m * m;
     dp = pnorm ? std::sqrt(zz > 0. ? zz : 0.) : std::sqrt(d[4]);
@@ -493,17 +661,23 @@ int fl_solve_cg_mg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts 
       break;
     }
     const double alpha = rz / pq;
-    hipLaunchKernelGGL(k_mg_pw<1>, dim3(nb), dim3(256), 0, s, g, alpha, 0., 0., (const double *)P, (const double *)Q, X, h->r);  // x += alpha p ; r -= alpha q
+    // x += alpha p ; r -= alpha q -- neither as a pass of its own: r on the first smoothing step of the cycle that follows, x together with p below
+    subq = Q;
+    suba = alpha;
     rz_old = rz;
-    FL_CHK(cycle_and_sums());                                               // z = M^-1 r and the five sums
+    FL_CHK(cycle_and_sums());                                               // r -= alpha q, z = M^-1 r and the five sums
+    subq = nullptr;
     ++it;
     hist.push_back(dp);
     reason = converged(dp);
     if (!reason && it >= o->maxit) reason = FL_DIVERGED_ITS;
     if (!reason && !(rz > 0.)) reason = std::isnan(rz) ? FL_DIVERGED_NANORINF : FL_DIVERGED_INDEFINITE_PC;
-    if (reason) break;
+    if (reason) {
+      hipLaunchKernelGGL(k_mg_pw<3>, dim3(nb), dim3(256), 0, s, g, alpha, 0., 0., (const double *)P, (const double *)nullptr, X, (double *)nullptr);  // x += alpha p
+      break;
+    }
     const double beta = rz / rz_old;
-    hipLaunchKernelGGL(k_mg_pw<0>, dim3(nb), dim3(256), 0, s, g, 1., beta, m, (const double *)h->xp, (const double *)nullptr, P, (double *)nullptr);  // p = z' + beta p
+    hipLaunchKernelGGL(k_mg_pw<4>, dim3(nb), dim3(256), 0, s, g, alpha, beta, m, (const double *)h->xp, (const double *)nullptr, P, X);  // x += alpha p ; p = z' + beta p
   }
   // answer, with the constant removed on the way out (the shift is handed over in device memory)
   double *shift = nullptr;
