@@ -360,6 +360,7 @@ int  fl_poll_scal(fl_poisson *h);
 int fl_apply_tiled(fl_poisson *h, const double *xpad, double *y, int unpadded_y);
 int fl_residual(fl_poisson *h, const double *x, const double *b, double *r);
 int fl_residual_padded(fl_poisson *h, double *xpad, const double *bpad, double *rpad);
+int fl_residual_restrict_padded(fl_poisson *h, double *xpad, const double *bpad, const double *wx, const double *wy, const double *wz, fl_poisson *hc, double *cpad);
 int fl_apply_padded_dot(fl_poisson *h, double *xpad, double *ypad, double *xy);
 int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero, bool *mgdots = nullptr, const double *subq = nullptr, double suba = 0.);
 int fl_solve_bcgs(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *o, fl_ksp_stats *st);

@@ -246,6 +246,10 @@ __global__ void __launch_bounds__(256) k_bcgs_pw(GridP g, const double *__restri
 //           sums 0 R.R, 1 R.RP, 2 sum R                                                               reads S0,P',X,RP  writes X,R         48
 // = 120 B/cell/iteration against 152 with V0 and T0 stored (k_apply_pc + k_bcgs_pw).  Scalars, lazy null-space shifts and the
 // convergence test are k_bcgs_fin's, unchanged.
+// MODE 11 only: where the restricted residual goes (row / plane stride and offset of cell (0,0,0) of the coarse padded array)
+struct StAux {
+  int64_t csx = 0, csxy = 0, coff = 0;
+};
 template <int MODE>
 struct BcgsIo {
   static constexpr int NE = (MODE == 4 || MODE == 10) ? 3 : ((MODE == 3 || MODE == 7 || MODE == 9) ? 0 : (MODE == 6 ? 2 : 1));  // extra per-cell input streams (plane of the product)
@@ -262,12 +266,16 @@ struct BcgsIo {
 // convergence test.  72 B/cell/iteration against 60 of the two-reduction pair (k_cg_A + k_cg_Bq): the price of one all-reduce and one
 // scalar kernel less per iteration, worth it where those weigh as much as the kernels (several ranks, small blocks).
 //   MODE 7  y = S x (padded), sums 0 sum y, 2 x.y, 3 y.y          MODE 8  r = o - S x (padded), no sums          (multigrid cycle, JAC = false)
+//   MODE 11 the residual of MODE 8, restricted on the way (every axis halved): a lane's pair, the wave's two rows and two consecutive planes
+//           are the eight children of one coarse cell; their weighted sum (k_mg_restrict's products in its order) goes to the coarse array
+//           w0, the fine residual is never written.  e1 / e2 / w1: the restriction weights along x / y / z.       reads x,o  writes 1/8     17
 //   MODE 6  (Chebyshev, one step: KSPCHEBYSHEV + PCJACOBI, the recurrence of k_cheb)  z = M (b - S x), x staged; d = rho d + c z (in place);
 //           x' = x + d into the other x buffer; sums 0 sum z, 1 z.z, 2 r.r                              reads x,b,d  writes x',d          40
 template <int RY, int NW, bool JAC, int MODE>
 __device__ __forceinline__ void st_body(const GridP &g, const double *__restrict__ stg, const double *e0, const double *e1, const double *e2, double *w0, double *w1 /* MODE 4: e1 == w0 (X); MODE 6: e1 == w1 (d) */,
-                                        const KspScal *__restrict__ s, double *__restrict__ partial, int stride, int nchunk, int zc, int tiles_x, int tiles, int remap)
+                                        const KspScal *__restrict__ s, double *__restrict__ partial, int stride, int nchunk, int zc, int tiles_x, int tiles, int remap, StAux ax = StAux())
 {
+  static_assert(MODE != 11 || RY == 2, "the restricted residual pairs the two rows of a wave");
   using T               = TileA<RY, NW>;
   constexpr int TX = T::TX, TY = T::TY, LX = T::LX, LY = T::LY;
   constexpr int NE = BcgsIo<MODE>::NE, NACC = BcgsIo<MODE>::NACC;
@@ -275,7 +283,7 @@ __device__ __forceinline__ void st_body(const GridP &g, const double *__restrict
   __shared__ __attribute__((aligned(16))) double lds[3][LY][LX];
   __shared__ double                              red[NACC * NW];
   double alpha = 0., omega = 0., beta = 0., ob = 0., vsh = 0., ssh = 0., tsh = 0., crho = 0., cc = 0., zsh = 0.;
-  if (MODE < 7 || MODE >= 9) {  // MODE 7 / 8 (plain products for the multigrid cycle) run without a scalar block
+  if (MODE < 7 || MODE == 9 || MODE == 10) {  // MODE 7 / 8 / 11 (plain products for the multigrid cycle) run without a scalar block
     if (s->reason != 0) return;
     alpha = s->alpha; omega = s->omega; beta = s->beta; ob = s->omega_old * s->beta; vsh = s->vshift; ssh = s->rshift; tsh = s->tshift;
     crho = s->cheb_rho; cc = s->cheb_c; zsh = s->zshift;
@@ -328,6 +336,8 @@ __device__ __forceinline__ void st_body(const GridP &g, const double *__restrict
 #pragma unroll
   for (int a = 0; a < NACC; ++a) acc[a] = 0.;
   double2 rprev[ZST ? RY : 1];  // ZST: the raw r of the plane whose product is formed (the staged copy is r / diag)
+  double  racc = 0.;            // MODE 11: the coarse cell's sum so far
+  const double rwx0 = MODE == 11 ? e1[min(i, g.nx - 1)] : 0., rwx1 = MODE == 11 ? e1[min(i + 1, g.nx - 1)] : 0.;
   double zlc = 0., zcc = 0., zhc = 0.;  // z-row of plane kk-1 (the plane whose product is formed)
   struct Raw {
     double2 v[RY];                 // staged vector, plane kn
@@ -453,6 +463,14 @@ __device__ __forceinline__ void st_body(const GridP &g, const double *__restrict
         } else if (MODE == 8) {
           const double2 ov = C.e[0][m];
           put(w0, make_double2(ov.x - y.x, ov.y - y.y));
+        } else if (MODE == 11) {
+          const double2 ov = C.e[0][m];
+          const double  wyz = e2[min(jb + m, g.ny - 1)] * reinterpret_cast<const double *>(w1)[kc];
+          racc += wyz * (rwx0 * (ov.x - y.x) + rwx1 * (ov.y - y.y));
+          if (m == RY - 1 && (kc & 1)) {
+            if (o1) w0[ax.coff + (int64_t)(kc >> 1) * ax.csxy + (int64_t)(jb >> 1) * ax.csx + (i >> 1)] = racc;
+            racc = 0.;
+          }
         } else if (MODE == 6) {
           const double2 bv = C.e[0][m], dv = C.e[NE >= 2 ? 1 : 0][m];
           const double  r0 = bv.x - y.x, r1 = bv.y - y.y;  // y = S x here (not preconditioned)
@@ -497,7 +515,7 @@ __device__ __forceinline__ void st_body(const GridP &g, const double *__restrict
     }
   }
 #undef RO
-  if (MODE == 5 || MODE == 8 || MODE == 10) return;  // no sums
+  if (MODE == 5 || MODE == 8 || MODE == 10 || MODE == 11) return;  // no sums
 #pragma unroll
   for (int a = 0; a < NACC; ++a) {
     acc[a] = wave_sum(acc[a]);
@@ -513,9 +531,9 @@ __device__ __forceinline__ void st_body(const GridP &g, const double *__restrict
 }
 template <int RY, int NW, bool JAC, int MODE>
 __global__ void __launch_bounds__(64 * NW, 2) k_bcgs_st(GridP g, const double *__restrict__ stg, const double *e0, const double *e1, const double *e2, double *w0, double *w1, const KspScal *__restrict__ s,
-                                                        double *__restrict__ partial, int stride, int nchunk, int zc, int tiles_x, int tiles, int remap)
+                                                        double *__restrict__ partial, int stride, int nchunk, int zc, int tiles_x, int tiles, int remap, StAux ax)
 {
-  st_body<RY, NW, JAC, MODE>(g, stg, e0, e1, e2, w0, w1, s, partial, stride, nchunk, zc, tiles_x, tiles, remap);
+  st_body<RY, NW, JAC, MODE>(g, stg, e0, e1, e2, w0, w1, s, partial, stride, nchunk, zc, tiles_x, tiles, remap, ax);
 }
 // One Chebyshev(-Jacobi) step on the LDS-staged walk (MODE 6): the buffers are picked on the device like in k_cheb (cur / dcur flip in the
 // scalar kernels, the host enqueues steps without waiting)
@@ -1152,12 +1170,12 @@ int fl_residual(fl_poisson *h, const double *x, const double *b, double *r)
 
 namespace {
 template <int RY, int NW, int MODE>
-void bcgs_st_t(fl_poisson *h, const PlanA &p, bool jac, const double *stg, const double *e0, const double *e1, const double *e2, double *w0, double *w1)
+void bcgs_st_t(fl_poisson *h, const PlanA &p, bool jac, const double *stg, const double *e0, const double *e1, const double *e2, double *w0, double *w1, StAux ax = StAux())
 {
   const int  tiles = p.tiles_x * p.tiles_y;
   const dim3 gr(p.nblocks), bl(64 * NW);
-  if (jac) hipLaunchKernelGGL((k_bcgs_st<RY, NW, true, MODE>), gr, bl, 0, h->stream, h->g, stg, e0, e1, e2, w0, w1, h->scal, h->partial, h->partial_stride, p.nchunk, p.zc, p.tiles_x, tiles, p.remap);
-  else hipLaunchKernelGGL((k_bcgs_st<RY, NW, false, MODE>), gr, bl, 0, h->stream, h->g, stg, e0, e1, e2, w0, w1, h->scal, h->partial, h->partial_stride, p.nchunk, p.zc, p.tiles_x, tiles, p.remap);
+  if (jac) hipLaunchKernelGGL((k_bcgs_st<RY, NW, true, MODE>), gr, bl, 0, h->stream, h->g, stg, e0, e1, e2, w0, w1, h->scal, h->partial, h->partial_stride, p.nchunk, p.zc, p.tiles_x, tiles, p.remap, ax);
+  else hipLaunchKernelGGL((k_bcgs_st<RY, NW, false, MODE>), gr, bl, 0, h->stream, h->g, stg, e0, e1, e2, w0, w1, h->scal, h->partial, h->partial_stride, p.nchunk, p.zc, p.tiles_x, tiles, p.remap, ax);
 }
 template <int MODE>
 void launch_bcgs_st(fl_poisson *h, const PlanA &p, bool jac, const double *stg, const double *e0, const double *e1, const double *e2, double *w0, double *w1)
@@ -1182,6 +1200,29 @@ int fl_residual_padded(fl_poisson *h, double *xpad, const double *bpad, double *
   }
   const TP tp = tile_plan(h->g);
   launch_apply_pc(h, tp, false, xpad, rpad, bpad, nullptr, nullptr, 3);
+  return 0;
+}
+
+// The coarse right-hand side of a multigrid cycle in one pass: cpad (padded, level hc) = R (b - S x), R = k_mg_restrict's weighted sum over the
+// eight children.  Only where every axis is halved, the block is even in every direction and the walk pairs rows and planes the way the
+// children pair (two rows per wave, even z chunks); returns 1 where it does not apply (the caller runs the residual and the restriction).
+int fl_residual_restrict_padded(fl_poisson *h, double *xpad, const double *bpad, const double *wx, const double *wy, const double *wz, fl_poisson *hc, double *cpad)
+{
+  static const int on = []() {
+    const char *e = std::getenv("FLUCA_MG_FUSED_RESTRICT");  // 0: residual and restriction as two passes (A/B runs)
+    return e ? std::atoi(e) : 1;
+  }();
+  const GridP &g = h->g, &gc = hc->g;
+  const PlanA  p = plan_cg_A(g, 0, 0);
+  if (!on || cheb_staged_mode() == 0 || p.ry != 2 || (p.nw != 8 && p.nw != 4) || (p.nchunk > 1 && (p.zc & 1))) return 1;
+  if ((g.nx & 1) || (g.ny & 1) || (g.nz & 1) || gc.nx * 2 != g.nx || gc.ny * 2 != g.ny || gc.nz * 2 != g.nz) return 1;
+  FL_CHK(fl_fill_ghosts(h, xpad));
+  StAux ax;
+  ax.csx  = gc.sx;
+  ax.csxy = gc.sxy;
+  ax.coff = gc.off0;
+  if (p.nw == 8) bcgs_st_t<2, 8, 11>(h, p, false, xpad, bpad, wx, wy, cpad, const_cast<double *>(wz), ax);
+  else bcgs_st_t<2, 4, 11>(h, p, false, xpad, bpad, wx, wy, cpad, const_cast<double *>(wz), ax);
   return 0;
 }
 

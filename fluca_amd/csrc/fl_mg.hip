@@ -531,8 +531,15 @@ int vcycle(fl_mg *mg, size_t l, const fl_ksp_opts *o, bool *sums = nullptr, cons
   const int nu = o->mg_smooth_its > 0 ? o->mg_smooth_its : 3;
   MgLevel  &C  = mg->lv[l + 1];
   FL_CHK(fl_cheb_smooth_padded(h, nu, true, true, nullptr, subq, suba));             // x = smooth(b), zero initial guess
-  FL_CHK(fl_residual_padded(h, h->xp, h->r, h->q));                                  // q = b - S x   (q: the smoother's scratch)
-  hipLaunchKernelGGL(k_mg_restrict, dim3(nblk(C.h->ncell)), dim3(256), 0, h->stream, C.h->g, h->g, L.r[0], L.r[1], L.r[2], L.w[0], L.w[1], L.w[2], h->q, C.h->r);
+  int fused = 1;
+  if (L.r[0] == 2 && L.r[1] == 2 && L.r[2] == 2) {
+    fused = fl_residual_restrict_padded(h, h->xp, h->r, L.w[0], L.w[1], L.w[2], C.h, C.h->r);       // coarse b = R (b - S x) in one pass
+    if (fused < 0) return fused;
+  }
+  if (fused != 0) {
+    FL_CHK(fl_residual_padded(h, h->xp, h->r, h->q));                                // q = b - S x   (q: the smoother's scratch)
+    hipLaunchKernelGGL(k_mg_restrict, dim3(nblk(C.h->ncell)), dim3(256), 0, h->stream, C.h->g, h->g, L.r[0], L.r[1], L.r[2], L.w[0], L.w[1], L.w[2], h->q, C.h->r);
+  }
   FL_CHK(vcycle(mg, l + 1, o));                                                      // e_c = V(R r)
   if (fl_mg_prolong_mode() == 1) {  // x += P e_c, tri-linear: the coarse correction with its edge and corner ghosts
     FL_CHK(fl_fill_ghosts_full(C.h, C.h->xp));
