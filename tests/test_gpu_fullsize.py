@@ -5,6 +5,7 @@ C3  512^3 channel [VELOCITY inlet, PRESSURE_OUTLET, walls in y, PERIODIC span], 
     (k_cheb_st) on the same handle -- the same arithmetic per cell, so 1e-13 -- and the damping a sweep must deliver.
 C4  512^3 with the immersed sphere of diameter 64 h (12 868 markers on a Fibonacci lattice): fl_ibm_interp / fl_ibm_spread against the
     oracle's fo_ibm_interp / fo_ibm_spread.  The host cost is O(markers), not O(cells): the oracle loops over the markers' supports.
+momentum  the same 512^3 channel: the momentum block with v0interp formed inside the kernel (k_mom3) against the stored-path kernel.
 The headline's own configuration (512^3 cavity Jacobi-PCG) is compared with the oracle at full size by bench.py's cpu_baseline leg
 (parity_on_full_grid) and by test_gpu_poisson.py::test_full_size_properties_512.
 """
@@ -86,4 +87,38 @@ def test_c4_sphere_ibm_matches_oracle_at_512(kind):
     lhs, rhs = float((U * F * dV).sum()), float((uh.reshape(3, -1) * fh).sum() * h ** 3)
     assert abs(lhs - rhs) <= 1e-11 * max(abs(lhs), abs(rhs))
     m.close()
+    P.close()
+
+
+def test_momentum_state_with_v0_equals_the_stored_fields_at_512():
+    """The momentum block of bench.py's `configs.momentum` at its own size (512^3 channel with an outlet and a periodic span, 403 M velocity
+    unknowns): k_mom3 (v0interp formed from v0 inside the kernel, fl_momentum_set_state_v0) against k_mom2 reading the nine stored fields
+    of the same state -- the same products in the same order per face value, so the two operators agree to the rounding of the row sums --
+    and the Jacobi-BiCGStab histories of the two paths."""
+    from fluca_amd.poisson import Momentum, Poisson
+    P = Poisson.uniform(N512, CAVITY_BOX, [V, O, V, V, PER, PER], 1e-3)
+    M = Momentum(P)
+    gen = torch.Generator(device="cuda").manual_seed(17)
+    rnd = lambda m: torch.rand(m, dtype=torch.float64, device="cuda", generator=gen) * 2 - 1  # noqa: E731
+    V0 = [rnd(P.nface[d]) for d in range(3)]
+    v0 = rnd(3 * P.ncell)
+    W = M.interp_faces(v0)
+    h = 1.0 / 512
+    x = rnd(3 * P.ncell)
+    M.set_state(0.5 * h, 1.0, 0.5 * h, V0, W)
+    y_stored, d_stored = M.apply(x), M.diagonal()
+    s_stored, i_stored = M.solve(x, history=True, rtol=1e-9, maxit=100)
+    M.set_state(0.5 * h, 1.0, 0.5 * h, V0, W, v0=v0)
+    del V0, W, v0
+    y_fly, d_fly = M.apply(x), M.diagonal()
+    assert float((y_fly - y_stored).abs().max()) <= 4e-15 * float(y_stored.abs().max())
+    assert float((d_fly - d_stored).abs().max()) <= 4e-15 * float(d_stored.abs().max())
+    del y_stored, d_stored, d_fly
+    s_fly, i_fly = M.solve(x, history=True, rtol=1e-9, maxit=100)
+    assert i_fly["reason"] == i_stored["reason"] == 2 and i_fly["iters"] == i_stored["iters"]
+    assert np.allclose(i_fly["history"], i_stored["history"], rtol=1e-6)
+    assert float((s_fly - s_stored).norm()) <= 1e-9 * float(s_stored.norm())
+    # and the answer solves the system
+    assert float((M.apply(s_fly) - x).norm()) <= 1e-7 * float(x.norm())
+    M.close()
     P.close()
