@@ -1,5 +1,7 @@
 #!/bin/bash
 # k_cheb2 data-movement ablations (rebuilt on the box; results are garbage, only the time counts): FL_CHEB2_ABL bits: 1 no ring loads, 2 no stores,
+# (the FL_CHEB2_ABL switches were temporary edits of fl_cheb2.hip -- ring loads replaced by constants, stores by a sum, the staging block and the barrier
+#  compiled out -- and are not in the tree; this script documents how profiles/r03_cheb2_diagnosis.txt (d) was produced)
 # 4 no LDS staging, 16 no barrier
 cd $GRAFT_REPO_ROOT
 for a in 0 1 2 4 16 3 20 23; do
