@@ -1272,7 +1272,10 @@ int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero, bool
   o.norm_type        = FL_NORM_NONE;
   o.maxit            = nu;
   o.remove_nullspace = 0;
-  const double lam = fl_gershgorin_bound(h, jac), emin = 0.1 * lam, emax = 1.1 * lam;
+  // PETSc's -mg_levels_ksp_chebyshev_esteig 0,0.1,0,1.1 applied to the bound (experiments: FLUCA_MG_CHEB_LO / _HI, fractions of the bound)
+  static const double flo = []() { const char *e = std::getenv("FLUCA_MG_CHEB_LO"); return e ? std::atof(e) : 0.1; }();
+  static const double fhi = []() { const char *e = std::getenv("FLUCA_MG_CHEB_HI"); return e ? std::atof(e) : 1.1; }();
+  const double lam = fl_gershgorin_bound(h, jac), emin = flo * lam, emax = fhi * lam;
   init_scal(h, &o);
   KspScal &S = *h->scal_host;
   S.scale     = 2. / (emax + emin);
