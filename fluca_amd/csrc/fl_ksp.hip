@@ -811,11 +811,15 @@ __global__ void __launch_bounds__(256) k_cheb_first(GridP g, double *X0w, double
   double       *xn = s->cur ? X0w : X1w;
   double *__restrict__ d = s->dcur ? D1 : D0;
   const double  cc = s->cheb_c;
-  const int64_t npr = (g.nx + 1) / 2, total = npr * (int64_t)g.ny * g.nz;
-  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
-    const int     i = 2 * (int)(q % npr);
-    const int64_t row = q / npr;
-    const int     j = (int)(row % g.ny), k = (int)(row / g.ny);
+  // a wave per 128-cell row segment, grid-stride over (segment, row): the row and plane numbers are wave-uniform, so the index arithmetic and
+  // the y / z table reads are scalar (the per-pair 64-bit divisions of a flat grid-stride loop cost more issue slots than the update itself)
+  const int     lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  const int     nseg = (g.nx + 127) / 128;
+  const int64_t nitem = (int64_t)nseg * g.ny * g.nz;
+  for (int64_t it = (int64_t)blockIdx.x * nw + w; it < nitem; it += (int64_t)gridDim.x * nw) {
+    const int     seg = (int)(it % nseg), row = (int)(it / nseg);
+    const int     j = row % g.ny, k = row / g.ny, i = seg * 128 + 2 * lane;
+    if (i >= g.nx) continue;
     const bool    two = i + 1 < g.nx;
     const int64_t off = g.off0 + (int64_t)k * g.sxy + (int64_t)j * g.sx + i;
     const double  dyz = g.sc[1][j] + g.sc[2][k];
@@ -1302,8 +1306,8 @@ int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero, bool
   for (int j = 0; j < nu;) {
     if (j == 0 && guess_zero) {
       // the sums k_cheb_fin would look at are not used without a norm and a null space: it only advances the recurrence
-      const int64_t pairs = (int64_t)((h->g.nx + 1) / 2) * h->g.ny * h->g.nz;
-      const int     nb    = (int)std::max<int64_t>(1, std::min<int64_t>((pairs + 255) / 256, 8192));
+      const int64_t items = (int64_t)((h->g.nx + 127) / 128) * h->g.ny * h->g.nz;  // 128-cell row segments, one per wave and trip
+      const int     nb    = (int)std::max<int64_t>(1, std::min<int64_t>((items + 3) / 4, 8192));
       if (subq) {
         if (jac) hipLaunchKernelGGL((k_cheb_first<true, true>), dim3(nb), dim3(256), 0, s, h->g, X0, X1, B, D0, D1, h->scal, subq, suba);
         else hipLaunchKernelGGL((k_cheb_first<false, true>), dim3(nb), dim3(256), 0, s, h->g, X0, X1, B, D0, D1, h->scal, subq, suba);

@@ -302,10 +302,16 @@ __global__ void __launch_bounds__(256) k_mg_dots(GridP g, const double *__restri
 template <int OP>
 __global__ void __launch_bounds__(256) k_mg_pw(GridP g, double a, double b, double c, const double *__restrict__ x0, const double *__restrict__ x1, double *__restrict__ y0, double *__restrict__ y1)
 {
-  const Owned o = owned_of(g);
-  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < o.npairs; q += (int64_t)gridDim.x * blockDim.x) {
-    bool          two;
-    const int64_t off = pair_off(g, o, q, two);
+  // a wave per 128-cell row segment (row and plane numbers wave-uniform: scalar index arithmetic instead of 64-bit divisions per pair)
+  const int     lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  const int     nseg = (g.nx + 127) / 128;
+  const int64_t nitem = (int64_t)nseg * g.ny * g.nz;
+  for (int64_t it = (int64_t)blockIdx.x * nw + w; it < nitem; it += (int64_t)gridDim.x * nw) {
+    const int seg = (int)(it % nseg), row = (int)(it / nseg);
+    const int j = row % g.ny, k = row / g.ny, i = seg * 128 + 2 * lane;
+    if (i >= g.nx) continue;
+    const bool    two = i + 1 < g.nx;
+    const int64_t off = g.off0 + (int64_t)k * g.sxy + (int64_t)j * g.sx + i;
     if (OP == 0) {
       const double2 xv = ldp(x0, off, two), yv = ldp(y0, off, two);
       stp(y0, off, two, make_double2((xv.x - c) + b * yv.x, (xv.y - c) + b * yv.y));

@@ -208,8 +208,9 @@ def test_rccl_unique_id_roundtrip():
     mpc.run_ranks(2, _rccl_probe)
 
 
-def _momentum_worker(rank, world, n, ranks, bc):
-    """The momentum block on a decomposed grid: ghost exchange of the three velocity components and of the twelve face
+def _momentum_worker(rank, world, n, ranks, bc, with_v0=False):
+    """The momentum block on a decomposed grid (with_v0: the state handed over with the cell-centred v0, so that k_mom3 forms v0interp on
+    the inner faces of every rank's block and reads the stored fields on the faces at its ends -- walls, periodic seams and rank boundaries): ghost exchange of the three velocity components and of the twelve face
     fields (high face of the last owned cell = the neighbour's first face), decomposed BiCGStab, vs the single-domain
     oracle CSR."""
     import torch
@@ -226,6 +227,9 @@ def _momentum_worker(rank, world, n, ranks, bc):
     rng = np.random.default_rng(99)
     V0 = [rng.standard_normal(g.nface[a]) for a in range(3)]
     W = [rng.standard_normal(g.nface[a]) for c in range(3) for a in range(3)]
+    v0 = rng.standard_normal(3 * g.ncell)
+    if with_v0:
+        W = g.apply_B(v0)
     hmin = min(1.0 / n[0], 1.0 / n[1], 0.5 / n[2])
     dt, rho, mu = 0.5 * hmin, 1.0, 0.5 * hmin
     A = g.assemble_momentum(1.0, dt, -0.5 * mu * dt / rho, V0, W)
@@ -235,7 +239,7 @@ def _momentum_worker(rank, world, n, ranks, bc):
     dev = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64).ravel(), device="cuda")
     loc = lambda v: np.stack([v.reshape(3, *shp)[c][blk].ravel() for c in range(3)]).ravel()
     fl = lambda a, ax: dev(a.reshape(fshape[ax])[mpc.face_block(d, ax, periodic)])
-    M.set_state(dt, rho, mu, [fl(V0[a], a) for a in range(3)], [fl(W[c * 3 + a], a) for c in range(3) for a in range(3)])
+    M.set_state(dt, rho, mu, [fl(V0[a], a) for a in range(3)], [fl(W[c * 3 + a], a) for c in range(3) for a in range(3)], v0=dev(loc(v0)) if with_v0 else None)
     v = rng.standard_normal(3 * g.ncell)
     want = A.mult(v)
     got = M.apply(dev(loc(v))).cpu().numpy()
@@ -261,6 +265,15 @@ def _momentum_worker(rank, world, n, ranks, bc):
 ])
 def test_decomposed_momentum_matches_single_domain_oracle(world, n, ranks, bc):
     mpc.run_ranks(world, _momentum_worker, n, ranks, bc)
+
+
+@pytest.mark.parametrize("world,n,ranks,bc", [
+    (2, (24, 20, 16), (1, 1, 2), [1, 1, 1, 1, 4, 1]),       # cavity BCs, z split
+    (2, (24, 20, 16), (2, 1, 1), [3, 3, 1, 2, 3, 3]),       # periodic axis over two ranks + a locally wrapped axis + an outlet
+    (2, (20, 36, 12), (1, 2, 1), [1, 2, 3, 3, 1, 1]),       # y split across a periodic axis (the staged block-end row of k_mom3 is a rank boundary)
+])
+def test_decomposed_momentum_with_v0_matches_single_domain_oracle(world, n, ranks, bc):
+    mpc.run_ranks(world, _momentum_worker, n, ranks, bc, True)
 
 
 def _mg_worker(rank, world, n, ranks, bc, levels, prolong="constant"):
