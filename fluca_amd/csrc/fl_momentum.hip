@@ -559,11 +559,13 @@ __global__ void __launch_bounds__(512) k_mom_pw3(GridP g, int64_t cs, const doub
         if (OP == 0) {
           const double2 r = ldk(a0, q), v = ldp(a1, q), p = ldp(w0, q);
           stp(w0, q, make_double2(r.x - ob * v.x + beta * p.x, r.y - ob * v.y + beta * p.y));
+        } else if (OP == 4) {  // the first iteration's OP 0: P and V are zero by definition, so P = R (nothing is zeroed or read for it)
+          stp(w0, q, ldk(a0, q));
         } else if (OP == 1) {
           const double2 r = ldp(a0, q), v = ldp(a1, q);
           stp(w0, q, make_double2(r.x - alpha * v.x, r.y - alpha * v.y));
-        } else if (OP == 2) {
-          const double2 P = ldp(a0, q), S = ldp(a1, q), T = ldp(a2, q), RP = ldk(a3, q), X = ldp(w0, q);
+        } else if (OP == 2 || OP == 5) {  // OP 5: the first iteration's OP 2 -- X is zero by definition and not read
+          const double2 P = ldp(a0, q), S = ldp(a1, q), T = ldp(a2, q), RP = ldk(a3, q), X = OP == 5 ? make_double2(0., 0.) : ldp(w0, q);
           const double2 rn = make_double2(S.x - omega * T.x, S.y - omega * T.y);
           double2       xn = X;
           xn.x += alpha * P.x + omega * S.x;
@@ -593,7 +595,7 @@ __global__ void __launch_bounds__(512) k_mom_pw3(GridP g, int64_t cs, const doub
       }
     }
   }
-  if (OP == 2 || OP == 3) {
+  if (OP == 2 || OP == 3 || OP == 5) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const double v = wave_sum(acc[a]);
@@ -685,6 +687,21 @@ __global__ void __launch_bounds__(256) k_pad_copy_ext(GridP g, const double *__r
     const int64_t r = q / ex;
     const int     j = (int)(r % ey), k = (int)(r / ey);
     dst[g.off0 + (int64_t)k * g.sxy + (int64_t)j * g.sx + i] = src[q];
+  }
+}
+
+// The same for the faces at the two ends of axis d only (index 0 and, where the array holds it, index n_d): what k_mom3 reads of a stored
+// v0interp field.  One thread per face of the two planes.
+__global__ void __launch_bounds__(256) k_pad_copy_ends(GridP g, const double *__restrict__ src, double *__restrict__ dst, int ex, int ey, int ez, int d)
+{
+  const int     nd = d == 0 ? g.nx : (d == 1 ? g.ny : g.nz), ed = d == 0 ? ex : (d == 1 ? ey : ez);
+  const int     na = d == 0 ? ey : ex, nb = d == 2 ? ey : ez;  // the two transverse extents, a fastest
+  const int     nend = ed > nd ? 2 : 1;
+  const int64_t n = (int64_t)na * nb * nend;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
+    const int a = (int)(q % na), b = (int)((q / na) % nb), f = (q / ((int64_t)na * nb)) ? nd : 0;
+    const int i = d == 0 ? f : a, j = d == 1 ? f : (d == 0 ? a : b), k = d == 2 ? f : b;
+    dst[g.off0 + (int64_t)k * g.sxy + (int64_t)j * g.sx + i] = src[((int64_t)k * ey + j) * ex + i];
   }
 }
 
@@ -1042,13 +1059,19 @@ int mom_set_state(fl_momentum *m, double dt, double rho, double mu, const double
       if (!v0interp_dev[c * 3 + d]) return FL_ERR_ARG_NULL;
   }
   const int ext[3][3] = {{g.fx, g.ny, g.nz}, {g.nx, g.fy, g.nz}, {g.nx, g.ny, g.fz}};
+  // with v0 handed over and k_mom3 certain to run (see mom_apply_t), the inner faces of the nine stored v0interp fields are never read: only their
+  // block-end faces are copied (FLUCA_MOM_KERNEL=2 and grids with ny <= 8 read the whole fields through k_mom2 and get whole copies)
+  const bool ends_only = v0_dev && mom_kernel() >= 3 && g.ny > 8;
   for (int f = 0; f < 12; ++f) {
     const int     d = f < 3 ? f : (f - 3) % 3;
     const double *src = f < 3 ? V0_dev[f] : v0interp_dev[f - 3];
     double       *dst = m->F + (size_t)f * h->padlen;
     const int64_t n = (int64_t)ext[d][0] * ext[d][1] * ext[d][2];
     const int     nb = (int)std::min<int64_t>((n + 255) / 256, 8192);
-    hipLaunchKernelGGL(k_pad_copy_ext, dim3(std::max(nb, 1)), dim3(256), 0, h->stream, g, src, dst, ext[d][0], ext[d][1], ext[d][2]);
+    if (f >= 3 && ends_only) {  // k_mom3 reads a stored v0interp field on the block-end faces only
+      const int64_t ne = 2 * n / std::max(ext[d][d], 1);
+      hipLaunchKernelGGL(k_pad_copy_ends, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((ne + 255) / 256, 8192))), dim3(256), 0, h->stream, g, src, dst, ext[d][0], ext[d][1], ext[d][2], d);
+    } else hipLaunchKernelGGL(k_pad_copy_ext, dim3(std::max(nb, 1)), dim3(256), 0, h->stream, g, src, dst, ext[d][0], ext[d][1], ext[d][2]);
     // high face of the last owned cell: periodic image or the neighbour's first face (the physical last face came with the copy)
     if (fl_any_ghost_exchange(h)) FL_CHK(fl_fill_ghosts(h, dst));
   }
@@ -1129,8 +1152,12 @@ extern "C" int fl_momentum_solve(fl_momentum *m, const double *b_dev, double *x_
   fl_ksp_opts o = *opts;
   o.remove_nullspace = 0;  // A = I + ... is non-singular
   FL_CHK(fl_ksp_begin(h, &o));
+  // P, V and X start as zero vectors: with the tile-walk updates the first iteration says so in its kernels (P = R; X is written, not read) and
+  // nothing is zeroed -- three 3N memsets and the reads of them less per solve; the older update kernels (FLUCA_MOM_PW < 3) keep the memsets
+  const bool   lazy0 = mom_pw_kernel() >= 3;
   const size_t bytes = sizeof(double) * 3 * h->padlen;
-  for (double *v : {P, V, X}) FL_HIP(hipMemsetAsync(v, 0, bytes, h->stream));
+  if (!lazy0)
+    for (double *v : {P, V, X}) FL_HIP(hipMemsetAsync(v, 0, bytes, h->stream));
   mom_pw<3>(m, b_dev, jac ? m->dg : nullptr, nullptr, nullptr, R, RP);
   FL_CHK(fl_bcgs_fin_step(h, 0, mom_pw_blocks(m), 3, nhist));
   const int every = o.check_every > 0 ? o.check_every : 4;
@@ -1139,7 +1166,8 @@ extern "C" int fl_momentum_solve(fl_momentum *m, const double *b_dev, double *x_
   while (!done) {
     const int stop = std::min(o.maxit, it + every);
     for (; it < stop; ++it) {
-      mom_pw<0>(m, R, V, nullptr, nullptr, P, nullptr);
+      if (lazy0 && it == 0) mom_pw<4>(m, R, nullptr, nullptr, nullptr, P, nullptr);
+      else mom_pw<0>(m, R, V, nullptr, nullptr, P, nullptr);
       FL_CHK(mom_ghosts(m, P));
       if (jac) mom_apply_t<1, true, 0>(m, P, V, RP, h->scal);
       else mom_apply_t<1, false, 0>(m, P, V, RP, h->scal);
@@ -1149,12 +1177,14 @@ extern "C" int fl_momentum_solve(fl_momentum *m, const double *b_dev, double *x_
       if (jac) mom_apply_t<2, true, 0>(m, S, T, nullptr, h->scal);
       else mom_apply_t<2, false, 0>(m, S, T, nullptr, h->scal);
       FL_CHK(fl_bcgs_fin_step(h, 3, mom_apply_blocks(m), 4, nhist));
-      mom_pw<2>(m, P, S, T, RP, X, R);
+      if (lazy0 && it == 0) mom_pw<5>(m, P, S, T, RP, X, R);
+      else mom_pw<2>(m, P, S, T, RP, X, R);
       FL_CHK(fl_bcgs_fin_step(h, 4, mom_pw_blocks(m), 3, nhist));
     }
     FL_CHK(fl_poll_scal(h));
     if (h->scal_host->reason != 0 || it >= o.maxit) done = true;
   }
+  if (lazy0 && h->scal_host->it == 0) FL_HIP(hipMemsetAsync(X, 0, bytes, h->stream));  // stopped before the first update wrote X: the answer is the zero guess
   for (int c = 0; c < 3; ++c) launch_unpad_copy(h->stream, h->g, X + (size_t)c * h->padlen, x_dev + (size_t)c * h->ncell, nullptr);
   return fl_ksp_finish(h, &o, stats);
 }
