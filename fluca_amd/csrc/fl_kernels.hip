@@ -17,6 +17,12 @@
 #include "fl_internal.h"
 #include "fl_stencil.h"
 
+#ifndef FL_CGA_WPE
+#define FL_CGA_WPE 2  // waves per SIMD the register allocator must leave room for: 2 = up to 256 VGPRs (one 512-thread block per CU), 4 = at most 128 (two blocks)
+#endif
+#ifndef FL_CGB_WPE
+#define FL_CGB_WPE 2
+#endif
 namespace fl {
 
 // ------------------------------------------------------------------------------------------------ helpers
@@ -905,7 +911,7 @@ __device__ __forceinline__ void cg_A_body(const GridP &g, const double *__restri
 
 #define FL_CG_A_ARGS GridP g, const double *__restrict__ r, double *__restrict__ P0, double *__restrict__ P1, double *__restrict__ q, double *__restrict__ x, KspScal *__restrict__ s, double *__restrict__ partial, int nchunk, int zc, int tiles_x, int tiles, int remap, FinCtx fin
 template <int RY, int NW, bool JAC, int PF, int NT, bool SQ>
-__global__ void __launch_bounds__(64 * NW, 2) k_cg_A(FL_CG_A_ARGS)
+__global__ void __launch_bounds__(64 * NW, FL_CGA_WPE) k_cg_A(FL_CG_A_ARGS)
 {
   cg_A_body<RY, NW, JAC, PF, NT, SQ>(g, r, P0, P1, q, x, s, partial, nchunk, zc, tiles_x, tiles, remap, fin);
 }
@@ -1098,7 +1104,7 @@ __device__ __forceinline__ void cg_Bq_body(const GridP &g, const double *__restr
 }
 #define FL_CG_BQ_ARGS GridP g, const double *__restrict__ P0, const double *__restrict__ P1, double *__restrict__ r, double *__restrict__ x, KspScal *__restrict__ s, double *__restrict__ partial, int stride, int nchunk, int zc, int tiles_x, int tiles, int remap, FinCtx fin
 template <int RY, int NW, bool JAC, int NT, int XM>
-__global__ void __launch_bounds__(64 * NW, 2) k_cg_Bq(FL_CG_BQ_ARGS)
+__global__ void __launch_bounds__(64 * NW, FL_CGB_WPE) k_cg_Bq(FL_CG_BQ_ARGS)
 {
   cg_Bq_body<RY, NW, JAC, NT, XM>(g, P0, P1, r, x, s, partial, stride, nchunk, zc, tiles_x, tiles, remap, fin);
 }

@@ -7,7 +7,7 @@ import sys
 src, pat = sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else ""
 subprocess.run(["mkdir", "-p", "/tmp/kres"])
 out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Iinclude", "-Ifluca_amd/csrc", "-x", "hip", "-c", src, "-o", "/tmp/kres/out.o",
-                      "-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True).stderr
+                      "-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"] + ["-D" + d for d in __import__("os").environ.get("FL_DEFINES", "").split()], capture_output=True, text=True).stderr
 cur, rows = None, {}
 for l in out.splitlines():
     m = re.search(r"remark:\s+\S+:\d+:\d+:\s+(.*?) \[-Rpass", l)
