@@ -529,8 +529,11 @@ __device__ __forceinline__ void st_body(const GridP &g, const double *__restrict
     partial[(int64_t)tid * stride + blockIdx.x] = t;
   }
 }
+#ifndef FL_ST11_WPE
+#define FL_ST11_WPE 4  // the restricted residual fits 128 VGPRs without spilling: two 512-thread blocks per CU (2: one block, 142 VGPRs)
+#endif
 template <int RY, int NW, bool JAC, int MODE>
-__global__ void __launch_bounds__(64 * NW, 2) k_bcgs_st(GridP g, const double *__restrict__ stg, const double *e0, const double *e1, const double *e2, double *w0, double *w1, const KspScal *__restrict__ s,
+__global__ void __launch_bounds__(64 * NW, (MODE == 11 && NW == 8) ? FL_ST11_WPE : 2) k_bcgs_st(GridP g, const double *__restrict__ stg, const double *e0, const double *e1, const double *e2, double *w0, double *w1, const KspScal *__restrict__ s,
                                                         double *__restrict__ partial, int stride, int nchunk, int zc, int tiles_x, int tiles, int remap, StAux ax)
 {
   st_body<RY, NW, JAC, MODE>(g, stg, e0, e1, e2, w0, w1, s, partial, stride, nchunk, zc, tiles_x, tiles, remap, ax);
