@@ -18,6 +18,18 @@
 
 namespace fl {
 
+// FL_MOM3_NT (experiment): 1 = the per-plane loads of the tile's own cells carry the non-temporal hint (they are read once by this block; what a
+// neighbouring block reads again are the tile's edge rows / columns), 2 = only the waves of the tile's inner rows do, 0 = plain loads
+#ifndef FL_MOM3_NT
+#define FL_MOM3_NT 0
+#endif
+__device__ __forceinline__ double2 LD2s(const double *base, unsigned byteoff, bool inner)
+{
+  const double *p = reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + byteoff);
+  if (FL_MOM3_NT == 1 || (FL_MOM3_NT == 2 && inner)) return ld2<1>(p);
+  return ld2<0>(p);
+}
+
 template <int NW>
 struct Mom3Lds {
   static constexpr int TX = 128, TY = NW, LXU = TX + 4;
@@ -60,6 +72,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_mom3(GridP g, MomP m, const doub
   const bool     xlo = i0 == 0, xhi = i0 + TX >= g.nx;  // block-uniform: the tile holds cell 0 / cell nx - 1
   const bool     ylo = jt == 0, yhi = jt == g.ny - 1;   // wave-uniform (the host only launches this kernel when ny > TY: never both)
   const bool     ywall = ylo || yhi;
+  const bool     inner = w != 0 && w != NW - 1;  // wave-uniform: the tile's edge rows are what the y-neighbour tiles read again as their ring
   const int64_t  sx = g.sx, sxy = g.sxy;
   const double   cI = m.cI;
   const int64_t  ncell = (int64_t)g.nx * g.ny * g.nz;
@@ -314,7 +327,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_mom3(GridP g, MomP m, const doub
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- G: V0 on the x-faces of plane k + 1
-    fxl = LD2(F + rb1, lo);
+    fxl = LD2s(F + rb1, lo, inner);
     __builtin_amdgcn_sched_barrier(0);
 
     // general rows of one cell (a = 0 / 1) of the pair: scalar arithmetic on copies of the pair accumulators
@@ -396,7 +409,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_mom3(GridP g, MomP m, const doub
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- E: V0 on the y-faces of plane k + 1
-    fyl = LD2(F + csl + rb1, lo);
+    fyl = LD2s(F + csl + rb1, lo, inner);
     __builtin_amdgcn_sched_barrier(0);
     // ---- H: the z axis (the shadow vector of the inner product is fetched here: it is consumed right after this phase)
 #pragma unroll
@@ -497,10 +510,10 @@ __global__ void __launch_bounds__(64 * NW, 2) k_mom3(GridP g, MomP m, const doub
     // ---- J: plane k + 2 into the registers that became free
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      uzm[c] = LD2(x + (int64_t)c * csl + rb2, lo);
-      vzm[c] = LD2(v0 + (int64_t)c * csl + rb2, lo);
+      uzm[c] = LD2s(x + (int64_t)c * csl + rb2, lo, inner);
+      vzm[c] = LD2s(v0 + (int64_t)c * csl + rb2, lo, inner);
     }
-    fzn = LD2(F + 2 * csl + rb2, lo);
+    fzn = LD2s(F + 2 * csl + rb2, lo, inner);
     __builtin_amdgcn_sched_barrier(0);  // ... and nowhere later: under register pressure the scheduler would sink them to their first use in the next plane
   };
   for (int kk = k0; kk < k1; kk += 3) {
