@@ -168,6 +168,9 @@ __global__ void __launch_bounds__(64 * NW) k_cheb2(GridP g, int perx, int pery, 
     hEii        = (c & 1) ? ie : -1;
   }
   const Halo HE = mk(hEok, hEjj, hEii);
+  // which kinds of ring items this WAVE holds at all (wave-uniform): a wave without any skips their loads, their step-1 arithmetic and their
+  // staging instead of executing them on a dummy cell -- with 512 threads rows live on waves 0..3, columns on waves 4 and 5, nothing on 6 and 7
+  const bool anyA = __builtin_amdgcn_ballot_w64(hAok) != 0, anyB = __builtin_amdgcn_ballot_w64(hBok) != 0, anyE = __builtin_amdgcn_ballot_w64(hEok) != 0;
   // 1-D coefficients of the cells where this thread forms step 1 (table index = local cell index, -1..n).  The y part of an
   // A cell is wave-uniform (rows -1 / je belong to waves 0,1 / 2,3); the five numbers of a B cell wait in LDS.
   const int    cAi = min(max(i0 + hai, -1), g.nx), cAj = __builtin_amdgcn_readfirstlane(min(max(j0 + hAjj, -1), g.ny));
@@ -204,14 +207,19 @@ __global__ void __launch_bounds__(64 * NW) k_cheb2(GridP g, int perx, int pery, 
       R.d[m] = c2_LD2<NTL>(d + rob[m] + plb, lo);
     }
     const double *hx = x + g.off0 + pl, *hb = b + g.off0 + plb, *hd = d + g.off0 + plb;
-    R.hxA = c2_LD1(hx, HA.off);
-    R.hbA = c2_LD1(hb, HA.off);
-    R.hdA = c2_LD1(hd, HA.off);
-    R.hxB = c2_LD1(hx, HB.off);
-    R.hbB = c2_LD1(hb, HB.off);
-    R.hdB = c2_LD1(hd, HB.off);
-    R.hxC = c2_LD1(hx, HC.off);
-    R.hxE = c2_LD1(hx, HE.off);
+    R.hxA = R.hbA = R.hdA = R.hxB = R.hbB = R.hdB = R.hxC = R.hxE = 0.;
+    if (anyA) {
+      R.hxA = c2_LD1(hx, HA.off);
+      R.hbA = c2_LD1(hb, HA.off);
+      R.hdA = c2_LD1(hd, HA.off);
+      R.hxC = c2_LD1(hx, HC.off);
+    }
+    if (anyB) {
+      R.hxB = c2_LD1(hx, HB.off);
+      R.hbB = c2_LD1(hb, HB.off);
+      R.hdB = c2_LD1(hd, HB.off);
+    }
+    if (anyE) R.hxE = c2_LD1(hx, HE.off);
     const int kz = min(max(kk, -1), g.nz);
     R.zl  = g.sl[2][kz];
     R.zc  = g.sc[2][kz];
@@ -272,14 +280,14 @@ __global__ void __launch_bounds__(64 * NW) k_cheb2(GridP g, int perx, int pery, 
           acc[2] += r1 * r1;
         }
       }
-      {
+      if (anyA) {
         const double cen = XJ[bc][HA.lr][HA.lc], dyz = Axc + (Ayc + z1c);
         const double v = dyz * cen + Axl * XJ[bc][HA.lr][HA.lc - 1] + Axh * XJ[bc][HA.lr][HA.lc + 1] + Ayl * XJ[bc][HA.lr - 1][HA.lc] + Ayh * XJ[bc][HA.lr + 1][HA.lc] + z1l * XJ[bp][HA.lr][HA.lc] + z1h * C.hxA;
         const double r = C.hbA - v, z = JAC ? r / dyz : r;
         const double e = (rho0 != 0. ? rho0 * C.hdA : 0.) + c0 * z;
         hx1A = (HA.in && pin1) ? cen + e : 0.;
       }
-      {
+      if (anyB) {
         const double cen = XJ[bc][HB.lr][HB.lc], dyz = cB[tbc][4] + z1c;
         const double v = dyz * cen + cB[tbc][0] * XJ[bc][HB.lr][HB.lc - 1] + cB[tbc][1] * XJ[bc][HB.lr][HB.lc + 1] + cB[tbc][2] * XJ[bc][HB.lr - 1][HB.lc] + cB[tbc][3] * XJ[bc][HB.lr + 1][HB.lc] + z1l * XJ[bp][HB.lr][HB.lc] + z1h * C.hxB;
         const double r = C.hbB - v, z = JAC ? r / dyz : r;
