@@ -1,5 +1,6 @@
 """Random small grids / boundary types / stretching: the matrix-free momentum block (apply, diagonal, BiCGStab and GMRES solves) and the
-face interpolations against the oracle's assembled rows.  usage: python tools/experiments/fuzz_momentum.py [seed] [cases]"""
+face interpolations against the oracle's assembled rows; every case also with the state handed over together with v0 (k_mom3: v0interp formed in
+the kernel on inner faces, stored values with a random boundary-only vbc on the block-end faces).  usage: python tools/experiments/fuzz_momentum.py [seed] [cases]"""
 import os
 import sys
 import traceback
@@ -16,7 +17,7 @@ rng = np.random.default_rng(seed)
 SIZES = [2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 33, 63, 64, 65, 66, 129]
 bad = 0
 for case in range(ncase):
-    n = tuple(int(rng.choice(SIZES[: (len(SIZES) if d == 0 else 10)])) for d in range(3))
+    n = tuple(int(rng.choice(SIZES[: (len(SIZES) if d == 0 else (11 if d == 1 else 10))])) for d in range(3))
     if n[0] * n[1] * n[2] > 60000:
         continue
     bc = []
@@ -56,6 +57,32 @@ for case in range(ncase):
         dg = host(M.diagonal())
         if np.abs(dg - A.diag()).max() > 2e-13 * np.abs(A.diag()).max():
             print("DIAG  ", tag, np.abs(dg - A.diag()).max()); bad += 1
+        # the same operator from (V0, v0, vbc on boundary faces): fl_momentum_set_state_v0
+        v0 = rng.standard_normal(3 * g.ncell)
+        Wb = g.apply_B(v0)
+        for c in range(3):
+            for d in range(3):
+                if not g.periodic[d]:
+                    shape = [g.n[2], g.n[1], g.n[0]]
+                    shape[2 - d] = g.nf[d]
+                    a = Wb[c * 3 + d].reshape(shape)
+                    for f in (0, g.n[d]):
+                        sl = [slice(None)] * 3
+                        sl[2 - d] = f
+                        a[tuple(sl)] += rng.standard_normal(a[tuple(sl)].shape)
+        M.set_state(dt, rho, mu, [dev(a) for a in V0], [dev(a) for a in Wb], v0=dev(v0))
+        Ab = g.assemble_momentum(1.0, dt, -0.5 * mu * dt / rho, V0, Wb)
+        want = Ab.mult(v)
+        got = host(M.apply(dev(v)))
+        if np.abs(got - want).max() > 2e-13 * np.abs(want).max():
+            print("APPLY0", tag, np.abs(got - want).max() / np.abs(want).max()); bad += 1
+        dg = host(M.diagonal())
+        if np.abs(dg - Ab.diag()).max() > 2e-13 * np.abs(Ab.diag()).max():
+            print("DIAG0 ", tag, np.abs(dg - Ab.diag()).max()); bad += 1
+        xo0, io0 = Ab.solve(v, ksp=fo.KSP_BCGS, pc=fo.PC_JACOBI, nullspace=False, rtol=1e-9, maxit=300)
+        xg0, ig0 = M.solve(dev(v), type=1, rtol=1e-9, maxit=300)
+        if io0["reason"] > 0 and (ig0["reason"] != io0["reason"] or np.abs(host(xg0) - xo0).max() > 1e-5 * np.abs(xo0).max()):
+            print("BCGS0 ", tag, "reason", ig0["reason"], io0["reason"], "iters", ig0["iters"], io0["iters"]); bad += 1
         # a well-conditioned system (small dt): both Krylov types to the oracle's answer
         dt2 = 1e-3
         M.set_state(dt2, 1.0, 0.01, [dev(a) for a in V0], [dev(a) for a in W])
