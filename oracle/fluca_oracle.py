@@ -519,6 +519,8 @@ class MgOracle:
             reason = conv(dp)
             if not reason and it >= maxit:
                 reason = -3
+            if not reason and not rz > 0:
+                reason = -8   # KSP_DIVERGED_INDEFINITE_PC: r.z <= 0 (KSPSolve_CG's test on beta; a non-symmetric S can get there)
             if reason:
                 break
             p = z + (rz / rz_old) * p

@@ -50,7 +50,7 @@ for case in range(ncase):
             p -= p.mean()
         b = S.mult(p)
         mg = fo.MgOracle(g, nullspace=singular)
-        mg = fo.MgOracle(g, nullspace=singular, bounds=bounds(mg))
+        mg = fo.MgOracle(g, nullspace=singular, bounds=bounds(mg), prolong="linear")  # the library's default since round 3 (knob mg_prolong = 1)
         xo, io = mg.pcg(b, rtol=1e-8, maxit=60)
         xg, ig = P.solve(dev(b), history=True, type=0, pc=2, remove_nullspace=int(singular), rtol=1e-8, maxit=60)
         xg = host(xg)
