@@ -136,6 +136,7 @@ PROTOTYPES = {
     "fl_boundary_add_cells": (C.c_int, [_P, C.c_int, C.c_double, _P, _P]),
     "fl_momentum_rhs": (C.c_int, [_P, C.c_double, C.c_double, C.c_double, _P, _P, _P, _P]),
     "fl_momentum_interp_faces": (C.c_int, [_P, _P, _P, _P]),
+    "fl_momentum_interp_faces_ends": (C.c_int, [_P, _P, _P, _P]),
     "fl_abf_jacobian_mult": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "fl_abf_apply": (C.c_int, [_P, C.POINTER(fl_ksp_opts), C.POINTER(fl_ksp_opts), _P, _P, _P, _P, _P, _P, C.POINTER(fl_ksp_stats)]),
     "fl_ibm_create": (C.c_int, [_P, C.c_int, C.c_int64, _P, _P, _P, C.POINTER(_P)]),

@@ -71,8 +71,10 @@ __global__ void k_unpad_copy(GridP g, const double *__restrict__ src, double *__
 }
 
 // periodic image inside one rank: ghost(-1) = cell(n-1), ghost(n) = cell(0) along `axis`
-__global__ void k_wrap_ghosts(GridP g, double *__restrict__ v, int axis)
+// blockIdx.z: which of several vectors laid out `vstride` doubles apart (the three components of a velocity: one launch instead of three)
+__global__ void k_wrap_ghosts(GridP g, double *__restrict__ v0_, int axis, int64_t vstride)
 {
+  double *__restrict__ v = v0_ + (int64_t)blockIdx.z * vstride;
   const int a = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y * 4 + threadIdx.y;
   int       na, nb;
   if (axis == 0) { na = g.ny; nb = g.nz; }
@@ -1243,10 +1245,10 @@ namespace fl {
 
 void launch_pad_copy(hipStream_t st, const GridP &g, const double *src, double *dst) { hipLaunchKernelGGL(k_pad_copy, grid3(g.nx, g.ny, g.nz), blk3(), 0, st, g, src, dst); }
 void launch_unpad_copy(hipStream_t st, const GridP &g, const double *src, double *dst, const double *shift) { hipLaunchKernelGGL(k_unpad_copy, grid3(g.nx, g.ny, g.nz), blk3(), 0, st, g, src, dst, shift); }
-void launch_wrap(hipStream_t st, const GridP &g, double *v, int axis)
+void launch_wrap(hipStream_t st, const GridP &g, double *v, int axis, int nvec, int64_t vstride)
 {
   const int na = axis == 0 ? g.ny : g.nx, nb = axis == 2 ? g.ny : g.nz;
-  hipLaunchKernelGGL(k_wrap_ghosts, grid3(na, nb, 1), blk3(), 0, st, g, v, axis);
+  hipLaunchKernelGGL(k_wrap_ghosts, grid3(na, nb, nvec), blk3(), 0, st, g, v, axis, vstride);
 }
 void launch_face_ext(hipStream_t st, const GridP &g, double *v, double *buf, int axis, int side, int ea, int eb, int mode)
 {

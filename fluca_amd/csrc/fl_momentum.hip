@@ -727,6 +727,29 @@ __global__ void __launch_bounds__(256) k_face_interp(GridP g, FaceT t, int kind,
   }
 }
 
+// The same row on the faces at the two ends of axis d only (face 0 and, where this rank owns it, face n_d): all fl_momentum_set_state_v0 reads of a
+// stored v0interp field.  One thread per face of the two planes.
+__global__ void __launch_bounds__(256) k_face_interp_ends(GridP g, FaceT t, int kind, int d, const double *__restrict__ vpad, const double *rhs, double *V)
+{
+  const int     ex = d == 0 ? g.fx : g.nx, ey = d == 1 ? g.fy : g.ny, ez = d == 2 ? g.fz : g.nz;
+  const int     nd = d == 0 ? g.nx : (d == 1 ? g.ny : g.nz), ed = d == 0 ? ex : (d == 1 ? ey : ez);
+  const int     na = d == 0 ? ey : ex, nb = d == 2 ? ey : ez;
+  const int64_t n = (int64_t)na * nb * (ed > nd ? 2 : 1);
+  const int64_t str = d == 0 ? 1 : (d == 1 ? (int64_t)g.sx : g.sxy);
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
+    const int     a = (int)(q % na), b = (int)((q / na) % nb), f = (q / ((int64_t)na * nb)) ? nd : 0;
+    const int     i = d == 0 ? f : a, j = d == 1 ? f : (d == 0 ? a : b), k = d == 2 ? f : b;
+    const int64_t u = ((int64_t)k * ey + j) * ex + i;
+    const int     c0 = t.c0[kind][d][f];
+    const int64_t base = g.off0 + (int64_t)k * g.sxy + (int64_t)j * g.sx + i + (int64_t)(c0 - f) * str;
+    const double  w0 = t.w0[kind][d][f], w1 = t.w1[kind][d][f];
+    double        s = rhs ? rhs[u] : 0.;
+    if (w0 != 0.) s += w0 * vpad[base];
+    if (w1 != 0.) s += w1 * vpad[base + str];
+    V[u] = s;
+  }
+}
+
 }  // namespace fl
 
 using namespace fl;
@@ -772,6 +795,11 @@ int mom_ghosts(fl_momentum *m, double *v3)
 {
   fl_poisson *h = m->p;
   if (!fl_any_ghost_exchange(h)) return 0;
+  if (!h->multi) {  // periodic images inside the one block: the three components in one launch per axis
+    for (int d = 0; d < 3; ++d)
+      if (h->wrap_local[d]) launch_wrap(h->stream, h->g, v3, d, 3, (int64_t)h->padlen);
+    return 0;
+  }
   for (int c = 0; c < 3; ++c) FL_CHK(fl_fill_ghosts(h, v3 + (size_t)c * h->padlen));
   return 0;
 }
@@ -1267,6 +1295,30 @@ extern "C" int fl_momentum_interp_faces(fl_momentum *m, const double *v_dev, con
       const int     nb = (int)std::min<int64_t>((n + 255) / 256, 8192);
       hipLaunchKernelGGL(k_face_interp, dim3(std::max(nb, 1)), dim3(256), 0, h->stream, h->g, m->ft, c == d ? 1 : 2, d, 1., m->vec[7] + (size_t)c * h->padlen, vbc_dev ? vbc_dev[c * 3 + d] : nullptr,
                          out_dev[c * 3 + d]);
+    }
+  FL_HIP(hipGetLastError());
+  return FL_SUCCESS;
+}
+
+// The block-end faces of the same nine fields only (face 0 and face n of each axis, where this rank owns them): what fl_momentum_set_state_v0 reads of
+// v0interp when the operator forms the inner faces from v0 itself.  The inner entries of out_dev are NOT written.
+extern "C" int fl_momentum_interp_faces_ends(fl_momentum *m, const double *v_dev, const double *const vbc_dev[9], double *const out_dev[9])
+{
+  if (!m || !v_dev || !out_dev) return FL_ERR_ARG_NULL;
+  fl_poisson *h = m->p;
+  const GridP &g = h->g;
+  // where the operator will read whole fields (k_mom2: FLUCA_MOM_KERNEL=2, or a block with ny <= 8) the whole fields are what is needed
+  if (!(mom_kernel() >= 3 && g.ny > 8)) return fl_momentum_interp_faces(m, v_dev, vbc_dev, out_dev);
+  FL_HIP(hipSetDevice(h->device));
+  FL_CHK(mom_vec(m, 7));
+  for (int c = 0; c < 3; ++c) launch_pad_copy(h->stream, h->g, v_dev + (size_t)c * h->ncell, m->vec[7] + (size_t)c * h->padlen);
+  FL_CHK(mom_ghosts(m, m->vec[7]));
+  for (int c = 0; c < 3; ++c)
+    for (int d = 0; d < 3; ++d) {
+      if (!out_dev[c * 3 + d]) return FL_ERR_ARG_NULL;
+      const int64_t n = 2 * h->nface[d] / std::max(d == 0 ? g.fx : (d == 1 ? g.fy : g.fz), 1);
+      const int     nb = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 8192));
+      hipLaunchKernelGGL(k_face_interp_ends, dim3(nb), dim3(256), 0, h->stream, g, m->ft, c == d ? 1 : 2, d, m->vec[7] + (size_t)c * h->padlen, vbc_dev ? vbc_dev[c * 3 + d] : nullptr, out_dev[c * 3 + d]);
     }
   FL_HIP(hipGetLastError());
   return FL_SUCCESS;

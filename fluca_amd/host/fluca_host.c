@@ -1536,7 +1536,8 @@ static FlErrorCode NSStep_CNLinear(NS ns)
 
   trace_begin("NSFormFunction"); /* the right-hand side of the step: PetscLogEvent NS_FormFunction (nsbasic.c:131) */
   /* v0interp = B v0 + vbc(t), cnlinearcart3d.c:2826-2829; vbc: :1749-1932 */
-  FLABI_T(fl_momentum_interp_faces(ns->momentum, c->sol0_v, NULL, c->W));
+  /* only the block-end faces are formed here: the operator forms the inner ones from v0 itself (fl_momentum_set_state_v0 below) */
+  FLABI_T(fl_momentum_interp_faces_ends(ns->momentum, c->sol0_v, NULL, c->W));
   /* momrhs = v0 + cv L v0 - kappa G p, :2976-2993 (p0 on the first step, phalf afterwards) */
   FLABI_T(fl_momentum_rhs(ns->momentum, dt, ns->rho, ns->mu, c->sol0_v, ns->step == 0 ? c->sol0_p : c->phalf, NULL, c->f_v));
   for (int d = 0; d < 3; ++d) FLABI_T(fl_vec_lincomb(h, c->sz[1 + d], 0., c->f_V[d], 0., NULL, c->f_V[d])); /* interprhs = 0 */

@@ -396,13 +396,18 @@ class Momentum:
         self.p._post()
         return fv, fV, fp
 
-    def interp_faces(self, v, vbc=None):
-        """cnl->v0interp = B v (+ vbc): 9 face tensors, [c*3+d] = component c on the d-faces (cnlinearcart3d.c:2826-2829)."""
-        out = [self.p.empty(self.p.nface[d]) for c in range(3) for d in range(3)]
+    def interp_faces(self, v, vbc=None, ends_only=False, out=None):
+        """cnl->v0interp = B v (+ vbc): 9 face tensors, [c*3+d] = component c on the d-faces (cnlinearcart3d.c:2826-2829).
+        ends_only: only the faces at the two ends of each axis are written (fl_momentum_interp_faces_ends; `out` may hand in the tensors)."""
+        if out is None:
+            out = [self.p.empty(self.p.nface[d]) for c in range(3) for d in range(3)]
         o = (C.c_void_p * 9)(*[t.data_ptr() for t in out])
         r = None if vbc is None else (C.c_void_p * 9)(*[None if t is None else t.data_ptr() for t in vbc])
         self.p._pre()
-        check(lib.fl_momentum_interp_faces(self.h, _ptr(v), r, o), "fl_momentum_interp_faces")
+        if ends_only:
+            check(lib.fl_momentum_interp_faces_ends(self.h, _ptr(v), r, o), "fl_momentum_interp_faces_ends")
+        else:
+            check(lib.fl_momentum_interp_faces(self.h, _ptr(v), r, o), "fl_momentum_interp_faces")
         self.p._post()
         return out
 

@@ -308,6 +308,11 @@ int fl_momentum_face_interp_scaled(fl_momentum *m, double alpha, const double *v
  * (cnlinearcart3d.c:2826-2829), B = ComputeFaceVelocityInterpolationOperator_Private (cnlinearcart3d.c:1513-1747).
  * vbc_dev (or any entry) may be NULL = 0; out may be handed straight to fl_momentum_set_state. */
 int fl_momentum_interp_faces(fl_momentum *m, const double *v_dev, const double *const vbc_dev[9], double *const out_dev[9]);
+/* The same rows on the faces at the two ends of each axis of this rank's block only (the inner entries of out are left alone): everything
+ * fl_momentum_set_state_v0 reads of v0interp while the operator forms the inner faces from v0 itself (k_mom3) -- a ninth of the work on a 512^3 block.
+ * Where the operator will read whole fields anyway (a block with ny <= 8, FLUCA_MOM_KERNEL=2) this IS fl_momentum_interp_faces.
+ * A state set with fl_momentum_set_state needs the whole fields: use fl_momentum_interp_faces there. */
+int fl_momentum_interp_faces_ends(fl_momentum *m, const double *v_dev, const double *const vbc_dev[9], double *const out_dev[9]);
 /* The cell-wise part of momrhs, NSFormFunction_CNLinear_Cart3d_Internal (cnlinearcart3d.c:2976-2998):
  *   momrhs = v0 + (mu dt / 2 rho) L v0 - kappa G p + vbc
  * p_dev: phalf (or p0 on the first step), may be NULL; vbc_dev (3*cells, may be NULL): the boundary-condition vectors of
