@@ -665,7 +665,9 @@ __global__ void __launch_bounds__(256) k_maxpy8(int64_t n, double *__restrict__ 
 }
 __global__ void __launch_bounds__(256) k_lincomb(int64_t n, double a, const double *x, double b, const double *z, double *y)
 {
-  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) y[q] = a * x[q] + (z ? b * z[q] : 0.);
+  // a zero coefficient means "not part of the sum": the vector is not read (VecSet(y, 0) as 0 x + 0 z must not keep a NaN of x alive, nor pay for reading it)
+  const bool ux = a != 0., uz = z && b != 0.;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) y[q] = (ux ? a * x[q] : 0.) + (uz ? b * z[q] : 0.);
 }
 
 // partial[block] = sum over this block's grid-stride share of x[q] y[q]
