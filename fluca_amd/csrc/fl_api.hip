@@ -946,10 +946,16 @@ extern "C" int fl_poisson_project(fl_poisson *h, const double *p_dev, double *vx
   launch_pad_copy(h->stream, h->g, p_dev, h->w0);
   FL_CHK(fl_fill_ghosts(h, h->w0));
   double *v[3] = {vx, vy, vz}, *V[3] = {Vx, Vy, Vz};
-  for (int d = 0; d < 3; ++d) {
-    if (v[d]) launch_project_cells(h->stream, h->g, h->w0, v[d], d);
-    if (V[d]) launch_project_faces(h->stream, h->g, h->w0, V[d], d);
-  }
+  static const int fused = []() {
+    const char *e = std::getenv("FLUCA_PROJECT_FUSED");  // 0: one kernel per output array (round 1's form; A/B runs)
+    return e ? std::atoi(e) : 1;
+  }();
+  if (fused) launch_project_all(h->stream, h->g, h->w0, v, V);  // the six updates in one pass over p
+  else
+    for (int d = 0; d < 3; ++d) {
+      if (v[d]) launch_project_cells(h->stream, h->g, h->w0, v[d], d);
+      if (V[d]) launch_project_faces(h->stream, h->g, h->w0, V[d], d);
+    }
   FL_HIP(hipGetLastError());
   return FL_SUCCESS;
 }

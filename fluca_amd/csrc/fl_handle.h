@@ -24,6 +24,7 @@ namespace fl {
 // launchers defined in fl_kernels.hip
 void launch_pad_copy(hipStream_t, const GridP &, const double *, double *);
 void launch_unpad_copy(hipStream_t, const GridP &, const double *, double *, const double *);
+void launch_project_all(hipStream_t, const GridP &, const double *p, double *const v[3], double *const V[3]);
 void launch_wrap(hipStream_t, const GridP &, double *, int axis, int nvec = 1, int64_t vstride = 0);
 void launch_face_ext(hipStream_t, const GridP &, double *v, double *buf, int axis, int side, int ea, int eb, int mode);
 void launch_pack(hipStream_t, const GridP &, const double *, double *, int, int);

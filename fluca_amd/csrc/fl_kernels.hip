@@ -270,6 +270,129 @@ __global__ void k_project_cells(GridP g, const double *__restrict__ p, double *_
   v[((int64_t)k * g.ny + j) * g.nx + i] -= g.kappa * gr;
 }
 
+// The whole stage-2 update of PCApply_ABF (abfpc.c:79-101) in ONE pass over p:  v_d -= kappa (G p)_d on the cells and V_d -= kappa (Gst p)_d on the
+// owned faces of all three axes -- the rows and the arithmetic of k_project_cells / k_project_faces (same products, same order: bit-identical), but p is
+// streamed once instead of six times and the three cell arrays / three face arrays are each touched by one kernel instead of their own.  A wave owns a
+// 64-cell segment of a row; it keeps its segment (the grid is a multiple of the segments per row), so the x rows are loaded once per wave, and row /
+// plane numbers are wave-uniform (scalar table reads).  A cell also does the face behind the last cell of an axis where this rank owns that face.
+// Any of the six outputs may be NULL.
+struct ProjOut {
+  double *v[3], *V[3];
+};
+// a lane owns two x-adjacent cells: 16-byte accesses to p along y / z, to the cell arrays and to the y- / z-face arrays (pairs: the caller's arrays are
+// 16-byte aligned and nx is even; the x-face array has rows of nx + 1 entries and keeps 8-byte accesses), 8-byte reads of p along x
+__global__ void __launch_bounds__(256) k_project_all(GridP g, const double *__restrict__ p, ProjOut o, int pairs)
+{
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  const int nseg = (g.nx + 127) / 128;
+  const int gw = (int)blockIdx.x * nw + w, nwaves = (int)gridDim.x * nw;  // nwaves is a multiple of nseg (launch_project_all)
+  const int seg = gw % nseg, i = seg * 128 + 2 * lane;
+  if (i >= g.nx) return;
+  const bool   two = i + 1 < g.nx, pr2 = two && pairs;
+  const int    i1 = two ? i + 1 : i;
+  const double kap = g.kappa;
+  // x rows of this lane's cells / their low faces (and of face nx behind the last cell)
+  const int    xs[2] = {g.Gs[0][i], g.Gs[0][i1]};
+  const double xg0[2] = {g.Gv0[0][i], g.Gv0[0][i1]}, xg1[2] = {g.Gv1[0][i], g.Gv1[0][i1]}, xg2[2] = {g.Gv2[0][i], g.Gv2[0][i1]};
+  const int    xc[2] = {g.gc0[0][i], g.gc0[0][i1]};
+  const double xa0[2] = {g.ga0[0][i], g.ga0[0][i1]}, xa1[2] = {g.ga1[0][i], g.ga1[0][i1]};
+  const int    il = two ? i + 1 : i;  // the lane's last cell
+  const bool   xlast = il == g.nx - 1 && g.fx > g.nx;
+  const int    xc0n = xlast ? g.gc0[0][g.nx] : 0;
+  const double xa0n = xlast ? g.ga0[0][g.nx] : 0., xa1n = xlast ? g.ga1[0][g.nx] : 0.;
+  auto ld = [&](const double *a, int64_t q) { return pr2 ? *reinterpret_cast<const double2 *>(a + q) : make_double2(a[q], two ? a[q + 1] : 0.); };
+  auto sub = [&](double *a, int64_t q, double2 d) {  // a[q], a[q + 1] -= kappa * d
+    if (pr2) {
+      double2 t = *reinterpret_cast<double2 *>(a + q);
+      t.x -= kap * d.x;
+      t.y -= kap * d.y;
+      *reinterpret_cast<double2 *>(a + q) = t;
+    } else {
+      a[q] -= kap * d.x;
+      if (two) a[q + 1] -= kap * d.y;
+    }
+  };
+  const int64_t nrows = (int64_t)g.ny * g.nz;
+  for (int64_t row = gw / nseg; row < nrows; row += nwaves / nseg) {
+    const int     j = (int)(row % g.ny), k = (int)(row / g.ny);
+    const int64_t pr = g.off0 + (int64_t)k * g.sxy + (int64_t)j * g.sx;  // cell (0, j, k) of the padded p
+    const int64_t cell = ((int64_t)k * g.ny + j) * g.nx + i;
+    // ---- x
+    if (o.v[0]) {
+      double2 gr;
+      gr.x = xg0[0] * p[pr + xs[0]] + xg1[0] * p[pr + xs[0] + 1];
+      if (xg2[0] != 0.) gr.x += xg2[0] * p[pr + xs[0] + 2];
+      gr.y = xg0[1] * p[pr + xs[1]] + xg1[1] * p[pr + xs[1] + 1];
+      if (xg2[1] != 0.) gr.y += xg2[1] * p[pr + xs[1] + 2];
+      sub(o.v[0], cell, gr);
+    }
+    if (o.V[0]) {
+      const int64_t fi = ((int64_t)k * g.ny + j) * g.fx + i;
+      o.V[0][fi] -= kap * (xa0[0] * p[pr + xc[0]] + xa1[0] * p[pr + xc[0] + 1]);
+      if (two) o.V[0][fi + 1] -= kap * (xa0[1] * p[pr + xc[1]] + xa1[1] * p[pr + xc[1] + 1]);
+      if (xlast) o.V[0][fi + (two ? 2 : 1)] -= kap * (xa0n * p[pr + xc0n] + xa1n * p[pr + xc0n + 1]);
+    }
+    // ---- y (wave-uniform rows); the padded p is 16-byte aligned at even i
+    auto ldp = [&](int64_t q) { return two ? *reinterpret_cast<const double2 *>(p + q) : make_double2(p[q], 0.); };
+    if (o.v[1]) {
+      const int     s0 = g.Gs[1][j];
+      const int64_t pc = pr + (int64_t)(s0 - j) * g.sx + i;
+      const double  c0 = g.Gv0[1][j], c1 = g.Gv1[1][j], c2 = g.Gv2[1][j];
+      const double2 a = ldp(pc), b = ldp(pc + g.sx);
+      double2       gr = make_double2(c0 * a.x + c1 * b.x, c0 * a.y + c1 * b.y);
+      if (c2 != 0.) {
+        const double2 c = ldp(pc + 2 * (int64_t)g.sx);
+        gr.x += c2 * c.x;
+        gr.y += c2 * c.y;
+      }
+      sub(o.v[1], cell, gr);
+    }
+    if (o.V[1]) {
+      const int     c0 = g.gc0[1][j];
+      const int64_t pc = pr + (int64_t)(c0 - j) * g.sx + i;
+      const int64_t fi = ((int64_t)k * g.fy + j) * g.nx + i;
+      const double  a0 = g.ga0[1][j], a1 = g.ga1[1][j];
+      const double2 a = ldp(pc), b = ldp(pc + g.sx);
+      sub(o.V[1], fi, make_double2(a0 * a.x + a1 * b.x, a0 * a.y + a1 * b.y));
+      if (j == g.ny - 1 && g.fy > g.ny) {
+        const int     c0n = g.gc0[1][g.ny];
+        const int64_t pn  = pr + (int64_t)(c0n - j) * g.sx + i;
+        const double  n0 = g.ga0[1][g.ny], n1 = g.ga1[1][g.ny];
+        const double2 an = ldp(pn), bn = ldp(pn + g.sx);
+        sub(o.V[1], fi + g.nx, make_double2(n0 * an.x + n1 * bn.x, n0 * an.y + n1 * bn.y));
+      }
+    }
+    // ---- z
+    if (o.v[2]) {
+      const int     s0 = g.Gs[2][k];
+      const int64_t pc = pr + (int64_t)(s0 - k) * g.sxy + i;
+      const double  c0 = g.Gv0[2][k], c1 = g.Gv1[2][k], c2 = g.Gv2[2][k];
+      const double2 a = ldp(pc), b = ldp(pc + g.sxy);
+      double2       gr = make_double2(c0 * a.x + c1 * b.x, c0 * a.y + c1 * b.y);
+      if (c2 != 0.) {
+        const double2 c = ldp(pc + 2 * g.sxy);
+        gr.x += c2 * c.x;
+        gr.y += c2 * c.y;
+      }
+      sub(o.v[2], cell, gr);
+    }
+    if (o.V[2]) {
+      const int     c0 = g.gc0[2][k];
+      const int64_t pc = pr + (int64_t)(c0 - k) * g.sxy + i;
+      const double  a0 = g.ga0[2][k], a1 = g.ga1[2][k];
+      const double2 a = ldp(pc), b = ldp(pc + g.sxy);
+      sub(o.V[2], cell, make_double2(a0 * a.x + a1 * b.x, a0 * a.y + a1 * b.y));
+      if (k == g.nz - 1 && g.fz > g.nz) {
+        const int     c0n = g.gc0[2][g.nz];
+        const int64_t pn  = pr + (int64_t)(c0n - k) * g.sxy + i;
+        const double  n0 = g.ga0[2][g.nz], n1 = g.ga1[2][g.nz];
+        const double2 an = ldp(pn), bn = ldp(pn + g.sxy);
+        sub(o.V[2], cell + (int64_t)g.nx * g.ny, make_double2(n0 * an.x + n1 * bn.x, n0 * an.y + n1 * bn.y));
+      }
+    }
+  }
+}
+
 // boundary face plane of V (axis, side) = coeff * pb     (INSERT_VALUES)
 __global__ void k_gst_bc(GridP g, const double *__restrict__ pb, double *__restrict__ V, int axis, int side, double coeff, int add)
 {
@@ -1305,6 +1428,22 @@ void launch_project_faces(hipStream_t st, const GridP &g, const double *p, doubl
 {
   const int lx = axis == 0 ? g.fx : g.nx, ly = axis == 1 ? g.fy : g.ny, lz = axis == 2 ? g.fz : g.nz;
   if (lz > 0) hipLaunchKernelGGL(k_project_faces, grid3(lx, ly, lz), blk3(), 0, st, g, p, V, axis);
+}
+void launch_project_all(hipStream_t st, const GridP &g, const double *p, double *const v[3], double *const V[3])
+{
+  ProjOut o;
+  for (int d = 0; d < 3; ++d) {
+    o.v[d] = v[d];
+    o.V[d] = V[d];
+  }
+  const int     nseg = (g.nx + 127) / 128;
+  const int64_t items = (int64_t)nseg * g.ny * g.nz;
+  int64_t       nwaves = std::max<int64_t>(nseg, std::min<int64_t>(items, 4 * 8192));
+  nwaves = (nwaves + 4 * nseg - 1) / (4 * nseg) * (4 * nseg);  // whole blocks of four waves, every wave keeps its segment
+  int pairs = g.nx % 2 == 0;  // 16-byte accesses to the caller's unpadded arrays: even rows and aligned bases
+  for (int d = 0; d < 3; ++d)
+    if ((v[d] && (reinterpret_cast<uintptr_t>(v[d]) & 15)) || (d > 0 && V[d] && (reinterpret_cast<uintptr_t>(V[d]) & 15))) pairs = 0;
+  hipLaunchKernelGGL(k_project_all, dim3((unsigned)(nwaves / 4)), dim3(256), 0, st, g, p, o, pairs);
 }
 void launch_project_cells(hipStream_t st, const GridP &g, const double *p, double *v, int axis) { hipLaunchKernelGGL(k_project_cells, grid3(g.nx, g.ny, g.nz), blk3(), 0, st, g, p, v, axis); }
 void launch_gst_bc(hipStream_t st, const GridP &g, const double *pb, double *V, int axis, int side, double coeff, int add)
