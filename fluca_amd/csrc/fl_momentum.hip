@@ -710,15 +710,19 @@ __global__ void __launch_bounds__(256) k_pad_copy_ends(GridP g, const double *__
 // V_d = rhs_d + alpha (T v)_d on the owned d-faces (unpadded face array, rhs may alias V); v: padded component d with valid ghosts
 __global__ void __launch_bounds__(256) k_face_interp(GridP g, FaceT t, int kind, int d, double alpha, const double *__restrict__ vpad, const double *rhs, double *V)
 {
+  // a wave per 64-face row segment: row and plane numbers are wave-uniform (scalar index arithmetic and, for d != 0, scalar table reads)
   const int     ex = d == 0 ? g.fx : g.nx, ey = d == 1 ? g.fy : g.ny, ez = d == 2 ? g.fz : g.nz;
-  const int64_t n = (int64_t)ex * ey * ez;
   const int64_t str = d == 0 ? 1 : (d == 1 ? (int64_t)g.sx : g.sxy);
-  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
-    const int     i = (int)(q % ex);
-    const int64_t r = q / ex;
-    const int     j = (int)(r % ey), k = (int)(r / ey);
+  const int     lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  const int     nseg = (ex + 63) / 64;
+  const int64_t nitem = (int64_t)nseg * ey * ez;
+  for (int64_t it = (int64_t)blockIdx.x * nw + w; it < nitem; it += (int64_t)gridDim.x * nw) {
+    const int seg = (int)(it % nseg), row = (int)(it / nseg);
+    const int j = row % ey, k = row / ey, i = seg * 64 + lane;
+    if (i >= ex) continue;
     const int     f = d == 0 ? i : (d == 1 ? j : k);
     const int     c0 = t.c0[kind][d][f];
+    const int64_t q = ((int64_t)k * ey + j) * ex + i;
     // cell (i,j,k) with the d-th index replaced by c0
     const int64_t base = g.off0 + (int64_t)k * g.sxy + (int64_t)j * g.sx + i + (int64_t)(c0 - f) * str;
     const double  w0 = alpha * t.w0[kind][d][f], w1 = alpha * t.w1[kind][d][f];
