@@ -25,7 +25,14 @@ f.restype = C.c_int
 f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
 
 cases = []
-if os.environ.get("KB_QUICK"):
+if os.environ.get("KB_TALL"):  # round 3: 128 x 32 tiles (four rows per wave) with the two register sets, against the shipped 128 x 16
+    for rd_ in range(1):
+        cases.append(("A", 0, 28, 112, 4, 24.0))
+        cases.append(("A", 0, 48, 112, 4, 24.0))
+        cases.append(("A", 0, 48, 112, 2, 24.0))
+        cases.append(("A", 0, 48, 112, 8, 24.0))
+        cases.append(("A", 0, 48, 102, 4, 24.0))
+elif os.environ.get("KB_QUICK"):
     cases.append(("A", 0, 28, 112, 4, 48.0))
     cases.append(("A", 0, 24, 111, 2, 48.0))
     cases.append(("B", 1, 44, 1, 8, 24.0))
