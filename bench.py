@@ -457,6 +457,28 @@ def other_configs(stream):
         "roofline": cg_roofline(info, P.ncell, 0, dt / K * 1e3)}
     capi.lib.fl_ibm_destroy(mc)
     P.close()
+    del b, x
+    torch.cuda.empty_cache()
+
+    # A whole time step of the reference's integrator on the C host mirror (examples/flow_configs.c, a child process: it opens the GPU itself):
+    # 512^3 channel with the immersed sphere of config 4, fractional step (-ns_ksp_type preonly: one PCApply_ABF per step -- BiCGStab + Jacobi on the
+    # momentum block, multigrid-CG on the Schur complement, IBM interpolation and spreading).  Wall time of the later steps (the first one allocates).
+    try:
+        import re
+        import subprocess
+        from fluca_amd import build as flbuild
+        exe = flbuild.build_example(name="flow_configs")
+        out = subprocess.run([exe, "-config", "sphere", "-n", "512", "-ns_max_steps", "4", "-ns_ksp_type", "preonly", "-ns_abf_schur_pc_type", "mg"], capture_output=True, text=True, timeout=300)
+        steps = re.findall(r"step\s+(\d+)\s+wall\s+(\S+) s\s+outer its\s+(\d+)\s+kspA its\s+(\d+)\s+kspS its\s+(\d+)", out.stdout)
+        if out.returncode != 0 or len(steps) < 3:
+            raise RuntimeError((out.stdout + out.stderr)[-400:])
+        later = [float(w) for _, w, _, _, _ in steps[1:]]
+        cfg["flow_step"] = {"workload": "512^3 channel + immersed sphere (12 868 markers), one CNLinear time step as a fractional step (PCApply_ABF: BiCGStab + Jacobi on A, "
+                                        "multigrid-CG on S, IBM direct forcing) on the C host mirror, child process", "metric": "seconds per time step", "higher_is_better": False,
+                            "value": min(later), "steps_timed": len(later), "seconds_per_step": later, "first_step_seconds": float(steps[0][1]),
+                            "kspA_its": [int(a) for _, _, _, a, _ in steps], "kspS_its": [int(s_) for _, _, _, _, s_ in steps], "cells": 512 ** 3}
+    except Exception as e:  # noqa: BLE001
+        cfg["flow_step"] = {"error": repr(e)[:500]}
     return cfg
 
 
