@@ -118,6 +118,17 @@ def test_argument_checks():
         M.solve(b, type=capi.KSP_CG)             # A is not symmetric
     x, info = M.solve(b)                          # before set_state: A = I
     assert info["reason"] == 3 and info["iters"] == 0       # zero rhs: CONVERGED_ATOL at iteration 0 (KSPConvergedDefault)
+    # ... and the answer is the zero guess even if an earlier solve left something in the work vector (no update kernel ran to write it)
+    rhs = torch.ones_like(b)
+    y, _ = M.solve(rhs)
+    assert float((y - rhs).abs().max()) == 0.0    # A = I
+    x, info = M.solve(b)
+    assert info["iters"] == 0 and float(x.abs().max()) == 0.0
+    # the entry points of the state with v0 refuse missing arrays
+    import ctypes as C
+    three, nine = (C.c_void_p * 3)(), (C.c_void_p * 9)()
+    assert capi.lib.fl_momentum_set_state_v0(M.h, 0.1, 1.0, 0.1, three, nine, None) == -85  # FL_ERR_ARG_NULL
+    assert capi.lib.fl_momentum_interp_faces_ends(M.h, None, None, nine) == -85  # FL_ERR_ARG_NULL
     M.close()
     P.close()
 
