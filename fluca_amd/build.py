@@ -52,7 +52,7 @@ HOST_LIB = os.path.join(LIBDIR, "libfluca_host.so")
 def build_host(force=False, verbose=False):
     """The C host mirror (gcc): links against libflucahip.so through its C-ABI only."""
     src = os.path.join(HERE, "host", "fluca_host.c")
-    hdrs = [os.path.normpath(os.path.join(HERE, "..", "include", h)) for h in ("fluca_host.h", "fluca_hip.h")]
+    hdrs = [os.path.normpath(os.path.join(HERE, "..", "include", h)) for h in ("fluca_host.h", "fluca_host_impl.h", "fluca_hip.h")]
     if force or _stale(HOST_LIB, [src, LIB] + hdrs):
         cmd = [os.environ.get("CC", "gcc"), "-std=gnu99", "-O2", "-fPIC", "-shared", "-Wall", "-o", HOST_LIB, src,
                "-L" + LIBDIR, "-lflucahip", "-Wl,-rpath,$ORIGIN", "-lm", "-ldl"]
@@ -82,7 +82,7 @@ def build_cgns(force=False, verbose=False):
         if verbose:
             print(f"no HDF5 under {HDF5_ROOT}: libfluca_cgns.so not built", flush=True)
         return None
-    hdrs = [os.path.normpath(os.path.join(HERE, "..", "include", h)) for h in ("fluca_cgns.h", "fluca_host.h", "fluca_hip.h")]
+    hdrs = [os.path.normpath(os.path.join(HERE, "..", "include", h)) for h in ("fluca_cgns.h", "fluca_host.h", "fluca_host_impl.h", "fluca_hip.h")]
     if force or _stale(CGNS_LIB, [src, HOST_LIB] + hdrs):
         # RUNPATH (new dtags), not RPATH: the HDF5 directory is searched for this library's direct dependencies only
         cmd = [os.environ.get("CC", "gcc"), "-std=gnu99", "-O2", "-fPIC", "-shared", "-Wall", "-o", CGNS_LIB, src,

@@ -8,6 +8,7 @@
  * name "HDF5 MotherNode", label "Root Node of HDF5 File", type MT and the datasets " format" and " hdf5version".
  */
 #include "../../include/fluca_cgns.h"
+#include "../../include/fluca_host_impl.h" /* struct _p_FlucaViewer: this file implements a viewer type */
 
 #include <hdf5.h>
 #include <stdio.h>
@@ -23,6 +24,7 @@
 #define E_FILE_READ 66
 #define E_FILE_UNEXPECTED 79
 #define E_MEM 55
+#define E_SUP 56
 #define E_LIB 76
 #define FLCHK(c) \
   do { \
@@ -516,10 +518,11 @@ FlErrorCode FlucaCGNSReadCoordinates(const char *filename, double *xf, double *y
 
 /* ------------------------------------------------------------------------------------------------ viewer */
 
-struct _p_FlucaViewerCGNS {
+/* PetscViewer_FlucaCGNS (flucacgns.h): the data of a FlucaViewer of type FLUCAVIEWERCGNS */
+#define CGNS_MAXPENDING 16
+typedef struct {
   char    *tmpl;     /* filename or template */
   int      is_template, batch_size;
-  char     mode;
   int      rank;     /* of the NS that wrote last */
   char    *filename; /* the file being written (NULL: none open) */
   char    *lastname;
@@ -527,46 +530,79 @@ struct _p_FlucaViewerCGNS {
   int      nsteps, cap;
   int64_t *steps;
   double  *times;
-};
+  /* one NSViewSolution / NSLoadSolution in flight (solutionbegin .. solutionend) */
+  FlucaCGNSLayout lay;
+  int64_t         step, sz[4];
+  int             device, newfile, skip;
+  int             ncell, nface;
+  char            cellname[CGNS_MAXPENDING][33], facename[CGNS_MAXPENDING][33];
+  double         *celldev[CGNS_MAXPENDING], *facedev[CGNS_MAXPENDING][3];
+} ViewerCGNS;
+
+static FlErrorCode ViewerDestroy_CGNS(FlucaViewer viewer);
+static FlErrorCode ViewerViewMesh_CGNS(FlucaViewer viewer, Mesh mesh);
+static FlErrorCode ViewerLoadMesh_CGNS(FlucaViewer viewer, int64_t N[3], double *xf[3]);
+static FlErrorCode ViewerSolutionBegin_CGNS(FlucaViewer viewer, NS ns, int write);
+static FlErrorCode ViewerCellField_CGNS(FlucaViewer viewer, NS ns, const char *name, int ncomp, double *dev);
+static FlErrorCode ViewerFaceField_CGNS(FlucaViewer viewer, NS ns, const char *name, double *const dev[3]);
+static FlErrorCode ViewerSolutionEnd_CGNS(FlucaViewer viewer, NS ns);
+
+#define CGNS_DATA(viewer)                                                                  \
+  if (!(viewer)) return E_ARG_NULL;                                                        \
+  if (!(viewer)->type || strcmp((viewer)->type, FLUCAVIEWERCGNS)) return E_ARG_WRONG;      \
+  ViewerCGNS *v = (ViewerCGNS *)(viewer)->data
 
 FlErrorCode FlucaViewerCGNSOpen(const char *filename, char mode, FlucaViewerCGNS *viewer)
 {
   if (!filename || !viewer) return E_ARG_NULL;
   if (mode != 'w' && mode != 'r') return E_ARG_WRONG; /* "Unsupported file mode", flucacgns.c:95 */
-  FlucaViewerCGNS v = (FlucaViewerCGNS)calloc(1, sizeof(*v));
+  ViewerCGNS *v = (ViewerCGNS *)calloc(1, sizeof(*v));
   if (!v) return E_MEM;
+  const FlErrorCode rc = FlucaViewerCreate(FLUCAVIEWERCGNS, mode, viewer);
+  if (rc) {
+    free(v);
+    return rc;
+  }
   v->tmpl        = strdup(filename);
   v->is_template = strstr(filename, "%d") != NULL || strstr(filename, "%0") != NULL; /* flucacgns.c:185-190: a '%' makes it a template */
   v->batch_size  = 1;                                                                /* flucacgns.c:220 */
-  v->mode        = mode;
   v->last_step   = -1;
+  (*viewer)->data               = v;
+  (*viewer)->ops->viewmesh      = ViewerViewMesh_CGNS;
+  (*viewer)->ops->loadmesh      = ViewerLoadMesh_CGNS;
+  (*viewer)->ops->solutionbegin = ViewerSolutionBegin_CGNS;
+  (*viewer)->ops->cellfield     = ViewerCellField_CGNS;
+  (*viewer)->ops->facefield     = ViewerFaceField_CGNS;
+  (*viewer)->ops->solutionend   = ViewerSolutionEnd_CGNS;
+  (*viewer)->ops->destroy       = ViewerDestroy_CGNS;
   no_hdf5_file_locking();
   H5Eset_auto2(H5E_DEFAULT, NULL, NULL); /* errors are reported through return codes */
-  *viewer = v;
   return 0;
 }
-FlErrorCode FlucaViewerCGNSSetBatchSize(FlucaViewerCGNS v, int batch_size)
+FlErrorCode FlucaViewerCGNSSetBatchSize(FlucaViewerCGNS viewer, int batch_size)
 {
-  if (!v) return E_ARG_NULL;
+  CGNS_DATA(viewer);
   if (batch_size < 1) return E_ARG_OUTOFRANGE;
   v->batch_size = batch_size;
   return 0;
 }
-FlErrorCode FlucaViewerCGNSGetBatchSize(FlucaViewerCGNS v, int *batch_size)
+FlErrorCode FlucaViewerCGNSGetBatchSize(FlucaViewerCGNS viewer, int *batch_size)
 {
-  if (!v || !batch_size) return E_ARG_NULL;
+  CGNS_DATA(viewer);
+  if (!batch_size) return E_ARG_NULL;
   *batch_size = v->batch_size;
   return 0;
 }
-FlErrorCode FlucaViewerCGNSGetFileName(FlucaViewerCGNS v, const char **filename)
+FlErrorCode FlucaViewerCGNSGetFileName(FlucaViewerCGNS viewer, const char **filename)
 {
-  if (!v || !filename) return E_ARG_NULL;
+  CGNS_DATA(viewer);
+  if (!filename) return E_ARG_NULL;
   *filename = v->filename ? v->filename : v->lastname;
   return 0;
 }
 
 /* flucacgns.c:22-70 on rank 0; every rank forgets the file */
-static FlErrorCode viewer_close_file(FlucaViewerCGNS v, int rank)
+static FlErrorCode viewer_close_file(ViewerCGNS *v, int rank)
 {
   FlErrorCode rc = 0;
   if (!v->filename) return 0;
@@ -578,86 +614,131 @@ static FlErrorCode viewer_close_file(FlucaViewerCGNS v, int rank)
   return rc;
 }
 
-FlErrorCode FlucaViewerCGNSDestroy(FlucaViewerCGNS *viewer)
+static FlErrorCode ViewerDestroy_CGNS(FlucaViewer viewer)
 {
-  if (!viewer || !*viewer) return 0;
-  FlucaViewerCGNS   v = *viewer;
-  const FlErrorCode rc = v->mode == 'w' ? viewer_close_file(v, v->rank) : 0;
+  ViewerCGNS *v = (ViewerCGNS *)viewer->data;
+  if (!v) return 0;
+  const FlErrorCode rc = viewer->mode == 'w' ? viewer_close_file(v, v->rank) : 0;
   free(v->tmpl);
   free(v->filename);
   free(v->lastname);
   free(v->steps);
   free(v->times);
   free(v);
-  *viewer = NULL;
+  viewer->data = NULL;
   return rc;
 }
+FlErrorCode FlucaViewerCGNSDestroy(FlucaViewerCGNS *viewer) { return FlucaViewerDestroy(viewer); }
 
-static FlErrorCode ns_layout(NS ns, FlucaCGNSLayout *lay)
+static FlErrorCode mesh_layout(Mesh mesh, FlucaCGNSLayout *lay)
 {
-  Mesh mesh;
-  FLCHK(NSGetMesh(ns, &mesh));
   if (!mesh) return E_ARG_WRONGSTATE;
   FLCHK(MeshCartGetGlobalSizes(mesh, &lay->N[0], &lay->N[1], &lay->N[2]));
   FLCHK(MeshCartGetCorners(mesh, &lay->lo[0], &lay->lo[1], &lay->lo[2], &lay->len[0], &lay->len[1], &lay->len[2]));
   FLCHK(MeshCartGetIsFirstRank(mesh, &lay->first[0], &lay->first[1], &lay->first[2]));
   FLCHK(MeshCartGetIsLastRank(mesh, &lay->last[0], &lay->last[1], &lay->last[2]));
   FLCHK(MeshGetRank(mesh, &lay->rank, &lay->size));
+  const Mesh_Cart *cart = (const Mesh_Cart *)mesh->data;
+  for (int d = 0; d < 3; ++d) lay->periodic[d] = cart->bndTypes[d] == MESHCART_BOUNDARY_PERIODIC;
+  return 0;
+}
+
+/* the name of the file a write viewer opens next: the template filled with the output sequence number (flucacgns.c:82) */
+static FlErrorCode viewer_open_name(ViewerCGNS *v, int64_t seq)
+{
+  char name[4096];
+  if (v->is_template) snprintf(name, sizeof(name), v->tmpl, (int)(seq < 0 ? 0 : seq));
+  else snprintf(name, sizeof(name), "%s", v->tmpl);
+  v->filename = strdup(name);
+  return v->filename ? 0 : E_MEM;
+}
+
+/* MeshView_Cart_CGNS (cartcgns.c:8-118): Base, Zone, the vertex coordinates and CellInfo/Rank of a file that has none yet.
+ * Outside NSViewSolution the mesh has no communicator to take turns on, so a decomposed mesh is written through NSViewSolution only. */
+static FlErrorCode ViewerViewMesh_CGNS(FlucaViewer viewer, Mesh mesh)
+{
+  ViewerCGNS *v = (ViewerCGNS *)viewer->data;
+  if (viewer->mode != 'w') return E_ARG_WRONGSTATE;
+  if (v->filename) return 0; /* "if (cgv->file_num && cgv->base)": the open file has its mesh (cartcgns.c:15) */
+  FlucaCGNSLayout lay;
+  FLCHK(mesh_layout(mesh, &lay));
+  if (lay.size > 1) return E_SUP;
+  const double *xf, *yf, *zf;
+  FLCHK(MeshCartGetCoordinateArraysRead(mesh, &xf, &yf, &zf));
+  FLCHK(viewer_open_name(v, viewer->seqnum));
+  v->rank = lay.rank;
+  FLCHK(FlucaCGNSCreateFile(v->filename, &lay, xf, yf, zf));
+  return FlucaCGNSWriteCellInfo(v->filename, &lay);
+}
+
+/* MeshLoad_Cart_CGNS (cartcgns.c:120-158) */
+static FlErrorCode ViewerLoadMesh_CGNS(FlucaViewer viewer, int64_t N[3], double *xf[3])
+{
+  ViewerCGNS *v = (ViewerCGNS *)viewer->data;
+  if (viewer->mode != 'r' || v->is_template) return E_ARG_WRONGSTATE;
+  FLCHK(FlucaCGNSReadInfo(v->tmpl, N, NULL, NULL, NULL));
   for (int d = 0; d < 3; ++d) {
-    int idx;
+    xf[d] = (double *)malloc(sizeof(double) * (size_t)(N[d] + 1));
+    if (!xf[d]) return E_MEM;
+  }
+  const FlErrorCode rc = FlucaCGNSReadCoordinates(v->tmpl, xf[0], xf[1], xf[2]);
+  if (rc)
+    for (int d = 0; d < 3; ++d) {
+      free(xf[d]);
+      xf[d] = NULL;
+    }
+  return rc;
+}
+
+static FlErrorCode ViewerSolutionBegin_CGNS(FlucaViewer viewer, NS ns, int write)
+{
+  ViewerCGNS *v = (ViewerCGNS *)viewer->data;
+  Mesh        mesh;
+  FLCHK(NSGetMesh(ns, &mesh));
+  FLCHK(mesh_layout(mesh, &v->lay));
+  for (int d = 0; d < 3; ++d) { /* the NS boundary conditions decide what is periodic (they agree with the mesh after NSSetUp) */
+    int                 idx;
     NSBoundaryCondition bc;
     FLCHK(MeshCartGetBoundaryIndex(mesh, (MeshCartBoundaryLocation)(2 * d), &idx));
     FLCHK(NSGetBoundaryCondition(ns, idx, &bc));
-    lay->periodic[d] = bc.type == NS_BC_PERIODIC;
+    v->lay.periodic[d] = bc.type == NS_BC_PERIODIC;
   }
-  return 0;
-}
-
-static const char *const cell_fields[] = {"VelocityX", "VelocityY", "VelocityZ", "Pressure", "PressureHalfStep"}; /* nsbasic.c:180-182 + "%s%c" cartcgns.c:383-386; cnlinear.c:54 */
-static const char *const face_fields[] = {"FaceNormalVelocity"};
-
-/* the five cell arrays and three face arrays of the solution on the device, and the owned sizes */
-static FlErrorCode ns_arrays(NS ns, double *cell[5], double *face[3], int64_t sz[4])
-{
-  double *v, *p, *ph;
-  FLCHK(NSGetSolutionArrays(ns, &v, face, &p));
-  FLCHK(NSGetPressureHalfStep(ns, &ph));
-  FLCHK(NSGetLocalSizes(ns, sz));
-  for (int c = 0; c < 3; ++c) cell[c] = v + (size_t)c * (size_t)sz[0];
-  cell[3] = p;
-  cell[4] = ph;
-  /* the copies below are plain blocking copies: the solver's own stream must have drained first */
-  fl_poisson *poisson;
-  FLCHK(NSGetPoisson(ns, &poisson));
-  if (fl_poisson_synchronize(poisson)) return E_LIB;
-  return 0;
-}
-
-FlErrorCode NSViewSolution(NS ns, FlucaViewerCGNS v)
-{
-  if (!ns || !v) return E_ARG_NULL;
-  if (v->mode != 'w') return E_ARG_WRONGSTATE;
-  FlucaCGNSLayout lay;
-  int64_t         step, sz[4];
-  double          t, *cell[5], *face[3];
-  int             device;
-  FLCHK(ns_layout(ns, &lay));
-  FLCHK(ns_arrays(ns, cell, face, sz));
-  FLCHK(NSGetTimeStep(ns, &step));
+  FLCHK(NSGetLocalSizes(ns, v->sz));
+  FLCHK(NSGetDevice(ns, &v->device));
+  { /* the copies below are plain blocking copies: the solver's own stream must have drained first */
+    fl_poisson *poisson;
+    FLCHK(NSGetPoisson(ns, &poisson));
+    if (fl_poisson_synchronize(poisson)) return E_LIB;
+  }
+  v->ncell = v->nface = 0;
+  v->skip = v->newfile = 0;
+  if (!write) {
+    if (v->is_template) return E_ARG_WRONGSTATE; /* PetscViewerCheckReadable */
+    int64_t N[3], step = -1;
+    double  t = 0.;
+    int     nsteps = 0;
+    FLCHK(FlucaCGNSReadInfo(v->tmpl, N, &step, &t, &nsteps));
+    for (int d = 0; d < 3; ++d)
+      if (N[d] != v->lay.N[d]) return E_LIB; /* "Mesh size does not match CGNS zone size", cartcgns.c:697 */
+    if (step < 0 || nsteps < 1) return E_LIB; /* no FlowSolution<n> / no BaseIterativeData */
+    v->step = step;
+    viewer->seqnum = step; /* what VecLoad_Cart_CGNS leaves in the mesh's output sequence (cartcgns.c:736-755) */
+    viewer->seqval = t;
+    return 0;
+  }
+  double t;
+  FLCHK(NSGetTimeStep(ns, &v->step));
   FLCHK(NSGetTime(ns, &t));
-  FLCHK(NSGetDevice(ns, &device));
-  v->rank = lay.rank; /* FlucaViewerCGNSDestroy has no NS argument: it closes the file as this rank */
-  if (v->last_step == step && v->filename) return 0; /* this step is in the file already (cgv->sol stays set, cartcgns.c:336) */
-
+  v->rank = v->lay.rank; /* the destroy routine has no NS argument: it closes the file as this rank */
+  if (v->last_step == v->step && v->filename) { /* this step is in the file already (cgv->sol stays set, cartcgns.c:336) */
+    v->skip = 1;
+    return 0;
+  }
   /* PetscViewerFlucaCGNSCheckBatch_Internal, flucacgns.c:104-115 */
-  if (v->is_template && v->filename && v->nsteps >= v->batch_size) FLCHK(viewer_close_file(v, lay.rank));
-  int newfile = 0;
+  if (v->is_template && v->filename && v->nsteps >= v->batch_size) FLCHK(viewer_close_file(v, v->lay.rank));
   if (!v->filename) {
-    char name[4096];
-    if (v->is_template) snprintf(name, sizeof(name), v->tmpl, (int)step); /* flucacgns.c:82 */
-    else snprintf(name, sizeof(name), "%s", v->tmpl);
-    v->filename = strdup(name);
-    newfile     = 1;
+    FLCHK(viewer_open_name(v, v->step));
+    v->newfile = 1;
   }
   if (v->nsteps == v->cap) {
     v->cap   = v->cap ? 2 * v->cap : 20;
@@ -665,84 +746,112 @@ FlErrorCode NSViewSolution(NS ns, FlucaViewerCGNS v)
     v->times = (double *)realloc(v->times, sizeof(double) * (size_t)v->cap);
     if (!v->steps || !v->times) return E_MEM;
   }
-  v->steps[v->nsteps] = step;
+  v->steps[v->nsteps] = v->step;
   v->times[v->nsteps] = t;
   ++v->nsteps;
-  v->last_step = step;
+  v->last_step = v->step;
+  return 0;
+}
 
-  /* device -> host once, then the ranks take turns on the file */
-  double *hc[5] = {0}, *hf[3] = {0};
+/* VecView_Cart_Local_CGNS / VecLoad_Cart_CGNS for a cell vector (cartcgns.c:293-401, 644-758): written when the solution ends (one
+ * device-to-host copy, then the ranks take turns on the file), read at once */
+static FlErrorCode ViewerCellField_CGNS(FlucaViewer viewer, NS ns, const char *name, int ncomp, double *dev)
+{
+  ViewerCGNS *v = (ViewerCGNS *)viewer->data;
+  (void)ns;
+  if (!name || !dev) return E_ARG_NULL;
+  if (ncomp != 1 && ncomp != 3) return E_ARG_OUTOFRANGE;
+  for (int c = 0; c < ncomp; ++c) {
+    char full[33];
+    if (ncomp == 1) snprintf(full, sizeof(full), "%s", name);
+    else snprintf(full, sizeof(full), "%s%c", name, 'X' + c); /* "%s%c", cartcgns.c:383-386 */
+    double *d = dev + (size_t)c * (size_t)v->sz[0];
+    if (viewer->mode == 'w') {
+      if (v->skip) continue;
+      if (v->ncell >= CGNS_MAXPENDING) return E_ARG_OUTOFRANGE;
+      snprintf(v->cellname[v->ncell], 33, "%s", full);
+      v->celldev[v->ncell++] = d;
+    } else {
+      double *h = (double *)malloc(sizeof(double) * (size_t)(v->sz[0] > 0 ? v->sz[0] : 1));
+      if (!h) return E_MEM;
+      FlErrorCode rc = FlucaCGNSReadCellField(v->tmpl, &v->lay, v->step, full, h);
+      if (!rc) rc = fl_memcpy_h2d(v->device, d, h, sizeof(double) * (size_t)v->sz[0]) ? E_LIB : 0;
+      free(h);
+      FLCHK(rc);
+    }
+  }
+  return 0;
+}
+static FlErrorCode ViewerFaceField_CGNS(FlucaViewer viewer, NS ns, const char *name, double *const dev[3])
+{
+  ViewerCGNS *v = (ViewerCGNS *)viewer->data;
+  (void)ns;
+  if (!name || !dev) return E_ARG_NULL;
+  if (viewer->mode == 'w') {
+    if (v->skip) return 0;
+    if (v->nface >= CGNS_MAXPENDING) return E_ARG_OUTOFRANGE;
+    snprintf(v->facename[v->nface], 33, "%s", name);
+    for (int l = 0; l < 3; ++l) v->facedev[v->nface][l] = dev[l];
+    ++v->nface;
+    return 0;
+  }
+  double     *hf[3] = {0};
   FlErrorCode rc = 0;
-  for (int q = 0; q < 5 && !rc; ++q) {
-    hc[q] = (double *)malloc(sizeof(double) * (size_t)(sz[0] > 0 ? sz[0] : 1));
-    rc    = !hc[q] ? E_MEM : fl_memcpy_d2h(device, hc[q], cell[q], sizeof(double) * (size_t)sz[0]);
-  }
   for (int l = 0; l < 3 && !rc; ++l) {
-    hf[l] = (double *)malloc(sizeof(double) * (size_t)(sz[1 + l] > 0 ? sz[1 + l] : 1));
-    rc    = !hf[l] ? E_MEM : fl_memcpy_d2h(device, hf[l], face[l], sizeof(double) * (size_t)sz[1 + l]);
+    hf[l] = (double *)malloc(sizeof(double) * (size_t)(v->sz[1 + l] > 0 ? v->sz[1 + l] : 1));
+    if (!hf[l]) rc = E_MEM;
   }
-  for (int turn = 0; turn < lay.size; ++turn) {
-    if (turn == lay.rank && !rc) {
-      if (lay.rank == 0) {
-        if (newfile) {
-          Mesh          mesh;
-          const double *xf, *yf, *zf;
-          rc = NSGetMesh(ns, &mesh);
-          if (!rc) rc = MeshCartGetCoordinateArraysRead(mesh, &xf, &yf, &zf);
-          if (!rc) rc = FlucaCGNSCreateFile(v->filename, &lay, xf, yf, zf);
-        }
-        if (!rc) rc = FlucaCGNSCreateSolution(v->filename, &lay, step, 5, cell_fields, 1, face_fields);
-      }
-      if (!rc && newfile) rc = FlucaCGNSWriteCellInfo(v->filename, &lay);
-      /* field order of NSViewSolution: Velocity, FaceNormalVelocity, Pressure (field links), then PressureHalfStep */
-      for (int q = 0; q < 3 && !rc; ++q) rc = FlucaCGNSWriteCellField(v->filename, &lay, step, cell_fields[q], hc[q]);
-      if (!rc) rc = FlucaCGNSWriteFaceField(v->filename, &lay, step, face_fields[0], (const double *const *)hf);
-      for (int q = 3; q < 5 && !rc; ++q) rc = FlucaCGNSWriteCellField(v->filename, &lay, step, cell_fields[q], hc[q]);
-    }
-    if (lay.size > 1) {
-      const FlErrorCode brc = NSBarrier(ns);
-      if (!rc) rc = brc;
-    }
-  }
-  for (int q = 0; q < 5; ++q) free(hc[q]);
+  if (!rc) rc = FlucaCGNSReadFaceField(v->tmpl, &v->lay, v->step, name, hf);
+  for (int l = 0; l < 3 && !rc; ++l) rc = fl_memcpy_h2d(v->device, dev[l], hf[l], sizeof(double) * (size_t)v->sz[1 + l]) ? E_LIB : 0;
   for (int l = 0; l < 3; ++l) free(hf[l]);
   return rc;
 }
 
-FlErrorCode NSLoadSolution(NS ns, FlucaViewerCGNS v)
+static FlErrorCode ViewerSolutionEnd_CGNS(FlucaViewer viewer, NS ns)
 {
-  if (!ns || !v) return E_ARG_NULL;
-  if (v->mode != 'r' || v->is_template) return E_ARG_WRONGSTATE; /* PetscViewerCheckReadable */
-  FlucaCGNSLayout lay;
-  int64_t         N[3], step = -1, sz[4];
-  double          t = 0., *cell[5], *face[3];
-  int             device, nsteps = 0;
-  FLCHK(ns_layout(ns, &lay));
-  FLCHK(ns_arrays(ns, cell, face, sz));
-  FLCHK(NSGetDevice(ns, &device));
-  FLCHK(FlucaCGNSReadInfo(v->tmpl, N, &step, &t, &nsteps));
-  for (int d = 0; d < 3; ++d)
-    if (N[d] != lay.N[d]) return E_LIB; /* "Mesh size does not match CGNS zone size", cartcgns.c:697 */
-  if (step < 0 || nsteps < 1) return E_LIB; /* no FlowSolution<n> / no BaseIterativeData */
-  size_t big = (size_t)sz[0];
-  for (int l = 0; l < 3; ++l)
-    if ((size_t)sz[1 + l] > big) big = (size_t)sz[1 + l];
-  double *h = (double *)malloc(sizeof(double) * (big ? big : 1)), *hf[3] = {0};
-  if (!h) return E_MEM;
+  ViewerCGNS *v = (ViewerCGNS *)viewer->data;
+  if (viewer->mode != 'w' || v->skip) return 0;
+  const FlucaCGNSLayout *lay = &v->lay;
+  /* device -> host once, then the ranks take turns on the file */
+  double     *hc[CGNS_MAXPENDING] = {0}, *hf[CGNS_MAXPENDING][3] = {{0}};
+  const char *cellnames[CGNS_MAXPENDING], *facenames[CGNS_MAXPENDING];
   FlErrorCode rc = 0;
-  for (int q = 0; q < 5 && !rc; ++q) {
-    rc = FlucaCGNSReadCellField(v->tmpl, &lay, step, cell_fields[q], h);
-    if (!rc) rc = fl_memcpy_h2d(device, cell[q], h, sizeof(double) * (size_t)sz[0]);
+  for (int q = 0; q < v->ncell && !rc; ++q) {
+    cellnames[q] = v->cellname[q];
+    hc[q] = (double *)malloc(sizeof(double) * (size_t)(v->sz[0] > 0 ? v->sz[0] : 1));
+    rc    = !hc[q] ? E_MEM : fl_memcpy_d2h(v->device, hc[q], v->celldev[q], sizeof(double) * (size_t)v->sz[0]) ? E_LIB : 0;
   }
-  for (int l = 0; l < 3 && !rc; ++l) {
-    hf[l] = (double *)malloc(sizeof(double) * (size_t)(sz[1 + l] > 0 ? sz[1 + l] : 1));
-    if (!hf[l]) rc = E_MEM;
+  for (int q = 0; q < v->nface && !rc; ++q) {
+    facenames[q] = v->facename[q];
+    for (int l = 0; l < 3 && !rc; ++l) {
+      hf[q][l] = (double *)malloc(sizeof(double) * (size_t)(v->sz[1 + l] > 0 ? v->sz[1 + l] : 1));
+      rc       = !hf[q][l] ? E_MEM : fl_memcpy_d2h(v->device, hf[q][l], v->facedev[q][l], sizeof(double) * (size_t)v->sz[1 + l]) ? E_LIB : 0;
+    }
   }
-  if (!rc) rc = FlucaCGNSReadFaceField(v->tmpl, &lay, step, face_fields[0], hf);
-  for (int l = 0; l < 3 && !rc; ++l) rc = fl_memcpy_h2d(device, face[l], hf[l], sizeof(double) * (size_t)sz[1 + l]);
-  for (int l = 0; l < 3; ++l) free(hf[l]);
-  free(h);
-  if (!rc) rc = NSSetTimeStepAndTime(ns, step, t); /* nssol.c:199-201 */
+  for (int turn = 0; turn < lay->size; ++turn) {
+    if (turn == lay->rank && !rc) {
+      if (lay->rank == 0) {
+        if (v->newfile) {
+          Mesh          mesh;
+          const double *xf, *yf, *zf;
+          rc = NSGetMesh(ns, &mesh);
+          if (!rc) rc = MeshCartGetCoordinateArraysRead(mesh, &xf, &yf, &zf);
+          if (!rc) rc = FlucaCGNSCreateFile(v->filename, lay, xf, yf, zf);
+        }
+        if (!rc) rc = FlucaCGNSCreateSolution(v->filename, lay, v->step, v->ncell, cellnames, v->nface, facenames);
+      }
+      if (!rc && v->newfile) rc = FlucaCGNSWriteCellInfo(v->filename, lay);
+      for (int q = 0; q < v->ncell && !rc; ++q) rc = FlucaCGNSWriteCellField(v->filename, lay, v->step, cellnames[q], hc[q]);
+      for (int q = 0; q < v->nface && !rc; ++q) rc = FlucaCGNSWriteFaceField(v->filename, lay, v->step, facenames[q], (const double *const *)hf[q]);
+    }
+    if (lay->size > 1) {
+      const FlErrorCode brc = NSBarrier(ns);
+      if (!rc) rc = brc;
+    }
+  }
+  for (int q = 0; q < v->ncell; ++q) free(hc[q]);
+  for (int q = 0; q < v->nface; ++q)
+    for (int l = 0; l < 3; ++l) free(hf[q][l]);
   return rc;
 }
 

@@ -3,7 +3,7 @@
  * (include/fluca_host.h lists the reference interfaces).  Pure C99; reaches the GPU only through the C-ABI of
  * include/fluca_hip.h (libflucahip.so).  No PETSc, no MPI: one process per GPU, rank/size set explicitly.
  */
-#include "../../include/fluca_host.h"
+#include "../../include/fluca_host_impl.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -12,7 +12,7 @@
 #include <strings.h>
 
 /* positive PETSC_ERR_* values */
-enum { E_MEM = 55, E_SUP = 56, E_ARG_WRONG = 62, E_ARG_OUTOFRANGE = 63, E_ARG_WRONGSTATE = 73, E_ARG_NULL = 85, E_ARG_UNKNOWN_TYPE = 86, E_ARG_TYPENOTSET = 89 };
+enum { E_MEM = 55, E_SUP = 56, E_ARG_WRONG = 62, E_FILE_OPEN = 65, E_ARG_OUTOFRANGE = 63, E_ARG_WRONGSTATE = 73, E_ARG_NULL = 85, E_ARG_UNKNOWN_TYPE = 86, E_ARG_TYPENOTSET = 89 };
 
 #define FLCHK(call)             \
   do {                          \
@@ -44,6 +44,8 @@ enum { E_MEM = 55, E_SUP = 56, E_ARG_WRONG = 62, E_ARG_OUTOFRANGE = 63, E_ARG_WR
     }                           \
   } while (0)
 static void trace_end(void);
+static void trace_begin(const char *name);
+static FlErrorCode ns_jacobian(NS ns);
 
 /* ------------------------------------------------------------------------------------------------ registries */
 
@@ -55,8 +57,6 @@ typedef struct {
 static TypeEntry MeshList[MAXTYPES], NSList[MAXTYPES];
 static int       nMeshTypes = 0, nNSTypes = 0, registered = 0;
 
-static FlErrorCode MeshCreate_Cart(Mesh);
-static FlErrorCode NSCreate_CNLinear(NS);
 
 static void RegisterAll(void)
 {
@@ -71,6 +71,24 @@ static const char *opt_find(int argc, char **argv, const char *name)
   for (int i = 1; i + 1 < argc; ++i)
     if (argv[i] && !strcmp(argv[i], name)) return argv[i + 1];
   return NULL;
+}
+/* PetscOptionsBool: a bare flag (last argument, or followed by another option) means true; otherwise the next token must be one of
+ * true / false / yes / no / on / off / 1 / 0 (PetscOptionsStringToBool).  Returns 1 if the flag is present, -1 on a bad value. */
+static int opt_flag(int argc, char **argv, const char *name, int *v)
+{
+  for (int i = 1; i < argc; ++i) {
+    if (!argv[i] || strcmp(argv[i], name)) continue;
+    const char *s = i + 1 < argc ? argv[i + 1] : NULL;
+    if (!s || (s[0] == '-' && !(s[1] >= '0' && s[1] <= '9'))) {
+      *v = 1;
+      return 1;
+    }
+    if (!strcasecmp(s, "true") || !strcasecmp(s, "yes") || !strcasecmp(s, "on") || !strcmp(s, "1")) *v = 1;
+    else if (!strcasecmp(s, "false") || !strcasecmp(s, "no") || !strcasecmp(s, "off") || !strcmp(s, "0")) *v = 0;
+    else return -1;
+    return 1;
+  }
+  return 0;
 }
 static int opt_int64(int argc, char **argv, const char *name, int64_t *v)
 {
@@ -87,24 +105,94 @@ static int opt_real(int argc, char **argv, const char *name, double *v)
   return 1;
 }
 
+/* ------------------------------------------------------------------------------------------------ Viewer */
+
+FlErrorCode FlucaViewerCreate(FlucaViewerType type, char mode, FlucaViewer *viewer)
+{
+  if (!type || !viewer) return E_ARG_NULL;
+  FlucaViewer v = (FlucaViewer)calloc(1, sizeof(*v));
+  if (!v) return E_MEM;
+  v->type   = type;
+  v->mode   = mode;
+  v->seqnum = -1; /* meshbasic.c:25-26 */
+  *viewer   = v;
+  return 0;
+}
+static FlErrorCode ViewerVPrintf_ASCII(FlucaViewer v, const char *fmt, va_list ap)
+{
+  FILE *f = (FILE *)v->data;
+  for (int i = 0; i < v->tab; ++i) fputs("  ", f); /* PetscViewerASCIIPrintf indents by two blanks per tab level */
+  return vfprintf(f, fmt, ap) < 0 ? 66 /* PETSC_ERR_FILE_WRITE */ : 0;
+}
+static FlErrorCode ViewerDestroy_ASCII(FlucaViewer v)
+{
+  FILE *f = (FILE *)v->data;
+  if (f && f != stdout) fclose(f);
+  else if (f) fflush(f);
+  return 0;
+}
+FlErrorCode FlucaViewerASCIIOpen(const char *filename, FlucaViewer *viewer)
+{
+  if (!viewer) return E_ARG_NULL;
+  FILE *f = !filename || !strcmp(filename, "stdout") ? stdout : fopen(filename, "w");
+  if (!f) return E_FILE_OPEN;
+  const FlErrorCode rc = FlucaViewerCreate(FLUCAVIEWERASCII, 'w', viewer);
+  if (rc) {
+    if (f != stdout) fclose(f);
+    return rc;
+  }
+  (*viewer)->data         = f;
+  (*viewer)->ops->vprintf = ViewerVPrintf_ASCII;
+  (*viewer)->ops->destroy = ViewerDestroy_ASCII;
+  return 0;
+}
+FlErrorCode FlucaViewerASCIIPrintf(FlucaViewer viewer, const char *fmt, ...)
+{
+  if (!viewer || !fmt) return E_ARG_NULL;
+  if (!viewer->ops->vprintf) return E_SUP;
+  va_list ap;
+  va_start(ap, fmt);
+  const FlErrorCode rc = viewer->ops->vprintf(viewer, fmt, ap);
+  va_end(ap);
+  return rc;
+}
+FlErrorCode FlucaViewerASCIIPushTab(FlucaViewer viewer) { if (!viewer) return E_ARG_NULL; ++viewer->tab; return 0; }
+FlErrorCode FlucaViewerASCIIPopTab(FlucaViewer viewer)
+{
+  if (!viewer) return E_ARG_NULL;
+  if (viewer->tab <= 0) return E_ARG_WRONGSTATE; /* "More tabs popped than pushed" */
+  --viewer->tab;
+  return 0;
+}
+FlErrorCode FlucaViewerGetType(FlucaViewer viewer, FlucaViewerType *type)
+{
+  if (!viewer || !type) return E_ARG_NULL;
+  *type = viewer->type;
+  return 0;
+}
+FlErrorCode FlucaViewerDestroy(FlucaViewer *viewer)
+{
+  if (!viewer || !*viewer) return 0;
+  const FlErrorCode rc = (*viewer)->ops->destroy ? (*viewer)->ops->destroy(*viewer) : 0;
+  free(*viewer);
+  *viewer = NULL;
+  return rc;
+}
+static int viewer_is(FlucaViewer v, const char *type) { return v && v->type && !strcmp(v->type, type); }
+/* viewer NULL = PetscViewerASCIIGetStdout: a stdout viewer for the length of the call */
+#define WITH_STDOUT_VIEWER(viewer, body)                          \
+  do {                                                            \
+    FlucaViewer own_ = NULL;                                      \
+    if (!(viewer)) {                                              \
+      FLCHK(FlucaViewerASCIIOpen(NULL, &own_));                   \
+      (viewer) = own_;                                            \
+    }                                                             \
+    FlErrorCode rc_ = (body);                                     \
+    if (own_) FlucaViewerDestroy(&own_);                          \
+    return rc_;                                                   \
+  } while (0)
+
 /* ------------------------------------------------------------------------------------------------ Mesh */
-
-typedef struct {
-  int64_t              N[3];
-  int                  nRanks[3];
-  int64_t             *l[3]; /* ownership ranges */
-  MeshCartBoundaryType bndTypes[3];
-  int64_t              refineFactor[3]; /* -cart_refine_{x,y,z}, default 2 (cart.c:276) */
-  double              *xf[3], *xc[3]; /* global coordinates, set by MeshSetUp / SetUniformCoordinates */
-} Mesh_Cart; /* = fluca/include/fluca/private/meshcartimpl.h:8-17 */
-
-struct _p_Mesh {
-  struct _MeshOps ops[1];
-  char            type_name[32];
-  int             dim, rank, size, setupcalled;
-  fl_decomp       decomp;
-  void           *data;
-};
 
 FlErrorCode MeshRegister(const char name[], FlErrorCode (*create)(Mesh))
 {
@@ -270,7 +358,15 @@ static FlErrorCode MeshSetUp_Cart(Mesh mesh)
   }
   mesh->setupcalled = 1;
   /* DMStagSetUniformCoordinatesProduct(sdm, 0, 1, 0, 1, 0, 1)  (cart.c:128) */
-  return MeshCartSetUniformCoordinates(mesh, 0., 1., 0., 1., 0., 1.);
+  FLCHK(MeshCartSetUniformCoordinates(mesh, 0., 1., 0., 1., 0., 1.));
+  /* coordinates MeshLoad read replace the uniform ones axis by axis (cart.c:131-140) */
+  for (int d = 0; d < 3; ++d)
+    if (cart->coordLoaded[d]) {
+      const int64_t n = cart->N[d];
+      memcpy(cart->xf[d], cart->coordLoaded[d], sizeof(double) * (size_t)(n + 1));
+      for (int64_t i = 0; i < n; ++i) cart->xc[d][i] = (cart->coordLoaded[d][i] + cart->coordLoaded[d][i + 1]) / 2.;
+    }
+  return 0;
 }
 
 static FlErrorCode MeshDestroy_Cart(Mesh mesh)
@@ -281,6 +377,7 @@ static FlErrorCode MeshDestroy_Cart(Mesh mesh)
     free(cart->l[d]);
     free(cart->xf[d]);
     free(cart->xc[d]);
+    free(cart->coordLoaded[d]);
   }
   free(cart);
   mesh->data = NULL;
@@ -293,7 +390,74 @@ static FlErrorCode MeshGetNumberBoundaries_Cart(Mesh mesh, int *nb)
   return 0;
 }
 
-static FlErrorCode MeshCreate_Cart(Mesh mesh) /* cart.c:262-288 */
+
+/* cart.c:171-206 */
+static FlErrorCode MeshView_Cart(Mesh mesh, FlucaViewer viewer)
+{
+  Mesh_Cart *cart = (Mesh_Cart *)mesh->data;
+  if (viewer_is(viewer, FLUCAVIEWERASCII)) {
+    if (!mesh->setupcalled) return E_ARG_WRONGSTATE; /* DMStagGetCorners on a DM that does not exist yet */
+    const fl_decomp *D = &mesh->decomp;
+    /* the reference prints cart->N[1] in the place of P (cart.c:193); the third size is meant and printed here */
+    FLCHK(FlucaViewerASCIIPrintf(viewer, "Processor [%d] M %lld N %lld P %lld m %d n %d p %d\n", mesh->rank, (long long)cart->N[0], (long long)cart->N[1], (long long)cart->N[2],
+                                 cart->nRanks[0], cart->nRanks[1], cart->nRanks[2]));
+    FLCHK(FlucaViewerASCIIPrintf(viewer, "X range of indices: %lld %lld, Y range of indices: %lld %lld, Z range of indices: %lld %lld\n", (long long)D->lo[0], (long long)(D->lo[0] + D->len[0]),
+                                 (long long)D->lo[1], (long long)(D->lo[1] + D->len[1]), (long long)D->lo[2], (long long)(D->lo[2] + D->len[2])));
+    return 0;
+  }
+  if (viewer_is(viewer, FLUCAVIEWERCGNS)) {
+    if (!mesh->setupcalled) return 0; /* cartcgns.c:14 */
+    return viewer->ops->viewmesh ? viewer->ops->viewmesh(viewer, mesh) : E_SUP;
+  }
+  return 0;
+}
+/* cart.c:208-216 with cartcgns.c:120-158 */
+static FlErrorCode MeshLoad_Cart(Mesh mesh, FlucaViewer viewer)
+{
+  Mesh_Cart *cart = (Mesh_Cart *)mesh->data;
+  if (!viewer_is(viewer, FLUCAVIEWERCGNS)) return 0;
+  if (!viewer->ops->loadmesh) return E_SUP;
+  if (mesh->setupcalled) return E_ARG_WRONGSTATE; /* MeshCartSetGlobalSizes: "This function must be called before MeshSetUp()" */
+  int64_t N[3];
+  double *xf[3] = {NULL, NULL, NULL};
+  FLCHK(viewer->ops->loadmesh(viewer, N, xf));
+  for (int d = 0; d < 3; ++d) {
+    free(cart->coordLoaded[d]);
+    cart->coordLoaded[d] = xf[d];
+    cart->N[d]           = N[d];
+    cart->bndTypes[d]    = MESHCART_BOUNDARY_NONE; /* cartcgns.c:155 */
+  }
+  mesh->dim = 3;
+  return 0;
+}
+/* cart.c:218-229: this rank's block of the DM as one zeroed device array */
+static FlErrorCode MeshCreateGlobalVector_Cart(Mesh mesh, MeshDMType type, int device, double **vec, int64_t *n)
+{
+  if (!mesh->setupcalled) return E_ARG_WRONGSTATE;
+  const fl_decomp *D = &mesh->decomp;
+  Mesh_Cart       *cart = (Mesh_Cart *)mesh->data;
+  const int64_t    cells = D->len[0] * D->len[1] * D->len[2];
+  int64_t          faces = 0;
+  for (int d = 0; d < 3; ++d) { /* DMStag ownership: the last rank of a non-periodic axis owns the extra face */
+    const int extra = cart->bndTypes[d] != MESHCART_BOUNDARY_PERIODIC && D->coord[d] == D->ranks[d] - 1;
+    faces += cells / D->len[d] * (D->len[d] + extra);
+  }
+  int64_t count;
+  switch (type) {
+  case MESH_DM_SCALAR: count = cells; break;
+  case MESH_DM_VECTOR: count = 3 * cells; break;
+  case MESH_DM_STAG_SCALAR: count = faces; break;
+  case MESH_DM_STAG_VECTOR: count = 3 * faces; break;
+  default: return E_ARG_OUTOFRANGE;
+  }
+  void *d = NULL;
+  FLABI(fl_malloc(device, sizeof(double) * (size_t)(count > 0 ? count : 1), &d)); /* zero-initialised, like a fresh Vec */
+  *vec = (double *)d;
+  if (n) *n = count;
+  return 0;
+}
+
+FlErrorCode MeshCreate_Cart(Mesh mesh) /* cart.c:262-288 */
 {
   Mesh_Cart *cart = (Mesh_Cart *)calloc(1, sizeof(*cart));
   if (!cart) return E_MEM;
@@ -306,6 +470,10 @@ static FlErrorCode MeshCreate_Cart(Mesh mesh) /* cart.c:262-288 */
   mesh->ops->setfromoptions      = MeshSetFromOptions_Cart;
   mesh->ops->setup               = MeshSetUp_Cart;
   mesh->ops->destroy             = MeshDestroy_Cart;
+  mesh->ops->view                = MeshView_Cart;
+  mesh->ops->load                = MeshLoad_Cart;
+  mesh->ops->createglobalvector  = MeshCreateGlobalVector_Cart;
+  mesh->ops->creatematrix        = NULL; /* MeshCreateMatrix_Cart (cart.c:231-260) hands out AIJ matrices; nothing here is assembled */
   mesh->ops->getnumberboundaries = MeshGetNumberBoundaries_Cart;
   return 0;
 }
@@ -471,6 +639,39 @@ FlErrorCode MeshGetNumberBoundaries(Mesh mesh, int *nb)
   if (!mesh->ops->getnumberboundaries) return E_ARG_TYPENOTSET;
   return mesh->ops->getnumberboundaries(mesh, nb);
 }
+static FlErrorCode MeshView_Body(Mesh mesh, FlucaViewer viewer)
+{
+  if (viewer_is(viewer, FLUCAVIEWERASCII)) /* PetscObjectPrintClassNamePrefixType */
+    FLCHK(FlucaViewerASCIIPrintf(viewer, "Mesh Object: %d MPI process%s\n  type: %s\n", mesh->size, mesh->size > 1 ? "es" : "", mesh->type_name[0] ? mesh->type_name : "not yet set"));
+  if (mesh->ops->view) FLCHK(mesh->ops->view(mesh, viewer)); /* PetscTryTypeMethod */
+  return 0;
+}
+FlErrorCode MeshView(Mesh mesh, FlucaViewer viewer) /* meshbasic.c:93-104 */
+{
+  if (!mesh) return E_ARG_NULL;
+  WITH_STDOUT_VIEWER(viewer, MeshView_Body(mesh, viewer));
+}
+FlErrorCode MeshLoad(Mesh mesh, FlucaViewer viewer) /* meshbasic.c:114-127 */
+{
+  if (!mesh || !viewer) return E_ARG_NULL;
+  if (viewer->mode != 'r') return E_ARG_WRONGSTATE; /* PetscViewerCheckReadable */
+  if (!viewer_is(viewer, FLUCAVIEWERCGNS)) return E_ARG_WRONG; /* "Invalid viewer; open viewer with PetscViewerFlucaCGNSOpen()" */
+  if (!mesh->type_name[0]) FLCHK(MeshSetType(mesh, MESHCART));
+  if (!mesh->ops->load) return E_SUP; /* PetscUseTypeMethod */
+  return mesh->ops->load(mesh, viewer);
+}
+FlErrorCode MeshCreateGlobalVector(Mesh mesh, MeshDMType type, int device, double **vec_dev, int64_t *n)
+{
+  if (!mesh || !vec_dev) return E_ARG_NULL;
+  if (!mesh->ops->createglobalvector) return E_SUP;
+  return mesh->ops->createglobalvector(mesh, type, device, vec_dev, n);
+}
+FlErrorCode MeshCreateMatrix(Mesh mesh, MeshDMType rtype, MeshDMType ctype, void **mat)
+{
+  if (!mesh || !mat) return E_ARG_NULL;
+  if (!mesh->ops->creatematrix) return E_SUP; /* matrix-free build: no type assembles a Mat */
+  return mesh->ops->creatematrix(mesh, rtype, ctype, mat);
+}
 FlErrorCode MeshDestroy(Mesh *mesh)
 {
   if (!mesh || !*mesh) return 0;
@@ -481,42 +682,6 @@ FlErrorCode MeshDestroy(Mesh *mesh)
 }
 
 /* ------------------------------------------------------------------------------------------------ NS */
-
-#define MAXNSMONITORS 10
-struct _p_NS {
-  struct _NSOps        ops[1];
-  char                 type_name[32];
-  double               rho, mu, dt, t;
-  int64_t              step, max_steps;
-  double               max_time; /* nsbasic.c:30: PETSC_MAX_REAL = not set */
-  int                  errorifstepfailed; /* nsbasic.c:46: PETSC_TRUE */
-  Mesh                 mesh;
-  NSBoundaryCondition *bcs;
-  int                  nb, device, setupcalled;
-  fl_poisson          *poisson;  /* plays PC_ABF's kspS + S */
-  fl_momentum         *momentum; /* plays PC_ABF's kspA + A (created by the first NSSetPreviousState) */
-  fl_ibm              *ibm;      /* immersed boundary (build-defined direct forcing, NSSetImmersedBoundary) */
-  int64_t              ibm_L;
-  const double        *ibm_dV, *ibm_Ut;
-  double              *ibm_U;
-  fl_ksp_opts          schur;    /* -ns_abf_schur_* */
-  fl_ksp_opts          mom;      /* -ns_abf_momentum_* */
-  int                  schur_ainv, upper_ainv; /* -ns_pc_abf_schur_ainv_type / -ns_pc_abf_upper_ainv_type (PCABFAinvType), default ID */
-  int                  ksp_type;           /* -ns_ksp_type: 0 richardson, 1 preonly, 2 gmres (the reference's default, nssol.c:21-29) */
-  int                  gmres_restart;      /* -ns_ksp_gmres_restart (PETSc default 30) */
-  double               ksp_rtol, ksp_atol; /* -ns_ksp_rtol 1e-5 (nssol.c:24), unpreconditioned norm (nssol.c:25) */
-  int                  ksp_max_it;
-  int                  ksp_its, reason;    /* of the last step */
-  int                  mom_its, schur_its; /* inner Krylov iterations summed over the last step's outer iterations */
-  double               ksp_rnorm;
-  double               ksp_rnorm0; /* norm of the right-hand side the outer solve started from (the reference norm of its rtol test) */
-  /* NSMonitorSet list (nsimpl.h: monitor[], monitorctx[], monitordestroy[], MAXNSMONITORS) */
-  int                  nmon;
-  FlErrorCode (*mon[MAXNSMONITORS])(NS, void *);
-  void *monctx[MAXNSMONITORS];
-  FlErrorCode (*mondestroy[MAXNSMONITORS])(void **);
-  void                *data;
-};
 
 FlErrorCode NSRegister(const char name[], FlErrorCode (*create)(NS))
 {
@@ -658,7 +823,12 @@ FlErrorCode NSSetFromOptions(NS ns, int argc, char **argv)
   if (opt_real(argc, argv, "-ns_time_step_size", &v)) FLCHK(NSSetTimeStepSize(ns, v));
   if (opt_int64(argc, argv, "-ns_max_steps", &iv)) ns->max_steps = iv;
   if (opt_real(argc, argv, "-ns_max_time", &v)) ns->max_time = v; /* nsopts.c:186 */
-  if ((s = opt_find(argc, argv, "-ns_error_if_step_failed"))) ns->errorifstepfailed = !(!strcmp(s, "0") || !strcasecmp(s, "false") || !strcasecmp(s, "no")); /* :188 */
+  {
+    int flg = 0;
+    const int got = opt_flag(argc, argv, "-ns_error_if_step_failed", &flg); /* :188 */
+    if (got < 0) return E_ARG_WRONG;
+    if (got) ns->errorifstepfailed = flg;
+  }
   /* sub-KSP of the Schur complement: prefix ns_ + abf_schur_ (nssol.c:19, abfpc.c:206) */
   if ((s = opt_find(argc, argv, "-ns_abf_schur_ksp_type"))) {
     if (!strcmp(s, "cg")) ns->schur.type = FL_KSP_CG;
@@ -685,9 +855,11 @@ FlErrorCode NSSetFromOptions(NS ns, int argc, char **argv)
   if (opt_real(argc, argv, "-ns_abf_schur_ksp_atol", &v)) ns->schur.atol = v;
   if (opt_real(argc, argv, "-ns_abf_schur_ksp_divtol", &v)) ns->schur.dtol = v;
   if (opt_int64(argc, argv, "-ns_abf_schur_ksp_max_it", &iv)) ns->schur.maxit = (int)iv;
-  if (opt_find(argc, argv, "-ns_abf_schur_ksp_cg_single_reduction")) { /* PetscOptionsBool: present without a value, or with true / 1, means on */
-    const char *sv = opt_find(argc, argv, "-ns_abf_schur_ksp_cg_single_reduction");
-    ns->schur.cg_single_reduction = !(sv[0] == '0' || sv[0] == 'f' || sv[0] == 'F' || sv[0] == 'n' || sv[0] == 'N');
+  {
+    int flg = 0;
+    const int got = opt_flag(argc, argv, "-ns_abf_schur_ksp_cg_single_reduction", &flg);
+    if (got < 0) return E_ARG_WRONG; /* "Unknown logical value" */
+    if (got) ns->schur.cg_single_reduction = flg;
   }
   if ((s = opt_find(argc, argv, "-ns_abf_schur_ksp_chebyshev_eigenvalues"))) {
     if (sscanf(s, "%lf,%lf", &ns->schur.emin, &ns->schur.emax) != 2) return E_ARG_WRONG;
@@ -806,6 +978,15 @@ static FlErrorCode NSSetUp_Body(NS ns) /* nsbasic.c:153-274, restricted to what 
     g.xc[d] = cart->xc[d];
   }
   FLABI(fl_poisson_create(&g, bc, ns->dt / ns->rho, ns->mesh->size > 1 ? &ns->mesh->decomp : NULL, ns->device, &ns->poisson));
+  /* "Create Jacobian" + "Initialize Jacobian" (nsbasic.c:203-207): NSFormJacobian(ns, ns->x = NULL, ns->J, NS_INIT_JACOBIAN) through the
+   * type's slot.  A block too small for the momentum rows (fewer than two cells along an axis) has no J: the pressure path
+   * (NSPressureCorrection) still works there and NSStep reports PETSC_ERR_SUP. */
+  {
+    const int rc = fl_momentum_create(ns->poisson, &ns->momentum);
+    if (rc && rc != FL_ERR_SUP) return -rc;
+    if (rc) ns->momentum = NULL;
+    else if (ns->ops->formjacobian) FLCHK(NSFormJacobian(ns, NULL, ns->momentum, NS_INIT_JACOBIAN));
+  }
   if (ns->ops->setup) FLCHK(ns->ops->setup(ns));
   ns->setupcalled = 1;
   return 0;
@@ -825,6 +1006,92 @@ static FlErrorCode NSStep_Body(NS ns) /* nsbasic.c:276-299 */
     NSMonitorCancel(ns);
     return 91; /* PETSC_ERR_NOT_CONVERGED: "NSStep has failed due to DIVERGED_NONLINEAR_SOLVE" */
   }
+  return 0;
+}
+
+/* nsbasic.c:301-323 */
+FlErrorCode NSFormJacobian(NS ns, const NSVec *x, NSMat J, NSFormJacobianType type)
+{
+  if (!ns || !J) return E_ARG_NULL;
+  if (!ns->ops->formjacobian) return E_SUP; /* PetscUseTypeMethod: "No method formjacobian for NS of type ..." */
+  trace_begin("NSFormJacobian");
+  const FlErrorCode rc = ns->ops->formjacobian(ns, x, J, type);
+  trace_end();
+  return rc;
+}
+FlErrorCode NSFormFunction(NS ns, const NSVec *x, NSVec *f)
+{
+  if (!ns || !f) return E_ARG_NULL;
+  if (!ns->ops->formfunction) return E_SUP;
+  trace_begin("NSFormFunction");
+  const FlErrorCode rc = ns->ops->formfunction(ns, x, f);
+  trace_end();
+  return rc;
+}
+FlErrorCode NSGetJacobian(NS ns, NSMat *J)
+{
+  if (!ns || !J) return E_ARG_NULL;
+  if (!ns->setupcalled) return E_ARG_WRONGSTATE;
+  FLCHK(ns_jacobian(ns));
+  *J = ns->momentum;
+  return 0;
+}
+
+static FlErrorCode NSView_Body(NS ns, FlucaViewer viewer) /* nsbasic.c:353-374 */
+{
+  if (!viewer_is(viewer, FLUCAVIEWERASCII)) return 0;
+  FLCHK(FlucaViewerASCIIPrintf(viewer, "NS Object: %d MPI process%s\n  type: %s\n", ns->mesh ? ns->mesh->size : 1, ns->mesh && ns->mesh->size > 1 ? "es" : "",
+                               ns->type_name[0] ? ns->type_name : "not yet set")); /* PetscObjectPrintClassNamePrefixType */
+  FLCHK(FlucaViewerASCIIPrintf(viewer, "Density: %g, Viscosity: %g, Time step size: %g\n", ns->rho, ns->mu, ns->dt));
+  FLCHK(FlucaViewerASCIIPrintf(viewer, "Current time step: %d, Current time: %g\n", (int)ns->step, ns->t));
+  FLCHK(FlucaViewerASCIIPushTab(viewer));
+  const FlErrorCode rc = ns->ops->view ? ns->ops->view(ns, viewer) : 0; /* PetscTryTypeMethod */
+  FLCHK(FlucaViewerASCIIPopTab(viewer));
+  return rc;
+}
+FlErrorCode NSView(NS ns, FlucaViewer viewer)
+{
+  if (!ns) return E_ARG_NULL;
+  WITH_STDOUT_VIEWER(viewer, NSView_Body(ns, viewer));
+}
+
+/* nssol.c:130-150.  The three field links of NSSetUp (nsbasic.c:180-182) in their order, then the type's own vectors. */
+FlErrorCode NSViewSolution(NS ns, FlucaViewer viewer)
+{
+  if (!ns || !viewer) return E_ARG_NULL;
+  if (!ns->setupcalled) return E_ARG_WRONGSTATE;
+  if (viewer->mode != 'w') return E_ARG_WRONGSTATE;
+  if (!viewer->ops->solutionbegin || !viewer->ops->cellfield || !viewer->ops->facefield || !viewer->ops->solutionend) return E_SUP;
+  double *v, *V[3], *p;
+  FLCHK(NSGetSolutionArrays(ns, &v, V, &p));
+  FLCHK(viewer->ops->solutionbegin(viewer, ns, 1));
+  FLCHK(viewer->ops->cellfield(viewer, ns, "Velocity", 3, v));
+  FLCHK(viewer->ops->facefield(viewer, ns, "FaceNormalVelocity", V));
+  FLCHK(viewer->ops->cellfield(viewer, ns, "Pressure", 1, p));
+  if (ns->ops->viewsolution) FLCHK(ns->ops->viewsolution(ns, viewer)); /* PetscTryTypeMethod(ns, viewsolution, viewer) */
+  return viewer->ops->solutionend(viewer, ns);
+}
+/* nssol.c:174-203 */
+FlErrorCode NSLoadSolution(NS ns, FlucaViewer viewer)
+{
+  if (!ns || !viewer) return E_ARG_NULL;
+  if (!ns->setupcalled) return E_ARG_WRONGSTATE; /* "This function must be called after NSSetUp()" */
+  if (viewer->mode != 'r') return E_ARG_WRONGSTATE; /* PetscViewerCheckReadable */
+  if (!viewer->ops->solutionbegin || !viewer->ops->cellfield || !viewer->ops->facefield || !viewer->ops->solutionend) return E_SUP;
+  double *v, *V[3], *p;
+  FLCHK(NSGetSolutionArrays(ns, &v, V, &p));
+  viewer->seqnum = -1; /* MeshSetOutputSequenceNumber(ns->mesh, -1, 0.): "reset here and will be set in VecLoad()" */
+  viewer->seqval = 0.;
+  FLCHK(viewer->ops->solutionbegin(viewer, ns, 0));
+  FLCHK(viewer->ops->cellfield(viewer, ns, "Velocity", 3, v));
+  FLCHK(viewer->ops->facefield(viewer, ns, "FaceNormalVelocity", V));
+  FLCHK(viewer->ops->cellfield(viewer, ns, "Pressure", 1, p));
+  if (!ns->ops->loadsolution) return E_SUP; /* PetscUseTypeMethod(ns, loadsolution, viewer) */
+  FLCHK(ns->ops->loadsolution(ns, viewer));
+  FLCHK(viewer->ops->solutionend(viewer, ns));
+  if (viewer->seqnum < 0) return 76; /* PETSC_ERR_LIB: the file held no solution */
+  ns->step = viewer->seqnum; /* MeshGetOutputSequenceNumber, nssol.c:199-201 */
+  ns->t    = viewer->seqval;
   return 0;
 }
 
@@ -1044,10 +1311,7 @@ FlErrorCode NSSetPreviousState(NS ns, const double *const V0[3], const double *c
 {
   if (!ns || !V0 || !v0interp) return E_ARG_NULL;
   if (!ns->setupcalled) return E_ARG_WRONGSTATE;
-  if (!ns->momentum) {
-    FLABI(fl_momentum_create(ns->poisson, &ns->momentum));
-    FLABI(fl_abf_set_ainv_types(ns->momentum, ns->schur_ainv, ns->upper_ainv));
-  }
+  FLCHK(ns_jacobian(ns));
   FLABI(fl_momentum_set_state(ns->momentum, ns->dt, ns->rho, ns->mu, V0, v0interp));
   return 0;
 }
@@ -1125,28 +1389,6 @@ FlErrorCode NSComputeStaggeredPressureGradientBC(NS ns, double t, double *V[3])
  * The fields and the step of NSStep_CNLinear_Cart3d_Internal / NSFormJacobian / NSFormFunction (cnlinearcart3d.c:2807-3060)
  * on device arrays, for all four boundary-condition types.  Outer solve:
  * -ns_ksp_type richardson (x += PCApply_ABF(f - J x), unpreconditioned norm, -ns_ksp_rtol) or preonly. */
-/* composite vector (v: 3*cells, V[3]: faces, p: cells) of the outer Krylov method */
-typedef struct {
-  double *v, *V[3], *p;
-} CVec;
-
-typedef struct {
-  int64_t sz[4];                               /* cells, x-, y-, z-faces of this rank */
-  double *sol_v, *sol_V[3], *sol_p;            /* ns->sol  */
-  double *sol0_v, *sol0_V[3], *sol0_p;         /* ns->sol0 */
-  double *phalf;                               /* cnl->phalf */
-  double *x_v, *x_V[3], *x_p;                  /* ns->x: v, V, dp */
-  double *f_v, *f_V[3];                        /* f: momrhs, interprhs; contrhs = 0 (:3046) */
-  double *W[9];                                /* cnl->v0interp */
-  double *r_v, *r_V[3], *r_p, *d_v, *d_V[3], *d_p;
-  double *plane_dev, *plane_host[7];           /* boundary values: 3 components at two times + one scratch plane */
-  int64_t plane_cap;
-  /* GMRES work vectors, kept from step to step (allocating and freeing ~70 GB of device memory per step at 512^3 left the
-   * GPU idle for a third of the step): w, t and the Krylov basis, grown lazily up to restart + 1 */
-  CVec  gm_w, gm_t, *gm_V;
-  int   gm_nalloc, gm_cap;
-} NS_CNLinear;
-
 static FlErrorCode cnl_alloc(NS ns, double **p, int64_t n)
 {
   void *d = NULL;
@@ -1163,7 +1405,7 @@ static FlErrorCode NSSetUp_CNLinear(NS ns)
   FLABI(fl_poisson_sizes(ns->poisson, c->sz));
   const int64_t N = c->sz[0];
   double      **cellv[] = {&c->sol_v, &c->sol0_v, &c->x_v, &c->f_v, &c->r_v, &c->d_v};
-  double      **cells[] = {&c->sol_p, &c->sol0_p, &c->phalf, &c->x_p, &c->r_p, &c->d_p};
+  double      **cells[] = {&c->sol_p, &c->sol0_p, &c->phalf, &c->x_p, &c->f_p, &c->r_p, &c->d_p};
   for (size_t a = 0; a < sizeof(cellv) / sizeof(cellv[0]); ++a) FLCHK(cnl_alloc(ns, cellv[a], 3 * N));
   for (size_t a = 0; a < sizeof(cells) / sizeof(cells[0]); ++a) FLCHK(cnl_alloc(ns, cells[a], N));
   int64_t pmax = 1;
@@ -1186,7 +1428,7 @@ static FlErrorCode NSDestroy_CNLinear(NS ns)
 {
   NS_CNLinear *c = (NS_CNLinear *)ns->data;
   if (!c) return 0;
-  double *cell[] = {c->sol_v, c->sol0_v, c->x_v, c->f_v, c->r_v, c->d_v, c->sol_p, c->sol0_p, c->phalf, c->x_p, c->r_p, c->d_p, c->plane_dev};
+  double *cell[] = {c->sol_v, c->sol0_v, c->x_v, c->f_v, c->r_v, c->d_v, c->sol_p, c->sol0_p, c->phalf, c->x_p, c->f_p, c->r_p, c->d_p, c->plane_dev};
   for (size_t a = 0; a < sizeof(cell) / sizeof(cell[0]); ++a)
     if (cell[a]) fl_free(ns->device, cell[a]);
   for (int d = 0; d < 3; ++d) {
@@ -1196,7 +1438,7 @@ static FlErrorCode NSDestroy_CNLinear(NS ns)
   }
   for (int q = 0; q < 7; ++q) free(c->plane_host[q]);
   for (int i = -2; i < c->gm_cap; ++i) { /* every slot of the table: a failed allocation may have left a partly filled one */
-    CVec   *a = i == -2 ? &c->gm_w : i == -1 ? &c->gm_t : &c->gm_V[i];
+    NSVec   *a = i == -2 ? &c->gm_w : i == -1 ? &c->gm_t : &c->gm_V[i];
     double *q[5] = {a->v, a->p, a->V[0], a->V[1], a->V[2]};
     for (int k = 0; k < 5; ++k)
       if (q[k]) fl_free(ns->device, q[k]);
@@ -1303,7 +1545,7 @@ static FlErrorCode cnl_residual(NS ns, double *rnorm)
     FLABI(fl_vec_dot(h, c->sz[1 + d], c->r_V[d], c->r_V[d], &part));
     s += part;
   }
-  FLABI(fl_vec_lincomb(h, c->sz[0], -1., c->r_p, 0., NULL, c->r_p)); /* contrhs = 0 */
+  FLABI(fl_vec_lincomb(h, c->sz[0], -1., c->r_p, 1., c->f_p, c->r_p));
   FLABI(fl_vec_dot(h, c->sz[0], c->r_p, c->r_p, &part));
   s += part;
   *rnorm = sqrt(s);
@@ -1311,7 +1553,7 @@ static FlErrorCode cnl_residual(NS ns, double *rnorm)
 }
 
 /* ---- composite vectors (v: 3*cells, V[3]: faces, p: cells) for the outer Krylov method ------------------------------- */
-static FlErrorCode cv_alloc(NS ns, CVec *a)
+static FlErrorCode cv_alloc(NS ns, NSVec *a)
 {
   NS_CNLinear *c = (NS_CNLinear *)ns->data;
   FLCHK(cnl_alloc(ns, &a->v, 3 * c->sz[0]));
@@ -1320,7 +1562,7 @@ static FlErrorCode cv_alloc(NS ns, CVec *a)
   return 0;
 }
 /* y = a x + b z (z may be NULL) */
-static FlErrorCode cv_lincomb(NS ns, double a, const CVec *x, double b, const CVec *z, CVec *y)
+static FlErrorCode cv_lincomb(NS ns, double a, const NSVec *x, double b, const NSVec *z, NSVec *y)
 {
   NS_CNLinear *c = (NS_CNLinear *)ns->data;
   fl_poisson  *h = ns->poisson;
@@ -1329,7 +1571,7 @@ static FlErrorCode cv_lincomb(NS ns, double a, const CVec *x, double b, const CV
   for (int d = 0; d < 3; ++d) FLABI(fl_vec_lincomb(h, c->sz[1 + d], a, x->V[d], b, z ? z->V[d] : NULL, y->V[d]));
   return 0;
 }
-static FlErrorCode cv_dot(NS ns, const CVec *x, const CVec *y, double *out)
+static FlErrorCode cv_dot(NS ns, const NSVec *x, const NSVec *y, double *out)
 {
   NS_CNLinear *c = (NS_CNLinear *)ns->data;
   fl_poisson  *h = ns->poisson;
@@ -1347,7 +1589,7 @@ static FlErrorCode cv_dot(NS ns, const CVec *x, const CVec *y, double *out)
 }
 /* VecMDot / VecMAXPY on composite vectors: out[i] = x . Y[i] ; x -= sum_i coef[i] Y[i]   (k <= CV_MAXK) */
 #define CV_MAXK 208
-static FlErrorCode cv_mdot(NS ns, const CVec *x, const CVec *Y, int k, double *out)
+static FlErrorCode cv_mdot(NS ns, const NSVec *x, const NSVec *Y, int k, double *out)
 {
   NS_CNLinear  *c = (NS_CNLinear *)ns->data;
   fl_poisson   *h = ns->poisson;
@@ -1364,7 +1606,7 @@ static FlErrorCode cv_mdot(NS ns, const CVec *x, const CVec *Y, int k, double *o
   }
   return 0;
 }
-static FlErrorCode cv_msub(NS ns, CVec *x, const double *coef, const CVec *Y, int k)
+static FlErrorCode cv_msub(NS ns, NSVec *x, const double *coef, const NSVec *Y, int k)
 {
   NS_CNLinear  *c = (NS_CNLinear *)ns->data;
   fl_poisson   *h = ns->poisson;
@@ -1380,7 +1622,7 @@ static FlErrorCode cv_msub(NS ns, CVec *x, const double *coef, const CVec *Y, in
   }
   return 0;
 }
-static FlErrorCode cv_pcapply(NS ns, const CVec *r, CVec *z) /* z = PCApply_ABF(r) */
+static FlErrorCode cv_pcapply(NS ns, const NSVec *r, NSVec *z) /* z = PCApply_ABF(r) */
 {
   fl_ksp_stats  st[2];
   const double *rV[3] = {r->V[0], r->V[1], r->V[2]};
@@ -1390,7 +1632,7 @@ static FlErrorCode cv_pcapply(NS ns, const CVec *r, CVec *z) /* z = PCApply_ABF(
   if (st[0].reason == FL_DIVERGED_NANORINF || st[1].reason == FL_DIVERGED_NANORINF) ns->reason = -1;
   return 0;
 }
-static FlErrorCode cv_jmult(NS ns, const CVec *x, CVec *y) /* y = J x */
+static FlErrorCode cv_jmult(NS ns, const NSVec *x, NSVec *y) /* y = J x */
 {
   const double *xV[3] = {x->V[0], x->V[1], x->V[2]};
   FLABI(fl_abf_jacobian_mult(ns->momentum, x->v, xV, x->p, y->v, y->V, y->p));
@@ -1400,20 +1642,20 @@ static FlErrorCode cv_jmult(NS ns, const CVec *x, CVec *y) /* y = J x */
 /* KSPGMRES as the reference's ns->snes uses it (nssol.c:21-29: rtol 1e-5, unpreconditioned norm => right preconditioning,
  * PETSc defaults: restart 30, classical Gram-Schmidt without refinement -- the same here).  Zero initial guess.  x = P^-1 (V y) at every restart / at the end.  PARITY UNPINNED like the
  * inner solvers (PETSc absent): restated from the published algorithm. */
-static FlErrorCode cnl_gmres(NS ns, const CVec *f, CVec *x)
+static FlErrorCode cnl_gmres(NS ns, const NSVec *f, NSVec *x)
 {
   const int    m = ns->gmres_restart;
   NS_CNLinear *c = (NS_CNLinear *)ns->data;
   if (c->gm_cap < m + 1) { /* the restart length grew: the basis table follows (the vectors in it stay) */
-    CVec *nv = (CVec *)calloc((size_t)m + 1, sizeof(CVec));
+    NSVec *nv = (NSVec *)calloc((size_t)m + 1, sizeof(NSVec));
     if (!nv) return E_MEM;
-    if (c->gm_V) memcpy(nv, c->gm_V, sizeof(CVec) * (size_t)c->gm_nalloc);
+    if (c->gm_V) memcpy(nv, c->gm_V, sizeof(NSVec) * (size_t)c->gm_nalloc);
     free(c->gm_V);
     c->gm_V   = nv;
     c->gm_cap = m + 1;
   }
-  CVec     *Vk = c->gm_V;
-  CVec     *w = &c->gm_w, *t = &c->gm_t; /* persistent work vectors */
+  NSVec     *Vk = c->gm_V;
+  NSVec     *w = &c->gm_w, *t = &c->gm_t; /* persistent work vectors */
   double   *H = (double *)calloc((size_t)(m + 1) * m, sizeof(double)), *cs = (double *)calloc(m, sizeof(double)), *sn = (double *)calloc(m, sizeof(double)),
            *g = (double *)calloc((size_t)m + 1, sizeof(double)), *y = (double *)calloc(m, sizeof(double));
   FlErrorCode rc = 0;
@@ -1517,30 +1759,22 @@ done:
   return rc;
 }
 
-static FlErrorCode NSStep_CNLinear(NS ns)
+/* NSFormFunction_CNLinear (cnlinear.c:86-109 -> cnlinearcart3d.c:2945-3060): the right-hand side of the step.  x is not read
+ * (the step is linear: SNESSetPicard, nsbasic.c:248).  Scratch: cnl->d_v, the host planes. */
+static FlErrorCode NSFormFunction_CNLinear(NS ns, const NSVec *x, NSVec *f)
 {
   NS_CNLinear *c = (NS_CNLinear *)ns->data;
-  if (!c) return E_ARG_WRONGSTATE;
+  (void)x;
+  if (!c || !f || !f->v || !f->p) return E_ARG_NULL;
+  if (!c->have_sol0 || !ns->momentum) return E_ARG_WRONGSTATE; /* ns->sol0 is what the function is formed from */
   Mesh_Cart    *cart = (Mesh_Cart *)ns->mesh->data;
   fl_poisson   *h = ns->poisson;
   const int64_t N = c->sz[0];
   const double  dt = ns->dt, t = ns->t, cv = 0.5 * ns->mu * dt / ns->rho;
-  if (!ns->momentum) {
-    FLABI(fl_momentum_create(h, &ns->momentum));
-    FLABI(fl_abf_set_ainv_types(ns->momentum, ns->schur_ainv, ns->upper_ainv));
-  }
-  /* NSStep: VecCopy(sol, sol0), nsbasic.c:281-282 */
-  FLABI(fl_vec_lincomb(h, 3 * N, 1., c->sol_v, 0., NULL, c->sol0_v));
-  FLABI(fl_vec_lincomb(h, N, 1., c->sol_p, 0., NULL, c->sol0_p));
-  for (int d = 0; d < 3; ++d) FLABI(fl_vec_lincomb(h, c->sz[1 + d], 1., c->sol_V[d], 0., NULL, c->sol0_V[d]));
-
-  trace_begin("NSFormFunction"); /* the right-hand side of the step: PetscLogEvent NS_FormFunction (nsbasic.c:131) */
-  /* v0interp = B v0 + vbc(t), cnlinearcart3d.c:2826-2829; vbc: :1749-1932 */
-  /* only the block-end faces are formed here: the operator forms the inner ones from v0 itself (fl_momentum_set_state_v0 below) */
-  FLABI_T(fl_momentum_interp_faces_ends(ns->momentum, c->sol0_v, NULL, c->W));
   /* momrhs = v0 + cv L v0 - kappa G p, :2976-2993 (p0 on the first step, phalf afterwards) */
-  FLABI_T(fl_momentum_rhs(ns->momentum, dt, ns->rho, ns->mu, c->sol0_v, ns->step == 0 ? c->sol0_p : c->phalf, NULL, c->f_v));
-  for (int d = 0; d < 3; ++d) FLABI_T(fl_vec_lincomb(h, c->sz[1 + d], 0., c->f_V[d], 0., NULL, c->f_V[d])); /* interprhs = 0 */
+  FLABI(fl_momentum_rhs(ns->momentum, dt, ns->rho, ns->mu, c->sol0_v, ns->step == 0 ? c->sol0_p : c->phalf, NULL, f->v));
+  for (int d = 0; d < 3; ++d) FLABI(fl_vec_lincomb(h, c->sz[1 + d], 0., f->V[d], 0., NULL, f->V[d])); /* interprhs = 0 */
+  FLABI(fl_vec_lincomb(h, N, 0., f->p, 0., NULL, f->p));                                               /* VecSet(contrhs, 0), :3046 */
   for (int b = 0; b < 6; ++b) {
     if (ns->bcs[b].type != NS_BC_VELOCITY || !cnl_touches(ns, b)) continue;
     const int        ax = b / 2, side = b % 2, a1 = ax == 0 ? 1 : 0, a2 = ax == 2 ? 1 : 2;
@@ -1548,14 +1782,11 @@ static FlErrorCode NSStep_CNLinear(NS ns)
     const int64_t    np = D->len[a1] * D->len[a2], n = cart->N[ax];
     const double    *xf = cart->xf[ax], *xc = cart->xc[ax];
     double          *vb0[3] = {c->plane_host[0], c->plane_host[1], c->plane_host[2]}, *vb1[3] = {c->plane_host[3], c->plane_host[4], c->plane_host[5]};
-    FLCHK_T(cnl_eval_velocity(ns, b, t, vb0));
-    FLCHK_T(cnl_eval_velocity(ns, b, t + dt, vb1));
+    FLCHK(cnl_eval_velocity(ns, b, t, vb0));
+    FLCHK(cnl_eval_velocity(ns, b, t + dt, vb1));
     /* coefficient of the wall value in the one-sided second-derivative row, :698-701 / :726-729 */
     double h1, h2, h3, hcell;
-    if (n < 3) {
-      trace_end();
-      return E_SUP;
-    }
+    if (n < 3) return E_SUP;
     if (!side) {
       h1 = xc[0] - xf[0]; h2 = xc[1] - xc[0]; h3 = xc[2] - xc[0]; hcell = xf[1] - xf[0];
     } else {
@@ -1564,23 +1795,20 @@ static FlErrorCode NSStep_CNLinear(NS ns)
     const double cl = 2. * (h2 + h3) / (h1 * (h1 + h2) * (h1 + h3)), sgn = side ? 0.5 : -0.5;
     double      *tmp = c->plane_host[6];
     for (int q = 0; q < 3; ++q) {
-      /* v0interp on the wall faces = the wall velocity at t (INSERT), :1788 */
-      FLCHK_T(cnl_upload(ns, vb0[q], np));
-      FLABI_T(fl_boundary_set_faces(h, b, 1., c->plane_dev, c->W[q * 3 + ax]));
       /* momrhs += cv (vbcL(t) + vbcL(t+dt)) - dt vbcC(t, t+dt), :2985-2998 with :698-701 and :1338 */
       for (int64_t a = 0; a < np; ++a) tmp[a] = cv * cl * (vb0[q][a] + vb1[q][a]) - dt * sgn * (vb1[q][a] * vb0[ax][a] + vb0[q][a] * vb1[ax][a]) / hcell;
-      FLCHK_T(cnl_upload(ns, tmp, np));
-      FLABI_T(fl_boundary_add_cells(h, b, 1., c->plane_dev, c->f_v + q * N));
+      FLCHK(cnl_upload(ns, tmp, np));
+      FLABI(fl_boundary_add_cells(h, b, 1., c->plane_dev, f->v + q * N));
     }
     /* interprhs on the wall faces = the wall-normal velocity at t + dt, :3003-3005 with :2178 */
-    FLCHK_T(cnl_upload(ns, vb1[ax], np));
-    FLABI_T(fl_boundary_set_faces(h, b, 1., c->plane_dev, c->f_V[ax]));
+    FLCHK(cnl_upload(ns, vb1[ax], np));
+    FLABI(fl_boundary_set_faces(h, b, 1., c->plane_dev, f->V[ax]));
   }
   /* immersed boundary: momrhs += spread(U_target - interp(v0)) */
   if (ns->ibm) {
-    FLABI_T(fl_ibm_interp(ns->ibm, 3, c->sol0_v, ns->ibm_U));
-    FLABI_T(fl_vec_lincomb(h, 3 * ns->ibm_L, -1., ns->ibm_U, 1., ns->ibm_Ut, ns->ibm_U)); /* U_target - U (z = NULL: target 0) */
-    FLABI_T(fl_ibm_spread(ns->ibm, 3, ns->ibm_U, ns->ibm_dV, c->f_v));
+    FLABI(fl_ibm_interp(ns->ibm, 3, c->sol0_v, ns->ibm_U));
+    FLABI(fl_vec_lincomb(h, 3 * ns->ibm_L, -1., ns->ibm_U, 1., ns->ibm_Ut, ns->ibm_U)); /* U_target - U (z = NULL: target 0) */
+    FLABI(fl_ibm_spread(ns->ibm, 3, ns->ibm_U, ns->ibm_dV, f->v));
   }
   /* PRESSURE_OUTLET: the boundary-condition vector of G in momrhs (:2976-2984, :219-423) and the Rhie-Chow boundary terms
    * of interprhs (:3013-3044).  As written in the reference, the G vector is NOT scaled by dt/rho in momrhs. */
@@ -1594,10 +1822,7 @@ static FlErrorCode NSStep_CNLinear(NS ns)
       const fl_decomp *D = &ns->mesh->decomp;
       const int64_t    n1 = D->len[a1], n2 = D->len[a2], np = n1 * n2, n = cart->N[ax];
       const double    *xf = cart->xf[ax], *xc = cart->xc[ax];
-      if (!ns->bcs[b].pressure || n < 2) {
-        trace_end();
-        return !ns->bcs[b].pressure ? E_ARG_WRONGSTATE : E_SUP;
-      }
+      if (!ns->bcs[b].pressure || n < 2) return !ns->bcs[b].pressure ? E_ARG_WRONGSTATE : E_SUP;
       double *pq = c->plane_host[0], *pp = c->plane_host[1], *tmp = c->plane_host[2];
       int     differs = 0;
       for (int64_t j = 0; j < n2; ++j)
@@ -1606,8 +1831,8 @@ static FlErrorCode NSStep_CNLinear(NS ns)
           xb[ax] = xf[side ? n : 0];
           xb[a1] = cart->xc[a1][D->lo[a1] + i];
           xb[a2] = cart->xc[a2][D->lo[a2] + j];
-          FLCHK_T(ns->bcs[b].pressure(3, tq, xb, &vq, ns->bcs[b].ctx_pressure));
-          FLCHK_T(ns->bcs[b].pressure(3, tp, xb, &vp, ns->bcs[b].ctx_pressure));
+          FLCHK(ns->bcs[b].pressure(3, tq, xb, &vq, ns->bcs[b].ctx_pressure));
+          FLCHK(ns->bcs[b].pressure(3, tp, xb, &vp, ns->bcs[b].ctx_pressure));
           pq[j * n1 + i] = vq;
           pp[j * n1 + i] = vp;
           differs |= vq != vp;
@@ -1615,48 +1840,101 @@ static FlErrorCode NSStep_CNLinear(NS ns)
       /* G: one-sided first derivative through the boundary value, :257-259 / :285-287 */
       const double h1 = side ? xf[n] - xc[n - 1] : xc[0] - xf[0], h2 = side ? xc[n - 1] - xc[n - 2] : xc[1] - xc[0];
       const double cg = (side ? 1. : -1.) * h2 / (h1 * (h1 + h2));
-      FLCHK_T(cnl_upload(ns, pq, np));
-      FLABI_T(fl_boundary_add_cells(h, b, -cg, c->plane_dev, c->f_v + ax * N)); /* VecAXPY(momrhs, -1, Gp), Gp = kappa G p + vbcG(tq) */
+      FLCHK(cnl_upload(ns, pq, np));
+      FLABI(fl_boundary_add_cells(h, b, -cg, c->plane_dev, f->v + ax * N)); /* VecAXPY(momrhs, -1, Gp), Gp = kappa G p + vbcG(tq) */
       if (differs) {
         /* Gst: :2641-2647 / :2669-2675 */
         const double g1 = side ? xf[n] - xc[n - 1] : xc[0] - xf[0], g2 = side ? xf[n] - xc[n - 2] : xc[1] - xf[0];
         const double cgst = (side ? 1. : -1.) * (g1 + g2) / (g1 * g2);
-        if (!rhiechow) FLABI_T(fl_vec_lincomb(h, 3 * N, 0., w, 0., NULL, w));
+        if (!rhiechow) FLABI(fl_vec_lincomb(h, 3 * N, 0., w, 0., NULL, w));
         rhiechow = 1;
         for (int64_t a = 0; a < np; ++a) tmp[a] = pq[a] - pp[a];
-        FLCHK_T(cnl_upload(ns, tmp, np));
-        FLABI_T(fl_boundary_add_cells(h, b, kappa * cg, c->plane_dev, w + ax * N));     /* kappa (vbcGq - vbcGp), :3031-3032 */
-        FLABI_T(fl_boundary_add_faces(h, b, kappa * cgst, c->plane_dev, c->f_V[ax]));   /* + kappa (vbcGstq - vbcGstp), :3034-3035 */
+        FLCHK(cnl_upload(ns, tmp, np));
+        FLABI(fl_boundary_add_cells(h, b, kappa * cg, c->plane_dev, w + ax * N));     /* kappa (vbcGq - vbcGp), :3031-3032 */
+        FLABI(fl_boundary_add_faces(h, b, kappa * cgst, c->plane_dev, f->V[ax]));     /* + kappa (vbcGstq - vbcGstp), :3034-3035 */
       }
     }
     if (rhiechow) {
       /* interprhs += (-T) w, :3033 */
-      const double *rhs[3] = {c->f_V[0], c->f_V[1], c->f_V[2]};
-      FLABI_T(fl_momentum_face_interp_scaled(ns->momentum, -1., w, rhs, c->f_V));
+      const double *rhs[3] = {f->V[0], f->V[1], f->V[2]};
+      FLABI(fl_momentum_face_interp_scaled(ns->momentum, -1., w, rhs, f->V));
     }
   }
-  trace_end(); /* NSFormFunction */
-  /* NSFormJacobian: A = I + dt C(V0, v0interp) - cv L, :2930-2941 */
-  {
+  return 0;
+}
+
+/* NSFormJacobian_CNLinear (cnlinear.c:62-84 -> cnlinearcart3d.c:2864-2943).  NS_INIT_JACOBIAN wires the constant blocks: kappa G, -T,
+ * I, -R = (-T)(kappa G) + kappa Gst, D and the composed "Laplacian" / "StaggeredGradient" (:2885-2928) -- all of them 1-D tables the
+ * handle J built when it was created (fl_momentum_create); what is left to do here is to tell it PC_ABF's Ainv types.  Then, for
+ * either type, "if (ns->sol0)": A = I + dt C(V0, v0interp) - (mu dt / 2 rho) L (:2930-2941), matrix-free from sol0's face-normal
+ * velocity, cnl->v0interp and v0 itself (the inner faces of v0interp are formed from v0 inside the kernel). */
+static FlErrorCode NSFormJacobian_CNLinear(NS ns, const NSVec *x, NSMat J, NSFormJacobianType type)
+{
+  NS_CNLinear *c = (NS_CNLinear *)ns->data;
+  (void)x;
+  if (!J) return E_ARG_NULL;
+  if (type == NS_INIT_JACOBIAN) FLABI(fl_abf_set_ainv_types(J, ns->schur_ainv, ns->upper_ainv));
+  if (c && c->have_sol0) {
     const double *V0[3] = {c->sol0_V[0], c->sol0_V[1], c->sol0_V[2]};
     const double *W[9];
     for (int q = 0; q < 9; ++q) W[q] = c->W[q];
-    trace_begin("NSFormJacobian"); /* PetscLogEvent NS_FormJacobian (nsbasic.c:118) */
-    /* W = B v0 with the boundary values set on boundary faces only (fl_boundary_set_faces above): the operator may form the inner ones from v0 */
-    FLABI_T(fl_momentum_set_state_v0(ns->momentum, dt, ns->rho, ns->mu, V0, W, c->sol0_v));
-    trace_end();
+    /* W = B v0 with the boundary values set on boundary faces only: the operator may form the inner ones from v0 */
+    FLABI(fl_momentum_set_state_v0(J, ns->dt, ns->rho, ns->mu, V0, W, c->sol0_v));
   }
+  return 0;
+}
+
+/* ns->J: created at NSSetUp (MatCreateNest, nsbasic.c:203-207) where the block is large enough for the momentum rows, else here */
+static FlErrorCode ns_jacobian(NS ns)
+{
+  if (ns->momentum) return 0;
+  if (!ns->poisson) return E_ARG_WRONGSTATE;
+  FLABI(fl_momentum_create(ns->poisson, &ns->momentum));
+  return NSFormJacobian(ns, NULL, ns->momentum, NS_INIT_JACOBIAN);
+}
+
+static FlErrorCode NSStep_CNLinear(NS ns)
+{
+  NS_CNLinear *c = (NS_CNLinear *)ns->data;
+  if (!c) return E_ARG_WRONGSTATE;
+  fl_poisson   *h = ns->poisson;
+  const int64_t N = c->sz[0];
+  FLCHK(ns_jacobian(ns));
+  /* NSStep: VecCopy(sol, sol0), nsbasic.c:281-282 (the vectors are this type's device arrays, so the copy is made here) */
+  FLABI(fl_vec_lincomb(h, 3 * N, 1., c->sol_v, 0., NULL, c->sol0_v));
+  FLABI(fl_vec_lincomb(h, N, 1., c->sol_p, 0., NULL, c->sol0_p));
+  for (int d = 0; d < 3; ++d) FLABI(fl_vec_lincomb(h, c->sz[1 + d], 1., c->sol_V[d], 0., NULL, c->sol0_V[d]));
+  c->have_sol0 = 1;
+
+  /* v0interp = B v0 + vbc(t), cnlinearcart3d.c:2826-2829; vbc: :1749-1932 */
+  /* only the block-end faces are formed here: the operator forms the inner ones from v0 itself (fl_momentum_set_state_v0) */
+  FLABI(fl_momentum_interp_faces_ends(ns->momentum, c->sol0_v, NULL, c->W));
+  for (int b = 0; b < 6; ++b) {
+    if (ns->bcs[b].type != NS_BC_VELOCITY || !cnl_touches(ns, b)) continue;
+    const int        ax = b / 2, a1 = ax == 0 ? 1 : 0, a2 = ax == 2 ? 1 : 2;
+    const fl_decomp *D = &ns->mesh->decomp;
+    const int64_t    np = D->len[a1] * D->len[a2];
+    double          *vb0[3] = {c->plane_host[0], c->plane_host[1], c->plane_host[2]};
+    FLCHK(cnl_eval_velocity(ns, b, ns->t, vb0));
+    for (int q = 0; q < 3; ++q) { /* v0interp on the wall faces = the wall velocity at t (INSERT), :1788 */
+      FLCHK(cnl_upload(ns, vb0[q], np));
+      FLABI(fl_boundary_set_faces(h, b, 1., c->plane_dev, c->W[q * 3 + ax]));
+    }
+  }
+  /* SNESSolve(ns->snes, NULL, ns->x), :2833, with SNESSetPicard (nsbasic.c:248): the right-hand side comes from the type's
+   * formfunction, the operator from its formjacobian -- both through the ops table (nsbasic.c:115-131) */
+  NSVec x = {c->x_v, {c->x_V[0], c->x_V[1], c->x_V[2]}, c->x_p}, f = {c->f_v, {c->f_V[0], c->f_V[1], c->f_V[2]}, c->f_p};
+  FLCHK(NSFormFunction(ns, &x, &f));
+  FLCHK(NSFormJacobian(ns, &x, ns->momentum, NS_UPDATE_JACOBIAN));
   /* KSPSolve(J, f, x) with PC_ABF */
   fl_ksp_stats  st[2];
   const double *fV[3] = {c->f_V[0], c->f_V[1], c->f_V[2]};
   if (ns->ksp_type == 2) {
-    CVec f = {c->f_v, {c->f_V[0], c->f_V[1], c->f_V[2]}, c->r_p}, x = {c->x_v, {c->x_V[0], c->x_V[1], c->x_V[2]}, c->x_p};
-    FLABI(fl_vec_lincomb(h, N, 0., c->r_p, 0., NULL, c->r_p)); /* contrhs = 0 */
     ns->reason  = 0;
     ns->mom_its = ns->schur_its = 0;
     FLCHK(cnl_gmres(ns, &f, &x));
   } else
-  FLABI(fl_abf_apply(ns->momentum, &ns->mom, &ns->schur, c->f_v, fV, NULL, c->x_v, c->x_V, c->x_p, st));
+  FLABI(fl_abf_apply(ns->momentum, &ns->mom, &ns->schur, c->f_v, fV, c->f_p, c->x_v, c->x_V, c->x_p, st));
   if (ns->ksp_type != 2) {
     ns->ksp_its   = 1;
     ns->reason    = 0;
@@ -1673,6 +1951,8 @@ static FlErrorCode NSStep_CNLinear(NS ns)
       FLABI(fl_vec_dot(h, c->sz[1 + d], c->f_V[d], c->f_V[d], &part));
       fnorm += part;
     }
+    FLABI(fl_vec_dot(h, N, c->f_p, c->f_p, &part));
+    fnorm += part;
     fnorm = sqrt(fnorm);
     ns->ksp_rnorm0 = fnorm;
     const double ttol = ns->ksp_rtol * fnorm > ns->ksp_atol ? ns->ksp_rtol * fnorm : ns->ksp_atol;
@@ -1701,11 +1981,53 @@ static FlErrorCode NSStep_CNLinear(NS ns)
   FLABI(fl_poisson_synchronize(h));
   return 0;
 }
-static FlErrorCode NSCreate_CNLinear(NS ns) /* cnlinear.c:164-187 */
+/* cnlinear.c:136-162 */
+static FlErrorCode NSView_CNLinear(NS ns, FlucaViewer viewer)
 {
-  ns->ops->setfromoptions = NULL;
+  (void)ns;
+  (void)viewer; /* "TODO: add view" in the reference: prints nothing */
+  return 0;
+}
+static FlErrorCode NSViewSolution_CNLinear(NS ns, FlucaViewer viewer) /* VecView(cnl->phalf, viewer) */
+{
+  NS_CNLinear *c = (NS_CNLinear *)ns->data;
+  if (!c) return E_ARG_WRONGSTATE;
+  return viewer->ops->cellfield(viewer, ns, "PressureHalfStep", 1, c->phalf); /* the name: cnlinear.c:54 */
+}
+static FlErrorCode NSLoadSolution_CNLinear(NS ns, FlucaViewer viewer) /* FlucaVecLoad(cnl->phalf, viewer) */
+{
+  NS_CNLinear *c = (NS_CNLinear *)ns->data;
+  if (!c) return E_ARG_WRONGSTATE;
+  return viewer->ops->cellfield(viewer, ns, "PressureHalfStep", 1, c->phalf);
+}
+FlErrorCode NSGetSolverVectors(NS ns, NSVec *x, NSVec *r)
+{
+  if (!ns) return E_ARG_NULL;
+  if (!ns->setupcalled || !ns->data) return E_ARG_WRONGSTATE;
+  NS_CNLinear *c = (NS_CNLinear *)ns->data;
+  if (x) {
+    x->v = c->x_v;
+    x->p = c->x_p;
+    for (int d = 0; d < 3; ++d) x->V[d] = c->x_V[d];
+  }
+  if (r) {
+    r->v = c->f_v;
+    r->p = c->f_p;
+    for (int d = 0; d < 3; ++d) r->V[d] = c->f_V[d];
+  }
+  return 0;
+}
+
+FlErrorCode NSCreate_CNLinear(NS ns) /* cnlinear.c:164-187 */
+{
+  ns->ops->setfromoptions = NULL; /* NSSetFromOptions_CNLinear (cnlinear.c:7-11) reads no option */
   ns->ops->setup          = NSSetUp_CNLinear;
   ns->ops->step           = NSStep_CNLinear;
+  ns->ops->formjacobian   = NSFormJacobian_CNLinear;
+  ns->ops->formfunction   = NSFormFunction_CNLinear;
   ns->ops->destroy        = NSDestroy_CNLinear;
+  ns->ops->view           = NSView_CNLinear;
+  ns->ops->viewsolution   = NSViewSolution_CNLinear;
+  ns->ops->loadsolution   = NSLoadSolution_CNLinear;
   return 0;
 }

@@ -59,7 +59,32 @@ PROTOTYPES = {
     "NSGetConvergedReason": [_P, _ip],
     "NSMonitorSet": [_P, _P, _P, _P], "NSMonitorCancel": [_P], "NSMonitor": [_P],
     "FlucaTraceEnabled": [],
+    # the ops-table entry points (nsimpl.h:21-31, meshimpl.h:16-25) and the viewer they take
+    "NSRegister": [C.c_char_p, _P], "MeshRegister": [C.c_char_p, _P],
+    "NSFormJacobian": [_P, _P, _P, C.c_int], "NSFormFunction": [_P, _P, _P], "NSGetJacobian": [_P, C.POINTER(_P)], "NSGetSolverVectors": [_P, _P, _P],
+    "NSView": [_P, _P], "NSViewSolution": [_P, _P], "NSLoadSolution": [_P, _P],
+    "MeshView": [_P, _P], "MeshLoad": [_P, _P], "MeshCreateGlobalVector": [_P, C.c_int, C.c_int, C.POINTER(_P), _i64p], "MeshCreateMatrix": [_P, C.c_int, C.c_int, C.POINTER(_P)],
+    "FlucaViewerASCIIOpen": [C.c_char_p, C.POINTER(_P)], "FlucaViewerGetType": [_P, C.POINTER(C.c_char_p)], "FlucaViewerDestroy": [C.POINTER(_P)],
 }
+MESH_DM_SCALAR, MESH_DM_VECTOR, MESH_DM_STAG_SCALAR, MESH_DM_STAG_VECTOR = range(4)
+NS_INIT_JACOBIAN, NS_UPDATE_JACOBIAN = 0, 1
+
+
+class NSVec(C.Structure):
+    """The composite vector (v, V[3], p) of device arrays: include/fluca_host.h."""
+    _fields_ = [("v", C.c_void_p), ("V", C.c_void_p * 3), ("p", C.c_void_p)]
+
+
+# struct _NSOps / struct _MeshOps: the slot names in the reference's order (nsimpl.h:21-31, meshimpl.h:16-25); the table is the first
+# member of the object, so a handle can be read as an array of that many function pointers
+NS_OPS = ("setfromoptions", "setup", "step", "formjacobian", "formfunction", "destroy", "view", "viewsolution", "loadsolution")
+MESH_OPS = ("setfromoptions", "setup", "destroy", "view", "load", "createglobalvector", "creatematrix", "getnumberboundaries")
+
+
+def ops_table(handle, names):
+    """{slot name: function address or None} of a Mesh / NS handle."""
+    tab = C.cast(handle, C.POINTER(C.c_void_p * len(names))).contents
+    return {n: tab[i] for i, n in enumerate(names)}
 MonitorFunc = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
 for _n, _a in PROTOTYPES.items():
     _f = getattr(lib, _n)
@@ -82,7 +107,7 @@ _names = C.POINTER(C.c_char_p)
 CGNS_PROTOTYPES = {
     "FlucaViewerCGNSOpen": [C.c_char_p, C.c_char, C.POINTER(_P)], "FlucaViewerCGNSSetBatchSize": [_P, C.c_int], "FlucaViewerCGNSGetBatchSize": [_P, _ip],
     "FlucaViewerCGNSGetFileName": [_P, C.POINTER(C.c_char_p)], "FlucaViewerCGNSDestroy": [C.POINTER(_P)],
-    "NSViewSolution": [_P, _P], "NSLoadSolution": [_P, _P], "NSMonitorSolutionCGNS": [_P, _P],
+    "NSMonitorSolutionCGNS": [_P, _P],
     "FlucaCGNSCreateFile": [C.c_char_p, _Lp, _P, _P, _P], "FlucaCGNSWriteCellInfo": [C.c_char_p, _Lp],
     "FlucaCGNSCreateSolution": [C.c_char_p, _Lp, C.c_int64, C.c_int, _names, C.c_int, _names],
     "FlucaCGNSWriteCellField": [C.c_char_p, _Lp, C.c_int64, C.c_char_p, _P], "FlucaCGNSWriteFaceField": [C.c_char_p, _Lp, C.c_int64, C.c_char_p, _dp3],
@@ -100,7 +125,7 @@ def load_cgns():
         if not os.path.exists(CGNS_LIB_PATH):
             raise ImportError(f"{CGNS_LIB_PATH} is missing: it needs an HDF5 C library at build time (HDF5_ROOT, default /opt/conda); run `python -m fluca_amd.build`")
         _cgns = C.CDLL(CGNS_LIB_PATH)
-        for n, a in CGNS_PROTOTYPES.items():
+        for n, a in list(CGNS_PROTOTYPES.items()) + [("NSViewSolution", [_P, _P]), ("NSLoadSolution", [_P, _P])]:   # the last two live in libfluca_host.so
             f = getattr(_cgns, n)
             f.restype = C.c_int
             f.argtypes = a

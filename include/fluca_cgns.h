@@ -31,7 +31,9 @@
 extern "C" {
 #endif
 
-typedef struct _p_FlucaViewerCGNS *FlucaViewerCGNS;
+/* a FlucaViewer (fluca_host.h) of type FLUCAVIEWERCGNS = the reference's PETSCVIEWERFLUCACGNS: NSViewSolution, NSLoadSolution,
+ * MeshView and MeshLoad (fluca_host.h) take it as they take any viewer, and dispatch through its ops table */
+typedef FlucaViewer FlucaViewerCGNS;
 
 /* PetscViewerFlucaCGNSOpen (flucacgns.c:281-315): `filename` may hold one %d, then every batch of output steps goes to
  * its own file numbered by the first step in it (-viewer_cgns_batch_size, default 1).  mode: 'w' or 'r'. */
@@ -40,15 +42,12 @@ FlErrorCode FlucaViewerCGNSSetBatchSize(FlucaViewerCGNS viewer, int batch_size);
 FlErrorCode FlucaViewerCGNSGetBatchSize(FlucaViewerCGNS viewer, int *batch_size);
 /* name of the file the viewer is writing (or last wrote); borrowed */
 FlErrorCode FlucaViewerCGNSGetFileName(FlucaViewerCGNS viewer, const char **filename);
-/* writes TimeIterValues / ZoneIterativeData / SimulationType of the open file (rank 0) and frees the viewer */
+/* writes TimeIterValues / ZoneIterativeData / SimulationType of the open file (rank 0) and frees the viewer (= FlucaViewerDestroy) */
 FlErrorCode FlucaViewerCGNSDestroy(FlucaViewerCGNS *viewer);
 
-/* NSViewSolution (nssol.c:130-150): Velocity, FaceNormalVelocity, Pressure, then the type's own PressureHalfStep, as
- * FlowSolution<step> of the current step and time; writes the mesh first if the file is new.  Collective over the ranks. */
-FlErrorCode NSViewSolution(NS ns, FlucaViewerCGNS viewer);
-/* NSLoadSolution (nssol.c:174-203): reads the LAST FlowSolution of the file into the solution arrays and sets step and
- * time from its name and TimeValues.  After NSSetUp; the mesh sizes must match. */
-FlErrorCode NSLoadSolution(NS ns, FlucaViewerCGNS viewer);
+/* NSViewSolution / NSLoadSolution (nssol.c:130-203) are declared in fluca_host.h: with this viewer the field links Velocity,
+ * FaceNormalVelocity, Pressure and the type's PressureHalfStep become FlowSolution<step> of the current step and time (the mesh is
+ * written first if the file is new; the ranks take turns), and the LAST FlowSolution of a file is read back with its step and time. */
 /* NSMonitorSolution (nsmon.c:91-100) as an NSMonitorSet callback: ctx = a FlucaCGNSMonitor */
 typedef struct {
   FlucaViewerCGNS viewer;

@@ -10,7 +10,14 @@
  *   struct _MeshOps, MeshRegister                                                                       fluca/include/fluca/private/meshimpl.h:16-25, flucamesh.h:43-44
  *   NSCreate / NSSetType / NSRegister / NSSetMesh / NSSet{Density,Viscosity,TimeStepSize} /
  *   NSSetBoundaryCondition / NSSetFromOptions / NSSetUp / NSDestroy                                     fluca/include/flucans.h:28-60,91-92
- *   struct _NSOps (setfromoptions, setup, step, destroy)                                                fluca/include/fluca/private/nsimpl.h:21-31
+ *   struct _NSOps: all nine slots in the reference's order (setfromoptions, setup, step, formjacobian,
+ *   formfunction, destroy, view, viewsolution, loadsolution); NSFormJacobian / NSFormFunction / NSView /
+ *   NSViewSolution / NSLoadSolution dispatch through them                                               fluca/include/fluca/private/nsimpl.h:21-31, cnlinear.c:177-185,
+ *                                                                                                       nsbasic.c:301-323,353-374, nssol.c:130-203
+ *   struct _MeshOps: all eight slots (setfromoptions, setup, destroy, view, load, createglobalvector,
+ *   creatematrix, getnumberboundaries); MeshView / MeshLoad / MeshCreateGlobalVector / MeshCreateMatrix  fluca/include/fluca/private/meshimpl.h:16-25, meshbasic.c:93-127, cart.c:171-260
+ *   PetscViewer as far as these slots need it: FlucaViewer (ASCII here, the CGNS one in fluca_cgns.h)   fluca/src/viewer/impl/cgns/flucacgns.c
+ *   The structs behind Mesh / NS / FlucaViewer, for code that registers a type: include/fluca_host_impl.h
  *   NSBoundaryCondition, NSBoundaryConditionFunction                                                    fluca/include/flucansbc.h:5-22
  *   PCApply_ABF without the momentum solve (NSPressureCorrection)                                       fluca/src/ns/utils/abfpc/abfpc.c:73-101
  *   PCApply_ABF in full (NSApplyPreconditioner) and the A block of NSFormJacobian (NSSetPreviousState)  abfpc.c:48-111, cnlinearcart3d.c:2930-2941
@@ -44,11 +51,32 @@ typedef const char *NSType;
 typedef enum { MESHCART_BOUNDARY_NONE, MESHCART_BOUNDARY_PERIODIC } MeshCartBoundaryType;
 typedef enum { MESHCART_LEFT, MESHCART_RIGHT, MESHCART_DOWN, MESHCART_UP, MESHCART_BACK, MESHCART_FRONT } MeshCartBoundaryLocation;
 
+/* ---- Viewer: what PetscViewer is to the view / load slots below ----
+ * An abstract sink / source of named fields with its own ops table (include/fluca_host_impl.h).  Two types exist:
+ * FLUCAVIEWERASCII (here; PETSCVIEWERASCII as far as NSView / MeshView print) and FLUCAVIEWERCGNS (fluca_cgns.h =
+ * PETSCVIEWERFLUCACGNS, flucacgns.c).  A FlucaViewerCGNS handle IS a FlucaViewer. */
+typedef struct _p_FlucaViewer *FlucaViewer;
+typedef const char            *FlucaViewerType;
+#define FLUCAVIEWERASCII "ascii"
+#define FLUCAVIEWERCGNS  "flucacgns"
+FlErrorCode FlucaViewerASCIIOpen(const char *filename, FlucaViewer *viewer); /* NULL or "stdout": standard output */
+FlErrorCode FlucaViewerGetType(FlucaViewer viewer, FlucaViewerType *type);
+FlErrorCode FlucaViewerDestroy(FlucaViewer *viewer);
+
 /* ---- Mesh ---- */
+/* MeshDMType (flucamesh.h:20-25): which of the mesh's four DMs a vector lives on */
+typedef enum { MESH_DM_SCALAR, MESH_DM_VECTOR, MESH_DM_STAG_SCALAR, MESH_DM_STAG_VECTOR } MeshDMType;
+/* meshimpl.h:16-25, same slots in the same order.  Vec -> a device array (`device` = the HIP device the NS runs on; the
+ * reference's Vec carries its own communicator and memory space), Mat -> nothing: every operator of the path is
+ * matrix-free, the Cart type leaves creatematrix NULL and MeshCreateMatrix answers PETSC_ERR_SUP. */
 struct _MeshOps {
   FlErrorCode (*setfromoptions)(Mesh, int, char **);
   FlErrorCode (*setup)(Mesh);
   FlErrorCode (*destroy)(Mesh);
+  FlErrorCode (*view)(Mesh, FlucaViewer);
+  FlErrorCode (*load)(Mesh, FlucaViewer);
+  FlErrorCode (*createglobalvector)(Mesh, MeshDMType, int device, double **vec_dev, int64_t *n);
+  FlErrorCode (*creatematrix)(Mesh, MeshDMType, MeshDMType, void **mat);
   FlErrorCode (*getnumberboundaries)(Mesh, int *);
 };
 FlErrorCode MeshRegister(const char name[], FlErrorCode (*create)(Mesh));
@@ -72,6 +100,16 @@ FlErrorCode MeshCartGetBoundaryIndex(Mesh mesh, MeshCartBoundaryLocation loc, in
 FlErrorCode MeshCartGetCoordinateArraysRead(Mesh mesh, const double **xf, const double **yf, const double **zf); /* cart.c:467-510; GLOBAL face coordinates, borrowed */
 FlErrorCode MeshGetRank(Mesh mesh, int *rank, int *size);
 FlErrorCode MeshGetNumberBoundaries(Mesh mesh, int *nb);
+/* meshbasic.c:93-104: "Mesh Object: type: cart" + the type's view (ASCII: this rank's sizes and index ranges, cart.c:182-201;
+ * CGNS: Base / Zone / coordinates / CellInfo of a new file, cartcgns.c:8-118).  viewer NULL = standard output. */
+FlErrorCode MeshView(Mesh mesh, FlucaViewer viewer);
+/* meshbasic.c:114-127: CGNS viewers only (PETSC_ERR_ARG_WRONG otherwise); before MeshSetUp.  Takes the global sizes and the
+ * face coordinates from the file (cartcgns.c:120-158: boundary types NONE, coordLoaded); MeshSetUp then uses them (cart.c:131-140) */
+FlErrorCode MeshLoad(Mesh mesh, FlucaViewer viewer);
+/* meshbasic.c: MeshCreateGlobalVector / MeshCreateMatrix.  The array is this rank's block of the DM (cells: N, 3N component-major;
+ * faces: x-, y-, z-face arrays one after the other, DMStag ownership), zeroed, freed with fl_free. */
+FlErrorCode MeshCreateGlobalVector(Mesh mesh, MeshDMType type, int device, double **vec_dev, int64_t *n);
+FlErrorCode MeshCreateMatrix(Mesh mesh, MeshDMType rtype, MeshDMType ctype, void **mat);
 FlErrorCode MeshDestroy(Mesh *mesh);
 
 /* ---- NS ---- */
@@ -85,11 +123,26 @@ typedef struct {
   void                       *ctx_pressure;
 } NSBoundaryCondition;
 
+/* The composite vector of ns->x / ns->r / ns->sol (a Vec over the DMComposite of vdm, Sdm, sdm in the reference): device
+ * arrays v (3*cells, component-major), V[3] (x-, y-, z-faces), p (cells). */
+typedef struct {
+  double *v, *V[3], *p;
+} NSVec;
+typedef enum { NS_INIT_JACOBIAN, NS_UPDATE_JACOBIAN } NSFormJacobianType; /* flucans.h:65-68 */
+/* ns->J: the reference's 3x3 MATNEST [A 0 kG; -T I -R; 0 D 0] is the fl_momentum handle here (fl_abf_jacobian_mult = MatMult(J)) */
+typedef fl_momentum *NSMat;
+
+/* nsimpl.h:21-31, the same nine slots in the same order (filled for NSCNLINEAR as at cnlinear.c:177-185) */
 struct _NSOps {
   FlErrorCode (*setfromoptions)(NS, int, char **);
   FlErrorCode (*setup)(NS);
-  FlErrorCode (*step)(NS); /* NSStep_CNLinear: VecCopy(sol, sol0) + the CNLinear step on device arrays (see NSStep below) */
+  FlErrorCode (*step)(NS);
+  FlErrorCode (*formjacobian)(NS, const NSVec *x, NSMat J, NSFormJacobianType type);
+  FlErrorCode (*formfunction)(NS, const NSVec *x, NSVec *f);
   FlErrorCode (*destroy)(NS);
+  FlErrorCode (*view)(NS, FlucaViewer);
+  FlErrorCode (*viewsolution)(NS, FlucaViewer);
+  FlErrorCode (*loadsolution)(NS, FlucaViewer);
 };
 FlErrorCode NSRegister(const char name[], FlErrorCode (*create)(NS));
 FlErrorCode NSCreate(NS *ns);
@@ -119,6 +172,23 @@ FlErrorCode NSGetBoundaryCondition(NS ns, int index, NSBoundaryCondition *bc);
 FlErrorCode NSSetFromOptions(NS ns, int argc, char **argv);
 FlErrorCode NSSetUp(NS ns);
 FlErrorCode NSStep(NS ns);
+/* nsbasic.c:301-323: PetscUseTypeMethod(ns, formjacobian / formfunction) inside the NS_FormJacobian / NS_FormFunction events.
+ * CNLinear is linear (SNESSetPicard, nsbasic.c:248): formfunction writes the right-hand side b of J x = b into f (momrhs,
+ * interprhs, contrhs = 0; x is not read), formjacobian refreshes the A block of J from ns->sol0 (INIT: wires the constant blocks
+ * first).  NSStep calls both through the table, so a type registered with NSRegister that replaces one of them is honoured. */
+FlErrorCode NSFormJacobian(NS ns, const NSVec *x, NSMat J, NSFormJacobianType type);
+FlErrorCode NSFormFunction(NS ns, const NSVec *x, NSVec *f);
+FlErrorCode NSGetJacobian(NS ns, NSMat *J);                /* ns->J */
+FlErrorCode NSGetSolverVectors(NS ns, NSVec *x, NSVec *r); /* ns->x, ns->r (the right-hand side the last step solved with) */
+/* nsbasic.c:353-374: ASCII viewers only, "NS Object: type: ...", parameters, step and time, then the type's view; NULL = stdout */
+FlErrorCode NSView(NS ns, FlucaViewer viewer);
+/* nssol.c:130-150: VecView of the field links Velocity, FaceNormalVelocity, Pressure, then PetscTryTypeMethod(viewsolution)
+ * (CNLinear: PressureHalfStep, cnlinear.c:146-153).  With a FlucaViewerCGNS: FlowSolution<step> of the current step and
+ * time; writes the mesh first if the file is new.  Collective over the ranks. */
+FlErrorCode NSViewSolution(NS ns, FlucaViewer viewer);
+/* nssol.c:174-203: FlucaVecLoad of the same fields from the LAST FlowSolution of the file, PetscUseTypeMethod(loadsolution),
+ * then step and time from the viewer's output sequence.  After NSSetUp; the mesh sizes must match. */
+FlErrorCode NSLoadSolution(NS ns, FlucaViewer viewer);
 FlErrorCode NSGetTimeStep(NS ns, int64_t *step);
 FlErrorCode NSGetTime(NS ns, double *t);
 FlErrorCode NSDestroy(NS *ns);
@@ -169,8 +239,9 @@ FlErrorCode NSGetInnerIterations(NS ns, int *momentum_its, int *schur_its);
 FlErrorCode NSSetPreviousState(NS ns, const double *const V0_dev[3], const double *const v0interp_dev[9]);
 /* the whole PCApply_ABF (abfpc.c:48-111): v* = A^-1 momrhs, V* = interprhs + T v*, p = S^-1(contrhs - D V*),
  * v = v* - G p, V = V* - Gst p.  v: 3*cells component-major.  stats[0] = kspA, stats[1] = kspS (may be NULL).
- * Options: -ns_abf_momentum_ksp_type bcgs (gmres, PETSc's default, is not built: PETSC_ERR_SUP),
- * -ns_abf_momentum_pc_type jacobi|none, -ns_abf_momentum_ksp_{rtol,atol,divtol,max_it}. */
+ * Options: -ns_abf_momentum_ksp_type bcgs|gmres (gmres = PETSc's default type for kspA, restart
+ * -ns_abf_momentum_ksp_gmres_restart 30), -ns_abf_momentum_pc_type jacobi|none (ilu, PETSc's default PC, has no
+ * matrix-free form: PETSC_ERR_SUP), -ns_abf_momentum_ksp_{rtol,atol,divtol,max_it}. */
 FlErrorCode NSApplyPreconditioner(NS ns, const double *momrhs_dev, const double *const interprhs_dev[3], const double *contrhs_dev, double *v_dev, double *const V_dev[3], double *p_dev, fl_ksp_stats stats[2]);
 FlErrorCode NSGetMomentumKSPOptions(NS ns, fl_ksp_opts **opts);
 FlErrorCode NSGetImmersedBoundary(NS ns, fl_ibm **ibm);

@@ -126,7 +126,7 @@ def test_overlapped_exchange_changes_nothing(tmp_path, world, n, ranks, bc):
     """The exchange of r hidden behind k_cg_Bq (the neighbour's ghost is formed as r - alpha q from the q that k_cg_A kept on the boundary
     layers, before k_cg_Bq has written the new r anywhere) against the sequential order (the new r packed after k_cg_Bq).  Each mode is
     bit-reproducible run to run; between the modes a ghost may differ from its owner's cell in the last bit (measured: histories equal for
-    four iterations, then 4e-16 apart, x 6e-16 -- tools/experiments/r03_overlap_det.py), so: same iteration count and reason, history and
+    four iterations, then 4e-16 apart, x 6e-16; measured in round 3), so: same iteration count and reason, history and
     x equal to 1e-12 relative."""
     for ov in (1, 0):
         mpc.run_ranks(world, _overlap_worker, n, ranks, bc, ov, str(tmp_path))

@@ -129,7 +129,7 @@ def test_degenerate_shapes(n, bc, ksp):
         assert np.linalg.norm((xg - xg.mean()) - (xo - xo.mean())) <= 1e-6 * max(np.linalg.norm(xo), 1e-300) + 1e-12
     else:
         # these thin grids are 1-D-like and ill conditioned (300 - 400 BiCGStab iterations): round-off moves the stopping iteration by
-        # tens and the answer by 1e-4 (the same for the stored-product kernels, tools/experiments/bcgs_diag2.py); what must hold is
+        # tens and the answer by 1e-4 (the same for the stored-product kernels; measured in round 2); what must hold is
         # the early history (above) and the true residual at the end
         assert abs(ig["iters"] - io["iters"]) <= max(3, io["iters"] // 4), (ig["iters"], io["iters"])
         assert np.linalg.norm(b - S.mult(xg)) <= 5e-8 * np.linalg.norm(b)

@@ -148,6 +148,16 @@ def test_ns_registry_options_and_state_errors(H):
     assert H.lib.NSSetTimeStep(ns, 0) == 0 and H.lib.NSSetTime(ns, 0.75) == 0
     assert H.lib.NSGetConvergedReason(ns, C.byref(why)) == 0 and why.value == 1             # NS_CONVERGED_TIME
     assert H.lib.NSSetTime(ns, 0.0) == 0 and H.lib.NSSetTimeStep(ns, -1) == H.ERR_ARG_OUTOFRANGE
+    # PetscOptionsBool: a bare flag means true -- as the last argument too, and in front of another option -- and a value must be a logical one
+    for opts, want in ((("-ns_abf_schur_ksp_cg_single_reduction",), 1), (("-ns_abf_schur_ksp_cg_single_reduction", "false"), 0),
+                       (("-ns_abf_schur_ksp_cg_single_reduction", "-ns_max_steps", 5), 1), (("-ns_abf_schur_ksp_cg_single_reduction", "0"), 0),
+                       (("-ns_max_steps", 5, "-ns_abf_schur_ksp_cg_single_reduction", "yes"), 1)):
+        argc, av = H.argv(*opts)
+        assert H.lib.NSSetFromOptions(ns, argc, av) == 0 and o.contents.cg_single_reduction == want, opts
+    argc, av = H.argv("-ns_abf_schur_ksp_cg_single_reduction", "maybe")
+    assert H.lib.NSSetFromOptions(ns, argc, av) == H.ERR_ARG_WRONG
+    argc, av = H.argv("-ns_error_if_step_failed")
+    assert H.lib.NSSetFromOptions(ns, argc, av) == 0 and H.lib.NSGetErrorIfStepFailed(ns, C.byref(flg)) == 0 and flg.value == 1
     assert H.lib.NSStep(ns) == H.ERR_ARG_WRONGSTATE                    # before NSSetUp
     argc, av = H.argv("-ns_ksp_type", "fgmres")                        # outer KSP: gmres (default), richardson, preonly
     assert H.lib.NSSetFromOptions(ns, argc, av) == H.ERR_SUP

@@ -1,11 +1,11 @@
 """Random grid sizes / boundary types / stretching: FL_PC_MG (fl_mg.hip) against the oracle's restatement of the same cycle.
-usage: python tools/experiments/fuzz_mg.py [seed] [cases]"""
+usage: python tools/fuzz_mg.py [seed] [cases]"""
 import ctypes as C
 import os
 import sys
 import traceback
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 
 from oracle import fluca_oracle as fo

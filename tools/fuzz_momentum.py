@@ -1,11 +1,11 @@
 """Random small grids / boundary types / stretching: the matrix-free momentum block (apply, diagonal, BiCGStab and GMRES solves) and the
 face interpolations against the oracle's assembled rows; every case also with the state handed over together with v0 (k_mom3: v0interp formed in
-the kernel on inner faces, stored values with a random boundary-only vbc on the block-end faces).  usage: python tools/experiments/fuzz_momentum.py [seed] [cases]"""
+the kernel on inner faces, stored values with a random boundary-only vbc on the block-end faces).  usage: python tools/fuzz_momentum.py [seed] [cases]"""
 import os
 import sys
 import traceback
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 
 from oracle import fluca_oracle as fo

@@ -1,10 +1,10 @@
 """Random small grids / boundary types / stretching: HIP path against the oracle for apply, rhs, projection, CG, BiCGStab, Chebyshev.
-Prints every case that deviates; the interesting ones go into tests/ as named cases.  usage: python tools/experiments/fuzz_parity.py [seed] [cases]"""
+Prints every case that deviates; the interesting ones go into tests/ as named cases.  usage: python tools/fuzz_parity.py [seed] [cases]"""
 import os
 import sys
 import traceback
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 
 from oracle import fluca_oracle as fo
