@@ -55,17 +55,18 @@ def cg_roofline(info, ncell, variant, ms_per_iter, traffic=None):
     ks = []
     for (name, algo, moved), ms, n in zip(CG_KERNELS[variant], (info["kernel_ms"], info["kernel2_ms"]), (info["kernel_launches"], info["kernel2_launches"])):
         ach = algo * ncell / (ms * 1e-3) / 1e9 if ms > 0 else None
-        tr = traffic.get(name.split(" ")[0]) if isinstance(traffic, dict) else None
+        tr, tstale = traffic.get(name.split(" ")[0], (None, None)) if isinstance(traffic, dict) else (None, None)
         tb, src = (tr, "rocprofv3 PMC pass (profiles/)") if tr else (moved * ncell, "moved bytes per cell x cells (no counter pass for this workload)")
         tg = tb / (ms * 1e-3) / 1e9 if ms > 0 else None
         ks.append({"kernel": name, "algorithmic_bytes_per_cell": algo, "moved_bytes_per_cell": moved, "avg_launch_ms": ms, "launches_timed": n, "achieved": ach,
                    "frac": ach / HBM_PEAK_GBS if ach else None, "moved_GBps": moved * ncell / (ms * 1e-3) / 1e9 if ms > 0 else None,
-                   "traffic": tr, "traffic_bytes_used": tb, "traffic_source": src, "traffic_GBps": tg, "traffic_frac": tg / HBM_PEAK_GBS if tg else None})
+                   "traffic": tr, "traffic_stale": tstale, "traffic_bytes_used": tb, "traffic_source": src, "traffic_GBps": tg, "traffic_frac": tg / HBM_PEAK_GBS if tg else None})
     dom = max(ks, key=lambda k: k["avg_launch_ms"] or 0.0)
     it_ach = B_ITER_ALGO * ncell / (ms_per_iter * 1e-3) / 1e9
     it_tb = sum(k["traffic_bytes_used"] for k in ks)
     it_tg = it_tb / (ms_per_iter * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": dom["traffic"],
+            "traffic_stale": (any(k["traffic_stale"] for k in ks) if any(k["traffic"] for k in ks) else None),
             "traffic_GBps": dom["traffic_GBps"], "traffic_frac": dom["traffic_frac"], "traffic_source": dom["traffic_source"],
             "frac_note": "frac = algorithmic bytes of the textbook steps this kernel replaces / time / peak (SURVEY 8d; may exceed 1); traffic_frac = bytes that crossed "
                          "the HBM interface / time / peak: the physical fraction",
@@ -129,9 +130,7 @@ def cpu_baseline(sample_n, sample_iters, full_n, full_iters):
     host has the memory (>= 32 GB available for the 12 GB CSR + vectors) the headline's OWN grid is run for the headline's own number
     of iterations -- `value` is then a measurement at the metric's size -- and the bounded 256^3 sample is kept as a second entry;
     otherwise the sample, scaled by the cell count, is the value and says so."""
-    from oracle import fluca_oracle as fo
-    # a one-GPU box's CPU share is 16 cores; never spawn more OpenMP threads than that (or than the affinity mask)
-    fo.set_num_threads(min(16, len(os.sched_getaffinity(0)), fo.num_threads()))
+    fo = _oracle_threads()
     mem = _host_mem_available_gb()
     full_ok = bool(mem and mem >= 32.0) and full_n is not None
     sample = _cpu_leg(sample_n, sample_iters)
@@ -202,6 +201,98 @@ def petsc_cpu(sample_n, iters, cores):
         return f"unavailable ({e!r})"
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the last committed counter pass (profiles/pmc_<kernel>.json; counters cannot be read from inside
+    the run) and whether that pass is STALE: it records the git blob hashes of the kernel's source files and the hipcc flags of the day it was
+    taken (fluca_amd/provenance.py); a tree whose hashes differ is running another kernel than the one that was counted."""
+    from fluca_amd import provenance
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", f"pmc_{kernel}.json")))
+    except Exception:  # noqa: BLE001
+        return None, None
+    return d.get("hbm_bytes_per_launch"), provenance.stale(kernel, d.get("sources_at_profiling"))
+
+
+def _oracle_threads():
+    from oracle import fluca_oracle as fo
+    # a one-GPU box's CPU share is 16 cores; never spawn more OpenMP threads than that (or than the affinity mask)
+    fo.set_num_threads(min(16, len(os.sched_getaffinity(0)), fo.num_threads()))
+    return fo
+
+
+def c3_parity(P, b, box, bc, steps=20):
+    """BASELINE config 3 at its own size against the oracle (not against another HIP kernel): the oracle's assembled 512^3 channel S and its
+    KSPCHEBYSHEV + PCJACOBI restatement, `steps` steps without a norm, on the right-hand side the timed sweep used; the HIP path runs the
+    kernel the sweep ran (the fused two-step kernel) with its own default interval (separable Gershgorin bound x (0.1, 1.1))."""
+    mem = _host_mem_available_gb()
+    if not (mem and mem >= 32.0):
+        return {"skipped": f"host memory {mem} GB < 32 GB for the 512^3 CSR"}
+    fo = _oracle_threads()
+    t0 = time.perf_counter()
+    g = fo.Grid.uniform((512,) * 3, box, bc, 1e-3)
+    S = g.assemble_S()
+    lam = S.gershgorin(fo.PC_JACOBI)
+    P.synchronize()
+    bh = b.cpu().numpy()
+    xo, io = S.solve(bh, ksp=fo.KSP_CHEBYSHEV, pc=fo.PC_JACOBI, norm=fo.NORM_NONE, nullspace=False, maxit=steps, emin=0.1 * lam, emax=1.1 * lam, history=False)
+    xg, ig = P.solve(b, type=2, norm_type=3, remove_nullspace=0, maxit=steps, check_every=100, profile=1)
+    P.synchronize()
+    xg = xg.cpu().numpy()
+    scale = float(np.abs(xo).max())
+    return {"steps": steps, "steps_gpu": ig["iters"], "steps_cpu": io["iters"], "reason_gpu": ig["reason"], "reason_cpu": io["reason"],
+            "fused_kernel": ig["kernel_launches"] * 2 == steps, "rel_max_diff_x": float(np.abs(xg - xo).max() / scale),
+            "rel_l2_diff_x": float(np.linalg.norm(xg - xo) / np.linalg.norm(xo)), "oracle_gershgorin": lam, "oracle_seconds": io["seconds"],
+            "seconds_total": time.perf_counter() - t0, "oracle": "assembled 512^3 CSR (oracle/fluca_oracle.c), KSPCHEBYSHEV + PCJACOBI restatement"}
+
+
+def momentum_parity(n1=256, its=5):
+    """The momentum block against the oracle's ASSEMBLED A (cnlinearcart3d.c:425-646, 873-1294 restated row by row) at 256^3 (50 M rows,
+    650 M non-zeros): MatMult(A) through k_mom3 (state handed over with v0, the way NSStep does it), diag(A), and `its` Jacobi-BiCGStab
+    iterations -- cavity boundary types, random V0 / v0, the bench's dt and viscosity scaled to this grid."""
+    mem = _host_mem_available_gb()
+    if not (mem and mem >= 40.0):
+        return {"skipped": f"host memory {mem} GB < 40 GB for the assembled 256^3 momentum matrix"}
+    fo = _oracle_threads()
+    from fluca_amd import poisson as flp
+    t0 = time.perf_counter()
+    box = [(0.0, 1.0), (0.0, 1.0), (0.0, 0.5)]
+    bc = [1, 1, 1, 1, 4, 1]
+    n = (n1,) * 3
+    g = fo.Grid.uniform(n, box, bc, 1e-3)
+    rng = np.random.default_rng(11)
+    V0 = [rng.uniform(-1, 1, g.nface[d]) for d in range(3)]
+    v0 = rng.uniform(-1, 1, 3 * g.ncell)
+    x = rng.uniform(-1, 1, 3 * g.ncell)
+    hh = 1.0 / n1
+    dt, rho, mu = 0.5 * hh, 1.0, 0.5 * hh
+    W = g.apply_B(v0)
+    A = g.assemble_momentum(1.0, dt, -0.5 * mu * dt / rho, V0, W)
+    del W
+    yo, do = A.mult(x), A.diag()
+    xo, io = A.solve(x, ksp=fo.KSP_BCGS, pc=fo.PC_JACOBI, nullspace=False, rtol=0.0, atol=0.0, maxit=its, history=True)
+    t_cpu = time.perf_counter() - t0
+    P = flp.Poisson.uniform(n, box, bc, 1e-3)      # on its own stream, ordered against torch's current one by the wrapper
+    M = flp.Momentum(P)
+    dev = lambda a: torch.as_tensor(a, device="cuda")  # noqa: E731
+    v0d = dev(v0)
+    Wd = M.interp_faces(v0d, ends_only=True)            # only the block-end faces are read from the stored fields (fl_momentum_interp_faces_ends)
+    M.set_state(dt, rho, mu, [dev(a) for a in V0], Wd, v0=v0d)
+    xd = dev(x)
+    yg, dg = M.apply(xd).cpu().numpy(), M.diagonal().cpu().numpy()
+    xg, ig = M.solve(xd, rtol=0.0, atol=0.0, maxit=its, history=True)
+    xg = xg.cpu().numpy()
+    hist_g, hist_o = np.asarray(ig["history"][:its + 1]), np.asarray(io["history"][:its + 1])
+    out = {"cells_per_axis": n1, "rows": int(A.nrow), "nnz": int(A.nnz), "kernel": "k_mom3 (fl_momentum_set_state_v0)",
+           "rel_max_diff_apply": float(np.abs(yg - yo).max() / np.abs(yo).max()), "rel_max_diff_diag": float(np.abs(dg - do).max() / np.abs(do).max()),
+           "bcgs_iters_gpu": ig["iters"], "bcgs_iters_cpu": io["iters"], "rel_max_diff_x": float(np.abs(xg - xo).max() / np.abs(xo).max()),
+           "rel_max_diff_history": float(np.abs(hist_g - hist_o).max() / np.abs(hist_o).max()), "rnorm_gpu": ig["rnorm"], "rnorm_cpu": io["rnorm"],
+           "oracle_seconds": t_cpu, "seconds_total": time.perf_counter() - t0,
+           "oracle": "assembled A = I + dt C - (mu dt / 2 rho) L (oracle/fluca_oracle.c fo_assemble_momentum), KSPBCGS + PCJACOBI restatement"}
+    M.close()
+    P.close()
+    return out
+
+
 def measured_stream_rates():
     import ctypes as C
 
@@ -231,7 +322,7 @@ def measured_stream_rates():
     return res
 
 
-def other_configs(stream):
+def other_configs(stream, parity=True):
     """Driver-timed lines for the other single-GPU configurations of BASELINE.json, each with its own roofline object (same
     conventions as the headline: inputs resident, host clock around a synchronised region, HIP events for the dominant kernel)."""
     import ctypes as C
@@ -279,24 +370,23 @@ def other_configs(stream):
     fused = info["kernel_launches"] * 2 == K            # the fused kernel applies two steps per launch
     per_launch = (2 if fused else 1) * B_CHEB_ALGO * P.ncell
     ach = per_launch / (info["kernel_ms"] * 1e-3) / 1e9
-    pmc = os.path.join(ROOT, "profiles", "pmc_k_cheb2.json")
-    traffic = None
-    if os.path.exists(pmc):
-        try:
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-        except Exception:  # noqa: BLE001
-            traffic = None
+    traffic, tstale = pmc_traffic("k_cheb2") if fused else (None, None)
     cfg["C3"] = {"workload": "512^3 channel [VELOCITY, PRESSURE_OUTLET, wall, wall, PERIODIC, PERIODIC], Chebyshev-Jacobi, KSP_NORM_NONE, fixed 100 steps",
                  "metric": "Chebyshev-Jacobi steps/s", "value": K / dt, "steps": K, "ms_per_step": dt / K * 1e3,
                  "step_algorithmic_GBps": B_CHEB_ALGO * P.ncell * K / dt / 1e9,
                  "roofline": {"bound": "hbm", "kernel": "k_cheb2 (two fused Chebyshev-Jacobi steps per launch)" if fused else "k_cheb", "achieved": ach, "peak": HBM_PEAK_GBS,
-                              "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                              "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_stale": tstale,
                               "traffic_GBps": (traffic or B_CHEB_ALGO * P.ncell) / (info["kernel_ms"] * 1e-3) / 1e9,
                               "traffic_frac": (traffic or B_CHEB_ALGO * P.ncell) / (info["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "traffic_source": "rocprofv3 PMC pass (profiles/pmc_k_cheb2.json)" if traffic else "40 B x cells per launch (x, b, d read; x', d' written once)",
                               "frac_note": "frac counts 40 algorithmic B/cell per STEP, two steps per launch; traffic_frac is the physical fraction",
                               "algorithmic_bytes_per_cell_per_launch": per_launch / P.ncell,
                               "steps_per_launch": 2 if fused else 1, "avg_launch_ms": info["kernel_ms"], "launches_timed": info["kernel_launches"]}}
+    if parity:
+        try:
+            cfg["C3"]["parity_on_full_grid"] = c3_parity(P, b, box, [1, 2, 1, 1, 3, 3])
+        except Exception as e:  # noqa: BLE001  (never lose the bench line over the cross-check)
+            cfg["C3"]["parity_on_full_grid"] = {"error": repr(e)}
     P.close()
     del b, x
 
@@ -369,11 +459,7 @@ def other_configs(stream):
         # per cell: x 24 + y 24 + v0 24 + V0 24 (k_mom3; the nine stored v0interp fields, 72 B more, are read by k_mom2 only); a BiCGStab iteration = 2 products
         # (one also reads the shadow residual) + 3 vector updates
         B_APPLY, B_BCGS = 96, 552
-        tr = None
-        try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_k_mom3.json"))).get("hbm_bytes_per_launch")
-        except Exception:  # noqa: BLE001
-            tr = None
+        tr, trstale = pmc_traffic("k_mom3")
         ach = B_APPLY * P.ncell / (kms["plain"] * 1e-3) / 1e9
         tg = (tr or B_APPLY * P.ncell) / (kms["plain"] * 1e-3) / 1e9
         cfg["momentum"] = {"workload": "512^3 cavity grid, momentum block A = I + dt C - (mu dt / 2 rho) L matrix-free (3 velocity components; V0 on faces, v0interp = B v0 formed in the kernel), "
@@ -381,7 +467,7 @@ def other_configs(stream):
                            "metric": "momentum BiCGStab iterations/s", "value": info["iters"] / dt, "steps": info["iters"], "ms_per_step": dt / max(info["iters"], 1) * 1e3,
                            "iteration_algorithmic_GBps": B_BCGS * P.ncell * info["iters"] / dt / 1e9, "kernel_ms": kms,
                            "roofline": {"bound": "hbm", "kernel": "k_mom3 (MatMult(A): two cells per lane on 128 x 8 tiles, v0interp formed from v0 in the kernel)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                        "frac": ach / HBM_PEAK_GBS, "traffic": tr, "traffic_GBps": tg, "traffic_frac": tg / HBM_PEAK_GBS,
+                                        "frac": ach / HBM_PEAK_GBS, "traffic": tr, "traffic_stale": trstale, "traffic_GBps": tg, "traffic_frac": tg / HBM_PEAK_GBS,
                                         "traffic_source": "rocprofv3 PMC pass (profiles/pmc_k_mom3.json)" if tr else "96 B x cells",
                                         "algorithmic_bytes_per_cell": B_APPLY, "avg_launch_ms": kms["plain"], "launches_timed": 10,
                                         "iteration": {"algorithmic_bytes_per_cell": B_BCGS, "ms": dt / max(info["iters"], 1) * 1e3,
@@ -390,6 +476,12 @@ def other_configs(stream):
         P.close()
         del v
         torch.cuda.empty_cache()
+        if parity:
+            try:
+                cfg["momentum"]["parity"] = momentum_parity()
+            except Exception as e:  # noqa: BLE001
+                cfg["momentum"]["parity"] = {"error": repr(e)}
+            torch.cuda.empty_cache()
     except Exception as e:  # noqa: BLE001
         cfg["momentum"] = {"error": repr(e)}
 
@@ -606,12 +698,7 @@ def main():
     # inside the run, so the last committed pass is quoted (null when the workload is not the one that was profiled)
     traffic = None
     if args.cells == 512 and args.variant == 0:
-        traffic = {}
-        for kname in ("k_cg_A", "k_cg_Bq"):
-            try:
-                traffic[kname] = json.load(open(os.path.join(ROOT, "profiles", f"pmc_{kname}.json"))).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic[kname] = None
+        traffic = {kname: pmc_traffic(kname) for kname in ("k_cg_A", "k_cg_Bq")}
     out = {
         "metric": "pressure-Poisson Jacobi-PCG iterations/s, 512^3 cells per GPU",
         "value": value, "unit": "512^3-equivalent PCG iterations/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
@@ -671,7 +758,7 @@ def main():
         del b, x, pstar
         torch.cuda.empty_cache()
         try:
-            out["configs"] = other_configs(stream)
+            out["configs"] = other_configs(stream, parity=not args.skip_cpu)
         except Exception as e:  # noqa: BLE001
             out["configs"] = {"error": repr(e)}
     if world == 1 and not args.skip_extras:

@@ -121,6 +121,7 @@ PROTOTYPES = {
     "fl_momentum_apply": (C.c_int, [_P, _P, _P]),
     "fl_momentum_diagonal": (C.c_int, [_P, _P]),
     "fl_momentum_rowsum": (C.c_int, [_P, _P]),
+    "fl_momentum_gershgorin": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "fl_abf_set_ainv_types": (C.c_int, [_P, C.c_int, C.c_int]),
     "fl_abf_schur_apply": (C.c_int, [_P, _P, _P]),
     "fl_momentum_solve": (C.c_int, [_P, _P, _P, C.POINTER(fl_ksp_opts), C.POINTER(fl_ksp_stats)]),

@@ -266,6 +266,25 @@ extern "C" int fl_poisson_barrier(fl_poisson *h)
   return FL_SUCCESS;
 }
 
+// max of one host number over the ranks of the handle's communicator, through the sum all-reduce it has: every rank writes its value into its
+// own slot of a zeroed array (at most NSLOT ranks).  A host wait; for set-up quantities only (bounds, estimates).
+int fl_allreduce_max(fl_poisson *h, double *v)
+{
+  if (!h->multi) return 0;
+  const int nr = h->comm.nranks;
+  if (nr > NSLOT) return FL_ERR_SUP;
+  double host[NSLOT] = {0., 0., 0., 0., 0., 0., 0., 0.};
+  host[h->comm.rank] = *v;
+  FL_HIP(hipMemcpyAsync(h->sums, host, sizeof(double) * NSLOT, hipMemcpyHostToDevice, h->stream));
+  FL_CHK(h->comm.allreduce(h->stream, h->sums, NSLOT));
+  FL_HIP(hipMemcpyAsync(host, h->sums, sizeof(double) * NSLOT, hipMemcpyDeviceToHost, h->stream));
+  FL_HIP(hipStreamSynchronize(h->stream));
+  double mx = host[0];
+  for (int a = 1; a < nr; ++a) mx = std::max(mx, host[a]);
+  *v = mx;
+  return 0;
+}
+
 extern "C" int fl_poisson_sizes(const fl_poisson *h, int64_t out[4])
 {
   if (!h || !out) return FL_ERR_ARG_NULL;

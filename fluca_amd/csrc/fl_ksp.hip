@@ -1530,18 +1530,8 @@ int fl_solve_cheb(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *
     emin = 0.1 * lam;  // -ksp_chebyshev_esteig 0,0.1,0,1.1 applied to the bound
     emax = 1.1 * lam;
   }
-  init_scal(h, o);
+  FL_CHK(fl_cheb_begin(h, o, emin, emax));
   KspScal &S = *h->scal_host;
-  S.scale     = 2. / (emax + emin);
-  const double alpha = 1. - S.scale * emin;
-  S.mu        = 1. / alpha;
-  S.omegaprod = 2. / alpha;
-  S.ckm1      = 1.;
-  S.ck        = S.mu;
-  S.cheb_rho  = 0.;        // step 0: d_1 = scale * z_0
-  S.cheb_c    = S.scale;
-  FL_HIP(hipEventRecord(h->ev0, s));
-  hipLaunchKernelGGL(k_scal_set, dim3(1), dim3(1), 0, s, h->scal, S);  // by value: the host copy may be refilled at once
   // X1 (P0) is fully written by the first step before anything reads it; its wall ghosts are zero since allocation
   for (double *v : {h->q, h->xp}) FL_CHK(fl_zero_vec(h, v));
   launch_pad_copy(s, g, b, h->r);
@@ -1634,3 +1624,30 @@ int fl_bcgs_fin_step(fl_poisson *h, int mode, int nblocks, int nslot, int nhist)
 }
 
 int fl_ksp_finish(fl_poisson *h, const fl_ksp_opts *o, fl_ksp_stats *st) { return finish_stats(h, o, st); }
+
+// KSPCHEBYSHEV's scalars for the interval [emin, emax] (PETSc's recurrence: scale = 2 / (emax + emin), mu = 1 / (1 - scale emin),
+// c_0 = 1, c_1 = mu, omega_k = (2 mu) c_k / c_{k+1}); step 0 is x_1 = x_0 + scale z_0.  The momentum solve shares them.
+int fl_cheb_begin(fl_poisson *h, const fl_ksp_opts *o, double emin, double emax)
+{
+  init_scal(h, o);
+  KspScal &S = *h->scal_host;
+  S.scale     = 2. / (emax + emin);
+  const double alpha = 1. - S.scale * emin;
+  S.mu        = 1. / alpha;
+  S.omegaprod = 2. / alpha;
+  S.ckm1      = 1.;
+  S.ck        = S.mu;
+  S.cheb_rho  = 0.;        // step 0: d_1 = scale * z_0
+  S.cheb_c    = S.scale;
+  FL_HIP(hipEventRecord(h->ev0, h->stream));
+  hipLaunchKernelGGL(k_scal_set, dim3(1), dim3(1), 0, h->stream, h->scal, S);  // by value: the host copy may be refilled at once
+  return 0;
+}
+
+int fl_cheb_fin_step(fl_poisson *h, int nblocks, int nhist)
+{
+  hipStream_t s = h->stream;
+  return fin_step(h, nblocks, 3, [=](const double *partial, int nb, int stride, const double *sums) {
+    hipLaunchKernelGGL(k_cheb_fin, dim3(1), dim3(256), 0, s, partial, nb, stride, sums, h->scal, h->hist, nhist);
+  });
+}

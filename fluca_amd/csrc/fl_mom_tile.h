@@ -96,11 +96,27 @@ __device__ __forceinline__ void mom_row_comp(const MomRow &r, double2 um, double
   y = fma2(wh, r.gh, fma2(wl, r.gl, fma2(r.ap, up, fma2(r.ac, uc, fma2(r.am, um, y)))));
 }
 
+// Sum of the absolute values of one axis' row of component c OUTSIDE the diagonal (the Gershgorin radius of the row, OUT == 3): the
+// entries on the component's own columns, am and ap, and -- through G = N . u_D -- wl t3, wl t4 + wh t5, wh t6 on the columns m, c, p of the
+// face-normal component D.  own = (c == D): those three fall on the component's own columns, m and p merge with am and ap, the centre one
+// is part of the diagonal (the term the DG path adds to da).  t3..t6: the face-interpolation numbers of mom_row_coef.
+__device__ __forceinline__ double2 abs2(double2 a) { return make_double2(fabs(a.x), fabs(a.y)); }
+__device__ __forceinline__ double2 add2(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 mom_row_abs(const MomRow &r, double2 t3, double2 t4, double2 t5, double2 t6, double2 wl, double2 wh, bool own)
+{
+  if (own) return add2(abs2(fma2(wl, t3, r.am)), abs2(fma2(wh, t6, r.ap)));
+  return add2(add2(abs2(r.am), abs2(r.ap)), add2(add2(abs2(mul2(wl, t3)), abs2(fma2(wh, t5, mul2(wl, t4)))), abs2(mul2(wh, t6))));
+}
+__device__ __forceinline__ double2 mom_row_abs(const MomRow &r, double t3, double t4, double t5, double t6, double2 wl, double2 wh, bool own)
+{
+  return mom_row_abs(r, make_double2(t3, t3), make_double2(t4, t4), make_double2(t5, t5), make_double2(t6, t6), wl, wh, own);
+}
+
 // general rows (a cell next to an end of the axis): T(q) = scaled number q of build_axis_momentum, uf = the far column of the
-// one-sided second-derivative rows
-template <int D, bool DG, class TF>
+// one-sided second-derivative rows.  AB: aacc[c] += the row's absolute off-diagonal sum (see mom_row_abs; the far column counts)
+template <int D, bool DG, bool AB = false, class TF>
 __device__ __forceinline__ void mom_row_wall(TF T, const double (&um)[3], const double (&uc)[3], const double (&up)[3], const double (&uf)[3], double vl, double vh, const double (&wl)[3],
-                                             const double (&wh)[3], double (&yacc)[3], double (&dacc)[3])
+                                             const double (&wh)[3], double (&yacc)[3], double (&dacc)[3], double *aacc = nullptr)
 {
   const double Nl0 = T(11), Nl1 = T(12), Nl2 = T(13), Nh0 = T(17), Nh1 = T(18), Nh2 = T(19);
   const double amt = fma(vh, T(14), fma(vl, T(8), T(0))), act = fma(vh, T(15), fma(vl, T(9), T(1))), apt = fma(vh, T(16), fma(vl, T(10), T(2))), aft = T(3);
@@ -111,6 +127,10 @@ __device__ __forceinline__ void mom_row_wall(TF T, const double (&um)[3], const 
     const double am = c == D ? amn : amt, ac = c == D ? acn : act, ap = c == D ? apn : apt, af = c == D ? afn : aft;
     yacc[c] = fma(wh[c], Ghi, fma(wl[c], Glo, fma(af, uf[c], fma(ap, up[c], fma(ac, uc[c], fma(am, um[c], yacc[c]))))));
     if (DG) dacc[c] += ac;
+    if (AB) {
+      const double gm = fma(wh[c], Nh0, wl[c] * Nl0), gc = fma(wh[c], Nh1, wl[c] * Nl1), gp = fma(wh[c], Nh2, wl[c] * Nl2);
+      aacc[c] += c == D ? fabs(am + gm) + fabs(ap + gp) + fabs(af) : fabs(am) + fabs(ap) + fabs(af) + fabs(gm) + fabs(gc) + fabs(gp);
+    }
   }
   if (DG) dacc[D] += fma(wh[D], Nh1, wl[D] * Nl1);
 }
@@ -136,7 +156,8 @@ __global__ void __launch_bounds__(64 * NW, 2) k_mom2(GridP g, MomP m, const doub
 {
   using LT              = Mom2Lds<NW>;
   constexpr int TX = LT::TX, TY = LT::TY, NTH = 64 * NW;
-  constexpr bool DG = JAC || OUT == 2;
+  constexpr bool AB = OUT == 3;  // OUT == 3: y = (sum of |a_ij|, j != i) / |a_ii|, the Gershgorin radius of the Jacobi-scaled row
+  constexpr bool DG = JAC || OUT == 2 || AB;
   __shared__ __attribute__((aligned(16))) LT lds;
   if (s && s->reason != 0) return;
 
@@ -299,21 +320,24 @@ __global__ void __launch_bounds__(64 * NW, 2) k_mom2(GridP g, MomP m, const doub
     }
     __syncthreads();
 
-    double2 ya[3] = {{0., 0.}, {0., 0.}, {0., 0.}}, da[3] = {{0., 0.}, {0., 0.}, {0., 0.}};
+    double2 ya[3] = {{0., 0.}, {0., 0.}, {0., 0.}}, da[3] = {{0., 0.}, {0., 0.}, {0., 0.}}, aa[3] = {{0., 0.}, {0., 0.}, {0., 0.}};
     // general rows of one cell (a = 0 / 1) of the pair: scalar arithmetic on copies of the pair accumulators
 #define MOM_WALL_CELL(D_, T_, UM, UC, UP, UF, VL, VH, WL, WH)                                        \
   {                                                                                                  \
     double y_[3] = {a ? ya[0].y : ya[0].x, a ? ya[1].y : ya[1].x, a ? ya[2].y : ya[2].x};            \
     double d_[3] = {a ? da[0].y : da[0].x, a ? da[1].y : da[1].x, a ? da[2].y : da[2].x};            \
-    mom_row_wall<D_, DG>(T_, UM, UC, UP, UF, VL, VH, WL, WH, y_, d_);                                \
+    double a_[3] = {a ? aa[0].y : aa[0].x, a ? aa[1].y : aa[1].x, a ? aa[2].y : aa[2].x};            \
+    mom_row_wall<D_, DG, AB>(T_, UM, UC, UP, UF, VL, VH, WL, WH, y_, d_, a_);                        \
     _Pragma("unroll") for (int c = 0; c < 3; ++c)                                                    \
     {                                                                                                \
       if (a) {                                                                                       \
         ya[c].y = y_[c];                                                                             \
         da[c].y = d_[c];                                                                             \
+        if (AB) aa[c].y = a_[c];                                                                     \
       } else {                                                                                       \
         ya[c].x = y_[c];                                                                             \
         da[c].x = d_[c];                                                                             \
+        if (AB) aa[c].x = a_[c];                                                                     \
       }                                                                                              \
     }                                                                                                \
   }
@@ -356,6 +380,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_mom2(GridP g, MomP m, const doub
         const double2 un = c == 1 ? un1 : *reinterpret_cast<const double2 *>(&lds.u[bf][c][w + 2][2 * lane + 2]);
         const double2 wh = *reinterpret_cast<const double2 *>(&lds.fy[bf][c + 1][w + 1][2 * lane]);
         mom_row_comp(r, us, ucc[c], un, fyl[c + 1], wh, ya[c]);
+        if (AB) aa[c] = add2(aa[c], mom_row_abs(r, tyi[3], tyi[4], tyi[5], tyi[6], fyl[c + 1], wh, c == 1));
         if (DG) {
           da[c].x += r.ac.x;
           da[c].y += r.ac.y;
@@ -414,6 +439,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_mom2(GridP g, MomP m, const doub
         const double  uw = lds.u[bf][c][w + 1][2 * lane + 1], ue = lds.u[bf][c][w + 1][2 * lane + 4];
         const double2 wh = make_double2(fxl[c + 1].y, from_next_lane(fxl[c + 1].x, lds.fxe[bf][c + 1][w]));
         mom_row_comp(r, make_double2(uw, ucc[c].x), ucc[c], make_double2(ucc[c].y, ue), fxl[c + 1], wh, ya[c]);
+        if (AB) aa[c] = add2(aa[c], mom_row_abs(r, tx[3], tx[4], tx[5], tx[6], fxl[c + 1], wh, c == 0));
         if (DG) {
           da[c].x += r.ac.x;
           da[c].y += r.ac.y;
@@ -458,6 +484,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_mom2(GridP g, MomP m, const doub
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           mom_row_comp(r, uzm[c], ucc[c], uzp[c], fzl[c + 1], fzh[c + 1], ya[c]);
+          if (AB) aa[c] = add2(aa[c], mom_row_abs(r, tz[3], tz[4], tz[5], tz[6], fzl[c + 1], fzh[c + 1], c == 2));
           if (DG) {
             da[c].x += r.ac.x;
             da[c].y += r.ac.y;
@@ -477,6 +504,9 @@ __global__ void __launch_bounds__(64 * NW, 2) k_mom2(GridP g, MomP m, const doub
         if (OUT == 2) {
           yv.x = d0;
           yv.y = d1;
+        } else if (AB) {
+          yv.x = aa[c].x / fabs(d0);
+          yv.y = aa[c].y / fabs(d1);
         } else {  // PCJacobi: VecReciprocal(diag) once, VecPointwiseMult per apply
           yv.x = yv.x * recip(d0);
           yv.y = yv.y * recip(d1);

@@ -52,7 +52,13 @@ __global__ void __launch_bounds__(64 * NW, 2) k_mom3(GridP g, MomP m, const doub
   static_assert(NW == 8, "the ring plan below is laid out for 512 threads");
   using LT              = Mom3Lds<NW>;
   constexpr int TX = LT::TX, TY = LT::TY, NTH = 64 * NW;
-  constexpr bool DG = JAC || OUT == 2;
+  constexpr bool AB = OUT == 3;  // OUT == 3: y = (sum of |a_ij|, j != i) / |a_ii| (see k_mom2)
+  // OUT == 4: one step of KSPCHEBYSHEV fused into the product (PETSc's three-term recurrence, x_{k+1} = x_k + rho (x_k - x_{k-1}) + c M (b - A x_k) with
+  // rho = omega - 1, c = omega Gamma scale from KspScal): x = x_k (staged with its ring as ever), o = b, y holds x_{k-1} on entry and x_{k+1} on
+  // exit (each lane reads and writes its own pair only), M = 1 / diag(A) with JAC.  Partial slots: 0 sum z, 1 z.z, 2 r.r (z = M r, r = b - A x_k):
+  // what k_cheb_fin tests.  144 B/cell per step where a BiCGStab iteration moves 552 for two products.
+  constexpr bool CH = OUT == 4;
+  constexpr bool DG = JAC || OUT == 2 || AB;
   __shared__ __attribute__((aligned(16))) LT lds;
   if (s && s->reason != 0) return;
 
@@ -75,6 +81,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_mom3(GridP g, MomP m, const doub
   const bool     inner = w != 0 && w != NW - 1;  // wave-uniform: the tile's edge rows are what the y-neighbour tiles read again as their ring
   const int64_t  sx = g.sx, sxy = g.sxy;
   const double   cI = m.cI;
+  const double   ch_rho = CH ? s->cheb_rho : 0., ch_c = CH ? s->cheb_c : 0.;
   const int64_t  ncell = (int64_t)g.nx * g.ny * g.nz;
   const int64_t  rb0 = g.off0 + (int64_t)jl * sx;
 
@@ -218,7 +225,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_mom3(GridP g, MomP m, const doub
   // a wait for the loads just issued, i.e. no prefetch at all.  The loads of plane k + 2 go straight into the set that held plane k - 1.
   auto plane = [&](int kl, double2 (&uzm)[3], double2 (&ucc)[3], double2 (&uzp)[3], double2 (&vzm)[3], double2 (&vcc)[3], double2 (&vzp)[3], double2 &fzl, double2 &fzh, double2 &fzn)
                    __attribute__((always_inline)) {
-    double2  oc[3];
+    double2  oc[3], xo[3];
     int      k = kl;
     unsigned lo = lo0;
     int64_t  csl = cs;
@@ -250,7 +257,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_mom3(GridP g, MomP m, const doub
     }
     __syncthreads();
 
-    double2 ya[3], da[3] = {{0., 0.}, {0., 0.}, {0., 0.}};
+    double2 ya[3], da[3] = {{0., 0.}, {0., 0.}, {0., 0.}}, aa[3] = {{0., 0.}, {0., 0.}, {0., 0.}};
     // ---- F: the x axis (first: the general rows of the two end cells overwrite what the fast path left in their lanes)
     {
       double2 tx[7];
@@ -279,6 +286,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_mom3(GridP g, MomP m, const doub
         }
         ya[c] = make_double2(0., 0.);
         mom_row_comp(r, make_double2(uw, ucc[c].x), ucc[c], make_double2(ucc[c].y, ue), make_double2(fA, fB), make_double2(fB, fC), ya[c]);
+        if (AB) aa[c] = mom_row_abs(r, tx[3], tx[4], tx[5], tx[6], make_double2(fA, fB), make_double2(fB, fC), c == 0);
         if (DG) {
           da[c] = r.ac;
           if (c == 0) da[0] = fma2(make_double2(fB, fC), tx[5], fma2(make_double2(fA, fB), tx[4], da[0]));
@@ -291,7 +299,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_mom3(GridP g, MomP m, const doub
           const int cell = i + a;
           if (cell == 0 || cell == g.nx - 1) {
             const int side = cell == 0 ? 0 : 1;
-            double    um[3], uc[3], up[3], uf[3], wl[3], wh[3], y_[3] = {0., 0., 0.}, d_[3] = {0., 0., 0.};
+            double    um[3], uc[3], up[3], uf[3], wl[3], wh[3], y_[3] = {0., 0., 0.}, d_[3] = {0., 0., 0.}, a_[3] = {0., 0., 0.};
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
               um[c] = a ? ucc[c].x : lds.u[bf][c][w + 1][2 * lane + 1];
@@ -310,15 +318,17 @@ __global__ void __launch_bounds__(64 * NW, 2) k_mom3(GridP g, MomP m, const doub
             }
             const double vl = a ? fxl.y : fxl.x, vh = a ? vhx : fxl.y;
             auto         T = [&](int q) { return lds.tabg[side][q]; };
-            mom_row_wall<0, DG>(T, um, uc, up, uf, vl, vh, wl, wh, y_, d_);
+            mom_row_wall<0, DG, AB>(T, um, uc, up, uf, vl, vh, wl, wh, y_, d_, a_);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
               if (a) {
                 ya[c].y = y_[c];
                 if (DG) da[c].y = d_[c];
+                if (AB) aa[c].y = a_[c];
               } else {
                 ya[c].x = y_[c];
                 if (DG) da[c].x = d_[c];
+                if (AB) aa[c].x = a_[c];
               }
             }
           }
@@ -335,15 +345,18 @@ __global__ void __launch_bounds__(64 * NW, 2) k_mom3(GridP g, MomP m, const doub
   {                                                                                                  \
     double y_[3] = {a ? ya[0].y : ya[0].x, a ? ya[1].y : ya[1].x, a ? ya[2].y : ya[2].x};            \
     double d_[3] = {a ? da[0].y : da[0].x, a ? da[1].y : da[1].x, a ? da[2].y : da[2].x};            \
-    mom_row_wall<D_, DG>(T_, UM, UC, UP, UF, VL, VH, WL, WH, y_, d_);                                \
+    double a_[3] = {a ? aa[0].y : aa[0].x, a ? aa[1].y : aa[1].x, a ? aa[2].y : aa[2].x};            \
+    mom_row_wall<D_, DG, AB>(T_, UM, UC, UP, UF, VL, VH, WL, WH, y_, d_, a_);                        \
     _Pragma("unroll") for (int c = 0; c < 3; ++c)                                                    \
     {                                                                                                \
       if (a) {                                                                                       \
         ya[c].y = y_[c];                                                                             \
         da[c].y = d_[c];                                                                             \
+        if (AB) aa[c].y = a_[c];                                                                     \
       } else {                                                                                       \
         ya[c].x = y_[c];                                                                             \
         da[c].x = d_[c];                                                                             \
+        if (AB) aa[c].x = a_[c];                                                                     \
       }                                                                                              \
     }                                                                                                \
   }
@@ -398,6 +411,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_mom3(GridP g, MomP m, const doub
           const double2 vs = *reinterpret_cast<const double2 *>(&lds.v[bf][c][w][2 * lane + 2]), vn = *reinterpret_cast<const double2 *>(&lds.v[bf][c][w + 2][2 * lane + 2]);
           const double2 wl = fma2(vcc[c], wl1[kr], mul2(vs, wl0[kr])), wh = fma2(vn, wh1[kr], mul2(vcc[c], wh0[kr]));
           mom_row_comp(r, us, ucc[c], un, wl, wh, ya[c]);
+          if (AB) aa[c] = add2(aa[c], mom_row_abs(r, tyi[3], tyi[4], tyi[5], tyi[6], wl, wh, c == 1));
           if (DG) {
             da[c].x += r.ac.x;
             da[c].y += r.ac.y;
@@ -413,7 +427,10 @@ __global__ void __launch_bounds__(64 * NW, 2) k_mom3(GridP g, MomP m, const doub
     __builtin_amdgcn_sched_barrier(0);
     // ---- H: the z axis (the shadow vector of the inner product is fetched here: it is consumed right after this phase)
 #pragma unroll
-    for (int c = 0; c < 3; ++c) oc[c] = ((DOT & 1) && o) ? LD2(o + (int64_t)c * csl + rb, lo) : make_double2(0., 0.);
+    for (int c = 0; c < 3; ++c) {
+      oc[c] = (((DOT & 1) || CH) && o) ? LD2(o + (int64_t)c * csl + rb, lo) : make_double2(0., 0.);
+      if (CH) xo[c] = LD2(y + (int64_t)c * csl + rb, lo);
+    }
     {
       const cdouble4 *tabz = as_const(m.stab[2]) + (int64_t)k * MOM_STAB;
       const int       fl = min(k, g.fz - 1), fh = min(k + 1, g.fz - 1);
@@ -456,6 +473,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_mom3(GridP g, MomP m, const doub
           const int     kr = c == 2 ? 0 : 1;
           const double2 wl = fma2(vcc[c], zl1[kr], mul2(vzm[c], zl0[kr])), wh = fma2(vzp[c], zh1[kr], mul2(vcc[c], zh0[kr]));
           mom_row_comp(r, uzm[c], ucc[c], uzp[c], wl, wh, ya[c]);
+          if (AB) aa[c] = add2(aa[c], mom_row_abs(r, tz[3], tz[4], tz[5], tz[6], wl, wh, c == 2));
           if (DG) {
             da[c].x += r.ac.x;
             da[c].y += r.ac.y;
@@ -470,15 +488,28 @@ __global__ void __launch_bounds__(64 * NW, 2) k_mom3(GridP g, MomP m, const doub
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       double2 yv = fma2(ucc[c], cI, ya[c]);
+      double2 rr = make_double2(0., 0.);
+      if (CH) {
+        rr = make_double2(oc[c].x - yv.x, oc[c].y - yv.y);  // r = b - A x_k; the Jacobi scaling below turns yv into z
+        yv = rr;
+      }
       if (DG) {
         const double d0 = cI + da[c].x, d1 = cI + da[c].y;
         if (OUT == 2) {
           yv.x = d0;
           yv.y = d1;
+        } else if (AB) {
+          yv.x = aa[c].x / fabs(d0);
+          yv.y = aa[c].y / fabs(d1);
         } else {
           yv.x = yv.x * recip(d0);
           yv.y = yv.y * recip(d1);
         }
+      }
+      double2 zz = yv;
+      if (CH) {
+        yv.x = fma(ch_c, zz.x, fma(ch_rho, ucc[c].x - xo[c].x, ucc[c].x));
+        yv.y = fma(ch_c, zz.y, fma(ch_rho, ucc[c].y - xo[c].y, ucc[c].y));
       }
       if (rown) {
         if (OUT == 1) {
@@ -492,6 +523,13 @@ __global__ void __launch_bounds__(64 * NW, 2) k_mom3(GridP g, MomP m, const doub
           if (own1) ST2nt<NT>(y + (int64_t)c * csl + rb, lo, yv);
           else if (own0) (y + (int64_t)c * csl + rb)[il] = yv.x;
         }
+      }
+      if (CH) {
+        const bool   o0 = rown && own0, o1 = rown && own1;
+        const double z0 = o0 ? zz.x : 0., z1 = o1 ? zz.y : 0., r0 = o0 ? rr.x : 0., r1 = o1 ? rr.y : 0.;
+        acc[0] += z0 + z1;
+        acc[1] += z0 * z0 + z1 * z1;
+        acc[2] += r0 * r0 + r1 * r1;
       }
       if (DOT) {
         const bool   o0 = rown && own0, o1 = rown && own1;
@@ -523,7 +561,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_mom3(GridP g, MomP m, const doub
     if (kk + 2 >= k1) break;
     plane(kk + 2, uC, uA, uB, vC, vA, vB, fzC, fzA, fzB);
   }
-  if (DOT) {
+  if (DOT || CH) {
     __syncthreads();  // the sums reuse tabx
     double *red = &lds.tabx[0][0];
 #pragma unroll

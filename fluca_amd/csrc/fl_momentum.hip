@@ -564,6 +564,19 @@ __global__ void __launch_bounds__(512) k_mom_pw3(GridP g, int64_t cs, const doub
         } else if (OP == 1) {
           const double2 r = ldp(a0, q), v = ldp(a1, q);
           stp(w0, q, make_double2(r.x - alpha * v.x, r.y - alpha * v.y));
+        } else if (OP == 6) {  // one Chebyshev step behind an un-fused product (see k_mom3, OUT == 4): a0 = x_k, a1 = A x_k, a2 = b, a3 = diag(A) or NULL, w0 = x_{k-1} -> x_{k+1}
+          const double2 xk = ldp(a0, q), ax = ldp(a1, q), bb = ldp(a2, q), xo = ldp(w0, q);
+          const double2 rr = make_double2(bb.x - ax.x, bb.y - ax.y);
+          double2       zz = rr;
+          if (a3) {
+            const double2 d = ldk(a3, q);
+            zz.x = rr.x * recip(d.x);
+            zz.y = two ? rr.y * recip(d.y) : 0.;
+          }
+          stp(w0, q, make_double2(fma(s->cheb_c, zz.x, fma(s->cheb_rho, xk.x - xo.x, xk.x)), fma(s->cheb_c, zz.y, fma(s->cheb_rho, xk.y - xo.y, xk.y))));
+          acc[0] += zz.x + (two ? zz.y : 0.);
+          acc[1] += zz.x * zz.x + (two ? zz.y * zz.y : 0.);
+          acc[2] += rr.x * rr.x + (two ? rr.y * rr.y : 0.);
         } else if (OP == 2 || OP == 5) {  // OP 5: the first iteration's OP 2 -- X is zero by definition and not read
           const double2 P = ldp(a0, q), S = ldp(a1, q), T = ldp(a2, q), RP = ldk(a3, q), X = OP == 5 ? make_double2(0., 0.) : ldp(w0, q);
           const double2 rn = make_double2(S.x - omega * T.x, S.y - omega * T.y);
@@ -595,7 +608,7 @@ __global__ void __launch_bounds__(512) k_mom_pw3(GridP g, int64_t cs, const doub
       }
     }
   }
-  if (OP == 2 || OP == 3 || OP == 5) {
+  if (OP == 2 || OP == 3 || OP == 5 || OP == 6) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const double v = wave_sum(acc[a]);
@@ -630,6 +643,23 @@ __global__ void __launch_bounds__(256) k_scale_by(int64_t n, const double *__res
   }
 }
 // VecMDot / VecMAXPY on up to 8 vectors per launch: x is read once for all of them
+// max over the owned cells of three padded components (one entry per block)
+__global__ void __launch_bounds__(256) k_max_owned(GridP g, int64_t cs, const double *__restrict__ v, double *__restrict__ partial)
+{
+  __shared__ double red[4];
+  const int64_t rows = (int64_t)3 * g.nz * g.ny;
+  double        mx = 0.;
+  for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+    const int     c = (int)(r / ((int64_t)g.nz * g.ny)), kj = (int)(r % ((int64_t)g.nz * g.ny)), k = kj / g.ny, j = kj % g.ny;
+    const double *row = v + (int64_t)c * cs + g.off0 + (int64_t)k * g.sxy + (int64_t)j * g.sx;
+    for (int i = threadIdx.x; i < g.nx; i += 256) mx = fmax(mx, row[i]);
+  }
+  for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_down(mx, off, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
 struct Vec8 {
   const double *p[8];
 };
@@ -783,6 +813,7 @@ struct fl_momentum {
   std::vector<double *> gm;  // cell vectors of the Schur solve with a variable-coefficient S
   std::vector<double *> kb;  // KSPGMRES on A: Krylov basis (3*cells each, allocated as the iteration needs them), w, x, r
   bool        have_state = false;
+  double      gersh = -1.;  // cached Gershgorin radius of the Jacobi-scaled operator (fl_momentum_gershgorin); < 0: not computed for this state
   int         tiles_x = 1, tiles_y = 1, nchunk = 1, zc = 1, nblocks = 1;  // 64 x 4 x zc tiles of the vector-update kernels
   int         anchunk = 1, azc = 1, ablocks = 1;                        // 64 x MOM_RY x azc tiles of k_mom_apply
   int         t2x = 1, t2chunk = 1, t2zc = 1, t2blocks = 1;             // 128 x 8 x t2zc tiles of k_mom2
@@ -1071,6 +1102,7 @@ extern "C" int fl_momentum_set_coefficients(fl_momentum *m, double cI, double cC
   m->mp.cI = cI;
   m->mp.cC = cC;
   m->mp.cL = cL;
+  m->gersh = -1.;
   fl_poisson *h = m->p;
   FL_HIP(hipSetDevice(h->device));
   FL_CHK(mom_scale_tables(m, 0, m->mp));
@@ -1161,6 +1193,113 @@ extern "C" int fl_momentum_diagonal(fl_momentum *m, double *d_dev)
   return FL_SUCCESS;
 }
 
+// Gershgorin radius of the Jacobi-scaled operator: max_i (sum_{j != i} |a_ij|) / |a_ii|, the entries taken from the same row
+// coefficients the product multiplies with (k_mom2 / k_mom3, OUT == 3).  Every eigenvalue of D^-1 A lies in the disc |lambda - 1| <= radius.
+// One product-sized launch and one host wait per state; cached until the state or the coefficients change.
+extern "C" int fl_momentum_gershgorin(fl_momentum *m, double *radius)
+{
+  if (!m || !radius) return FL_ERR_ARG_NULL;
+  if (!m->have_state && m->mp.cC != 0.) return FL_ERR_ARG_WRONGSTATE;
+  if (mom_kernel() < 2) return FL_ERR_SUP;
+  fl_poisson *h = m->p;
+  FL_HIP(hipSetDevice(h->device));
+  if (m->gersh < 0.) {
+    FL_CHK(mom_vec(m, 7));
+    mom_apply_t<0, false, 3>(m, m->F, m->vec[7], nullptr, nullptr);  // x is not used for the row sums: any valid padded array
+    const int64_t rows = (int64_t)3 * h->g.nz * h->g.ny;
+    const int     nb = (int)std::max<int64_t>(1, std::min<int64_t>(rows, 1024));
+    FL_CHK(fl_ensure_partials(h, nb));
+    hipLaunchKernelGGL(k_max_owned, dim3(nb), dim3(256), 0, h->stream, h->g, (int64_t)h->padlen, (const double *)m->vec[7], h->partial);
+    FL_HIP(hipGetLastError());
+    std::vector<double> part((size_t)nb);
+    FL_HIP(hipMemcpyAsync(part.data(), h->partial, sizeof(double) * (size_t)nb, hipMemcpyDeviceToHost, h->stream));
+    FL_HIP(hipStreamSynchronize(h->stream));
+    double mx = 0.;
+    for (double v : part) mx = std::max(mx, v);
+    double all = mx;
+    FL_CHK(fl_allreduce_max(h, &all));  // several ranks: the bound of the whole operator
+    m->gersh = all;
+  }
+  *radius = m->gersh;
+  return FL_SUCCESS;
+}
+
+// KSPCHEBYSHEV on the momentum block (-ns_abf_momentum_ksp_type chebyshev, a PETSc option the reference's kspA accepts like any other):
+// PETSc's three-term recurrence with PCJACOBI / PCNONE, zero initial guess.  Interval: opts->emin / emax (-ksp_chebyshev_eigenvalues), or, with
+// PCJACOBI, from the Gershgorin disc of D^-1 A (centre 1, radius g = fl_momentum_gershgorin): [1 - g, 1 + g] while the operator is diagonally
+// dominant enough for that to be an interval of positive numbers (g <= 0.9), else PETSc's default transform of an estimate, (0.1, 1.1) x (1 + g).
+// One fused launch per step where the state came with v0 (k_mom3, OUT == 4: 144 B/cell), the product and a vector update otherwise.
+static int momentum_cheb(fl_momentum *m, const double *b_dev, double *x_dev, const fl_ksp_opts *opts, fl_ksp_stats *stats)
+{
+  if (opts->pc != FL_PC_JACOBI && opts->pc != FL_PC_NONE) return FL_ERR_SUP;
+  if (opts->norm_type == FL_NORM_NATURAL) return FL_ERR_SUP;
+  if (opts->maxit < 0) return FL_ERR_ARG_OUTOFRANGE;
+  if (mom_kernel() < 2 || mom_pw_kernel() < 3) return FL_ERR_SUP;
+  fl_poisson *h = m->p;
+  FL_HIP(hipSetDevice(h->device));
+  std::memset(stats, 0, sizeof(*stats));
+  const bool jac = opts->pc == FL_PC_JACOBI;
+  double     emin = opts->emin, emax = opts->emax;
+  if (emin == 0. && emax == 0.) {
+    if (!jac) return FL_ERR_SUP;  // no bound of the unscaled operator is formed: give -ksp_chebyshev_eigenvalues
+    double g = 0.;
+    FL_CHK(fl_momentum_gershgorin(m, &g));
+    if (g <= 0.9) {
+      emin = 1. - g;
+      emax = 1. + g;
+    } else {
+      emin = 0.1 * (1. + g);
+      emax = 1.1 * (1. + g);
+    }
+  }
+  if (!(emax > emin) || !(emin > 0.)) return FL_ERR_ARG_OUTOFRANGE;
+  const bool fused = mom_kernel() >= 3 && m->fly && h->g.ny > 8;
+  for (int a : {0, 2, 4}) FL_CHK(mom_vec(m, a));
+  if (!fused) FL_CHK(mom_vec(m, 3));
+  double *B = m->vec[0], *X0 = m->vec[4], *X1 = m->vec[2], *AX = m->vec[3];
+  const int nhist = opts->maxit + 2;
+  FL_CHK(fl_ensure_hist(h, nhist));
+  FL_CHK(fl_ensure_partials(h, std::max(std::max(m->nblocks, m->ablocks), m->t2blocks)));
+  fl_ksp_opts o = *opts;
+  o.remove_nullspace = 0;  // A = I + ... is non-singular
+  FL_CHK(fl_cheb_begin(h, &o, emin, emax));
+  const size_t bytes = sizeof(double) * 3 * h->padlen;
+  // x_0 = 0 and "x_-1" (multiplied by rho_0 = 0) must be finite numbers
+  for (double *v : {X0, X1}) FL_HIP(hipMemsetAsync(v, 0, bytes, h->stream));
+  for (int c = 0; c < 3; ++c) launch_pad_copy(h->stream, h->g, b_dev + (size_t)c * h->ncell, B + (size_t)c * h->padlen);
+  const int every = o.check_every > 0 ? o.check_every : 8;
+  const int total = o.norm_type == FL_NORM_NONE ? o.maxit : o.maxit + 1;  // with a norm, launch maxit is only the final test
+  int       j = 0, hostcur = 0;
+  bool      done = total <= 0;
+  int       flags = mom_order() & 1;
+  while (!done) {
+    const int stop = std::min(total, j + every);
+    for (; j < stop; ++j) {
+      double *xin = hostcur ? X1 : X0, *xout = hostcur ? X0 : X1;
+      if (j > 0) FL_CHK(mom_ghosts(m, xin));
+      if (fused) {
+        if (jac) hipLaunchKernelGGL((k_mom3<8, 0, true, 4, 1>), dim3(m->t2blocks), dim3(512), 0, h->stream, h->g, m->mp, (const double *)xin, xout, m->F, (const double *)m->v0p, (int64_t)h->padlen, (const double *)B,
+                                    (const KspScal *)h->scal, h->partial, h->partial_stride, m->t2x, m->t2chunk, m->t2zc, flags);
+        else hipLaunchKernelGGL((k_mom3<8, 0, false, 4, 1>), dim3(m->t2blocks), dim3(512), 0, h->stream, h->g, m->mp, (const double *)xin, xout, m->F, (const double *)m->v0p, (int64_t)h->padlen, (const double *)B,
+                                (const KspScal *)h->scal, h->partial, h->partial_stride, m->t2x, m->t2chunk, m->t2zc, flags);
+        FL_CHK(fl_cheb_fin_step(h, m->t2blocks, nhist));
+      } else {
+        mom_apply_t<0, false, 0>(m, xin, AX, nullptr, h->scal);
+        mom_pw<6>(m, xin, AX, B, jac ? m->dg : nullptr, xout, nullptr);
+        FL_CHK(fl_cheb_fin_step(h, mom_pw_blocks(m), nhist));
+      }
+      hostcur ^= 1;
+    }
+    FL_HIP(hipGetLastError());
+    FL_CHK(fl_poll_scal(h));
+    if (h->scal_host->reason != 0 || j >= total) done = true;
+  }
+  FL_CHK(fl_poll_scal(h));
+  const double *ans = h->scal_host->cur ? X1 : X0;
+  for (int c = 0; c < 3; ++c) launch_unpad_copy(h->stream, h->g, ans + (size_t)c * h->padlen, x_dev + (size_t)c * h->ncell, nullptr);
+  return fl_ksp_finish(h, &o, stats);
+}
+
 static int momentum_gmres(fl_momentum *m, const double *b_dev, double *x_dev, const fl_ksp_opts *opts, fl_ksp_stats *stats);
 
 // KSPSolve(kspA): left-preconditioned BiCGStab (KSPBCGS) or restarted GMRES (KSPGMRES, the reference's default type for kspA,
@@ -1170,6 +1309,7 @@ extern "C" int fl_momentum_solve(fl_momentum *m, const double *b_dev, double *x_
   if (!m || !b_dev || !x_dev || !opts || !stats) return FL_ERR_ARG_NULL;
   if (!m->have_state && m->mp.cC != 0.) return FL_ERR_ARG_WRONGSTATE;
   if (opts->type == FL_KSP_GMRES) return momentum_gmres(m, b_dev, x_dev, opts, stats);
+  if (opts->type == FL_KSP_CHEBYSHEV) return momentum_cheb(m, b_dev, x_dev, opts, stats);
   if (opts->type != FL_KSP_BCGS) return FL_ERR_SUP;
   if (opts->pc != FL_PC_JACOBI && opts->pc != FL_PC_NONE) return FL_ERR_SUP;
   if (opts->norm_type != FL_NORM_PRECONDITIONED) return FL_ERR_SUP;

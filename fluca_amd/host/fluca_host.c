@@ -882,6 +882,7 @@ FlErrorCode NSSetFromOptions(NS ns, int argc, char **argv)
   if ((s = opt_find(argc, argv, "-ns_abf_momentum_ksp_type"))) {
     if (!strcmp(s, "bcgs")) ns->mom.type = FL_KSP_BCGS;
     else if (!strcmp(s, "gmres")) ns->mom.type = FL_KSP_GMRES; /* the reference's own default type of kspA (abfpc.c:72) */
+    else if (!strcmp(s, "chebyshev")) ns->mom.type = FL_KSP_CHEBYSHEV; /* KSPCHEBYSHEV fused into the product; interval below or from the Gershgorin disc */
     else return !strcmp(s, "cg") || !strcmp(s, "fgmres") ? E_SUP : E_ARG_UNKNOWN_TYPE;
   }
   if (opt_int64(argc, argv, "-ns_abf_momentum_ksp_gmres_restart", &iv)) {
@@ -892,6 +893,15 @@ FlErrorCode NSSetFromOptions(NS ns, int argc, char **argv)
     if (!strcmp(s, "jacobi")) ns->mom.pc = FL_PC_JACOBI;
     else if (!strcmp(s, "none")) ns->mom.pc = FL_PC_NONE;
     else return !strcmp(s, "ilu") || !strcmp(s, "bjacobi") ? E_SUP : E_ARG_UNKNOWN_TYPE;
+  }
+  if ((s = opt_find(argc, argv, "-ns_abf_momentum_ksp_chebyshev_eigenvalues"))) {
+    if (sscanf(s, "%lf,%lf", &ns->mom.emin, &ns->mom.emax) != 2) return E_ARG_WRONG;
+  }
+  if ((s = opt_find(argc, argv, "-ns_abf_momentum_ksp_norm_type"))) {
+    if (!strcmp(s, "preconditioned")) ns->mom.norm_type = FL_NORM_PRECONDITIONED;
+    else if (!strcmp(s, "unpreconditioned")) ns->mom.norm_type = FL_NORM_UNPRECONDITIONED;
+    else if (!strcmp(s, "none")) ns->mom.norm_type = FL_NORM_NONE;
+    else return !strcmp(s, "natural") ? E_SUP : E_ARG_UNKNOWN_TYPE;
   }
   if (opt_real(argc, argv, "-ns_abf_momentum_ksp_rtol", &v)) ns->mom.rtol = v;
   if (opt_real(argc, argv, "-ns_abf_momentum_ksp_atol", &v)) ns->mom.atol = v;

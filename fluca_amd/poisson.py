@@ -326,6 +326,14 @@ class Momentum:
         self.p._post()
         return d
 
+    def gershgorin(self):
+        """max_i sum_{j != i} |a_ij| / |a_ii|: the radius of the Gershgorin disc of the Jacobi-scaled operator around 1."""
+        g = C.c_double()
+        self.p._pre()
+        check(lib.fl_momentum_gershgorin(self.h, C.byref(g)), "fl_momentum_gershgorin")
+        self.p._post()
+        return g.value
+
     def set_ainv_types(self, schur=0, upper=0):
         """PCABFSetSchurComplementAinvType / PCABFSetUpperTriangularAinvType: 0 ID, 1 DIAG, 2 ROWSUM"""
         check(lib.fl_abf_set_ainv_types(self.h, int(schur), int(upper)), "fl_abf_set_ainv_types")
@@ -344,7 +352,7 @@ class Momentum:
         x = self.p.empty(3 * self.p.ncell) if x is None else x
         hist = None
         if history:
-            hist = np.full(o.maxit + 1, np.nan)
+            hist = np.full(o.maxit + 2, np.nan)
             o.history = hist.ctypes.data_as(C.POINTER(C.c_double))
             o.nhistory = hist.size
         st = capi.fl_ksp_stats()

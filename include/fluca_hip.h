@@ -295,8 +295,11 @@ int fl_momentum_set_state_v0(fl_momentum *m, double dt, double rho, double mu, c
 int fl_momentum_set_coefficients(fl_momentum *m, double cI, double cC, double cL);
 int fl_momentum_apply(fl_momentum *m, const double *v_dev, double *y_dev); /* y = A v      (MatMult) */
 int fl_momentum_diagonal(fl_momentum *m, double *d_dev);                   /* MatGetDiagonal(A) */
-/* KSPSolve(abf->kspA, momrhs, vstar), abfpc.c:72: opts->type must be FL_KSP_BCGS, pc JACOBI or NONE, preconditioned norm,
- * zero initial guess; remove_nullspace is ignored (A is non-singular). */
+/* KSPSolve(abf->kspA, momrhs, vstar), abfpc.c:72, zero initial guess, pc JACOBI or NONE; remove_nullspace is ignored (A is non-singular).
+ * opts->type: FL_KSP_BCGS (left-preconditioned KSPBCGS, preconditioned norm), FL_KSP_GMRES (PETSc's default type for kspA; restart
+ * opts->gmres_restart) or FL_KSP_CHEBYSHEV (KSPCHEBYSHEV's three-term recurrence fused into the product: 144 B per cell and step where a
+ * BiCGStab iteration moves 552 -- the method of choice while the operator is diffusion-dominated, e.g. nu dt / h^2 > 1; interval from
+ * opts->emin / emax = -ksp_chebyshev_eigenvalues, or with PCJACOBI from the Gershgorin disc of D^-1 A, see fl_momentum_gershgorin). */
 int fl_momentum_solve(fl_momentum *m, const double *b_dev, double *x_dev, const fl_ksp_opts *opts, fl_ksp_stats *stats);
 /* V_d = rhs_d + (T v)_d on the d-faces: MatMult(abf->negT, vstar, Vstar); VecAYPX(Vstar, -1, interprhs), abfpc.c:73-74.
  * T = ComputeFaceNormalVelocityInterpolationOperator_Private, cnlinearcart3d.c:1934-2140.  rhs_dev (or any entry) may
@@ -321,16 +324,15 @@ int fl_momentum_interp_faces_ends(fl_momentum *m, const double *v_dev, const dou
 int fl_momentum_rhs(fl_momentum *m, double dt, double rho, double mu, const double *v0_dev, const double *p_dev, const double *vbc_dev, double *momrhs_dev);
 
 /* ---- the whole preconditioner application ---------------------------------------------------- */
+/* MatMult of the 3 x 3 block Jacobian the preconditioner belongs to (MatNest of cnlinearcart3d.c:2885-2941), for an outer
+ * Krylov method that keeps its vectors on the device:
+ *   fv = A v + kappa G p ;  fV = V - T v - R p,  -R = (-T)(kappa G) + kappa Gst ;  fp = D V */
+int fl_abf_jacobian_mult(fl_momentum *m, const double *v_dev, const double *const V_dev[3], const double *p_dev, double *fv_dev, double *const fV_dev[3], double *fp_dev);
 /* PCApply_ABF, abfpc.c:48-111, with the reference's default upperainv = schurainv = ID (abfpc.c:328-329):
  *   v* = A^-1 momrhs ; V* = interprhs + T v* ; p = S^-1 (contrhs - D V*) ; v = v* - kappa G p ; V = V* - kappa Gst p
  * v_dev (3*cells, component-major), V_dev[3] (faces) and p_dev (cells) are outputs; interprhs_dev / contrhs_dev may be
  * NULL = 0.  stats[0] = KSPSolve(kspA), stats[1] = KSPSolve(kspS).  A non-converged inner solve is reported in stats,
  * not as an error (PETSc's behaviour without -ksp_error_if_not_converged). */
-
-/* MatMult of the 3 x 3 block Jacobian the preconditioner belongs to (MatNest of cnlinearcart3d.c:2885-2941), for an outer
- * Krylov method that keeps its vectors on the device:
- *   fv = A v + kappa G p ;  fV = V - T v - R p,  -R = (-T)(kappa G) + kappa Gst ;  fp = D V */
-int fl_abf_jacobian_mult(fl_momentum *m, const double *v_dev, const double *const V_dev[3], const double *p_dev, double *fv_dev, double *const fV_dev[3], double *fp_dev);
 int fl_abf_apply(fl_momentum *m, const fl_ksp_opts *momentum_opts, const fl_ksp_opts *schur_opts, const double *momrhs_dev, const double *const interprhs_dev[3], const double *contrhs_dev, double *v_dev,
                  double *const V_dev[3], double *p_dev, fl_ksp_stats stats[2]);
 /* PCABFAinvType (flucans.h:99-103): the approximation of A^-1 inside the Schur complement (PCABFSetSchurComplementAinvType,
@@ -344,6 +346,10 @@ int fl_abf_set_ainv_types(fl_momentum *m, int schur_type, int upper_type);
 int fl_abf_schur_apply(fl_momentum *m, const double *p_dev, double *y_dev);
 /* MatGetRowSum(A) into 3*cells doubles (component-major), like fl_momentum_diagonal */
 int fl_momentum_rowsum(fl_momentum *m, double *out_dev);
+/* Gershgorin radius of the Jacobi-scaled momentum operator: max over the rows of (sum of |a_ij|, j != i) / |a_ii|, over all ranks.  Every
+ * eigenvalue of D^-1 A lies in the disc of this radius around 1.  The default interval of FL_KSP_CHEBYSHEV on kspA is [1 - g, 1 + g] while
+ * g <= 0.9, else PETSc's default transform (0.1, 1.1) of the estimate 1 + g.  One product-sized launch and a host wait per state. */
+int fl_momentum_gershgorin(fl_momentum *m, double *radius);
 
 /* ---- immersed boundary (build-defined; no reference function) -------------------------------- */
 typedef enum { FL_DELTA_PESKIN4 = 0, FL_DELTA_ROMA3 = 1 } fl_delta_kind;

@@ -239,8 +239,9 @@ FlErrorCode NSGetInnerIterations(NS ns, int *momentum_its, int *schur_its);
 FlErrorCode NSSetPreviousState(NS ns, const double *const V0_dev[3], const double *const v0interp_dev[9]);
 /* the whole PCApply_ABF (abfpc.c:48-111): v* = A^-1 momrhs, V* = interprhs + T v*, p = S^-1(contrhs - D V*),
  * v = v* - G p, V = V* - Gst p.  v: 3*cells component-major.  stats[0] = kspA, stats[1] = kspS (may be NULL).
- * Options: -ns_abf_momentum_ksp_type bcgs|gmres (gmres = PETSc's default type for kspA, restart
- * -ns_abf_momentum_ksp_gmres_restart 30), -ns_abf_momentum_pc_type jacobi|none (ilu, PETSc's default PC, has no
+ * Options: -ns_abf_momentum_ksp_type bcgs|gmres|chebyshev (gmres = PETSc's default type for kspA, restart
+ * -ns_abf_momentum_ksp_gmres_restart 30; chebyshev: -ns_abf_momentum_ksp_chebyshev_eigenvalues emin,emax or the Gershgorin disc,
+ * -ns_abf_momentum_ksp_norm_type preconditioned|unpreconditioned|none), -ns_abf_momentum_pc_type jacobi|none (ilu, PETSc's default PC, has no
  * matrix-free form: PETSC_ERR_SUP), -ns_abf_momentum_ksp_{rtol,atol,divtol,max_it}. */
 FlErrorCode NSApplyPreconditioner(NS ns, const double *momrhs_dev, const double *const interprhs_dev[3], const double *contrhs_dev, double *v_dev, double *const V_dev[3], double *p_dev, fl_ksp_stats stats[2]);
 FlErrorCode NSGetMomentumKSPOptions(NS ns, fl_ksp_opts **opts);

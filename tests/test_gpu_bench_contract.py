@@ -79,3 +79,14 @@ def test_two_ranks_without_rccl_fail_instead_of_falling_back():
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode != 0
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_quoted_counter_passes_are_of_the_kernels_in_the_tree():
+    """roofline.traffic is replayed from profiles/pmc_*.json (counters cannot be read inside the run): every pass bench.py quotes must
+    carry the git blob hashes of the kernel's sources as they are in this tree (fluca_amd/provenance.py), or the line says traffic_stale."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for kernel in ("k_cg_A", "k_cg_Bq", "k_cheb2", "k_mom3"):
+        traffic, stale = bench.pmc_traffic(kernel)
+        assert traffic and traffic > 0, kernel
+        assert stale is False, f"profiles/pmc_{kernel}.json was taken from other sources than the tree's: re-run the counter pass"

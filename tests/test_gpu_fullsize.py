@@ -6,9 +6,15 @@ C3  512^3 channel [VELOCITY inlet, PRESSURE_OUTLET, walls in y, PERIODIC span], 
 C4  512^3 with the immersed sphere of diameter 64 h (12 868 markers on a Fibonacci lattice): fl_ibm_interp / fl_ibm_spread against the
     oracle's fo_ibm_interp / fo_ibm_spread.  The host cost is O(markers), not O(cells): the oracle loops over the markers' supports.
 momentum  the same 512^3 channel: the momentum block with v0interp formed inside the kernel (k_mom3) against the stored-path kernel.
-The headline's own configuration (512^3 cavity Jacobi-PCG) is compared with the oracle at full size by bench.py's cpu_baseline leg
-(parity_on_full_grid) and by test_gpu_poisson.py::test_full_size_properties_512.
+Against the ORACLE at full size (round 4; the host has the memory for the assembled matrices: 12 GB for a 512^3 S, 8 GB for a 256^3 A) --
+the same functions bench.py prints as parity_on_full_grid / configs.C3.parity_on_full_grid / configs.momentum.parity:
+headline  512^3 cavity Jacobi-PCG, the driver's 20 iterations, against the oracle's assembled CSR + KSPCG restatement;
+C3        512^3 channel, 20 Chebyshev-Jacobi steps of the fused kernel against the oracle's KSPCHEBYSHEV on the assembled channel S;
+momentum  256^3 cavity: MatMult(A), diag(A) and five Jacobi-BiCGStab iterations against the oracle's assembled A (50 M rows).
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -122,3 +128,58 @@ def test_momentum_state_with_v0_equals_the_stored_fields_at_512():
     assert float((M.apply(s_fly) - x).norm()) <= 1e-7 * float(x.norm())
     M.close()
     P.close()
+
+
+def _bench():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    return bench
+
+
+def _needs_host_memory(gb):
+    avail = _bench()._host_mem_available_gb()
+    if not (avail and avail >= gb):
+        pytest.skip(f"host memory {avail} GB < {gb} GB for the assembled oracle matrix")
+
+
+def test_headline_512_cavity_pcg_matches_oracle():
+    """BASELINE's metric configuration at its own size: 20 Jacobi-PCG iterations (the driver's K) on the 512^3 cavity Schur complement,
+    HIP path against the oracle's assembled S + KSPCG: same iteration count, residual norms to 1e-10, x to 1e-12."""
+    _needs_host_memory(32.0)
+    bench = _bench()
+    bench._oracle_threads()
+    leg = bench._cpu_leg(512, 20)
+    par = leg["parity"]
+    assert "error" not in par, par
+    assert par["iters_gpu"] == par["iters_cpu"] == 20
+    assert par["rel_max_diff_x"] <= 1e-12, par
+    assert abs(par["rnorm_gpu"] - par["rnorm_cpu"]) <= 1e-10 * par["rnorm_cpu"], par
+
+
+def test_c3_channel_chebyshev_matches_oracle_at_512():
+    from fluca_amd.poisson import Poisson
+    _needs_host_memory(32.0)
+    bench = _bench()
+    bc = [V, O, V, V, PER, PER]
+    P = Poisson.uniform(N512, CAVITY_BOX, bc, 1e-3)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    p = torch.rand(P.ncell, generator=gen, dtype=torch.float64, device="cuda") * 2 - 1
+    b = P.apply(p)
+    del p
+    par = bench.c3_parity(P, b, CAVITY_BOX, bc, steps=20)
+    P.close()
+    assert par.get("fused_kernel") is True, par             # the kernel the C3 bench line times
+    assert par["steps_gpu"] == par["steps_cpu"] == 20 and par["reason_gpu"] == par["reason_cpu"] == 4
+    assert par["rel_max_diff_x"] <= 1e-12 and par["rel_l2_diff_x"] <= 1e-12, par
+
+
+def test_momentum_block_matches_the_assembled_oracle_at_256():
+    _needs_host_memory(40.0)
+    bench = _bench()
+    par = bench.momentum_parity(n1=256, its=5)
+    assert par["rows"] == 3 * 256 ** 3
+    assert par["rel_max_diff_apply"] <= 1e-12 and par["rel_max_diff_diag"] <= 1e-12, par
+    assert par["bcgs_iters_gpu"] == par["bcgs_iters_cpu"] == 5
+    assert par["rel_max_diff_history"] <= 1e-9 and par["rel_max_diff_x"] <= 1e-9, par

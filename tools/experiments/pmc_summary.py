@@ -10,6 +10,8 @@ import sys
 
 R, tag = sys.argv[1], sys.argv[2]
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+sys.path.insert(0, ROOT)
+from fluca_amd import provenance  # noqa: E402  (the pass records which sources it counted: bench.py's traffic_stale)
 N = 512 ** 3
 
 
@@ -62,6 +64,8 @@ for k, name in (("fl::k_cg_A<2, 8, true, 1, 2, false>", "pmc_k_cg_A.json"), ("fl
                 ("fl::k_cg_Bq (mean of the even- and odd-iteration launches)", "pmc_k_cg_Bq.json")):
     if k in out:
         o = dict(out[k])
+        key = name[len("pmc_"):-len(".json")]
+        o.update({"kernel_key": key, "sources_at_profiling": provenance.source_hashes(key)})
         o.update({"kernel": k, "fetch_bytes_corrected": o["fetch_GB"] * 1e9, "write_bytes": o["write_GB"] * 1e9,
                   "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `python3 bench.py --steps 8 --warmup 2 --skip-cpu --skip-extras` "
                             f"(tools/experiments/r0N_profile.sh, summarised by tools/experiments/pmc_summary.py, {tag}); FETCH_SIZE in KB doubled per MI355X_MICROARCH.md"})

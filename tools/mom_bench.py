@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--nosolve", action="store_true")
     ap.add_argument("--modes", type=int, default=4)
+    ap.add_argument("--dif", type=float, default=2.56, help="nu dt / h^2 of the BiCGStab-against-Chebyshev comparison (512^3 at Re 100, CFL 0.5: 2.56); 0 skips it")
     ap.add_argument("--fly", type=int, default=1, help="1: v0interp = B v0, state handed over with v0 (k_mom3); 0: random v0interp fields, stored path (k_mom2)")
     a = ap.parse_args()
     n = (a.cells,) * 3
@@ -58,6 +59,17 @@ def main():
       x, info = M.solve(v, rtol=1e-8, maxit=200)
       out.update(solve_iters=info["iters"], solve_reason=info["reason"], solve_ms=info["seconds"] * 1e3,
                ms_per_iter=info["seconds"] * 1e3 / max(info["iters"], 1))
+      # KSPCHEBYSHEV on the same system with a viscous part of nu dt / h^2 = a.dif (the bench state above has 0.25: convection-dominated)
+      if a.dif > 0:
+        M.set_coefficients(1.0, 0.5 * h, -0.5 * a.dif * h * h)   # cI, cC = dt, cL = -mu dt / (2 rho)
+        out["gershgorin_radius"] = M.gershgorin()
+        for name, kw in (("bcgs", dict(type=1)), ("chebyshev", dict(type=2))):
+            M.solve(v, rtol=1e-5, maxit=400, **kw)
+            x, info = M.solve(v, rtol=1e-5, maxit=400, **kw)
+            out[name + "_rtol1e-5"] = dict(iters=info["iters"], reason=info["reason"], ms=info["seconds"] * 1e3, ms_per_iter=info["seconds"] * 1e3 / max(info["iters"], 1))
+        x, info = M.solve(v, type=2, norm_type=3, maxit=40)
+        x, info = M.solve(v, type=2, norm_type=3, maxit=40)
+        out["chebyshev_40_steps_no_norm_ms_per_step"] = info["seconds"] * 1e3 / 40
     out["env"] = {k: v for k, v in os.environ.items() if k.startswith("FLUCA_")}
     import ctypes as C
     from fluca_amd.capi import lib
