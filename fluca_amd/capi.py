@@ -86,6 +86,7 @@ PROTOTYPES = {
     "fl_poisson_sizes": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "fl_ksp_opts_default": (None, [C.POINTER(fl_ksp_opts)]),
     "fl_version": (C.c_char_p, []),
+    "fl_abi_version": (C.c_int, []),
     "fl_current_device": (C.c_int, [C.POINTER(C.c_int)]),
     "fl_malloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(_P)]),
     "fl_free": (C.c_int, [C.c_int, _P]),
@@ -122,6 +123,7 @@ PROTOTYPES = {
     "fl_momentum_diagonal": (C.c_int, [_P, _P]),
     "fl_momentum_rowsum": (C.c_int, [_P, _P]),
     "fl_momentum_gershgorin": (C.c_int, [_P, C.POINTER(C.c_double)]),
+    "fl_momentum_chebyshev_interval": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "fl_abf_set_ainv_types": (C.c_int, [_P, C.c_int, C.c_int]),
     "fl_abf_schur_apply": (C.c_int, [_P, _P, _P]),
     "fl_momentum_solve": (C.c_int, [_P, _P, _P, C.POINTER(fl_ksp_opts), C.POINTER(fl_ksp_stats)]),

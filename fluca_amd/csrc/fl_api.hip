@@ -29,7 +29,11 @@ static int plane_size(const fl_poisson *h, int d)
   return d == 0 ? g.ny * g.nz : (d == 1 ? g.nx * g.nz : g.nx * g.ny);
 }
 
-extern "C" const char *fl_version(void) { return "fluca_amd 0.1 (gfx950)"; }
+// "abi N": bumped whenever a struct of include/fluca_hip.h grows or an entry point changes its meaning (FL_ABI_VERSION there): a caller built
+// against another header must not be handed this library.  5: fl_ksp_opts carries cg_single_reduction (round 3's trailing field), the
+// momentum solve accepts FL_KSP_CHEBYSHEV, fl_momentum_gershgorin / fl_momentum_chebyshev_interval exist.
+extern "C" const char *fl_version(void) { return "fluca_amd 0.2 (gfx950, abi 5)"; }
+extern "C" int fl_abi_version(void) { return FL_ABI_VERSION; }
 
 extern "C" void fl_ksp_opts_default(fl_ksp_opts *o)
 {
@@ -385,6 +389,7 @@ static VmmArena *vmm_arena_create(int device, size_t want, size_t chunk_hint)
   hipMemAccessDesc acc = {};
   acc.location         = prop.location;
   acc.flags            = hipMemAccessFlagsProtReadWrite;
+  size_t accessible = 0;
   for (size_t c = 0; c < n; ++c) {
     hipMemGenericAllocationHandle_t hd;
     if (hipMemCreate(&hd, A->chunk, &prop, 0) != hipSuccess) break;
@@ -395,8 +400,9 @@ static VmmArena *vmm_arena_create(int device, size_t want, size_t chunk_hint)
     A->handles.push_back(hd);
     A->live.push_back(1);
     if (hipMemSetAccess(A->va + c * A->chunk, A->chunk, &acc, 1) != hipSuccess) break;
+    ++accessible;
   }
-  if (A->handles.size() != n) {
+  if (accessible != n) {  // a chunk that could not be created, mapped or made accessible: the arena's destructor unmaps and releases what exists
     (void)hipGetLastError();
     delete A;
     return nullptr;
@@ -557,17 +563,20 @@ int place_vectors(fl_poisson *h)
           sc.vmm[a]    = nullptr;
           sc.arenas[a] = nullptr;
         }
+      // `chosen` left the search's guard above: until the handle owns it, every early return below must give it back
+      struct Owner {
+        VmmArena *a;
+        ~Owner() { delete a; }
+      } own{chosen};
       chosen->release_outside(best, best + winb);
       FL_HIP(hipMemsetAsync((char *)arena + best, 0, winb, s));
       double again = 0.;
       const int prc = probe(arena, best, &again);
-      if (prc != 0) {
-        delete chosen;
-        return prc;
-      }
+      if (prc != 0) return prc;
       if (verbose) std::fprintf(stderr, "[fluca placement] window at %.2f GiB kept (%.2f GiB live of %.2f), probe again %.4f ms (search %.4f, first %.4f)\n", (double)best / (double)((size_t)1 << 30), (double)chosen->bytes_live() / (double)((size_t)1 << 30), (double)chosen->size / (double)((size_t)1 << 30), again, best_ms, first_ms);
       FL_HIP(hipMemsetAsync((char *)arena + best, 0, winb, s));
       FL_HIP(hipStreamSynchronize(s));
+      own.a          = nullptr;
       h->vmm         = chosen;
       h->arena       = nullptr;  // no side pools: every other vector is a plain allocation
       h->arena_bytes = chosen->bytes_live();
@@ -1246,6 +1255,7 @@ extern "C" int fl_poisson_solve(fl_poisson *h, const double *b_dev, double *x_de
   std::memset(stats, 0, sizeof(*stats));
   if (opts->pc == FL_PC_MG) {
     if (opts->type != FL_KSP_CG) return FL_ERR_SUP;
+    if (opts->cg_single_reduction) return FL_ERR_SUP;  // the cycle's sums ride on its last smoothing sweep: no single-reduction form of that loop is built
     return fl_solve_cg_mg(h, b_dev, x_dev, opts, stats);
   }
   switch (opts->type) {

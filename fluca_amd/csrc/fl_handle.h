@@ -348,6 +348,7 @@ int &fl_placement_mode();
 void fl_vmm_destroy(fl_poisson *h);
 int &fl_cg_xbatch_mode();
 int &fl_mg_prolong_mode();  // fl_mg.hip: 0 piecewise constant, 1 tri-linear
+int &fl_mg_flexible_mode(); // fl_mg.hip: 0 KSPCG's beta, 1 the Polak-Ribiere form (flexible CG)
 int  fl_ensure_partials(fl_poisson *h, int nblocks);
 int  fl_ensure_hist(fl_poisson *h, int nhist);
 int  fl_zero_vec(fl_poisson *h, double *v);

@@ -1125,6 +1125,10 @@ extern "C" int fl_tuning_set(const char *name, int value)
     cheb_staged_mode() = value;
     return FL_SUCCESS;
   }
+  if (std::strcmp(name, "mg_flexible") == 0) {
+    fl_mg_flexible_mode() = value != 0;
+    return FL_SUCCESS;
+  }
   if (std::strcmp(name, "mg_prolong") == 0) {
     fl_mg_prolong_mode() = value;
     return FL_SUCCESS;
@@ -1148,6 +1152,10 @@ extern "C" int fl_tuning_get(const char *name, int *value)
   }
   if (std::strcmp(name, "placement") == 0) {
     *value = fl_placement_mode();
+    return FL_SUCCESS;
+  }
+  if (std::strcmp(name, "mg_flexible") == 0) {
+    *value = fl_mg_flexible_mode();
     return FL_SUCCESS;
   }
   if (std::strcmp(name, "mg_prolong") == 0) {
@@ -1465,6 +1473,7 @@ int fl_solve_cg_sr(fl_poisson *h, const double *b, double *x, const fl_ksp_opts 
   // p, W, x enter the first update with factor b = 0 / as the zero initial guess: they must be finite, so they are cleared; the ghost
   // layers of both r buffers likewise (a wall ghost is divided by its infinite diagonal, whatever finite value it holds)
   for (double *v : {h->r, h->q, h->P0, h->P1, h->xp}) FL_CHK(fl_zero_vec(h, v));
+  h->poisoned = false;  // every work vector a poisoned handle would have cleared has just been cleared
   double *R = h->r, *Rn = h->q, *P = h->P0, *W = h->P1, *X = h->xp;
   launch_pad_copy(s, g, b, R);
   const bool ghosts = fl_any_ghost_exchange(h);

@@ -13,7 +13,7 @@
 //   cycle      : V(nu, nu):  x = smooth(b); r = b - S x; e = V(R r); x += P e; r = b - S x; x += smooth(r)
 //   coarsest   : Jacobi-PCG to rtol 1e-2 (at most 200 iterations)
 //   outer      : KSPCG, left preconditioning, preconditioned norm ||z||, KSPConvergedDefault, constant null space
-//                removed from every preconditioner output
+//                removed from every preconditioner output; beta in the Polak-Ribiere form (flexible CG, "mg_flexible" below)
 //
 // Shape: every level is a full fl_poisson handle on the fine handle's stream, and the cycle works on the PADDED work
 // vectors of those handles (right-hand side h->r, iterate h->xp, scratch h->q) through the padded entry points of
@@ -367,6 +367,21 @@ int &fl_mg_prolong_mode()
   return m;
 }
 
+// "mg_flexible" (fl_tuning_set; initial value from FLUCA_MG_FLEXIBLE): 1 (default since round 4) the outer CG takes the Polak-Ribiere form
+// of beta, beta = z_new . (r_new - r_old) / (z_old . r_old) = -alpha (q . z_new) / (z_old . r_old) -- KSPFCG truncated to one direction
+// (-ksp_fcg_mmax 1) --, 0 the Fletcher-Reeves form of KSPCG, r_new . z_new / (r_old . z_old).  The two agree for a fixed symmetric
+// preconditioner; the V-cycle is neither once the restriction is not a multiple of the transposed prolongation (tri-linear against
+// volume-weighted; any transfer pair on a stretched grid): with two smoothing steps a stretched channel needed 100 iterations with the
+// KSPCG form and 17 with this one (oracle study, profiles/r04_mg_flexible.txt).  Costs one more pass over (z, q) per iteration.
+int &fl_mg_flexible_mode()
+{
+  static int m = []() {
+    const char *e = std::getenv("FLUCA_MG_FLEXIBLE");
+    return e ? std::atoi(e) : 1;
+  }();
+  return m;
+}
+
 namespace {
 
 constexpr int MG_BLOCKS = 4096;
@@ -689,7 +704,12 @@ int fl_solve_cg_mg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts 
       hipLaunchKernelGGL(k_mg_pw<3>, dim3(nb), dim3(256), 0, s, g, alpha, 0., 0., (const double *)P, (const double *)nullptr, X, (double *)nullptr);  // x += alpha p
       break;
     }
-    const double beta = rz / rz_old;
+    double beta = rz / rz_old;
+    if (fl_mg_flexible_mode()) {  // z' . (r_new - r_old) = -alpha q . z',  q . z' = q . z - m sum q
+      double d2[5];
+      FL_CHK(dots(h, h->xp, Q, d2));
+      beta = -alpha * (d2[2] - m * d2[3]) / rz_old;
+    }
     hipLaunchKernelGGL(k_mg_pw<4>, dim3(nb), dim3(256), 0, s, g, alpha, beta, m, (const double *)h->xp, (const double *)nullptr, P, X);  // x += alpha p ; p = z' + beta p
   }
   // answer, with the constant removed on the way out (the shift is handed over in device memory)
@@ -708,8 +728,12 @@ int fl_solve_cg_mg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts 
   FL_HIP(hipEventElapsedTime(&ms, e0, e1));
   st->iters   = it;
   st->reason  = reason;
-  if (reason == FL_DIVERGED_NANORINF || reason == FL_DIVERGED_DTOL) {
+  if (reason == FL_DIVERGED_NANORINF || reason == FL_DIVERGED_DTOL || !std::isfinite(dp)) {
     for (MgLevel &L : mg->lv) L.h->poisoned = true;  // work vectors of every level may hold NaN: cleared before their next CG solve
+  } else {
+    // the unmonitored smoothing sweeps mark their handle (fl_cheb_smooth_padded: no norm is looked at in there), but the outer iteration did
+    // look: a finite ||z|| after the last cycle says that no level's work vector holds a NaN or an Inf, so nothing needs clearing
+    for (MgLevel &L : mg->lv) L.h->poisoned = false;
   }
   st->rnorm0  = rnorm0;
   st->rnorm   = dp;

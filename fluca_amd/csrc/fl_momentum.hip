@@ -813,6 +813,7 @@ struct fl_momentum {
   std::vector<double *> gm;  // cell vectors of the Schur solve with a variable-coefficient S
   std::vector<double *> kb;  // KSPGMRES on A: Krylov basis (3*cells each, allocated as the iteration needs them), w, x, r
   bool        have_state = false;
+  double      dmax = 1.;    // max_i a_ii, formed with gersh
   double      gersh = -1.;  // cached Gershgorin radius of the Jacobi-scaled operator (fl_momentum_gershgorin); < 0: not computed for this state
   int         tiles_x = 1, tiles_y = 1, nchunk = 1, zc = 1, nblocks = 1;  // 64 x 4 x zc tiles of the vector-update kernels
   int         anchunk = 1, azc = 1, ablocks = 1;                        // 64 x MOM_RY x azc tiles of k_mom_apply
@@ -1193,6 +1194,25 @@ extern "C" int fl_momentum_diagonal(fl_momentum *m, double *d_dev)
   return FL_SUCCESS;
 }
 
+// max over the owned cells (all ranks) of three padded components: a set-up quantity, one host wait
+static int max_owned(fl_momentum *m, const double *v3, double *out)
+{
+  fl_poisson   *h = m->p;
+  const int64_t rows = (int64_t)3 * h->g.nz * h->g.ny;
+  const int     nb = (int)std::max<int64_t>(1, std::min<int64_t>(rows, 1024));
+  FL_CHK(fl_ensure_partials(h, nb));
+  hipLaunchKernelGGL(k_max_owned, dim3(nb), dim3(256), 0, h->stream, h->g, (int64_t)h->padlen, v3, h->partial);
+  FL_HIP(hipGetLastError());
+  std::vector<double> part((size_t)nb);
+  FL_HIP(hipMemcpyAsync(part.data(), h->partial, sizeof(double) * (size_t)nb, hipMemcpyDeviceToHost, h->stream));
+  FL_HIP(hipStreamSynchronize(h->stream));
+  double mx = 0.;
+  for (double v : part) mx = std::max(mx, v);
+  FL_CHK(fl_allreduce_max(h, &mx));  // several ranks: the bound of the whole operator
+  *out = mx;
+  return 0;
+}
+
 // Gershgorin radius of the Jacobi-scaled operator: max_i (sum_{j != i} |a_ij|) / |a_ii|, the entries taken from the same row
 // coefficients the product multiplies with (k_mom2 / k_mom3, OUT == 3).  Every eigenvalue of D^-1 A lies in the disc |lambda - 1| <= radius.
 // One product-sized launch and one host wait per state; cached until the state or the coefficients change.
@@ -1206,28 +1226,31 @@ extern "C" int fl_momentum_gershgorin(fl_momentum *m, double *radius)
   if (m->gersh < 0.) {
     FL_CHK(mom_vec(m, 7));
     mom_apply_t<0, false, 3>(m, m->F, m->vec[7], nullptr, nullptr);  // x is not used for the row sums: any valid padded array
-    const int64_t rows = (int64_t)3 * h->g.nz * h->g.ny;
-    const int     nb = (int)std::max<int64_t>(1, std::min<int64_t>(rows, 1024));
-    FL_CHK(fl_ensure_partials(h, nb));
-    hipLaunchKernelGGL(k_max_owned, dim3(nb), dim3(256), 0, h->stream, h->g, (int64_t)h->padlen, (const double *)m->vec[7], h->partial);
-    FL_HIP(hipGetLastError());
-    std::vector<double> part((size_t)nb);
-    FL_HIP(hipMemcpyAsync(part.data(), h->partial, sizeof(double) * (size_t)nb, hipMemcpyDeviceToHost, h->stream));
-    FL_HIP(hipStreamSynchronize(h->stream));
-    double mx = 0.;
-    for (double v : part) mx = std::max(mx, v);
-    double all = mx;
-    FL_CHK(fl_allreduce_max(h, &all));  // several ranks: the bound of the whole operator
-    m->gersh = all;
+    FL_CHK(max_owned(m, m->vec[7], &m->gersh));
+    FL_CHK(max_owned(m, m->dg, &m->dmax));
   }
   *radius = m->gersh;
   return FL_SUCCESS;
 }
 
+// The interval KSPCHEBYSHEV on kspA uses when none is given (PCJACOBI): emax = 1 + g from the Gershgorin disc of D^-1 A (a bound), emin = the
+// larger of 1 - g (the disc again, while the operator is diagonally dominant) and 0.9 / max_i a_ii -- the field of values of
+// D^-1/2 A D^-1/2 lies to the right of 1 / max a_ii as long as dt C - (mu dt / 2 rho) L has a non-negative symmetric part (exactly so for a
+// skew convection operator and a symmetric Laplacian; the one-sided wall rows and a discretely non-solenoidal V0 spoil that a little,
+// hence the factor 0.9).  With a viscous operator in the lead (nu dt / h^2 > 1) that IS the small end of the spectrum.
+extern "C" int fl_momentum_chebyshev_interval(fl_momentum *m, double *emin, double *emax)
+{
+  if (!m || !emin || !emax) return FL_ERR_ARG_NULL;
+  double g = 0.;
+  FL_CHK(fl_momentum_gershgorin(m, &g));
+  *emax = 1. + g;
+  *emin = std::max(1. - g, 0.9 / m->dmax);
+  return FL_SUCCESS;
+}
+
 // KSPCHEBYSHEV on the momentum block (-ns_abf_momentum_ksp_type chebyshev, a PETSc option the reference's kspA accepts like any other):
 // PETSc's three-term recurrence with PCJACOBI / PCNONE, zero initial guess.  Interval: opts->emin / emax (-ksp_chebyshev_eigenvalues), or, with
-// PCJACOBI, from the Gershgorin disc of D^-1 A (centre 1, radius g = fl_momentum_gershgorin): [1 - g, 1 + g] while the operator is diagonally
-// dominant enough for that to be an interval of positive numbers (g <= 0.9), else PETSc's default transform of an estimate, (0.1, 1.1) x (1 + g).
+// PCJACOBI, fl_momentum_chebyshev_interval: [max(1 - g, 0.9 / max a_ii), 1 + g], g the Gershgorin radius of D^-1 A.
 // One fused launch per step where the state came with v0 (k_mom3, OUT == 4: 144 B/cell), the product and a vector update otherwise.
 static int momentum_cheb(fl_momentum *m, const double *b_dev, double *x_dev, const fl_ksp_opts *opts, fl_ksp_stats *stats)
 {
@@ -1242,15 +1265,7 @@ static int momentum_cheb(fl_momentum *m, const double *b_dev, double *x_dev, con
   double     emin = opts->emin, emax = opts->emax;
   if (emin == 0. && emax == 0.) {
     if (!jac) return FL_ERR_SUP;  // no bound of the unscaled operator is formed: give -ksp_chebyshev_eigenvalues
-    double g = 0.;
-    FL_CHK(fl_momentum_gershgorin(m, &g));
-    if (g <= 0.9) {
-      emin = 1. - g;
-      emax = 1. + g;
-    } else {
-      emin = 0.1 * (1. + g);
-      emax = 1.1 * (1. + g);
-    }
+    FL_CHK(fl_momentum_chebyshev_interval(m, &emin, &emax));
   }
   if (!(emax > emin) || !(emin > 0.)) return FL_ERR_ARG_OUTOFRANGE;
   const bool fused = mom_kernel() >= 3 && m->fly && h->g.ny > 8;

@@ -334,6 +334,14 @@ class Momentum:
         self.p._post()
         return g.value
 
+    def chebyshev_interval(self):
+        """(emin, emax) FL_KSP_CHEBYSHEV uses on this state when none is given."""
+        a, b = C.c_double(), C.c_double()
+        self.p._pre()
+        check(lib.fl_momentum_chebyshev_interval(self.h, C.byref(a), C.byref(b)), "fl_momentum_chebyshev_interval")
+        self.p._post()
+        return a.value, b.value
+
     def set_ainv_types(self, schur=0, upper=0):
         """PCABFSetSchurComplementAinvType / PCABFSetUpperTriangularAinvType: 0 ID, 1 DIAG, 2 ROWSUM"""
         check(lib.fl_abf_set_ainv_types(self.h, int(schur), int(upper)), "fl_abf_set_ainv_types")

@@ -90,6 +90,9 @@ typedef enum { FL_NORM_PRECONDITIONED = 0, FL_NORM_UNPRECONDITIONED = 1, FL_NORM
 #define FL_DIVERGED_NANORINF (-9)
 #define FL_DIVERGED_INDEFINITE_MAT (-10)
 
+/* Every field must hold a defined value: start from fl_ksp_opts_default (or a zeroed struct) and set what differs.  The struct grows at
+ * its END between ABI versions (FL_ABI_VERSION / fl_abi_version below): a caller compiled against an older header hands over a shorter
+ * struct, so check fl_abi_version() == FL_ABI_VERSION once at start-up. */
 typedef struct fl_ksp_opts {
   int     type;             /* fl_ksp_type */
   int     pc;               /* fl_pc_type */
@@ -114,7 +117,8 @@ typedef struct fl_ksp_opts {
   int     cg_single_reduction; /* FL_KSP_CG with FL_PC_JACOBI / FL_PC_NONE: -ksp_cg_single_reduction (on the reference's sub-KSP:
                                -ns_abf_schur_ksp_cg_single_reduction, prefix built at abfpc.c:206): all inner products of an iteration in
                                ONE reduction -- one all-reduce and one scalar kernel per iteration on several ranks instead of two, for
-                               72 instead of 60 B/cell/iteration (W = A p kept by recurrence).  0 (default) = off, as in PETSc */
+                               72 instead of 60 B/cell/iteration (W = A p kept by recurrence).  0 (default) = off, as in PETSc.
+                               With FL_PC_MG: FL_ERR_SUP (not built).  Other Krylov types ignore it, as PETSc ignores an option of another type. */
 } fl_ksp_opts;
 
 typedef struct fl_ksp_stats {
@@ -147,6 +151,8 @@ int fl_poisson_barrier(fl_poisson *h);
 int fl_poisson_sizes(const fl_poisson *h, int64_t out[4]);
 void fl_ksp_opts_default(fl_ksp_opts *o); /* PETSc defaults + cg/jacobi/preconditioned norm */
 const char *fl_version(void);
+#define FL_ABI_VERSION 5
+int fl_abi_version(void); /* the FL_ABI_VERSION the library was built with */
 
 /* ---- device memory for hosts that have no allocator of their own (the C host mirror, a PETSc host without HIP Vecs) - */
 int fl_current_device(int *device);                      /* the calling thread's current HIP device (hipGetDevice) */
@@ -174,6 +180,10 @@ int fl_vec_maxpy(fl_poisson *h, int64_t n, double *x_dev, const double *alphas, 
  *   "cg_xbatch"  1 (default) = the CG solver updates x every second iteration (both updates of the pair at once, while the older
  *                direction is still in its buffer); 0 = one update per iteration.  The same x bit for bit.
  *   "cheb_staged" 1 (default) = the one-step Chebyshev kernel walks LDS-staged tiles like the CG kernels (k_cheb_st); 0 = round 1's k_cheb.
+ *   "mg_prolong" 1 (default) = tri-linear prolongation of the FL_PC_MG cycle; 0 = piecewise constant.  (This one and the next change the
+ *                preconditioner, i.e. iteration counts -- not the converged answer.)
+ *   "mg_flexible" 1 (default) = the CG around the FL_PC_MG cycle forms beta in the Polak-Ribiere way (flexible CG, KSPFCG with
+ *                -ksp_fcg_mmax 1): robust against the cycle not being a symmetric operator; 0 = KSPCG's beta.
  * Returns FL_ERR_ARG_WRONG for an unknown name.  Process-wide; set before the solve it should affect. */
 int fl_tuning_set(const char *name, int value);
 int fl_tuning_get(const char *name, int *value);
@@ -299,7 +309,7 @@ int fl_momentum_diagonal(fl_momentum *m, double *d_dev);                   /* Ma
  * opts->type: FL_KSP_BCGS (left-preconditioned KSPBCGS, preconditioned norm), FL_KSP_GMRES (PETSc's default type for kspA; restart
  * opts->gmres_restart) or FL_KSP_CHEBYSHEV (KSPCHEBYSHEV's three-term recurrence fused into the product: 144 B per cell and step where a
  * BiCGStab iteration moves 552 -- the method of choice while the operator is diffusion-dominated, e.g. nu dt / h^2 > 1; interval from
- * opts->emin / emax = -ksp_chebyshev_eigenvalues, or with PCJACOBI from the Gershgorin disc of D^-1 A, see fl_momentum_gershgorin). */
+ * opts->emin / emax = -ksp_chebyshev_eigenvalues, or with PCJACOBI fl_momentum_chebyshev_interval). */
 int fl_momentum_solve(fl_momentum *m, const double *b_dev, double *x_dev, const fl_ksp_opts *opts, fl_ksp_stats *stats);
 /* V_d = rhs_d + (T v)_d on the d-faces: MatMult(abf->negT, vstar, Vstar); VecAYPX(Vstar, -1, interprhs), abfpc.c:73-74.
  * T = ComputeFaceNormalVelocityInterpolationOperator_Private, cnlinearcart3d.c:1934-2140.  rhs_dev (or any entry) may
@@ -347,9 +357,11 @@ int fl_abf_schur_apply(fl_momentum *m, const double *p_dev, double *y_dev);
 /* MatGetRowSum(A) into 3*cells doubles (component-major), like fl_momentum_diagonal */
 int fl_momentum_rowsum(fl_momentum *m, double *out_dev);
 /* Gershgorin radius of the Jacobi-scaled momentum operator: max over the rows of (sum of |a_ij|, j != i) / |a_ii|, over all ranks.  Every
- * eigenvalue of D^-1 A lies in the disc of this radius around 1.  The default interval of FL_KSP_CHEBYSHEV on kspA is [1 - g, 1 + g] while
- * g <= 0.9, else PETSc's default transform (0.1, 1.1) of the estimate 1 + g.  One product-sized launch and a host wait per state. */
+ * eigenvalue of D^-1 A lies in the disc of this radius around 1.  One product-sized launch and a host wait per state (cached). */
 int fl_momentum_gershgorin(fl_momentum *m, double *radius);
+/* The interval FL_KSP_CHEBYSHEV on kspA uses when opts->emin = emax = 0 (PCJACOBI): emax = 1 + g, emin = max(1 - g, 0.9 / max_i a_ii) -- the
+ * second is where the spectrum of a viscous-dominated A = I + dt C - (mu dt / 2 rho) L ends (fl_momentum.hip says why). */
+int fl_momentum_chebyshev_interval(fl_momentum *m, double *emin, double *emax);
 
 /* ---- immersed boundary (build-defined; no reference function) -------------------------------- */
 typedef enum { FL_DELTA_PESKIN4 = 0, FL_DELTA_ROMA3 = 1 } fl_delta_kind;

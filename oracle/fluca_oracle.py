@@ -417,8 +417,9 @@ class MgOracle:
     V(nu,nu) cycle as left preconditioner.  `bounds[l]` = the eigenvalue bound of D^-1 S the product uses on level l
     (fl_poisson_gershgorin); None = the row-wise Gershgorin bound of the assembled matrix."""
 
-    def __init__(self, g, max_levels=0, nu=3, nullspace=True, bounds=None, prolong="constant"):
-        self.nu, self.nullspace, self.prolong = int(nu), bool(nullspace), prolong
+    def __init__(self, g, max_levels=0, nu=3, nullspace=True, bounds=None, prolong="constant", flexible=True):
+        # flexible: the outer CG's beta in the Polak-Ribiere form, -alpha (q . z_new) / (r_old . z_old) (fl_mg.hip "mg_flexible", the default)
+        self.nu, self.nullspace, self.prolong, self.flexible = int(nu), bool(nullspace), prolong, bool(flexible)
         self.grids, self.S, self.ratio = [g], [g.assemble_S()], []
         while max_levels <= 0 or len(self.grids) < max_levels:
             gf = self.grids[-1]
@@ -523,7 +524,8 @@ class MgOracle:
                 reason = -8   # KSP_DIVERGED_INDEFINITE_PC: r.z <= 0 (KSPSolve_CG's test on beta; a non-symmetric S can get there)
             if reason:
                 break
-            p = z + (rz / rz_old) * p
+            beta = -alpha * (q @ z) / rz_old if self.flexible else rz / rz_old
+            p = z + beta * p
         return proj(x), dict(iters=it, reason=reason, history=np.array(hist))
 
 

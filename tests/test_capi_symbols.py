@@ -58,6 +58,11 @@ def test_host_mirror_and_cgns_headers_are_exported_and_bound(capi):
 
 def test_version_and_defaults(capi):
     assert b"gfx950" in capi.lib.fl_version()
+    # the ABI number of the header the library was built from = the one in the tree's header, and it is what fl_version prints
+    import re
+    hdr = open(os.path.join(ROOT, "include", "fluca_hip.h")).read()
+    want = int(re.search(r"#define FL_ABI_VERSION (\d+)", hdr).group(1))
+    assert capi.lib.fl_abi_version() == want and f"abi {want}".encode() in capi.lib.fl_version()
     o = capi.fl_ksp_opts()
     capi.lib.fl_ksp_opts_default(C.byref(o))
     # PETSc KSP defaults + what the reference's docs recommend for kspS (-ns_abf_schur_ksp_type cg -pc_type jacobi)

@@ -107,3 +107,47 @@ def test_one_level_hierarchy_keeps_the_outer_residual(n, levels):
     assert np.linalg.norm(b - S.mult(xg)) / np.linalg.norm(b) < 1e-6      # a clobbered residual reports convergence with a wrong x
     assert np.linalg.norm((xg - xg.mean()) - xo) <= 1e-5 * np.linalg.norm(xo)
     P.close()
+
+
+@pytest.mark.parametrize("n,bc,nonuni,nullspace,nu", [
+    ((40, 24, 16), [O, V, V, V, V, V], True, False, 2),            # stretched + outlet, two smoothing steps: KSPCG's beta needs 80 iterations here
+    ((48, 48, 24), [V, O, V, V, PER, PER], True, False, 2),        # the channel of BASELINE config 3, stretched: 100 with KSPCG's beta
+    ((64, 32, 32), [PER, PER, V, V, SYM, V], True, True, 3),       # stretched, two periodic axes, null space
+    ((32, 16, 16), [PER] * 6, False, True, 3),
+])
+def test_flexible_beta_is_the_default_and_matches_the_oracle(n, bc, nonuni, nullspace, nu):
+    """ADVICE (round 3): the tri-linear prolongation against the volume-weighted restriction makes the cycle a non-symmetric operator.  The
+    outer CG therefore takes beta in the Polak-Ribiere form ("mg_flexible" = 1, the default): same iteration counts as the oracle's
+    restatement of that form, and never more than with the piecewise-constant transfer."""
+    from fluca_amd import capi
+    P, g = make_pair(n, bc, kappa=1e-3, nonuniform=nonuni)
+    S = g.assemble_S()
+    p = np.random.default_rng(3).standard_normal(g.ncell)
+    if nullspace:
+        p -= p.mean()
+    b = S.mult(p)
+    mg0 = fo.MgOracle(g, nullspace=nullspace, nu=nu)
+    bounds = _bounds(mg0)
+    its = {}
+    try:
+        for prolong in ("linear", "constant"):
+            capi.check(capi.lib.fl_tuning_set(b"mg_prolong", 1 if prolong == "linear" else 0))
+            xo, io = fo.MgOracle(g, nullspace=nullspace, nu=nu, bounds=bounds, prolong=prolong).pcg(b, rtol=1e-8, maxit=200)
+            xg, ig = P.solve(dev(b), history=True, type=0, pc=2, remove_nullspace=int(nullspace), rtol=1e-8, maxit=200, mg_smooth_its=nu)
+            assert ig["reason"] == io["reason"] == 2, (prolong, ig["iters"], io["iters"], ig["reason"], io["reason"])
+            assert abs(ig["iters"] - io["iters"]) <= max(1, io["iters"] // 10), (prolong, ig["iters"], io["iters"])
+            assert np.allclose(ig["history"][:3], io["history"][:3], rtol=1e-6)
+            xg = host(xg)
+            assert np.linalg.norm(b - S.mult(xg)) <= 1e-6 * np.linalg.norm(b)
+            its[prolong] = ig["iters"]
+        assert its["linear"] <= its["constant"], its
+        # and with KSPCG's beta the tri-linear cycle is what the advisor feared on the first two grids
+        if nu == 2:
+            capi.check(capi.lib.fl_tuning_set(b"mg_prolong", 1))
+            capi.check(capi.lib.fl_tuning_set(b"mg_flexible", 0))
+            _, i0 = P.solve(dev(b), type=0, pc=2, remove_nullspace=int(nullspace), rtol=1e-8, maxit=200, mg_smooth_its=nu)
+            assert i0["iters"] >= 2 * its["linear"], (i0["iters"], its["linear"])
+    finally:
+        capi.check(capi.lib.fl_tuning_set(b"mg_prolong", 1))
+        capi.check(capi.lib.fl_tuning_set(b"mg_flexible", 1))
+    P.close()
