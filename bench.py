@@ -686,11 +686,27 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
     assert info["iters"] == args.steps, info
-    per_rank = None
+    per_rank, wire = None, None
     if world > 1:
         per_rank = [None] * world
         dist.all_gather_object(per_rank, {"rank": rank, "device": local, "k_cg_A_ms": info["kernel_ms"], "k_cg_Bq_ms": info["kernel2_ms"], "seconds_device": info["seconds"],
-                                          "placement_probe_ms": list(probe)})
+                                          "placement_probe_ms": list(probe), "comm": P.comm_info()})
+        # the line checks itself: every rank's communicator must BE the transport that was asked for, span the whole job (as RCCL itself
+        # reports it: ncclCommCount / ncclCommUserRank), and the ranks must be all different -- a curve over anything else is worthless
+        comms = [r["comm"] for r in per_rank]
+        want = 1 if transport == "rccl" else 2
+        assert all(c["transport"] == want for c in comms), f"transport mismatch: {comms}"
+        assert all(c["nranks"] == world for c in comms) and sorted(c["rank"] for c in comms) == list(range(world)), f"communicator does not span the job: {comms}"
+        assert all(c["loopback"] == 0 for c in comms), "FLUCA_COMM_LOOPBACK is set: a rank would be talking to itself"
+        ka = [r["k_cg_A_ms"] for r in per_rank]
+        kb = [r["k_cg_Bq_ms"] for r in per_rank]
+        wire = {"transport": "rccl" if want == 1 else "host", "nranks_reported_by_the_communicator": comms[0]["nranks"], "ranks_reported": sorted(c["rank"] for c in comms),
+                "neighbours_per_rank": [c["neighbours"] for c in comms], "messages_per_exchange_per_rank": [c["messages"] for c in comms],
+                # one ghost exchange of r per iteration (ghost p is recomputed from ghost r), two all-reduces of 8 doubles
+                "halo_bytes_per_iter": int(sum(c["halo_bytes"] for c in comms)), "halo_bytes_per_iter_per_rank": [int(c["halo_bytes"]) for c in comms],
+                "allreduce_bytes_per_iter_per_rank": 2 * 8 * 8,
+                "k_cg_A_ms_spread": {"min": min(ka), "max": max(ka), "max_over_min": max(ka) / min(ka) if min(ka) > 0 else None},
+                "k_cg_Bq_ms_spread": {"min": min(kb), "max": max(kb), "max_over_min": max(kb) / min(kb) if min(kb) > 0 else None}}
 
     cells_job = float(P.ncell) * world
     value = cells_job / 512.0 ** 3 * args.steps / dt
@@ -711,7 +727,7 @@ def main():
                    "halo": ("RCCL Send/Recv" if transport == "rccl" else "host-staged gloo (NOT the production transport)") if world > 1 else "none"},
         "iteration_algorithmic_GBps_per_gpu": B_ITER_ALGO * P.ncell * args.steps / dt / 1e9,
         "solve_seconds_device": info["seconds"],
-        "ranks": per_rank, "transport_ranks": world if world > 1 else None,
+        "ranks": per_rank, "transport_ranks": (len(set(wire["ranks_reported"])) if wire else None), "wire": wire,
         "placement": {"mode": args.placement, "probe_ms_all_vectors_in_one_block": probe[0], "probe_ms_chosen": probe[1],
                       "note": "probe = one k_cg_A + one odd-iteration k_cg_Bq; the search arena is given back, the handle keeps five vectors (include/fluca_hip.h fl_poisson_tune_placement)"},
         "hbm_bytes_held": P.vector_bytes(),

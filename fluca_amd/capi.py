@@ -41,6 +41,10 @@ def check(rc, what="libflucahip"):
         raise FlucaError(rc, what)
 
 
+class fl_comm_info(C.Structure):
+    _fields_ = [("transport", C.c_int), ("rank", C.c_int), ("nranks", C.c_int), ("loopback", C.c_int), ("neighbours", C.c_int), ("messages", C.c_int), ("halo_bytes", C.c_int64)]
+
+
 class fl_grid(C.Structure):
     _fields_ = [("n", C.c_int64 * 3), ("xf", C.c_void_p * 3), ("xc", C.c_void_p * 3)]
 
@@ -87,6 +91,7 @@ PROTOTYPES = {
     "fl_ksp_opts_default": (None, [C.POINTER(fl_ksp_opts)]),
     "fl_version": (C.c_char_p, []),
     "fl_abi_version": (C.c_int, []),
+    "fl_poisson_comm_info": (C.c_int, [_P, C.POINTER(fl_comm_info)]),
     "fl_current_device": (C.c_int, [C.POINTER(C.c_int)]),
     "fl_malloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(_P)]),
     "fl_free": (C.c_int, [C.c_int, _P]),

@@ -1376,6 +1376,34 @@ extern "C" int fl_poisson_comm_init_host(fl_poisson *h, fl_exchange_fn xchg, fl_
   return FL_SUCCESS;
 }
 
+extern "C" int fl_poisson_comm_info(fl_poisson *h, fl_comm_info *out)
+{
+  if (!h || !out) return FL_ERR_ARG_NULL;
+  std::memset(out, 0, sizeof(*out));
+  out->transport = h->comm.kind == Comm::RCCL ? 1 : h->comm.kind == Comm::HOST ? 2 : 0;
+  out->rank      = h->comm.rank;
+  out->nranks    = h->comm.nranks;
+  out->loopback  = h->loopback ? 1 : 0;
+  if (h->comm.kind == Comm::RCCL && h->comm.nccl) {  // what the communicator itself says, not what init was told
+    FL_NCCL(g_rccl.CommCount(h->comm.nccl, &out->nranks));
+    FL_NCCL(g_rccl.CommUserRank(h->comm.nccl, &out->rank));
+  }
+  if (h->multi) {
+    int periodic[3];
+    for (int d = 0; d < 3; ++d) periodic[d] = h->ax[d].periodic;
+    fl_halo_msg plan[12];
+    const int   np = fl_halo_plan(&h->dec, periodic, plan);
+    std::vector<int> peers;
+    for (int a = 0; a < np; ++a) {
+      if (plan[a].send_boundary >= 0) out->halo_bytes += (int64_t)sizeof(double) * (int64_t)plane_size(h, plan[a].send_boundary / 2);
+      if (std::find(peers.begin(), peers.end(), plan[a].peer) == peers.end()) peers.push_back(plan[a].peer);
+    }
+    out->messages   = np;
+    out->neighbours = (int)peers.size();
+  }
+  return FL_SUCCESS;
+}
+
 // ------------------------------------------------------------------------------------------------ kernel micro-bench (tools/kbench.py)
 // Not part of the public C-ABI (not declared in fluca_hip.h): times one hot kernel in isolation with HIP events.
 //   kernel 0: k_cg_A (ry, pf, nchunk)   1: k_cg_B (ry, nchunk)   2: streaming reference with ry reads / pf writes

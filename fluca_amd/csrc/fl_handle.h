@@ -83,6 +83,8 @@ struct Rccl {
   decltype(&ncclGroupStart)     GroupStart     = nullptr;
   decltype(&ncclGroupEnd)       GroupEnd       = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclCommCount)      CommCount      = nullptr;
+  decltype(&ncclCommUserRank)   CommUserRank   = nullptr;
   int load()
   {
     if (lib) return 0;
@@ -99,7 +101,7 @@ struct Rccl {
     std::fprintf(stderr, "[flucahip] librccl lacks nccl" #n "\n"); \
     return FL_ERR_LIB;                                           \
   }
-    FL_SYM(GetUniqueId) FL_SYM(CommInitRank) FL_SYM(CommDestroy) FL_SYM(Send) FL_SYM(Recv) FL_SYM(AllReduce) FL_SYM(GroupStart) FL_SYM(GroupEnd) FL_SYM(GetErrorString)
+    FL_SYM(GetUniqueId) FL_SYM(CommInitRank) FL_SYM(CommDestroy) FL_SYM(Send) FL_SYM(Recv) FL_SYM(AllReduce) FL_SYM(GroupStart) FL_SYM(GroupEnd) FL_SYM(GetErrorString) FL_SYM(CommCount) FL_SYM(CommUserRank)
 #undef FL_SYM
     return 0;
   }

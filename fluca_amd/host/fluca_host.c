@@ -45,6 +45,10 @@ enum { E_MEM = 55, E_SUP = 56, E_ARG_WRONG = 62, E_FILE_OPEN = 65, E_ARG_OUTOFRA
   } while (0)
 static void trace_end(void);
 static void trace_begin(const char *name);
+/* FLUCA_STEP_TIMING=1: NSStep prints the wall time of its phases (each closed by a stream synchronise, so the sum is larger than an
+ * untimed step): where a time step goes, without a profiler */
+static int    step_timing(void);
+static double step_clock(NS ns);
 static FlErrorCode ns_jacobian(NS ns);
 
 /* ------------------------------------------------------------------------------------------------ registries */
@@ -1894,6 +1898,24 @@ static FlErrorCode NSFormJacobian_CNLinear(NS ns, const NSVec *x, NSMat J, NSFor
   return 0;
 }
 
+#include <time.h>
+static int step_timing(void)
+{
+  static int on = -1;
+  if (on < 0) {
+    const char *e = getenv("FLUCA_STEP_TIMING");
+    on = e && atoi(e) != 0;
+  }
+  return on;
+}
+static double step_clock(NS ns)
+{
+  struct timespec ts;
+  if (ns->poisson) (void)fl_poisson_synchronize(ns->poisson);
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
 /* ns->J: created at NSSetUp (MatCreateNest, nsbasic.c:203-207) where the block is large enough for the momentum rows, else here */
 static FlErrorCode ns_jacobian(NS ns)
 {
@@ -1910,6 +1932,9 @@ static FlErrorCode NSStep_CNLinear(NS ns)
   fl_poisson   *h = ns->poisson;
   const int64_t N = c->sz[0];
   FLCHK(ns_jacobian(ns));
+  const int timing = step_timing();
+  double    tm[6] = {0., 0., 0., 0., 0., 0.};
+  if (timing) tm[0] = step_clock(ns);
   /* NSStep: VecCopy(sol, sol0), nsbasic.c:281-282 (the vectors are this type's device arrays, so the copy is made here) */
   FLABI(fl_vec_lincomb(h, 3 * N, 1., c->sol_v, 0., NULL, c->sol0_v));
   FLABI(fl_vec_lincomb(h, N, 1., c->sol_p, 0., NULL, c->sol0_p));
@@ -1934,8 +1959,11 @@ static FlErrorCode NSStep_CNLinear(NS ns)
   /* SNESSolve(ns->snes, NULL, ns->x), :2833, with SNESSetPicard (nsbasic.c:248): the right-hand side comes from the type's
    * formfunction, the operator from its formjacobian -- both through the ops table (nsbasic.c:115-131) */
   NSVec x = {c->x_v, {c->x_V[0], c->x_V[1], c->x_V[2]}, c->x_p}, f = {c->f_v, {c->f_V[0], c->f_V[1], c->f_V[2]}, c->f_p};
+  if (timing) tm[1] = step_clock(ns);
   FLCHK(NSFormFunction(ns, &x, &f));
+  if (timing) tm[2] = step_clock(ns);
   FLCHK(NSFormJacobian(ns, &x, ns->momentum, NS_UPDATE_JACOBIAN));
+  if (timing) tm[3] = step_clock(ns);
   /* KSPSolve(J, f, x) with PC_ABF */
   fl_ksp_stats  st[2];
   const double *fV[3] = {c->f_V[0], c->f_V[1], c->f_V[2]};
@@ -1983,12 +2011,18 @@ static FlErrorCode NSStep_CNLinear(NS ns)
       ++ns->ksp_its;
     }
   }
+  if (timing) tm[4] = step_clock(ns);
   if (ns->reason < 0) return 0; /* NSStep reports it; the solution is left untouched (NSCheckDiverged) */
   /* v, V <- x; pressure update, :2841-2854 */
   FLABI(fl_vec_lincomb(h, 3 * N, 1., c->x_v, 0., NULL, c->sol_v));
   for (int d = 0; d < 3; ++d) FLABI(fl_vec_lincomb(h, c->sz[1 + d], 1., c->x_V[d], 0., NULL, c->sol_V[d]));
   FLABI(fl_pressure_update(h, ns->step == 0, c->x_p, c->sol0_p, c->phalf, c->sol_p));
   FLABI(fl_poisson_synchronize(h));
+  if (timing) {
+    tm[5] = step_clock(ns);
+    fprintf(stderr, "[fluca step %lld] copy sol0 + v0interp ends %.4f s | NSFormFunction %.4f | NSFormJacobian %.4f | KSPSolve (PCApply_ABF: kspA %d its, kspS %d its) %.4f | update %.4f\n",
+            (long long)ns->step + 1, tm[1] - tm[0], tm[2] - tm[1], tm[3] - tm[2], ns->mom_its, ns->schur_its, tm[4] - tm[3], tm[5] - tm[4]);
+  }
   return 0;
 }
 /* cnlinear.c:136-162 */

@@ -212,6 +212,13 @@ class Poisson:
         buf = (C.c_char * capi.UNIQUE_ID_BYTES).from_buffer_copy(id_bytes)
         check(lib.fl_poisson_comm_init_rccl(self.h, buf, rank, nranks), "fl_poisson_comm_init_rccl")
 
+    def comm_info(self):
+        """What the handle's communicator is (fl_poisson_comm_info): transport 0 none / 1 RCCL / 2 host callbacks, rank and nranks as the
+        communicator itself reports them, neighbours, messages and bytes sent per ghost exchange of one cell vector."""
+        ci = capi.fl_comm_info()
+        check(lib.fl_poisson_comm_info(self.h, C.byref(ci)), "fl_poisson_comm_info")
+        return {k: getattr(ci, k) for k, _ in capi.fl_comm_info._fields_}
+
     def comm_init_host(self, exchange, allreduce, rank, nranks):
         """exchange(list of (peer, sendtag, recvtag, send_ndarray|None, recv_ndarray|None)); allreduce(ndarray) in place."""
         self._cb = host_transport_callbacks(exchange, allreduce)

@@ -265,6 +265,14 @@ int fl_poisson_comm_init_rccl(fl_poisson *h, const void *id128, int rank, int nr
 typedef int (*fl_exchange_fn)(void *ctx, int nmsg, const int *peer, const int *sendtag, const int *recvtag, void *const *send, void *const *recv, const int64_t *nbytes);
 typedef int (*fl_allreduce_fn)(void *ctx, double *vals, int n);
 int fl_poisson_comm_init_host(fl_poisson *h, fl_exchange_fn xchg, fl_allreduce_fn allred, void *ctx, int rank, int nranks);
+/* What the handle's communicator IS, for a caller (bench.py) that must prove which wire carried its halos: transport 0 none, 1 RCCL, 2 host
+ * callbacks; rank / nranks as RCCL itself reports them (ncclCommUserRank / ncclCommCount) for transport 1, as given at init otherwise;
+ * neighbours = ranks this one exchanges ghost layers with; halo_bytes = bytes this rank SENDS per ghost exchange of one cell vector. */
+typedef struct fl_comm_info {
+  int     transport, rank, nranks, loopback, neighbours, messages;
+  int64_t halo_bytes;
+} fl_comm_info;
+int fl_poisson_comm_info(fl_poisson *h, fl_comm_info *out);
 
 /* The ghost-exchange plan of one rank (host-only, no GPU): what fl_poisson_* does before every stencil application, the
  * analogue of DMGlobalToLocal on the reference's star-stencil DMStag (cart.c:66,91).  For each message: swap with `peer`;

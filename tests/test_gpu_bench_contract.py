@@ -52,6 +52,11 @@ def test_two_ranks_through_the_driver_launch_line():
     assert d["n_gpus"] == 2 and d["config"]["rank_grid"] == [1, 1, 2] and d["config"]["cells_per_gpu"] == 32 ** 3
     assert "NOT the production transport" in d["config"]["halo"] and d["cpu_baseline"] is None and d["value"] > 0
     assert [r["rank"] for r in d["ranks"]] == [0, 1] and d["transport_ranks"] == 2
+    # the line says which wire carried the halos, how much, and how evenly the ranks ran (the first SCALE record can be judged without a second run)
+    w = d["wire"]
+    assert w["transport"] == "host" and w["nranks_reported_by_the_communicator"] == 2 and w["ranks_reported"] == [0, 1]
+    assert w["neighbours_per_rank"] == [1, 1] and w["halo_bytes_per_iter_per_rank"] == [32 * 32 * 8] * 2 and w["halo_bytes_per_iter"] == 2 * 32 * 32 * 8
+    assert w["k_cg_A_ms_spread"]["max_over_min"] >= 1.0
 
 
 def test_strong_scaling_option_splits_one_grid():
