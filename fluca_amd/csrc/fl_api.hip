@@ -120,12 +120,22 @@ static int poisson_init(fl_poisson *h, const fl_grid *grid, const int bc[6], dou
     if (h->nv_il < 2) h->nv_il = 1;
     if (h->nv_il > 8) h->nv_il = 8;
   }
-  h->sx0  = ((PADX + g.nx + 1 + 15) / 16) * 16;
+  // Ghost width of the padded layout: 1 = the reference's star stencil (cart.c:66,91), what every operator needs; 2 where a neighbouring RANK
+  // sits behind a boundary, so that the two-deep exchange of fl_fill_ghosts_deep has somewhere to put its second layer and the fused
+  // two-step smoother (k_cheb2) can run on several ranks.  Kernels only ever see (off0, sx, sxy): the width is a property of the handle,
+  // not of the kernels.  FLUCA_GHOST_WIDTH=2 forces the wide layout on a single rank (tests: the whole suite must not care).
+  {
+    const char *e = std::getenv("FLUCA_GHOST_WIDTH");
+    h->gw         = e ? std::atoi(e) : (h->multi && !h->loopback ? 2 : 1);
+    if (h->gw < 1 || h->gw > 2 || h->nv_il > 1) h->gw = 1;
+  }
+  const int gw = h->gw;
+  h->sx0  = ((PADX + g.nx + gw + 15) / 16) * 16;
   g.sx    = h->sx0 * h->nv_il;
-  g.sxy   = (int64_t)g.sx * (g.ny + 2);
-  g.off0  = g.sxy + g.sx + PADX;
+  g.sxy   = (int64_t)g.sx * (g.ny + 2 * gw);
+  g.off0  = (int64_t)gw * g.sxy + (int64_t)gw * g.sx + PADX;
   g.kappa = kappa;
-  h->padlen = (size_t)g.sxy * (g.nz + 2) + 256;  // doubles spanned by one vector (interleaved: by the whole slab)
+  h->padlen = (size_t)g.sxy * (g.nz + 2 * gw) + 256;  // doubles spanned by one vector (interleaved: by the whole slab)
   h->ncell  = (int64_t)g.nx * g.ny * g.nz;
   h->nface[0] = (int64_t)g.fx * g.ny * g.nz;
   h->nface[1] = (int64_t)g.nx * g.fy * g.nz;
@@ -818,6 +828,20 @@ int fl_fill_ghosts(fl_poisson *h, double *v)
   return 0;
 }
 
+// staging buffers of the extended-face exchanges: two layers of the largest face with two cells of extension on every side
+static int ensure_xbufs(fl_poisson *h, int sb, int rb)
+{
+  const GridP &g = h->g;
+  const size_t cap = 2 * (size_t)(std::max(g.nx, g.ny) + 4) * (size_t)(std::max(g.ny, g.nz) + 4);
+  for (int bnd : {sb, rb}) {
+    if (bnd < 0 || h->xsend[bnd]) continue;
+    FL_CHK(fl_dev_alloc(h, (void **)&h->xsend[bnd], sizeof(double) * cap, true));
+    FL_CHK(fl_dev_alloc(h, (void **)&h->xrecv[bnd], sizeof(double) * cap, true));
+  }
+  h->xcap = cap;
+  return 0;
+}
+
 // Ghost layers INCLUDING the edge and corner cells (what a 27-point footprint reads: the tri-linear prolongation of the multigrid cycle):
 // the axes are handled one after the other, and the face exchanged / wrapped along axis d spans the ghost layers the axes before it
 // have already filled, so that an edge cell arrives in two hops and a corner cell in three -- the reference's DMStag would do the same
@@ -849,12 +873,7 @@ int fl_fill_ghosts_full(fl_poisson *h, double *v)
     for (int a = 0; a < np; ++a) {
       const int sb = plan[a].send_boundary, rb = plan[a].recv_boundary;
       if (sb / 2 != d) continue;
-      for (int bnd : {sb, rb}) {
-        if (h->xsend[bnd]) continue;
-        const size_t cap = (size_t)(std::max(g.nx, g.ny) + 2) * (size_t)(std::max(g.ny, g.nz) + 2);
-        FL_CHK(fl_dev_alloc(h, (void **)&h->xsend[bnd], sizeof(double) * cap, true));
-        FL_CHK(fl_dev_alloc(h, (void **)&h->xrecv[bnd], sizeof(double) * cap, true));
-      }
+      FL_CHK(ensure_xbufs(h, sb, rb));
       launch_face_ext(h->stream, g, v, h->xsend[sb], d, sb % 2, ea, eb, 1);
       msgs.push_back({plan[a].peer, h->xsend[sb], h->xrecv[rb], cnt, plan[a].sendtag + 64, plan[a].recvtag + 64});
       recv_side[rb % 2] = true;
@@ -862,6 +881,45 @@ int fl_fill_ghosts_full(fl_poisson *h, double *v)
     FL_CHK(h->comm.exchange(h->stream, msgs));
     for (int side = 0; side < 2; ++side)
       if (recv_side[side]) launch_face_ext(h->stream, g, v, h->xrecv[2 * d + side], d, side, ea, eb, 2);
+  }
+  return 0;
+}
+
+// TWO ghost layers across every boundary behind which a neighbouring rank sits, edge and corner cells of that shell included (the reference's
+// DMStag has stencil width 1, cart.c:66: this layer is a build-side extension): what two fused stencil steps read (k_cheb2: x at distance two
+// along an axis and at the diagonal neighbours in a plane).  Dimension by dimension like fl_fill_ghosts_full: the two layers sent along axis d
+// span the ghost layers the axes before it have received.  Axes held by one rank are left alone (a periodic one wraps inside the block, and
+// the kernel wraps its indices there; behind a wall there is nothing).  Needs the wide layout (h->gw == 2).
+int fl_fill_ghosts_deep(fl_poisson *h, double *v)
+{
+  const GridP &g = h->g;
+  if (!h->multi) return 0;
+  if (h->gw < 2) return FL_ERR_ARG_WRONGSTATE;
+  if (h->comm.kind == Comm::NONE) return FL_ERR_ARG_WRONGSTATE;
+  int periodic[3];
+  for (int d = 0; d < 3; ++d) periodic[d] = h->ax[d].periodic;
+  fl_halo_msg plan[12];
+  const int   np = fl_halo_plan(&h->dec, periodic, plan);
+  int         ext[3] = {0, 0, 0};  // ghost layers axis d holds once it has been handled
+  for (int d = 0; d < 3; ++d) {
+    const int a1 = d == 0 ? 1 : 0, a2 = d == 2 ? 1 : 2;  // in-face directions: (y, z), (x, z), (x, y)
+    const int ea = ext[a1], eb = ext[a2];
+    const int64_t    cnt = 2 * (int64_t)((d == 0 ? g.ny : g.nx) + 2 * ea) * ((d == 2 ? g.ny : g.nz) + 2 * eb);
+    std::vector<Msg> msgs;
+    bool             recv_side[2] = {false, false};
+    for (int a = 0; a < np; ++a) {
+      const int sb = plan[a].send_boundary, rb = plan[a].recv_boundary;
+      if (sb / 2 != d) continue;
+      FL_CHK(ensure_xbufs(h, sb, rb));
+      launch_face_ext_deep(h->stream, g, v, h->xsend[sb], d, sb % 2, ea, eb, 2, 1);
+      msgs.push_back({plan[a].peer, h->xsend[sb], h->xrecv[rb], cnt, plan[a].sendtag + 128, plan[a].recvtag + 128});
+      recv_side[rb % 2] = true;
+    }
+    if (msgs.empty()) continue;
+    FL_CHK(h->comm.exchange(h->stream, msgs));
+    for (int side = 0; side < 2; ++side)
+      if (recv_side[side]) launch_face_ext_deep(h->stream, g, v, h->xrecv[2 * d + side], d, side, ea, eb, 2, 2);
+    ext[d] = 2;
   }
   return 0;
 }

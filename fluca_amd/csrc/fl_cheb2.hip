@@ -12,10 +12,10 @@
 //     step 1 on plane kk-1, on the tile AND its one-cell ring (x of plane kk-1 and kk-2 from LDS, plane kk from registers),
 //     step 2 on plane kk-2, on the tile (x' of plane kk-2, kk-3 from LDS, plane kk-1 from registers),
 // stages x(kk) and x'(kk-1) in LDS (three planes each, one barrier per trip) and stores x'', d'' of plane kk-2.
-// Ring cells are fetched from where they live: across a periodic seam the index wraps, outside a wall the cell does not
-// exist (its stencil coefficient is 0; x' there is set to 0).  Ghost layers of the padded vectors are neither read nor
-// written, so no ghost fill is needed in front of this kernel -- and it cannot be used when a neighbouring RANK owns the
-// ring (a two-deep halo exchange would be needed): callers fall back to k_cheb then.
+// Ring cells are fetched from where they live: across a periodic seam inside the block the index wraps, outside a wall the cell does not
+// exist (its stencil coefficient is 0; x' there is set to 0) -- on one rank no ghost layer is read or written and no ghost fill is needed in
+// front of this kernel.  Where a neighbouring RANK owns the ring (round 4) the values come from the ghost layers of the wide layout: two
+// layers of x with the edge cells of that shell (fl_fill_ghosts_deep), one layer of b and d (fl_fill_ghosts), filled by the caller.
 // d is double-buffered like x (a neighbouring block still reads the old d of this tile's cells as its ring).
 #include <type_traits>
 
@@ -53,16 +53,21 @@ template <int NT>
 __device__ __forceinline__ void c2_ST2(double *base, unsigned byteoff, double2 v) { c2_st2<NT>(reinterpret_cast<double *>(reinterpret_cast<char *>(base) + byteoff), v); }
 __device__ __forceinline__ void c2_ST1(double *base, unsigned byteoff, double v) { *reinterpret_cast<double *>(reinterpret_cast<char *>(base) + byteoff) = v; }
 
-// logical index gi in [-2, n+1] -> index of the cell that holds the value; in = false: no such cell (outside a wall)
+// logical index gi in [-2, n+1] -> index of the cell that holds the value; in = false: no such cell (outside a wall).
+// per: what lies behind the low end (bits 0-1) and the high end (bits 2-3) of the axis -- 0 a wall, 1 the periodic image inside this block
+// (the index wraps), 2 a neighbouring rank: the value sits in the ghost layers of the padded array (two of them: fl_fill_ghosts_deep), the
+// index stays as it is.
 __device__ __forceinline__ int c2_wrap(int gi, int n, int per, bool &in)
 {
   if (gi < 0) {
-    in = per != 0;
-    return per ? gi + n : 0;
+    const int m = per & 3;
+    in = m != 0;
+    return m == 1 ? gi + n : (m == 2 ? gi : 0);
   }
   if (gi >= n) {
-    in = per != 0;
-    return per ? gi - n : n - 1;
+    const int m = (per >> 2) & 3;
+    in = m != 0;
+    return m == 1 ? gi - n : (m == 2 ? gi : n - 1);
   }
   in = true;
   return gi;
@@ -127,13 +132,12 @@ __global__ void __launch_bounds__(64 * NW) k_cheb2(GridP g, int perx, int pery, 
   }
 
   // ---- halo cells of this thread ---------------------------------------------------------------------------------------
-  // A (step 1 is formed here): rows jj = -1 (tid < 128) / je (128 <= tid < 256), column ii = tid & 127
-  // B (step 1 is formed here): columns ii = -1 / ie, rows jj = 0..je-1
-  // C (x only): rows jj = -2 / je+1, column ii = tid & 127
-  // E (x only): columns ii = -2 / ie+1, rows 0..je-1, and the four corners (-1|je, -1|ie) of ring 1
+  // rows (16-byte pairs, one row per wave, see below): jj = -1 / je (ring 1: step 1 is formed there), jj = -2 / je+1 (ring 2: x only)
+  // B (step 1 is formed here): columns ii = -1 / ie, rows jj = 0..je-1                                    -- 8-byte items, one per thread
+  // E (x only): columns ii = -2 / ie+1, rows 0..je-1, and the four corners (-1|je, -1|ie) of ring 1       -- 8-byte items
   constexpr int HB0 = NTH > 256 ? 256 : 0, HE0 = NTH > 256 ? 256 + 2 * TY : 0;
   struct Halo {
-    unsigned off;  // byte offset of the cell inside a plane, relative to cell (0,0)
+    unsigned off;  // byte offset of the cell inside a plane, relative to cell (-2,-2) (a ghost cell may have negative coordinates)
     bool ok, in;
     int  lr, lc;  // XJ position
   };
@@ -143,15 +147,23 @@ __global__ void __launch_bounds__(64 * NW) k_cheb2(GridP g, int perx, int pery, 
     const int pi = c2_wrap(i0 + ii, g.nx, perx, inx), pj = c2_wrap(j0 + jj, g.ny, pery, iny);
     H.ok  = ok;
     H.in  = ok && inx && iny;
-    H.off = ok ? 8u * (unsigned)(pj * g.sx + pi) : 0u;
+    H.off = ok ? 8u * (unsigned)((pj + 2) * g.sx + (pi + 2)) : 8u * (unsigned)(2 * g.sx + 2);
     H.lr  = ok ? jj + 2 : 1;  // a thread without such a cell reads around (1, 1) and stages nothing
     H.lc  = ok ? ii + 2 : 1;
     return H;
   };
-  const int  hai = tid & 127, tb = tid - HB0, te = tid - HE0;
-  const int  hAjj = tid < 128 ? -1 : je, hCjj = tid < 128 ? -2 : je + 1;
-  const bool hAok = tid < 256 && hai < ie;
-  const Halo HA = mk(hAok, hAjj, hai), HC = mk(hAok, hCjj, hai);
+  const int  tb = tid - HB0, te = tid - HE0;
+  // ring ROWS travel as 16-byte pairs, one row per wave (wave-uniform kind): wave 0 row -1 and wave 1 row je (ring 1: x, b, d, step 1 is formed
+  // there), wave 2 row -2 and wave 3 row je + 1 (ring 2: x only).  A lane holds the same two columns as in its tile rows, so the x coefficients
+  // and the lane offset `lo` are the tile's.  (Until round 4 these were 8-byte items, four loads per thread of waves 0..3.)
+  const bool rowA = w < 2, rowC = w == 2 || w == 3;  // wave-uniform
+  const int  rjj = w == 0 ? -1 : w == 1 ? je : w == 2 ? -2 : je + 1;
+  bool       riny;
+  const int  rpj  = c2_wrap(j0 + rjj, g.ny, pery, riny);
+  const int64_t rrow = g.off0 + (int64_t)rpj * g.sx;  // cell (0, row, plane 0) of the wave's ring row
+  const bool rok0 = w < 4 && 2 * lane < ie, rok1 = w < 4 && 2 * lane + 1 < ie;
+  const bool rinn0 = rok0 && riny, rinn1 = rok1 && riny;
+  const int  rlr = min(rjj + 2, TY + 3);  // XJ row of the ring row (waves without one never use it)
   const bool hBok = tb >= 0 && tb < 2 * TY && (tb >> 1) < je;
   const int  hBjj = tb >> 1, hBii = (tb & 1) ? ie : -1;
   const Halo HB = mk(hBok, hBjj, hBii);
@@ -168,13 +180,11 @@ __global__ void __launch_bounds__(64 * NW) k_cheb2(GridP g, int perx, int pery, 
     hEii        = (c & 1) ? ie : -1;
   }
   const Halo HE = mk(hEok, hEjj, hEii);
-  // which kinds of ring items this WAVE holds at all (wave-uniform): a wave without any skips their loads, their step-1 arithmetic and their
-  // staging instead of executing them on a dummy cell -- with 512 threads rows live on waves 0..3, columns on waves 4 and 5, nothing on 6 and 7
-  const bool anyA = __builtin_amdgcn_ballot_w64(hAok) != 0, anyB = __builtin_amdgcn_ballot_w64(hBok) != 0, anyE = __builtin_amdgcn_ballot_w64(hEok) != 0;
-  // 1-D coefficients of the cells where this thread forms step 1 (table index = local cell index, -1..n).  The y part of an
-  // A cell is wave-uniform (rows -1 / je belong to waves 0,1 / 2,3); the five numbers of a B cell wait in LDS.
-  const int    cAi = min(max(i0 + hai, -1), g.nx), cAj = __builtin_amdgcn_readfirstlane(min(max(j0 + hAjj, -1), g.ny));
-  const double Axl = g.sl[0][cAi], Axh = g.sh[0][cAi], Axc = g.sc[0][cAi];
+  // which kinds of column items this WAVE holds at all (wave-uniform): a wave without any skips their loads, their step-1 arithmetic and their
+  // staging instead of executing them on a dummy cell -- with 512 threads columns live on waves 4 and 5, nothing on 6 and 7
+  const bool anyB = __builtin_amdgcn_ballot_w64(hBok) != 0, anyE = __builtin_amdgcn_ballot_w64(hEok) != 0;
+  // 1-D y coefficients of the ring-1 row of this wave (wave-uniform; table index = local cell index, -1..n); the five numbers of a B cell wait in LDS
+  const int    cAj = __builtin_amdgcn_readfirstlane(min(max(j0 + rjj, -1), g.ny));
   const double Ayl = g.sl[1][cAj], Ayh = g.sh[1][cAj], Ayc = g.sc[1][cAj];
   if (hBok) {
     const int cBi = min(max(i0 + hBii, -1), g.nx), cBj = min(max(j0 + hBjj, -1), g.ny);
@@ -189,7 +199,8 @@ __global__ void __launch_bounds__(64 * NW) k_cheb2(GridP g, int perx, int pery, 
   // inputs of one trip, fetched one trip ahead: x of plane kk (z-high neighbour of step 1), b and d of plane kk-1 (step 1 itself)
   struct Raw {
     double2 x[RY], b[RY], d[RY];
-    double  hxA, hbA, hdA, hxB, hbB, hdB, hxC, hxE;
+    double2 hxR, hbR, hdR;  // the wave's ring row: x (rows of ring 1 and 2), b and d (ring 1 only)
+    double  hxB, hbB, hdB, hxE;
     double  zl, zc, zh;
     bool    pin;
   };
@@ -206,13 +217,14 @@ __global__ void __launch_bounds__(64 * NW) k_cheb2(GridP g, int perx, int pery, 
       R.b[m] = c2_LD2<NTL>(b + rob[m] + plb, lo);
       R.d[m] = c2_LD2<NTL>(d + rob[m] + plb, lo);
     }
-    const double *hx = x + g.off0 + pl, *hb = b + g.off0 + plb, *hd = d + g.off0 + plb;
-    R.hxA = R.hbA = R.hdA = R.hxB = R.hbB = R.hdB = R.hxC = R.hxE = 0.;
-    if (anyA) {
-      R.hxA = c2_LD1(hx, HA.off);
-      R.hbA = c2_LD1(hb, HA.off);
-      R.hdA = c2_LD1(hd, HA.off);
-      R.hxC = c2_LD1(hx, HC.off);
+    const int64_t hbase = g.off0 - 2 * (int64_t)g.sx - 2;  // cell (-2,-2) of plane 0: the origin of the items' offsets
+    const double *hx = x + hbase + pl, *hb = b + hbase + plb, *hd = d + hbase + plb;
+    R.hxB = R.hbB = R.hdB = R.hxE = 0.;
+    R.hxR = R.hbR = R.hdR = make_double2(0., 0.);
+    if (rowA || rowC) R.hxR = c2_LD2<0>(x + rrow + pl, lo);
+    if (rowA) {
+      R.hbR = c2_LD2<0>(b + rrow + plb, lo);
+      R.hdR = c2_LD2<0>(d + rrow + plb, lo);
     }
     if (anyB) {
       R.hxB = c2_LD1(hx, HB.off);
@@ -241,7 +253,8 @@ __global__ void __launch_bounds__(64 * NW) k_cheb2(GridP g, int perx, int pery, 
     const int kc = kk - 1, k2 = kk - 2;
     const int lc = 2 * lane + 2;
     double2   x1v[RY], d1v[RY];
-    double    hx1A = 0., hx1B = 0.;
+    double    hx1B = 0.;
+    double2   hx1R = make_double2(0., 0.);
 #pragma unroll
     for (int m = 0; m < RY; ++m) x1v[m] = d1v[m] = make_double2(0., 0.);
 
@@ -280,12 +293,21 @@ __global__ void __launch_bounds__(64 * NW) k_cheb2(GridP g, int perx, int pery, 
           acc[2] += r1 * r1;
         }
       }
-      if (anyA) {
-        const double cen = XJ[bc][HA.lr][HA.lc], dyz = Axc + (Ayc + z1c);
-        const double v = dyz * cen + Axl * XJ[bc][HA.lr][HA.lc - 1] + Axh * XJ[bc][HA.lr][HA.lc + 1] + Ayl * XJ[bc][HA.lr - 1][HA.lc] + Ayh * XJ[bc][HA.lr + 1][HA.lc] + z1l * XJ[bp][HA.lr][HA.lc] + z1h * C.hxA;
-        const double r = C.hbA - v, z = JAC ? r / dyz : r;
-        const double e = (rho0 != 0. ? rho0 * C.hdA : 0.) + c0 * z;
-        hx1A = (HA.in && pin1) ? cen + e : 0.;
+      if (rowA) {  // step 1 on the wave's ring-1 row: the tile's arithmetic with the row's y coefficients
+        const double2 cen   = *reinterpret_cast<const double2 *>(&XJ[bc][rlr][lc]);
+        const double2 south = *reinterpret_cast<const double2 *>(&XJ[bc][rlr - 1][lc]);
+        const double2 north = *reinterpret_cast<const double2 *>(&XJ[bc][rlr + 1][lc]);
+        const double2 below = *reinterpret_cast<const double2 *>(&XJ[bp][rlr][lc]);
+        const double  west = XJ[bc][rlr][lc - 1], east = XJ[bc][rlr][lc + 2];
+        const double  dyz = Ayc + z1c;
+        const double  v0 = (xc0 + dyz) * cen.x + xl0 * west + xh0 * cen.y + Ayl * south.x + Ayh * north.x + z1l * below.x + z1h * C.hxR.x;
+        const double  v1 = (xc1 + dyz) * cen.y + xl1 * cen.x + xh1 * east + Ayl * south.y + Ayh * north.y + z1l * below.y + z1h * C.hxR.y;
+        const double  r0 = C.hbR.x - v0, r1 = C.hbR.y - v1;
+        const double  z0 = JAC ? r0 / (xc0 + dyz) : r0, z1 = JAC ? r1 / (xc1 + dyz) : r1;
+        const double  e0 = (rho0 != 0. ? rho0 * C.hdR.x : 0.) + c0 * z0;
+        const double  e1 = (rho0 != 0. ? rho0 * C.hdR.y : 0.) + c0 * z1;
+        hx1R.x = (rinn0 && pin1) ? cen.x + e0 : 0.;
+        hx1R.y = (rinn1 && pin1) ? cen.y + e1 : 0.;
       }
       if (anyB) {
         const double cen = XJ[bc][HB.lr][HB.lc], dyz = cB[tbc][4] + z1c;
@@ -367,10 +389,14 @@ __global__ void __launch_bounds__(64 * NW) k_cheb2(GridP g, int perx, int pery, 
           }
         }
       }
-      if (HA.ok) {
-        XJ[bj][HA.lr][HA.lc]     = C.hxA;
-        if constexpr (DO1) XN[bn][HA.lr - 1][HA.lc] = hx1A;  // XN rows are XJ rows - 1
-        XJ[bj][HC.lr][HC.lc]     = C.hxC;
+      if (rok1) {
+        *reinterpret_cast<double2 *>(&XJ[bj][rlr][lc]) = C.hxR;
+        if constexpr (DO1)
+          if (rowA) *reinterpret_cast<double2 *>(&XN[bn][rlr - 1][lc]) = hx1R;  // XN rows are XJ rows - 1
+      } else if (rok0) {
+        XJ[bj][rlr][lc] = C.hxR.x;
+        if constexpr (DO1)
+          if (rowA) XN[bn][rlr - 1][lc] = hx1R.x;
       }
       if (HB.ok) {
         XJ[bj][HB.lr][HB.lc]     = C.hxB;
@@ -437,12 +463,13 @@ using namespace fl;
 // least two cells along a periodic axis, planes addressable with 32-bit offsets.
 bool fl_cheb2_usable(const fl_poisson *h)
 {
-  if (h->multi) return false;
+  // several ranks: the wide layout and a communicator for the two-deep exchange (not the one-rank loopback rehearsal: its layout is narrow)
+  if (h->multi && (h->gw < 2 || h->loopback || h->comm.kind == Comm::NONE)) return false;
   const GridP &g = h->g;
   const int    n[3] = {g.nx, g.ny, g.nz};
   for (int d = 0; d < 3; ++d)
     if (n[d] < 2) return false;
-  if (g.sxy >= ((int64_t)1 << 31)) return false;
+  if (g.sxy + 4 * (int64_t)g.sx >= ((int64_t)1 << 28)) return false;  // 32-bit byte offsets inside a plane
   return true;
 }
 
@@ -476,7 +503,12 @@ Cheb2Plan fl_cheb2_plan(const GridP &g)
 template <int NW, bool JAC, bool MGD = false>
 static void cheb2_t(fl_poisson *h, const Cheb2Plan &p, double *X0, double *X1, const double *B, double *D0, double *D1)
 {
-  const int per[3] = {h->ax[0].periodic, h->ax[1].periodic, h->ax[2].periodic};
+  int per[3];
+  for (int d = 0; d < 3; ++d) {  // per side: 0 wall, 1 periodic image inside the block, 2 a neighbouring rank (ghost layers)
+    int m[2];
+    for (int side = 0; side < 2; ++side) m[side] = (h->multi && h->nbr[2 * d + side] >= 0 && !h->wrap_local[d]) ? 2 : (h->ax[d].periodic ? 1 : 0);
+    per[d] = m[0] | (m[1] << 2);
+  }
   hipLaunchKernelGGL((k_cheb2<2, NW, JAC, 2, MGD>), dim3(p.nblocks), dim3(64 * NW), 0, h->stream, h->g, per[0], per[1], per[2], X0, X1, X0, X1, B, D0, D1, D0, D1, h->scal, h->partial, h->partial_stride, p.zc, p.tiles_x, p.tiles, 1);
 }
 

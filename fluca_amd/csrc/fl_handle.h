@@ -27,6 +27,7 @@ void launch_unpad_copy(hipStream_t, const GridP &, const double *, double *, con
 void launch_project_all(hipStream_t, const GridP &, const double *p, double *const v[3], double *const V[3]);
 void launch_wrap(hipStream_t, const GridP &, double *, int axis, int nvec = 1, int64_t vstride = 0);
 void launch_face_ext(hipStream_t, const GridP &, double *v, double *buf, int axis, int side, int ea, int eb, int mode);
+void launch_face_ext_deep(hipStream_t, const GridP &, double *v, double *buf, int axis, int side, int ea, int eb, int dp, int mode);
 void launch_pack(hipStream_t, const GridP &, const double *, double *, int, int);
 void launch_unpack(hipStream_t, const GridP &, double *, const double *, int, int);
 void launch_pack_faces(hipStream_t, const GridP &, const double *, double *const bufs[6]);
@@ -259,6 +260,7 @@ struct fl_poisson {
   int64_t     ncell = 0, nface[3] = {0, 0, 0};
   size_t      padlen = 0;
   int         nv_il = 1, sx0 = 0;  // row-interleave factor of the padded vectors and the un-interleaved row length
+  int         gw = 1;              // ghost layers of the padded layout around the owned block (2 on several ranks: fl_fill_ghosts_deep)
   // solver workspace (padded vectors)
   double *r = nullptr, *P0 = nullptr, *P1 = nullptr, *q = nullptr, *xp = nullptr, *w0 = nullptr, *w1 = nullptr, *w2 = nullptr;
   double *cd1 = nullptr;  // second d buffer of the fused two-step Chebyshev kernel (fl_cheb2.hip)
@@ -284,7 +286,8 @@ struct fl_poisson {
   int      hist_cap = 0;
   double  *fsend[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, *frecv[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   double  *hiface[3] = {nullptr, nullptr, nullptr}, *loface_send[3] = {nullptr, nullptr, nullptr};
-  double  *xsend[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, *xrecv[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // extended faces of fl_fill_ghosts_full
+  double  *xsend[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, *xrecv[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // extended faces of fl_fill_ghosts_full / fl_fill_ghosts_deep
+  size_t   xcap = 0;  // doubles each of them holds
   Comm     comm;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // halo exchange overlapped with k_cg_B (fl_exchange_r_begin / _end): its own stream and the two events that order it
@@ -360,6 +363,7 @@ int  fl_exchange_r_begin(fl_poisson *h, double *r, const double *q);
 int  fl_exchange_r_end(fl_poisson *h, double *r);
 bool fl_any_ghost_exchange(const fl_poisson *h);
 int  fl_poll_scal(fl_poisson *h);
+int  fl_fill_ghosts_deep(fl_poisson *h, double *v);
 // fl_ksp.hip
 int fl_apply_tiled(fl_poisson *h, const double *xpad, double *y, int unpadded_y);
 int fl_residual(fl_poisson *h, const double *x, const double *b, double *r);

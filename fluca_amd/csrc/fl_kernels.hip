@@ -111,6 +111,25 @@ __global__ void k_face_ext(GridP g, double *__restrict__ v, double *__restrict__
   else v[at(side ? n : -1)] = buf[(int64_t)tb * na + ta];
 }
 
+// The same for `dp` layers (a two-deep ghost exchange: the fused two-step smoother on several ranks): ea / eb = how many cells the face is
+// extended on either side of the first / second in-face direction (0 .. 2: the ghost layers the axes before this one have filled).
+// Layer l = 0 is the one next to the boundary: pack reads the owned layer l from `side`, unpack writes the ghost layer l beyond it;
+// buffer [l][tb][ta].  mode 1 pack, 2 unpack.
+__global__ void k_face_ext_deep(GridP g, double *__restrict__ v, double *__restrict__ buf, int axis, int side, int ea, int eb, int dp, int mode)
+{
+  const int na = (axis == 0 ? g.ny : g.nx) + 2 * ea, nb = (axis == 2 ? g.ny : g.nz) + 2 * eb;
+  const int ta = blockIdx.x * 64 + threadIdx.x, tb = blockIdx.y * 4 + threadIdx.y;
+  if (ta >= na || tb >= nb) return;
+  const int a = ta - ea, b = tb - eb;
+  const int n = axis == 0 ? g.nx : (axis == 1 ? g.ny : g.nz);
+  auto      at = [&](int c) { return axis == 0 ? pidx(g, c, a, b) : (axis == 1 ? pidx(g, a, c, b) : pidx(g, a, b, c)); };
+  for (int l = 0; l < dp; ++l) {
+    const int64_t q = ((int64_t)l * nb + tb) * na + ta;
+    if (mode == 1) buf[q] = v[at(side ? n - 1 - l : l)];
+    else v[at(side ? n + l : -1 - l)] = buf[q];
+  }
+}
+
 // faces <-> contiguous buffers (multi-rank halo exchange).  side 0 = low, 1 = high.  pack reads owned boundary cells,
 // unpack writes the ghost layer.
 __global__ void k_pack_face(GridP g, const double *__restrict__ v, double *__restrict__ buf, int axis, int side)
@@ -1377,6 +1396,11 @@ void launch_face_ext(hipStream_t st, const GridP &g, double *v, double *buf, int
 {
   const int na = (axis == 0 ? g.ny : g.nx) + 2 * ea, nb = (axis == 2 ? g.ny : g.nz) + 2 * eb;
   hipLaunchKernelGGL(k_face_ext, grid3(na, nb, 1), blk3(), 0, st, g, v, buf, axis, side, ea, eb, mode);
+}
+void launch_face_ext_deep(hipStream_t st, const GridP &g, double *v, double *buf, int axis, int side, int ea, int eb, int dp, int mode)
+{
+  const int na = (axis == 0 ? g.ny : g.nx) + 2 * ea, nb = (axis == 2 ? g.ny : g.nz) + 2 * eb;
+  hipLaunchKernelGGL(k_face_ext_deep, grid3(na, nb, 1), blk3(), 0, st, g, v, buf, axis, side, ea, eb, dp, mode);
 }
 void launch_pack(hipStream_t st, const GridP &g, const double *v, double *buf, int axis, int side)
 {

@@ -1313,7 +1313,11 @@ int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero, bool
   const bool ghosts = fl_any_ghost_exchange(h);
   auto       finl = [=](const double *partial, int nb, int stride, const double *sums) { hipLaunchKernelGGL(k_cheb_fin, dim3(1), dim3(256), 0, s, partial, nb, stride, sums, h->scal, h->hist, nhist); };
   auto       fin2 = [=](const double *partial, int nb, int stride, const double *sums) { hipLaunchKernelGGL(k_cheb_fin2, dim3(1), dim3(256), 0, s, partial, nb, stride, sums, h->scal); };
-  int        cur = 0;
+  int        cur = 0, dcur = 0;
+  // several ranks under the fused sweep: its ring comes from the ghost layers -- two of x with the shell's edges, one of d, one of b (b once
+  // per call, after the first step has possibly updated it in place)
+  const bool deep = fuse && h->multi;
+  bool       bghost = false;
   for (int j = 0; j < nu;) {
     if (j == 0 && guess_zero) {
       // the sums k_cheb_fin would look at are not used without a norm and a null space: it only advances the recurrence
@@ -1324,13 +1328,20 @@ int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero, bool
         else hipLaunchKernelGGL((k_cheb_first<false, true>), dim3(nb), dim3(256), 0, s, h->g, X0, X1, B, D0, D1, h->scal, subq, suba);
       } else if (jac) hipLaunchKernelGGL((k_cheb_first<true>), dim3(nb), dim3(256), 0, s, h->g, X0, X1, B, D0, D1, h->scal, (const double *)nullptr, 0.);
       else hipLaunchKernelGGL((k_cheb_first<false>), dim3(nb), dim3(256), 0, s, h->g, X0, X1, B, D0, D1, h->scal, (const double *)nullptr, 0.);
-      FL_CHK(fin_step(h, tp.nblocks, 3, finl));
+      finl(h->partial, tp.nblocks, h->partial_stride, (const double *)nullptr);  // no norm, no null space: the sums are not looked at, only the recurrence advances -- nothing to all-reduce
       j += 1;
     } else if (fuse && j + 2 <= nu && !(want && jac && !h->multi && ((nu - j) & 1))) {  // (asked for the sums: an odd step count takes its single step first, so that a fused sweep ends the call)
-      // two steps in one sweep; reads no ghost layer (fl_cheb2.hip)
+      // two steps in one sweep; on one rank it reads no ghost layer (fl_cheb2.hip)
       const bool md = want && jac && j + 2 == nu && !h->multi;
+      if (deep) {
+        if (!bghost) FL_CHK(fl_fill_ghosts(h, B));
+        bghost = true;
+        FL_CHK(fl_fill_ghosts_deep(h, cur ? X1 : X0));
+        FL_CHK(fl_fill_ghosts(h, dcur ? D1 : D0));
+      }
       fl_launch_cheb2(h, cp, jac, X0, X1, B, D0, D1, md);
-      FL_CHK(fin_step(h, cp.nblocks, 6, fin2));  // without a norm and a null space the sums only advance the recurrence
+      dcur ^= 1;
+      fin2(h->partial, cp.nblocks, h->partial_stride, (const double *)nullptr);  // without a norm and a null space the sums only advance the recurrence: no all-reduce on several ranks either
       if (md) {
         launch_reduce(s, h->partial, cp.nblocks, h->partial_stride, 5, h->sums);
         *mgdots = true;
@@ -1339,7 +1350,7 @@ int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero, bool
     } else {
       if (ghosts) FL_CHK(fl_fill_ghosts(h, cur ? X1 : X0));
       const int nbc = launch_cheb(h, tp, jac, X0, X1, B, D0, D1);
-      FL_CHK(fin_step(h, nbc, 3, finl));
+      finl(h->partial, nbc, h->partial_stride, (const double *)nullptr);
       j += 1;
     }
     cur ^= 1;
@@ -1558,7 +1569,9 @@ int fl_solve_cheb(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *
   const bool ghosts = fl_any_ghost_exchange(h);
   auto       finl   = [=](const double *partial, int nb, int stride, const double *sums) { hipLaunchKernelGGL(k_cheb_fin, dim3(1), dim3(256), 0, s, partial, nb, stride, sums, h->scal, h->hist, nhist); };
   auto       fin2   = [=](const double *partial, int nb, int stride, const double *sums) { hipLaunchKernelGGL(k_cheb_fin2, dim3(1), dim3(256), 0, s, partial, nb, stride, sums, h->scal); };
-  int        j = 0, hostcur = 0, nprof = 0;
+  int        j = 0, hostcur = 0, hostdcur = 0, nprof = 0;
+  const bool deep = fuse && h->multi;  // the fused sweep's ring comes from ghost layers: see fl_cheb_smooth_padded
+  if (deep) FL_CHK(fl_fill_ghosts(h, B));
   bool       done = total <= 0;
   ProfEvents prof;  // profile = 1: HIP events around every launch of the dominant kernel (the fused sweep where it is used)
   if (o->profile) FL_CHK(prof.create(2 * (size_t)std::min(total, 2048)));
@@ -1570,8 +1583,13 @@ int fl_solve_cheb(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *
     while (j < stop) {
       if (fuse && j + 2 <= total) {
         const bool pr = (size_t)(2 * nprof + 1) < prof.ev.size();
+        if (deep) {
+          FL_CHK(fl_fill_ghosts_deep(h, hostcur ? X1 : X0));
+          FL_CHK(fl_fill_ghosts(h, hostdcur ? D1 : D0));
+        }
         if (pr) FL_HIP(hipEventRecord(prof.ev[2 * nprof], s));
         fl_launch_cheb2(h, cp, jac, X0, X1, B, D0, D1);
+        hostdcur ^= 1;
         if (pr) FL_HIP(hipEventRecord(prof.ev[2 * nprof++ + 1], s));
         FL_CHK(fin_step(h, cp.nblocks, 6, fin2));
         j += 2;

@@ -342,6 +342,79 @@ def test_decomposed_multigrid_with_trilinear_prolongation(world, n, ranks, bc, l
     mpc.run_ranks(world, _mg_worker, n, ranks, bc, levels, "linear")
 
 
+def _cheb2_worker(rank, world, n, ranks, bc, levels):
+    """The fused two-step Chebyshev kernel on several ranks (round 4): its ring comes from a TWO-deep ghost exchange of x (with the edge cells
+    of that shell) and one layer of b and d (fl_fill_ghosts_deep, the wide layout).  Fixed-length sweeps and a multigrid solve, forced through
+    the fused kernel ("cheb_fuse" = 2), against the one-step kernel on the same ranks (same arithmetic per cell) and against the
+    single-domain oracle."""
+    import torch
+    from fluca_amd import capi
+    from fluca_amd.poisson import Poisson
+    from oracle import fluca_oracle as fo
+    d = mpc.decomp_of(capi, n, ranks, rank)
+    box = [(0.0, 1.0), (0.0, 1.0), (0.0, 0.5)]
+    P = Poisson.uniform(n, box, bc, 1e-3, decomp=d)
+    P.comm_init_host(mpc.gloo_exchange, mpc.gloo_allreduce, rank, world)
+    g = fo.Grid.uniform(n, box, bc, 1e-3)
+    S = g.assemble_S()
+    nullspace = 2 not in bc
+    rng = np.random.default_rng(78)
+    p = rng.standard_normal(g.ncell)
+    if nullspace:
+        p -= p.mean()
+    b = S.mult(p)
+    shp = (n[2], n[1], n[0])
+    blk = mpc.block(d)
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64).ravel(), device="cuda")
+    bd = dev(b.reshape(shp)[blk])
+
+    def rel(xg, xo):
+        diff = np.array([((xg - xo.reshape(shp)[blk].ravel()) ** 2).sum(), (xo ** 2).sum() / world])
+        mpc.gloo_allreduce(diff)
+        return np.sqrt(diff[0] / diff[1])
+
+    lam = S.gershgorin(fo.PC_JACOBI)
+    try:
+        for steps in (2, 7):
+            xo, _ = S.solve(b, ksp=fo.KSP_CHEBYSHEV, pc=fo.PC_JACOBI, norm=fo.NORM_NONE, nullspace=nullspace, maxit=steps, emin=0.1 * lam, emax=1.1 * lam)
+            out = {}
+            for mode in (0, 2):
+                capi.check(capi.lib.fl_tuning_set(b"cheb_fuse", mode))
+                xg, ig = P.solve(bd, type=2, pc=1, norm_type=3, remove_nullspace=int(nullspace), maxit=steps, emin=0.1 * lam, emax=1.1 * lam, profile=1)
+                assert ig["iters"] == steps and ig["reason"] == 4
+                # which kernel ran: the fused one needs one launch for two steps
+                assert ig["kernel_launches"] == (steps if mode == 0 else (steps + 1) // 2), (mode, ig)
+                out[mode] = xg.cpu().numpy()
+                assert rel(out[mode], xo) <= 1e-9, (steps, mode)
+            pair = np.array([((out[2] - out[0]) ** 2).sum(), (out[0] ** 2).sum()])
+            mpc.gloo_allreduce(pair)
+            assert np.sqrt(pair[0] / pair[1]) <= 1e-13
+        # the multigrid solve with the fused smoother on every level that is large enough for the kernel
+        hist = {}
+        for mode in (0, 2):
+            capi.check(capi.lib.fl_tuning_set(b"cheb_fuse", mode))
+            xg, ig = P.solve(bd, history=True, type=0, pc=2, remove_nullspace=int(nullspace), rtol=1e-6, maxit=50, mg_levels=levels)
+            assert ig["reason"] == 2
+            hist[mode] = (ig["iters"], np.asarray(ig["history"]), xg.cpu().numpy())
+        assert hist[0][0] == hist[2][0] and np.allclose(hist[0][1], hist[2][1], rtol=1e-10)
+        mg = fo.MgOracle(g, max_levels=levels, nullspace=nullspace)
+        xo, io = mg.pcg(b, rtol=1e-6, maxit=50)
+        assert abs(hist[2][0] - io["iters"]) <= 1 and rel(hist[2][2], xo) <= 1e-4
+    finally:
+        capi.check(capi.lib.fl_tuning_set(b"cheb_fuse", 1))
+    P.close()
+
+
+@pytest.mark.parametrize("world,n,ranks,bc,levels", [
+    (2, (16, 16, 32), (1, 1, 2), [1, 1, 1, 1, 4, 1], 2),       # z split between walls: a wall on one side of the axis, a rank on the other
+    (2, (32, 16, 16), (2, 1, 1), [3, 3, 1, 2, 1, 1], 2),       # a periodic axis over two ranks (both sides of the axis are ghosts) + an outlet
+    (4, (24, 32, 32), (1, 2, 2), [1, 2, 1, 1, 3, 3], 2),       # BASELINE config 3's boundary types over 2 x 2 ranks: the shell's edge cells travel in two hops
+    (4, (32, 32, 16), (2, 2, 1), [3, 3, 3, 3, 3, 3], 2),       # all periodic, 2 x 2 ranks, the third axis wraps inside the block
+])
+def test_fused_chebyshev_on_several_ranks(world, n, ranks, bc, levels):
+    mpc.run_ranks(world, _cheb2_worker, n, ranks, bc, levels)
+
+
 def _nsstep_worker(rank, world, n, ranks, opts, dump_dir=None):
     """Whole CNLinear time steps through the C host mirror on a decomposed mesh (MeshSetRank + -cart_ranks_*): each rank
     compares its block with the same run on the undecomposed mesh, made in the same process."""
