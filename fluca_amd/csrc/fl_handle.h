@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <limits>
 #include <string>
 
@@ -160,6 +161,16 @@ struct Comm {
     }
     if (kind == HOST) {
       const int n = (int)m.size();
+      static const bool trace = []() { const char *e = std::getenv("FLUCA_COMM_TRACE"); return e && std::atoi(e) != 0; }();
+      if (trace) {
+        static long seq = 0;
+        struct timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        std::fprintf(stderr, "[%.3f comm r%d #%ld] exchange %d msgs:", ts.tv_sec % 1000 + 1e-9 * ts.tv_nsec, rank, seq++, n);
+        for (const Msg &x : m) std::fprintf(stderr, " (peer %d stag %d rtag %d n %lld%s%s)", x.peer, x.sendtag, x.recvtag, (long long)x.count, x.send ? " S" : "", x.recv ? " R" : "");
+        std::fprintf(stderr, "\n");
+        std::fflush(stderr);
+      }
       if ((int)hsend.size() < n) {
         hsend.resize(n, nullptr);
         hrecv.resize(n, nullptr);

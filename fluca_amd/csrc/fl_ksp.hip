@@ -2,6 +2,7 @@
 // Fluca user reaches for: BiCGStab because S is non-symmetric on stretched grids, cnlinearcart3d.c:2348-2361; Chebyshev
 // as the Jacobi smoother of BASELINE.json config 3).  Same conventions as the CG path in fl_kernels.hip: padded vectors,
 // scalars in device memory (KspScal), fixed-order partial sums, lazy constant-null-space removal.
+#include <ctime>
 #include "fl_handle.h"
 #include "fl_device.h"
 #include "fl_stencil.h"
@@ -1314,6 +1315,16 @@ int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero, bool
   auto       finl = [=](const double *partial, int nb, int stride, const double *sums) { hipLaunchKernelGGL(k_cheb_fin, dim3(1), dim3(256), 0, s, partial, nb, stride, sums, h->scal, h->hist, nhist); };
   auto       fin2 = [=](const double *partial, int nb, int stride, const double *sums) { hipLaunchKernelGGL(k_cheb_fin2, dim3(1), dim3(256), 0, s, partial, nb, stride, sums, h->scal); };
   int        cur = 0, dcur = 0;
+  static const bool trace = []() { const char *e = std::getenv("FLUCA_COMM_TRACE"); return e && std::atoi(e) != 0; }();
+  auto mark = [&](const char *what, int j) {  // debugging aid: where a sweep stops making progress (each mark waits for the stream)
+    if (!trace) return;
+    static const bool sync = []() { const char *e = std::getenv("FLUCA_COMM_TRACE"); return e && std::atoi(e) >= 2; }();
+    const hipError_t e = sync ? hipStreamSynchronize(s) : hipSuccess;
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    std::fprintf(stderr, "[%.3f smooth r%d n=%dx%dx%d] %s j=%d cur=%d dcur=%d -> %s\n", ts.tv_sec % 1000 + 1e-9 * ts.tv_nsec, h->comm.rank, h->g.nx, h->g.ny, h->g.nz, what, j, cur, dcur, hipGetErrorString(e));
+    std::fflush(stderr);
+  };
   // several ranks under the fused sweep: its ring comes from the ghost layers -- two of x with the shell's edges, one of d, one of b (b once
   // per call, after the first step has possibly updated it in place)
   const bool deep = fuse && h->multi;
@@ -1339,7 +1350,9 @@ int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero, bool
         FL_CHK(fl_fill_ghosts_deep(h, cur ? X1 : X0));
         FL_CHK(fl_fill_ghosts(h, dcur ? D1 : D0));
       }
+      mark("ghosts filled, before fused", j);
       fl_launch_cheb2(h, cp, jac, X0, X1, B, D0, D1, md);
+      mark("fused done", j);
       dcur ^= 1;
       fin2(h->partial, cp.nblocks, h->partial_stride, (const double *)nullptr);  // without a norm and a null space the sums only advance the recurrence: no all-reduce on several ranks either
       if (md) {
@@ -1349,8 +1362,11 @@ int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero, bool
       j += 2;
     } else {
       if (ghosts) FL_CHK(fl_fill_ghosts(h, cur ? X1 : X0));
+      mark("before single", j);
       const int nbc = launch_cheb(h, tp, jac, X0, X1, B, D0, D1);
+      mark("single done", j);
       finl(h->partial, nbc, h->partial_stride, (const double *)nullptr);
+      mark("fin done", j);
       j += 1;
     }
     cur ^= 1;

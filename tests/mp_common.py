@@ -22,6 +22,18 @@ def _entry(rank, world, port, fn, args, errq):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
+        # the oracle is OpenMP-parallel: `world` ranks each spinning up one thread per core turn a two-second CPU solve into minutes
+        # (round 4: a four-rank case sat in MgOracle.pcg for 140 s and looked like a hang).  Share the cores out before the oracle loads.
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:  # pragma: no cover
+            cores = os.cpu_count() or 1
+        os.environ["OMP_NUM_THREADS"] = str(max(1, cores // world))
+        torch.set_num_threads(max(1, cores // world))
+        if os.environ.get("FLUCA_MP_DUMP"):   # debugging aid: the Python stack of every rank after that many seconds (where a hang sits)
+            import faulthandler
+            import sys
+            faulthandler.dump_traceback_later(float(os.environ["FLUCA_MP_DUMP"]), exit=False, file=sys.stderr)
         dist.init_process_group("gloo", rank=rank, world_size=world)
         fn(rank, world, *args)
         dist.barrier()
@@ -37,10 +49,20 @@ def run_ranks(world, fn, *args, timeout=600):
     errq = ctx.SimpleQueue()
     port = free_port()
     procs = [ctx.Process(target=_entry, args=(r, world, port, fn, args, errq)) for r in range(world)]
+    import time
     for p in procs:
         p.start()
+    # a rank that dies (assertion, GPU fault) leaves the others blocked in gloo: stop waiting a little after the first failure instead of
+    # sitting out the whole timeout in silence
+    t0, first_fail = time.time(), None
+    while any(p.is_alive() for p in procs):
+        if first_fail is None and any(p.exitcode not in (None, 0) for p in procs):
+            first_fail = time.time()
+        if (first_fail is not None and time.time() - first_fail > 10.0) or time.time() - t0 > timeout:
+            break
+        time.sleep(0.2)
     for p in procs:
-        p.join(timeout)
+        p.join(0.1)
     failed = [p for p in procs if p.exitcode != 0]
     for p in procs:
         if p.is_alive():
