@@ -472,6 +472,18 @@ def other_configs(stream, parity=True):
                                         "algorithmic_bytes_per_cell": B_APPLY, "avg_launch_ms": kms["plain"], "launches_timed": 10,
                                         "iteration": {"algorithmic_bytes_per_cell": B_BCGS, "ms": dt / max(info["iters"], 1) * 1e3,
                                                       "achieved": B_BCGS * P.ncell * info["iters"] / dt / 1e9, "frac": B_BCGS * P.ncell * info["iters"] / dt / 1e9 / HBM_PEAK_GBS}}}
+        # the two Krylov methods to rtol 1e-5 on the viscous-dominated operator of the 512^3 flow configurations (nu dt / h^2 = 2.56; the state
+        # above has 0.25): Jacobi-BiCGStab against KSPCHEBYSHEV fused into the product (k_mom3, OUT 4: 144 B/cell per step against 552 per iteration)
+        try:
+            M.set_coefficients(1.0, 0.5 * hh, -0.5 * 2.56 * hh * hh)
+            tts = {"nu_dt_over_h2": 2.56, "rtol": 1e-5, "gershgorin_radius": M.gershgorin(), "chebyshev_interval": list(M.chebyshev_interval())}
+            for name, kw in (("bcgs_jacobi", dict(type=1)), ("chebyshev_jacobi", dict(type=2))):
+                M.solve(v, rtol=1e-5, maxit=400, **kw)
+                (_, si), dts = timed(lambda: M.solve(v, rtol=1e-5, maxit=400, **kw))
+                tts[name] = {"iters": si["iters"], "reason": si["reason"], "seconds": dts, "ms_per_iter": dts / max(si["iters"], 1) * 1e3}
+            cfg["momentum"]["time_to_solution"] = tts
+        except Exception as e:  # noqa: BLE001
+            cfg["momentum"]["time_to_solution"] = {"error": repr(e)}
         M.close()
         P.close()
         del v
@@ -560,15 +572,22 @@ def other_configs(stream, parity=True):
         import subprocess
         from fluca_amd import build as flbuild
         exe = flbuild.build_example(name="flow_configs")
-        out = subprocess.run([exe, "-config", "sphere", "-n", "512", "-ns_max_steps", "4", "-ns_ksp_type", "preonly", "-ns_abf_schur_pc_type", "mg"], capture_output=True, text=True, timeout=300)
-        steps = re.findall(r"step\s+(\d+)\s+wall\s+(\S+) s\s+outer its\s+(\d+)\s+kspA its\s+(\d+)\s+kspS its\s+(\d+)", out.stdout)
-        if out.returncode != 0 or len(steps) < 3:
-            raise RuntimeError((out.stdout + out.stderr)[-400:])
-        later = [float(w) for _, w, _, _, _ in steps[1:]]
+        def flow(extra):
+            out = subprocess.run([exe, "-config", "sphere", "-n", "512", "-ns_max_steps", "4", "-ns_ksp_type", "preonly", "-ns_abf_schur_pc_type", "mg"] + extra, capture_output=True, text=True, timeout=300)
+            steps = re.findall(r"step\s+(\d+)\s+wall\s+(\S+) s\s+outer its\s+(\d+)\s+kspA its\s+(\d+)\s+kspS its\s+(\d+)", out.stdout)
+            if out.returncode != 0 or len(steps) < 3:
+                raise RuntimeError((out.stdout + out.stderr)[-400:])
+            later = [float(w) for _, w, _, _, _ in steps[1:]]
+            return {"value": min(later), "steps_timed": len(later), "seconds_per_step": later, "first_step_seconds": float(steps[0][1]),
+                    "kspA_its": [int(a) for _, _, _, a, _ in steps], "kspS_its": [int(s_) for _, _, _, _, s_ in steps]}
+        base = flow([])
         cfg["flow_step"] = {"workload": "512^3 channel + immersed sphere (12 868 markers), one CNLinear time step as a fractional step (PCApply_ABF: BiCGStab + Jacobi on A, "
                                         "multigrid-CG on S, IBM direct forcing) on the C host mirror, child process", "metric": "seconds per time step", "higher_is_better": False,
-                            "value": min(later), "steps_timed": len(later), "seconds_per_step": later, "first_step_seconds": float(steps[0][1]),
-                            "kspA_its": [int(a) for _, _, _, a, _ in steps], "kspS_its": [int(s_) for _, _, _, _, s_ in steps], "cells": 512 ** 3}
+                            "cells": 512 ** 3, **base}
+        try:  # the same step with -ns_abf_momentum_ksp_type chebyshev (KSPCHEBYSHEV fused into the momentum product, interval from the Gershgorin disc)
+            cfg["flow_step"]["with_momentum_chebyshev"] = {"options": "-ns_abf_momentum_ksp_type chebyshev (default interval)", **flow(["-ns_abf_momentum_ksp_type", "chebyshev"])}
+        except Exception as e:  # noqa: BLE001
+            cfg["flow_step"]["with_momentum_chebyshev"] = {"error": repr(e)[:300]}
     except Exception as e:  # noqa: BLE001
         cfg["flow_step"] = {"error": repr(e)[:500]}
     return cfg

@@ -299,6 +299,18 @@ int fl_allreduce_max(fl_poisson *h, double *v)
   return 0;
 }
 
+int fl_allreduce_sum(fl_poisson *h, double *v)
+{
+  if (!h->multi) return 0;
+  double host[NSLOT] = {*v, 0., 0., 0., 0., 0., 0., 0.};
+  FL_HIP(hipMemcpyAsync(h->sums, host, sizeof(double) * NSLOT, hipMemcpyHostToDevice, h->stream));
+  FL_CHK(h->comm.allreduce(h->stream, h->sums, NSLOT));
+  FL_HIP(hipMemcpyAsync(host, h->sums, sizeof(double) * NSLOT, hipMemcpyDeviceToHost, h->stream));
+  FL_HIP(hipStreamSynchronize(h->stream));
+  *v = host[0];
+  return 0;
+}
+
 extern "C" int fl_poisson_sizes(const fl_poisson *h, int64_t out[4])
 {
   if (!h || !out) return FL_ERR_ARG_NULL;

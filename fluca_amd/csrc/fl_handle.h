@@ -388,6 +388,7 @@ int fl_ksp_begin(fl_poisson *h, const fl_ksp_opts *o);
 int fl_bcgs_fin_step(fl_poisson *h, int mode, int nblocks, int nslot, int nhist);
 int fl_ksp_finish(fl_poisson *h, const fl_ksp_opts *o, fl_ksp_stats *st);
 int fl_allreduce_max(fl_poisson *h, double *v);
+int fl_allreduce_sum(fl_poisson *h, double *v);
 int fl_cheb_begin(fl_poisson *h, const fl_ksp_opts *o, double emin, double emax);
 int fl_cheb_fin_step(fl_poisson *h, int nblocks, int nhist);
 int fl_solve_cheb(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *o, fl_ksp_stats *st);

@@ -643,7 +643,8 @@ __global__ void __launch_bounds__(256) k_scale_by(int64_t n, const double *__res
   }
 }
 // VecMDot / VecMAXPY on up to 8 vectors per launch: x is read once for all of them
-// max over the owned cells of three padded components (one entry per block)
+// max (SUM = false) or sum (SUM = true) over the owned cells of three padded components (one entry per block)
+template <bool SUM>
 __global__ void __launch_bounds__(256) k_max_owned(GridP g, int64_t cs, const double *__restrict__ v, double *__restrict__ partial)
 {
   __shared__ double red[4];
@@ -652,12 +653,15 @@ __global__ void __launch_bounds__(256) k_max_owned(GridP g, int64_t cs, const do
   for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
     const int     c = (int)(r / ((int64_t)g.nz * g.ny)), kj = (int)(r % ((int64_t)g.nz * g.ny)), k = kj / g.ny, j = kj % g.ny;
     const double *row = v + (int64_t)c * cs + g.off0 + (int64_t)k * g.sxy + (int64_t)j * g.sx;
-    for (int i = threadIdx.x; i < g.nx; i += 256) mx = fmax(mx, row[i]);
+    for (int i = threadIdx.x; i < g.nx; i += 256) mx = SUM ? mx + row[i] : fmax(mx, row[i]);
   }
-  for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_down(mx, off, 64));
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o = __shfl_down(mx, off, 64);
+    mx = SUM ? mx + o : fmax(mx, o);
+  }
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
   __syncthreads();
-  if (threadIdx.x == 0) partial[blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  if (threadIdx.x == 0) partial[blockIdx.x] = SUM ? (red[0] + red[1]) + (red[2] + red[3]) : fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
 }
 
 struct Vec8 {
@@ -813,7 +817,7 @@ struct fl_momentum {
   std::vector<double *> gm;  // cell vectors of the Schur solve with a variable-coefficient S
   std::vector<double *> kb;  // KSPGMRES on A: Krylov basis (3*cells each, allocated as the iteration needs them), w, x, r
   bool        have_state = false;
-  double      dmax = 1.;    // max_i a_ii, formed with gersh
+  double      dmean = 1.;   // mean_i a_ii, formed with gersh
   double      gersh = -1.;  // cached Gershgorin radius of the Jacobi-scaled operator (fl_momentum_gershgorin); < 0: not computed for this state
   int         tiles_x = 1, tiles_y = 1, nchunk = 1, zc = 1, nblocks = 1;  // 64 x 4 x zc tiles of the vector-update kernels
   int         anchunk = 1, azc = 1, ablocks = 1;                        // 64 x MOM_RY x azc tiles of k_mom_apply
@@ -1194,21 +1198,23 @@ extern "C" int fl_momentum_diagonal(fl_momentum *m, double *d_dev)
   return FL_SUCCESS;
 }
 
-// max over the owned cells (all ranks) of three padded components: a set-up quantity, one host wait
-static int max_owned(fl_momentum *m, const double *v3, double *out)
+// max, or sum, over the owned cells (all ranks) of three padded components: a set-up quantity, one host wait
+static int max_owned(fl_momentum *m, const double *v3, double *out, bool sum = false)
 {
   fl_poisson   *h = m->p;
   const int64_t rows = (int64_t)3 * h->g.nz * h->g.ny;
   const int     nb = (int)std::max<int64_t>(1, std::min<int64_t>(rows, 1024));
   FL_CHK(fl_ensure_partials(h, nb));
-  hipLaunchKernelGGL(k_max_owned, dim3(nb), dim3(256), 0, h->stream, h->g, (int64_t)h->padlen, v3, h->partial);
+  if (sum) hipLaunchKernelGGL(k_max_owned<true>, dim3(nb), dim3(256), 0, h->stream, h->g, (int64_t)h->padlen, v3, h->partial);
+  else hipLaunchKernelGGL(k_max_owned<false>, dim3(nb), dim3(256), 0, h->stream, h->g, (int64_t)h->padlen, v3, h->partial);
   FL_HIP(hipGetLastError());
   std::vector<double> part((size_t)nb);
   FL_HIP(hipMemcpyAsync(part.data(), h->partial, sizeof(double) * (size_t)nb, hipMemcpyDeviceToHost, h->stream));
   FL_HIP(hipStreamSynchronize(h->stream));
   double mx = 0.;
-  for (double v : part) mx = std::max(mx, v);
-  FL_CHK(fl_allreduce_max(h, &mx));  // several ranks: the bound of the whole operator
+  for (double v : part) mx = sum ? mx + v : std::max(mx, v);  // fixed order: the same number run to run
+  if (sum) FL_CHK(fl_allreduce_sum(h, &mx));
+  else FL_CHK(fl_allreduce_max(h, &mx));  // several ranks: the bound of the whole operator
   *out = mx;
   return 0;
 }
@@ -1227,24 +1233,29 @@ extern "C" int fl_momentum_gershgorin(fl_momentum *m, double *radius)
     FL_CHK(mom_vec(m, 7));
     mom_apply_t<0, false, 3>(m, m->F, m->vec[7], nullptr, nullptr);  // x is not used for the row sums: any valid padded array
     FL_CHK(max_owned(m, m->vec[7], &m->gersh));
-    FL_CHK(max_owned(m, m->dg, &m->dmax));
+    double dsum = 0.;
+    FL_CHK(max_owned(m, m->dg, &dsum, true));
+    m->dmean = dsum / (3. * (double)h->ax[0].n * (double)h->ax[1].n * (double)h->ax[2].n);
   }
   *radius = m->gersh;
   return FL_SUCCESS;
 }
 
 // The interval KSPCHEBYSHEV on kspA uses when none is given (PCJACOBI): emax = 1 + g from the Gershgorin disc of D^-1 A (a bound), emin = the
-// larger of 1 - g (the disc again, while the operator is diagonally dominant) and 0.9 / max_i a_ii -- the field of values of
-// D^-1/2 A D^-1/2 lies to the right of 1 / max a_ii as long as dt C - (mu dt / 2 rho) L has a non-negative symmetric part (exactly so for a
-// skew convection operator and a symmetric Laplacian; the one-sided wall rows and a discretely non-solenoidal V0 spoil that a little,
-// hence the factor 0.9).  With a viscous operator in the lead (nu dt / h^2 > 1) that IS the small end of the spectrum.
+// larger of 1 - g (the disc again, while the operator is diagonally dominant) and 0.9 / mean_i a_ii.  Why the mean: with E = dt C - (mu dt /
+// 2 rho) L of non-negative symmetric part (a skew convection operator, a symmetric negative Laplacian) the Rayleigh quotient of
+// D^-1/2 A D^-1/2 is (x.x + x.E x) / (x.D x) >= x.x / x.D x, and the vectors that make x.E x small are the smooth ones, for which x.D x / x.x
+// is the MEAN diagonal entry -- 1 / max a_ii, the rigorous bound, is decided by the wall rows (twice the interior diagonal) and costs half
+// again as many steps: a 32^3 channel at nu dt / h^2 = 2.56 has lambda_min = 0.1188, 1 / mean = 0.112, 1 / max = 0.061; 24 steps with
+// the true interval, 27 with this rule, 37 with 1 / max (profiles/r04_mom_cheb.txt).  An emin above the true one slows the lowest modes
+// down, it does not break the iteration.
 extern "C" int fl_momentum_chebyshev_interval(fl_momentum *m, double *emin, double *emax)
 {
   if (!m || !emin || !emax) return FL_ERR_ARG_NULL;
   double g = 0.;
   FL_CHK(fl_momentum_gershgorin(m, &g));
   *emax = 1. + g;
-  *emin = std::max(1. - g, 0.9 / m->dmax);
+  *emin = std::max(1. - g, 0.9 / m->dmean);
   return FL_SUCCESS;
 }
 

@@ -367,7 +367,7 @@ int fl_momentum_rowsum(fl_momentum *m, double *out_dev);
 /* Gershgorin radius of the Jacobi-scaled momentum operator: max over the rows of (sum of |a_ij|, j != i) / |a_ii|, over all ranks.  Every
  * eigenvalue of D^-1 A lies in the disc of this radius around 1.  One product-sized launch and a host wait per state (cached). */
 int fl_momentum_gershgorin(fl_momentum *m, double *radius);
-/* The interval FL_KSP_CHEBYSHEV on kspA uses when opts->emin = emax = 0 (PCJACOBI): emax = 1 + g, emin = max(1 - g, 0.9 / max_i a_ii) -- the
+/* The interval FL_KSP_CHEBYSHEV on kspA uses when opts->emin = emax = 0 (PCJACOBI): emax = 1 + g, emin = max(1 - g, 0.9 / mean_i a_ii) -- the
  * second is where the spectrum of a viscous-dominated A = I + dt C - (mu dt / 2 rho) L ends (fl_momentum.hip says why). */
 int fl_momentum_chebyshev_interval(fl_momentum *m, double *emin, double *emax);
 
