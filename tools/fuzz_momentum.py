@@ -94,6 +94,24 @@ for case in range(ncase):
             d = np.abs(host(xg) - xo).max() / np.abs(xo).max()
             if ig["reason"] != 2 or d > 1e-6:
                 print(name.ljust(6), tag, "reason", ig["reason"], "iters", ig["iters"], io["iters"], "diff", d); bad += 1
+        # round 4: the Gershgorin radius of D^-1 A from the row coefficients (k_mom2 here, k_mom3 below) and KSPCHEBYSHEV on the default interval
+        for with_v0 in (False, True):
+            if with_v0:
+                M.set_state(dt2, 1.0, 0.01, [dev(a) for a in V0], [dev(a) for a in Wb], v0=dev(v0))
+                Ac = g.assemble_momentum(1.0, dt2, -0.5 * 0.01 * dt2, V0, Wb)
+            else:
+                Ac = A2
+            G, rad = Ac.gershgorin(fo.PC_JACOBI), M.gershgorin()
+            # (a periodic axis of two cells folds two columns of a row into one matrix entry: the kernel's sum of absolute values is then an upper bound)
+            two = any(g.periodic[d] and g.n[d] == 2 for d in range(3))
+            if (abs(1.0 + rad - G) > 1e-11 * G) if not two else (1.0 + rad < G * (1 - 1e-11)):
+                print("GERSH" + "0 "[with_v0], tag, 1.0 + rad, G); bad += 1
+            emin, emax = M.chebyshev_interval()
+            xo, io = Ac.solve(b, ksp=fo.KSP_CHEBYSHEV, pc=fo.PC_JACOBI, nullspace=False, rtol=1e-9, maxit=400, emin=emin, emax=emax)
+            xg, ig = M.solve(dev(b), type=2, rtol=1e-9, maxit=400)
+            d = np.abs(host(xg) - xo).max() / np.abs(xo).max()
+            if ig["reason"] != io["reason"] or ig["iters"] != io["iters"] or d > 1e-7:
+                print("CHEB" + "0 "[with_v0] + " ", tag, "reason", ig["reason"], io["reason"], "iters", ig["iters"], io["iters"], "diff", d, "interval", emin, emax); bad += 1
     except Exception:  # noqa: BLE001
         print("EXC   ", tag)
         traceback.print_exc()
