@@ -961,6 +961,29 @@ int fl_exchange_r_begin(fl_poisson *h, double *r, const double *q)  // q: valid 
   return 0;
 }
 
+// The single-reduction CG's exchange behind its update kernel (MODE 10): the boundary layers of the new residual are packed from r, the kept S and W
+// (k_pack_faces_sr) on the handle's stream, a second stream runs the transfers and writes the ghost layers of rn -- the buffer MODE 10 fills with the
+// new residual's owned cells meanwhile.  fl_exchange_r_end(h, rn) closes it.
+int fl_exchange_sr_begin(fl_poisson *h, const double *r, const double *sb, const double *W, double *rn)
+{
+  if (!h->multi) return 0;
+  if (h->comm.kind == Comm::NONE) return FL_ERR_ARG_WRONGSTATE;
+  if (!h->comm_stream) {
+    FL_HIP(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+    FL_HIP(hipEventCreateWithFlags(&h->ev_packed, hipEventDisableTiming));
+    FL_HIP(hipEventCreateWithFlags(&h->ev_ghosts, hipEventDisableTiming));
+  }
+  std::vector<Msg> msgs;
+  double          *sbuf[6], *rbuf[6];
+  FL_CHK(halo_messages(h, msgs, sbuf, rbuf));
+  if (!msgs.empty()) launch_pack_faces_sr(h->stream, h->g, r, sb, W, h->scal, sbuf);
+  FL_HIP(hipEventRecord(h->ev_packed, h->stream));
+  FL_HIP(hipStreamWaitEvent(h->comm_stream, h->ev_packed, 0));
+  FL_CHK(h->comm.exchange(h->comm_stream, msgs));
+  if (!msgs.empty()) launch_unpack_faces(h->comm_stream, h->g, rn, rbuf);
+  FL_HIP(hipEventRecord(h->ev_ghosts, h->comm_stream));
+  return 0;
+}
 int fl_exchange_r_end(fl_poisson *h, double *r)
 {
   for (int d = 0; d < 3; ++d)

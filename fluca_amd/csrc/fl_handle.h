@@ -27,6 +27,7 @@ void launch_pad_copy(hipStream_t, const GridP &, const double *, double *);
 void launch_unpad_copy(hipStream_t, const GridP &, const double *, double *, const double *);
 void launch_project_all(hipStream_t, const GridP &, const double *p, double *const v[3], double *const V[3]);
 void launch_wrap(hipStream_t, const GridP &, double *, int axis, int nvec = 1, int64_t vstride = 0);
+void launch_pack_faces_sr(hipStream_t, const GridP &, const double *r, const double *sb, const double *W, const KspScal *s, double *const bufs[6]);
 void launch_face_ext(hipStream_t, const GridP &, double *v, double *buf, int axis, int side, int ea, int eb, int mode);
 void launch_face_ext_deep(hipStream_t, const GridP &, double *v, double *buf, int axis, int side, int ea, int eb, int dp, int mode);
 void launch_pack(hipStream_t, const GridP &, const double *, double *, int, int);
@@ -375,6 +376,7 @@ int  fl_exchange_r_end(fl_poisson *h, double *r);
 bool fl_any_ghost_exchange(const fl_poisson *h);
 int  fl_poll_scal(fl_poisson *h);
 int  fl_fill_ghosts_deep(fl_poisson *h, double *v);
+int  fl_exchange_sr_begin(fl_poisson *h, const double *r, const double *sb, const double *W, double *rn);
 // fl_ksp.hip
 int fl_apply_tiled(fl_poisson *h, const double *xpad, double *y, int unpadded_y);
 int fl_residual(fl_poisson *h, const double *x, const double *b, double *r);

@@ -191,6 +191,21 @@ __global__ void k_pack_faces_rq(GridP g, const double *__restrict__ r, const dou
   const int64_t p = axis == 0 ? pidx(g, c, a, b) : (axis == 1 ? pidx(g, a, c, b) : pidx(g, a, b, c));
   buf[(int64_t)b * na + a] = s->reason != 0 ? r[p] : fma(-alpha, q[p], r[p]);
 }
+// The same for the single-reduction CG (MODE 9 / 10 of st_body, fl_ksp.hip): the boundary layers of the NEW residual r - a (S + b W), from the S = A z
+// MODE 9 kept on those layers, packed before MODE 10 forms it for the whole block -- the same two fma, so a neighbour's ghost equals this
+// rank's cell bit for bit.
+__global__ void k_pack_faces_sr(GridP g, const double *__restrict__ r, const double *__restrict__ sb, const double *__restrict__ W, const KspScal *__restrict__ s, FaceBufs fb)
+{
+  const int bnd = blockIdx.z, axis = bnd / 2, side = bnd % 2;
+  double   *buf = fb.buf[bnd];
+  if (!buf) return;
+  const int a = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y * 4 + threadIdx.y;
+  const int na = axis == 0 ? g.ny : g.nx, nb = axis == 2 ? g.ny : g.nz;
+  if (a >= na || b >= nb) return;
+  const int     n = axis == 0 ? g.nx : (axis == 1 ? g.ny : g.nz), c = side ? n - 1 : 0;
+  const int64_t p = axis == 0 ? pidx(g, c, a, b) : (axis == 1 ? pidx(g, a, c, b) : pidx(g, a, b, c));
+  buf[(int64_t)b * na + a] = s->reason != 0 ? r[p] : fma(-s->alpha, fma(s->beta, W[p], sb[p]), r[p]);
+}
 __global__ void k_unpack_faces(GridP g, double *__restrict__ v, FaceBufs fb)
 {
   const int     bnd = blockIdx.z, axis = bnd / 2, side = bnd % 2;
@@ -1428,6 +1443,14 @@ void launch_pack_faces_rq(hipStream_t st, const GridP &g, const double *r, const
   const int na = std::max(g.nx, g.ny), nb = std::max(g.ny, g.nz);
   dim3      grid((na + 63) / 64, (nb + 3) / 4, 6);
   hipLaunchKernelGGL(k_pack_faces_rq, grid, dim3(64, 4), 0, st, g, r, q, s, fb);
+}
+void launch_pack_faces_sr(hipStream_t st, const GridP &g, const double *r, const double *sb, const double *W, const KspScal *s, double *const bufs[6])
+{
+  FaceBufs fb;
+  for (int b = 0; b < 6; ++b) fb.buf[b] = bufs[b];
+  const int na = std::max(g.nx, g.ny), nb = std::max(g.ny, g.nz);
+  dim3      grid((na + 63) / 64, (nb + 3) / 4, 6);
+  hipLaunchKernelGGL(k_pack_faces_sr, grid, dim3(64, 4), 0, st, g, r, sb, W, s, fb);
 }
 void launch_unpack_faces(hipStream_t st, const GridP &g, double *v, double *const bufs[6])
 {

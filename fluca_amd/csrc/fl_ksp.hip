@@ -434,6 +434,15 @@ __device__ __forceinline__ void st_body(const GridP &g, const double *__restrict
           acc[2] += (o0 ? rn.x : 0.) + (o1 ? rn.y : 0.);
         } else if (MODE == 9) {
           const double2 rr = rprev[ZST ? m : 0];
+          if (w0) {  // several ranks: S = A z of the block's six boundary layers is kept (in the r buffer that is dead until MODE 10 refills it) for the pack of
+                     // the overlapped exchange, which forms r - a (S + b W) there before MODE 10 does (k_pack_faces_sr) -- what PlanA::qb is to the pair
+            const int jrow = jb + m;
+            if (kc == 0 || kc == g.nz - 1 || jrow == 0 || jrow == g.ny - 1) put(w0, y);
+            else {
+              if (o0 && (i == 0 || i == g.nx - 1)) w0[rob[m] + pc + il] = y.x;
+              if (o1 && i + 1 == g.nx - 1) w0[rob[m] + pc + il + 1] = y.y;
+            }
+          }
           acc[0] += (o0 ? cen.x * rr.x : 0.) + (o1 ? cen.y * rr.y : 0.);
           acc[1] += (o0 ? cen.x * y.x : 0.) + (o1 ? cen.y * y.y : 0.);
           acc[2] += (o0 ? cen.x * cen.x : 0.) + (o1 ? cen.y * cen.y : 0.);
@@ -446,8 +455,8 @@ __device__ __forceinline__ void st_body(const GridP &g, const double *__restrict
           double2       pn, wn, xn, rn;
           pn.x = (cen.x - zsh) + beta * P.x;
           pn.y = (cen.y - zsh) + beta * P.y;
-          wn.x = y.x + beta * Wv.x;
-          wn.y = y.y + beta * Wv.y;
+          wn.x = fma(beta, Wv.x, y.x);  // explicit: k_pack_faces_sr forms the same two fma for the neighbour's ghost, bit for bit
+          wn.y = fma(beta, Wv.y, y.y);
           xn.x = fma(alpha, pn.x, X.x);
           xn.y = fma(alpha, pn.y, X.y);
           rn.x = fma(-alpha, wn.x, rr.x);
@@ -1508,7 +1517,15 @@ int fl_solve_cg_sr(fl_poisson *h, const double *b, double *x, const fl_ksp_opts 
   auto fin = [&](int mode) {
     return [=](const double *partial, int nb, int stride, const double *sums) { hipLaunchKernelGGL(k_cgsr_fin, dim3(1), dim3(256), 0, s, mode, partial, nb, stride, sums, h->scal, h->hist, nhist); };
   };
-  launch_bcgs_st<9>(h, pa, jac, R, nullptr, nullptr, nullptr, nullptr, nullptr);
+  // several ranks: the ghost exchange of the new residual runs on a second stream behind the update kernel (MODE 10), as the pair hides it behind
+  // k_cg_Bq -- MODE 9 keeps S = A z on the block's boundary layers in the r buffer that is dead until MODE 10 refills it, and the pack forms
+  // r - a (S + b W) there.  FLUCA_OVERLAP=0 restores the sequential order (A/B runs).  (Periodic axes inside the block are wrapped at the end.)
+  static const bool overlap_env = []() {
+    const char *e = std::getenv("FLUCA_OVERLAP");
+    return e ? std::atoi(e) != 0 : true;
+  }();
+  const bool overlap = h->multi && overlap_env;
+  launch_bcgs_st<9>(h, pa, jac, R, nullptr, nullptr, nullptr, overlap ? Rn : nullptr, nullptr);
   FL_CHK(fin_step(h, pa.nblocks, 7, fin(0)));
   const int every = o->check_every > 0 ? o->check_every : 16;
   int       it = 0;
@@ -1516,10 +1533,12 @@ int fl_solve_cg_sr(fl_poisson *h, const double *b, double *x, const fl_ksp_opts 
   while (!done) {
     const int stop = std::min(o->maxit, it + every);
     for (; it < stop; ++it) {
+      if (overlap) FL_CHK(fl_exchange_sr_begin(h, R, Rn, W, Rn));  // packs before MODE 10 overwrites the kept S with the new residual
       launch_bcgs_st<10>(h, pa, jac, R, P, W, X, Rn, nullptr);
       std::swap(R, Rn);
-      if (ghosts) FL_CHK(fl_fill_ghosts(h, R));
-      launch_bcgs_st<9>(h, pa, jac, R, nullptr, nullptr, nullptr, nullptr, nullptr);
+      if (overlap) FL_CHK(fl_exchange_r_end(h, R));
+      else if (ghosts) FL_CHK(fl_fill_ghosts(h, R));
+      launch_bcgs_st<9>(h, pa, jac, R, nullptr, nullptr, nullptr, overlap ? Rn : nullptr, nullptr);
       FL_CHK(fin_step(h, pa.nblocks, 7, fin(1)));
     }
     FL_CHK(fl_poll_scal(h));
