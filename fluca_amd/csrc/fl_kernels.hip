@@ -1590,8 +1590,27 @@ PlanA plan_cg_A(const GridP &g, int ry_force, int nchunk_force)
     p = plan_tiles(g, ry, 4, 0, 512, 2);
     if (p.nblocks < MIN_BLOCKS && ry == 2) p = plan_tiles(g, 1, 4, 0, 512, 2);
   }
+  // 256^3 .. 512^3 (round 4, profiles/r04_cg256.txt, r04_cg_plans.txt): an 8-wave block holds 147 - 186 VGPRs, so a CU runs ONE of them; the pair is
+  // fastest when every CU has exactly one -- as many z chunks of 128 x 16 tiles as fit into 256 blocks, never a second round (384^3: 216 blocks
+  // 0.633 ms per iteration against 0.844 with the 288 four-wave blocks of round 2's rule; 256^3: 0.188 - 0.198 against 0.204; 512^3 unchanged)
+  if (ry_force <= 0 && nchunk_force <= 0 && target_env <= 0 && ry == 2 && g.ny >= 32 && (int64_t)g.nx * g.ny * g.nz >= ((int64_t)1 << 24) && tiles16 < 128) {
+    const int nchunk = std::max(1, std::min(256 / tiles16, g.nz / 8));
+    if (tiles16 * nchunk >= 192) p = plan_tiles(g, 2, 8, nchunk, 0);
+  }
   p.pf         = 1;
   p.nt         = 2;
+  // experiments (tools/experiments/r04_cg256.sh): FLUCA_CG_PLAN="ry,nw,nchunk" replaces the tiling of k_cg_A / k_cg_Bq on every grid
+  struct Force { int ry = 0, nw = 0, nchunk = 0; };
+  static const Force force = []() {
+    Force f;
+    if (const char *e = std::getenv("FLUCA_CG_PLAN")) std::sscanf(e, "%d,%d,%d", &f.ry, &f.nw, &f.nchunk);
+    return f;
+  }();
+  if (ry_force <= 0 && nchunk_force <= 0 && (force.ry == 1 || force.ry == 2) && (force.nw == 4 || (force.nw == 8 && force.ry == 2)) && g.ny >= 8) {
+    p    = plan_tiles(g, force.ry, force.nw, std::max(force.nchunk, 1), 0);
+    p.pf = 1;
+    p.nt = 2;
+  }
   return p;
 }
 PlanA plan_cg_B(const GridP &g)
