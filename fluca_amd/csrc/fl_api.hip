@@ -1063,14 +1063,27 @@ extern "C" int fl_poisson_project(fl_poisson *h, const double *p_dev, double *vx
 {
   if (!h || !p_dev) return FL_ERR_ARG_NULL;
   FL_HIP(hipSetDevice(h->device));
+  double *v[3] = {vx, vy, vz}, *V[3] = {Vx, Vy, Vz};
+  static const int fused = []() {
+    const char *e = std::getenv("FLUCA_PROJECT_FUSED");  // A/B runs.  0: one kernel per output array (round 1); 1: k_project_all (round 3);
+    return e ? std::atoi(e) : 3;                         // 2: k_project_six on the padded p; 3 (default): on the caller's p where one rank holds the grid
+  }();
+  // all six arrays (PCApply_ABF's call), one rank: k_project_six reads the caller's p itself -- no padded copy, no ghost layers
+  if (fused >= 3 && !h->multi && project_six_usable(h->g, p_dev, v, V)) {
+    int per = 0;
+    for (int d = 0; d < 3; ++d) per |= h->wrap_local[d] ? (1 << d) : 0;
+    launch_project_six(h->stream, h->g, p_dev, true, per, v, V);
+    FL_HIP(hipGetLastError());
+    return FL_SUCCESS;
+  }
   FL_CHK(fl_ensure_vec(h, &h->w0));
   launch_pad_copy(h->stream, h->g, p_dev, h->w0);
   FL_CHK(fl_fill_ghosts(h, h->w0));
-  double *v[3] = {vx, vy, vz}, *V[3] = {Vx, Vy, Vz};
-  static const int fused = []() {
-    const char *e = std::getenv("FLUCA_PROJECT_FUSED");  // 0: one kernel per output array (round 1's form; A/B runs)
-    return e ? std::atoi(e) : 1;
-  }();
+  if (fused >= 2 && project_six_usable(h->g, nullptr, v, V)) {
+    launch_project_six(h->stream, h->g, h->w0, false, 0, v, V);
+    FL_HIP(hipGetLastError());
+    return FL_SUCCESS;
+  }
   if (fused) launch_project_all(h->stream, h->g, h->w0, v, V);  // the six updates in one pass over p
   else
     for (int d = 0; d < 3; ++d) {

@@ -26,6 +26,8 @@ namespace fl {
 void launch_pad_copy(hipStream_t, const GridP &, const double *, double *);
 void launch_unpad_copy(hipStream_t, const GridP &, const double *, double *, const double *);
 void launch_project_all(hipStream_t, const GridP &, const double *p, double *const v[3], double *const V[3]);
+bool project_six_usable(const GridP &, const double *p_unpadded, double *const v[3], double *const V[3]);
+void launch_project_six(hipStream_t, const GridP &, const double *p, bool direct, int per, double *const v[3], double *const V[3]);
 void launch_wrap(hipStream_t, const GridP &, double *, int axis, int nvec = 1, int64_t vstride = 0);
 void launch_pack_faces_sr(hipStream_t, const GridP &, const double *r, const double *sb, const double *W, const KspScal *s, double *const bufs[6]);
 void launch_face_ext(hipStream_t, const GridP &, double *v, double *buf, int axis, int side, int ea, int eb, int mode);

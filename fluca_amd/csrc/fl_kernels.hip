@@ -427,6 +427,147 @@ __global__ void __launch_bounds__(256) k_project_all(GridP g, const double *__re
   }
 }
 
+// Round 4: the same update when all six arrays are there (PCApply_ABF's call) as straight-line code -- every load of a row (the six arrays, 25 values of
+// p) is issued before the first use, the arrays with the non-temporal hint (they are touched once; p is read seven times and should stay cached) -- and
+// with the work divided so that p stays in an XCD's L2: XCD x (block number mod 8) owns the rows j in [x ny / 8, (x + 1) ny / 8) of every plane and
+// walks them plane by plane, so the three planes of p a row needs are three 1/8 slabs.  DIRECT: p is the caller's unpadded array (single rank: no ghost
+// layer is needed -- a tap outside the block exists on periodic axes only, and is wrapped here), which saves the padded copy (16 B per cell) in front of
+// the kernel.  The products and their order are those of k_project_cells / k_project_faces.  U rows per wave and pass.
+template <bool DIRECT, int NT, int U>
+__global__ void __launch_bounds__(256) k_project_six(GridP g, const double *__restrict__ p, ProjOut o, int per, int nxcd)
+{
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nseg = (g.nx + 127) / 128;
+  const int xcd = (int)blockIdx.x % nxcd, lw = ((int)blockIdx.x / nxcd) * 4 + w, WX = ((int)gridDim.x / nxcd) * 4;  // WX is a multiple of nseg (launcher)
+  const int j0 = (int)((int64_t)xcd * g.ny / nxcd), sn = (int)((int64_t)(xcd + 1) * g.ny / nxcd) - j0;
+  const int seg = lw % nseg, i = seg * 128 + 2 * lane;  // nx is even (launcher): a lane owns cells i, i + 1
+  if (i >= g.nx || sn <= 0) return;
+  const double kap = g.kappa;
+  const int     sy = DIRECT ? g.nx : g.sx;
+  const int64_t sz = DIRECT ? (int64_t)g.nx * g.ny : g.sxy;
+  auto fix = [](int s, int n, bool periodic) { return s < 0 ? (periodic ? s + n : 0) : (s >= n ? (periodic ? s - n : n - 1) : s); };
+  // x rows of the lane's cells / their low faces (and of face nx behind the last cell): offsets of the taps from cell 0 of the row
+  int    xv[2][3], xf[2][2], xn[2] = {0, 0};
+  double xg0[2], xg1[2], xg2[2], xa0[2], xa1[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int s0 = g.Gs[0][i + c], c0 = g.gc0[0][i + c];
+    xg0[c] = g.Gv0[0][i + c]; xg1[c] = g.Gv1[0][i + c]; xg2[c] = g.Gv2[0][i + c];
+    xa0[c] = g.ga0[0][i + c]; xa1[c] = g.ga1[0][i + c];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) xv[c][m] = DIRECT ? fix(s0 + m, g.nx, per & 1) : s0 + m;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) xf[c][m] = DIRECT ? fix(c0 + m, g.nx, per & 1) : c0 + m;
+  }
+  const bool   xlast = i + 1 == g.nx - 1 && g.fx > g.nx;
+  const double xa0n = xlast ? g.ga0[0][g.nx] : 0., xa1n = xlast ? g.ga1[0][g.nx] : 0.;
+  if (xlast) {
+    const int c0 = g.gc0[0][g.nx];
+    xn[0] = DIRECT ? fix(c0, g.nx, per & 1) : c0;
+    xn[1] = DIRECT ? fix(c0 + 1, g.nx, per & 1) : c0 + 1;
+  }
+  struct Row {
+    int     j, k;
+    int64_t pr, cell, fxi, fyi;
+    double2 a0, a1, a2, b1, b2, py[3], pyf[2], pz[3], pzf[2];
+    double  bx0, bx1, px[2][3], pf[2][2];
+  };
+  auto ldp = [&](int64_t q) { return *reinterpret_cast<const double2 *>(p + q); };
+  auto ldn = [&](const double *a) { return NT ? __builtin_nontemporal_load(a) : *a; };
+  auto stn = [&](double *a, double v) { if (NT) __builtin_nontemporal_store(v, a); else *a = v; };
+  auto load = [&](Row &R, uint32_t rowi) {
+    R.j = j0 + (int)(rowi % (uint32_t)sn);
+    R.k = (int)(rowi / (uint32_t)sn);
+    const int j = R.j, k = R.k;
+    R.pr   = DIRECT ? ((int64_t)k * g.ny + j) * g.nx : g.off0 + (int64_t)k * g.sxy + (int64_t)j * g.sx;
+    R.cell = ((int64_t)k * g.ny + j) * g.nx + i;
+    R.fxi  = ((int64_t)k * g.ny + j) * g.fx + i;
+    R.fyi  = ((int64_t)k * g.fy + j) * g.nx + i;
+    R.a0 = ld2<NT>(o.v[0] + R.cell); R.a1 = ld2<NT>(o.v[1] + R.cell); R.a2 = ld2<NT>(o.v[2] + R.cell);
+    R.b1 = ld2<NT>(o.V[1] + R.fyi);  R.b2 = ld2<NT>(o.V[2] + R.cell);
+    R.bx0 = ldn(o.V[0] + R.fxi);     R.bx1 = ldn(o.V[0] + R.fxi + 1);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+      for (int m = 0; m < 3; ++m) R.px[c][m] = p[R.pr + xv[c][m]];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) R.pf[c][m] = p[R.pr + xf[c][m]];
+    }
+    const int ys = g.Gs[1][j], yc = g.gc0[1][j], zs = g.Gs[2][k], zc = g.gc0[2][k];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      R.py[m] = ldp(R.pr + i + (int64_t)((DIRECT ? fix(ys + m, g.ny, per & 2) : ys + m) - j) * sy);
+      R.pz[m] = ldp(R.pr + i + (int64_t)((DIRECT ? fix(zs + m, g.nz, per & 4) : zs + m) - k) * sz);
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      R.pyf[m] = ldp(R.pr + i + (int64_t)((DIRECT ? fix(yc + m, g.ny, per & 2) : yc + m) - j) * sy);
+      R.pzf[m] = ldp(R.pr + i + (int64_t)((DIRECT ? fix(zc + m, g.nz, per & 4) : zc + m) - k) * sz);
+    }
+  };
+  auto cellrow = [&](double c0, double c1, double c2, const double2 *t) {
+    double2 gr = make_double2(c0 * t[0].x + c1 * t[1].x, c0 * t[0].y + c1 * t[1].y);
+    if (c2 != 0.) {
+      gr.x += c2 * t[2].x;
+      gr.y += c2 * t[2].y;
+    }
+    return gr;
+  };
+  auto sub2 = [&](double2 t, double2 d) {
+    t.x -= kap * d.x;
+    t.y -= kap * d.y;
+    return t;
+  };
+  auto finish = [&](Row &R) {
+    const int j = R.j, k = R.k;
+    // ---- x
+    double2 gr;
+    gr.x = xg0[0] * R.px[0][0] + xg1[0] * R.px[0][1];
+    if (xg2[0] != 0.) gr.x += xg2[0] * R.px[0][2];
+    gr.y = xg0[1] * R.px[1][0] + xg1[1] * R.px[1][1];
+    if (xg2[1] != 0.) gr.y += xg2[1] * R.px[1][2];
+    st2<NT>(o.v[0] + R.cell, sub2(R.a0, gr));
+    stn(o.V[0] + R.fxi, R.bx0 - kap * (xa0[0] * R.pf[0][0] + xa1[0] * R.pf[0][1]));
+    stn(o.V[0] + R.fxi + 1, R.bx1 - kap * (xa0[1] * R.pf[1][0] + xa1[1] * R.pf[1][1]));
+    if (xlast) o.V[0][R.fxi + 2] -= kap * (xa0n * p[R.pr + xn[0]] + xa1n * p[R.pr + xn[1]]);
+    // ---- y, z (wave-uniform rows)
+    st2<NT>(o.v[1] + R.cell, sub2(R.a1, cellrow(g.Gv0[1][j], g.Gv1[1][j], g.Gv2[1][j], R.py)));
+    st2<NT>(o.v[2] + R.cell, sub2(R.a2, cellrow(g.Gv0[2][k], g.Gv1[2][k], g.Gv2[2][k], R.pz)));
+    {
+      const double a0 = g.ga0[1][j], a1 = g.ga1[1][j];
+      st2<NT>(o.V[1] + R.fyi, sub2(R.b1, make_double2(a0 * R.pyf[0].x + a1 * R.pyf[1].x, a0 * R.pyf[0].y + a1 * R.pyf[1].y)));
+    }
+    {
+      const double a0 = g.ga0[2][k], a1 = g.ga1[2][k];
+      st2<NT>(o.V[2] + R.cell, sub2(R.b2, make_double2(a0 * R.pzf[0].x + a1 * R.pzf[1].x, a0 * R.pzf[0].y + a1 * R.pzf[1].y)));
+    }
+    if (j == g.ny - 1 && g.fy > g.ny) {  // the face behind the last row / plane, where this rank owns it
+      const int     c0n = g.gc0[1][g.ny];
+      const double  n0 = g.ga0[1][g.ny], n1 = g.ga1[1][g.ny];
+      const double2 an = ldp(R.pr + i + (int64_t)((DIRECT ? fix(c0n, g.ny, per & 2) : c0n) - j) * sy), bn = ldp(R.pr + i + (int64_t)((DIRECT ? fix(c0n + 1, g.ny, per & 2) : c0n + 1) - j) * sy);
+      double2      *q = reinterpret_cast<double2 *>(o.V[1] + R.fyi + g.nx);
+      *q = sub2(*q, make_double2(n0 * an.x + n1 * bn.x, n0 * an.y + n1 * bn.y));
+    }
+    if (k == g.nz - 1 && g.fz > g.nz) {
+      const int     c0n = g.gc0[2][g.nz];
+      const double  n0 = g.ga0[2][g.nz], n1 = g.ga1[2][g.nz];
+      const double2 an = ldp(R.pr + i + (int64_t)((DIRECT ? fix(c0n, g.nz, per & 4) : c0n) - k) * sz), bn = ldp(R.pr + i + (int64_t)((DIRECT ? fix(c0n + 1, g.nz, per & 4) : c0n + 1) - k) * sz);
+      double2      *q = reinterpret_cast<double2 *>(o.V[2] + R.cell + (int64_t)g.nx * g.ny);
+      *q = sub2(*q, make_double2(n0 * an.x + n1 * bn.x, n0 * an.y + n1 * bn.y));
+    }
+  };
+  const uint32_t nrows = (uint32_t)sn * (uint32_t)g.nz, step = (uint32_t)(WX / nseg);
+  for (uint32_t rowi = (uint32_t)(lw / nseg); rowi < nrows; rowi += U * step) {
+    Row R[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (u == 0 || rowi + u * step < nrows) load(R[u], rowi + u * step);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (u == 0 || rowi + u * step < nrows) finish(R[u]);
+  }
+}
+
 // boundary face plane of V (axis, side) = coeff * pb     (INSERT_VALUES)
 __global__ void k_gst_bc(GridP g, const double *__restrict__ pb, double *__restrict__ V, int axis, int side, double coeff, int add)
 {
@@ -1491,6 +1632,46 @@ void launch_project_all(hipStream_t st, const GridP &g, const double *p, double 
   for (int d = 0; d < 3; ++d)
     if ((v[d] && (reinterpret_cast<uintptr_t>(v[d]) & 15)) || (d > 0 && V[d] && (reinterpret_cast<uintptr_t>(V[d]) & 15))) pairs = 0;
   hipLaunchKernelGGL(k_project_all, dim3((unsigned)(nwaves / 4)), dim3(256), 0, st, g, p, o, pairs);
+}
+// k_project_six is for all six arrays, even rows, 16-byte aligned bases and (DIRECT) a 16-byte aligned unpadded p
+bool project_six_usable(const GridP &g, const double *p_unpadded, double *const v[3], double *const V[3])
+{
+  if (g.nx % 2 != 0 || (int64_t)g.ny * g.nz >= ((int64_t)1 << 31)) return false;
+  for (int d = 0; d < 3; ++d)
+    if (!v[d] || !V[d] || (reinterpret_cast<uintptr_t>(v[d]) & 15) || (d > 0 && (reinterpret_cast<uintptr_t>(V[d]) & 15))) return false;
+  return !p_unpadded || (reinterpret_cast<uintptr_t>(p_unpadded) & 15) == 0;
+}
+// direct: p is the caller's unpadded array, per = bit d set where axis d is periodic (single rank); else p is padded with its ghost layers filled
+void launch_project_six(hipStream_t st, const GridP &g, const double *p, bool direct, int per, double *const v[3], double *const V[3])
+{
+  ProjOut o;
+  for (int d = 0; d < 3; ++d) {
+    o.v[d] = v[d];
+    o.V[d] = V[d];
+  }
+  // experiments (tools/experiments/r04_project.sh): FLUCA_PROJECT_VAR="nt,nxcd,blocks_per_xcd".  512^3 (profiles/r04_project.txt): 1024 - 2048 blocks
+  // per XCD 2.69 ms, 256: 2.97, 16384 (a row per wave): 2.87; without the slabs (nxcd 1) 2.76 - 2.86; without the hint 2.78; two rows per pass
+  // (244 VGPRs) 2.86; capped at 128 VGPRs 2.85
+  struct Var { int nt = 1, nxcd = 8, nbx = 1024; };
+  static const Var var = []() {
+    Var x;
+    if (const char *e = std::getenv("FLUCA_PROJECT_VAR")) std::sscanf(e, "%d,%d,%d", &x.nt, &x.nxcd, &x.nbx);
+    return x;
+  }();
+  const int nseg = (g.nx + 127) / 128;
+  const int nxcd = (var.nxcd == 1 || g.ny < 8) ? 1 : 8;
+  // blocks of four waves per XCD: a multiple of nseg (a wave keeps its segment), no more than the rows of a slab need
+  const int64_t items = (int64_t)nseg * ((g.ny + nxcd - 1) / nxcd) * g.nz;
+  int64_t       nbx = std::max<int64_t>(1, std::min<int64_t>((items + 3) / 4, (int64_t)std::max(var.nbx, 1) * (8 / nxcd)));
+  nbx = (nbx + nseg - 1) / nseg * nseg;
+  const dim3 gr((unsigned)(nbx * nxcd)), bl(256);
+  if (direct) {
+    if (var.nt) hipLaunchKernelGGL((k_project_six<true, 1, 1>), gr, bl, 0, st, g, p, o, per, nxcd);
+    else hipLaunchKernelGGL((k_project_six<true, 0, 1>), gr, bl, 0, st, g, p, o, per, nxcd);
+  } else {
+    if (var.nt) hipLaunchKernelGGL((k_project_six<false, 1, 1>), gr, bl, 0, st, g, p, o, per, nxcd);
+    else hipLaunchKernelGGL((k_project_six<false, 0, 1>), gr, bl, 0, st, g, p, o, per, nxcd);
+  }
 }
 void launch_project_cells(hipStream_t st, const GridP &g, const double *p, double *v, int axis) { hipLaunchKernelGGL(k_project_cells, grid3(g.nx, g.ny, g.nz), blk3(), 0, st, g, p, v, axis); }
 void launch_gst_bc(hipStream_t st, const GridP &g, const double *pb, double *V, int axis, int side, double coeff, int add)

@@ -74,6 +74,46 @@ def test_rhs_and_projection(n, bc, nonuni):
     P.close()
 
 
+# stage 2 with all six arrays on even rows runs k_project_six on the caller's unpadded p (one rank): wrapped taps on periodic axes, slabs of rows per
+# XCD (ny < 8: one slab), several 128-cell segments per row, one-cell and two-cell axes
+SIX = [
+    ((2, 2, 2), [PER] * 6, False),
+    ((4, 9, 1), [V, V, V, V, PER, PER], False),
+    ((4, 3, 5), [PER, PER, V, V, PER, PER], True),
+    ((256, 16, 3), [V, O, PER, PER, V, V], True),
+    ((258, 24, 4), [PER, PER, PER, PER, V, O], False),
+    ((64, 64, 10), [O, V, V, O, O, O], True),
+]
+
+
+@pytest.mark.parametrize("n,bc,nonuni", SIX)
+def test_projection_of_all_six_arrays(n, bc, nonuni):
+    P, g = make_pair(n, bc, kappa=0.7, nonuniform=nonuni)
+    rng = np.random.default_rng(11)
+    p = rng.standard_normal(g.ncell)
+    Vf = [rng.standard_normal(nf) for nf in g.nface]
+    vs = [rng.standard_normal(g.ncell) for _ in range(3)]
+    Vd, vd = [dev(a) for a in Vf], [dev(a) for a in vs]
+    P.project(dev(p), v=vd, V=Vd)
+    Gst = g.apply_gst(p)
+    for d in range(3):
+        ref = Vf[d] - Gst[d]
+        assert abs(host(Vd[d]) - ref).max() <= 1e-12 * max(1.0, abs(ref).max()), d
+    if min(n) >= 3:
+        Gc = g.apply_G(p)
+        for d in range(3):
+            ref = vs[d] - Gc[d]
+            assert abs(host(vd[d]) - ref).max() <= 1e-12 * max(1.0, abs(ref).max()), d
+    # the same numbers as the general kernel on a subset of the arrays (k_project_all on the padded copy), bit for bit
+    V2, v2 = [dev(a) for a in Vf], [dev(a) for a in vs]
+    P.project(dev(p), v=(v2[0], None, None), V=(None, V2[1], None))
+    P.project(dev(p), v=(None, v2[1], v2[2]), V=(V2[0], None, V2[2]))
+    for d in range(3):
+        assert np.array_equal(host(V2[d]), host(Vd[d])), d
+        assert np.array_equal(host(v2[d]), host(vd[d])), d
+    P.close()
+
+
 def _check_solve(P, g, b, ksp=None, variant=0, rtol=1e-5, nullspace=True, norm=fo.NORM_PRECONDITIONED, pc=fo.PC_JACOBI, maxit=10000):
     S = g.assemble_S()
     xo, io = S.solve(b, ksp=fo.KSP_CG, pc=pc, norm=norm, nullspace=nullspace, rtol=rtol, maxit=maxit)
