@@ -61,6 +61,21 @@ for case in range(ncase):
             ref = Vf[d] - Gst[d]
             if np.abs(host(Vd[d]) - ref).max() > 1e-12 * max(1.0, np.abs(ref).max()):
                 print("PROJ  ", tag, d, np.abs(host(Vd[d]) - ref).max()); bad += 1
+        # all six arrays at once (k_project_six on even rows) against the subset calls (k_project_all), bit for bit, and against the oracle
+        vs = [rng.standard_normal(g.ncell) for _ in range(3)]
+        v6, V6 = [dev(a) for a in vs], [dev(a) for a in Vf]
+        P.project(dev(p), v=v6, V=V6)
+        v3 = [dev(a) for a in vs]
+        P.project(dev(p), v=v3)
+        for d in range(3):
+            if not np.array_equal(host(V6[d]), host(Vd[d])) or not np.array_equal(host(v6[d]), host(v3[d])):
+                print("PROJ6 ", tag, d, np.abs(host(V6[d]) - host(Vd[d])).max(), np.abs(host(v6[d]) - host(v3[d])).max()); bad += 1
+        if min(n) >= 3:
+            Gc = g.apply_G(p)
+            for d in range(3):
+                ref = vs[d] - Gc[d]
+                if np.abs(host(v6[d]) - ref).max() > 1e-12 * max(1.0, np.abs(ref).max()):
+                    print("PROJ6v", tag, d, np.abs(host(v6[d]) - ref).max()); bad += 1
         symmetric = not nonuni
         for ksp, name in ((fo.KSP_CG, "CG"), (fo.KSP_BCGS, "BCGS")):
             if ksp == fo.KSP_CG and not symmetric:
