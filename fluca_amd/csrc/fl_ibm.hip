@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(256) k_ibm_interp(IbmP P, const int *__restric
 
 // f[c*ncell + x] += sum_l w_l(x) F[c*L + l] dV_l / (hx hy hz), gather over the tile's bin, markers in ascending id order
 __global__ void __launch_bounds__(256) k_ibm_spread(IbmP P, const int *__restrict__ i0, const double *__restrict__ w, const int *__restrict__ off, const int *__restrict__ list, const int *__restrict__ active, int ncomp, int64_t ncell, const double *__restrict__ F,
-                                                      const double *__restrict__ dV, double *__restrict__ f)
+                                                      const double *__restrict__ dV, double *__restrict__ f, int dbg)
 {
   __shared__ int    sraw[BIN_CHUNK];
   __shared__ int    si0[3][BIN_CHUNK];
@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(256) k_ibm_spread(IbmP P, const int *__restric
       for (int c = 0; c < 3; ++c) sF[c][threadIdx.x] = c < ncomp ? F[(int64_t)c * P.L + m] * dv : 0.;
     }
     __syncthreads();
-    if (ci < P.n[0] && cj < P.n[1]) {
+    if (ci < P.n[0] && cj < P.n[1] && !(dbg & 1)) {
       for (int e = 0; e < n; ++e) {
         int a = ci + P.lo[0] - si0[0][e], b = cj + P.lo[1] - si0[1][e];
         if (P.periodic[0]) { if (a < 0) a += P.ng[0]; else if (a >= P.ng[0]) a -= P.ng[0]; }
@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(256) k_ibm_spread(IbmP P, const int *__restric
       }
     }
   }
-  if (ci < P.n[0] && cj < P.n[1])
+  if (ci < P.n[0] && cj < P.n[1] && !(dbg & 2))
     for (int half = 0; half < 2; ++half) {
       const int ck = tz * TB + lk + 4 * half;
       if (ck >= P.n[2]) continue;
@@ -412,13 +412,36 @@ extern "C" int fl_ibm_interp(fl_ibm *m, int ncomp, const double *u, double *U)
   return FL_SUCCESS;
 }
 
+static int ibm_dbg()
+{
+  static const int v = []() {
+    const char *e = std::getenv("FLUCA_IBM_DBG");  // experiments: bit 0 skips the marker loop of k_ibm_spread, bit 1 its read-modify-write of f
+    return e ? std::atoi(e) : 0;
+  }();
+  return v;
+}
+// bin statistics of the current marker positions (experiments): tiles with a non-empty bin, entries of all bins, the largest bin
+extern "C" int fldbg_ibm_stats(fl_ibm *m, int *nactive, int *entries, int *maxbin)
+{
+  if (!m) return FL_ERR_ARG_NULL;
+  std::vector<int> off((size_t)m->ntiles + 1);
+  FL_HIP(hipStreamSynchronize(m->gp->stream));
+  FL_HIP(hipMemcpy(off.data(), m->off, sizeof(int) * off.size(), hipMemcpyDeviceToHost));
+  int mx = 0;
+  for (int t = 0; t < m->ntiles; ++t) mx = std::max(mx, off[(size_t)t + 1] - off[(size_t)t]);
+  if (nactive) *nactive = m->nactive;
+  if (entries) *entries = off[(size_t)m->ntiles];
+  if (maxbin) *maxbin = mx;
+  return FL_SUCCESS;
+}
+
 extern "C" int fl_ibm_spread(fl_ibm *m, int ncomp, const double *F, const double *dV, double *f)
 {
   if (!m || !F || !dV || !f) return FL_ERR_ARG_NULL;
   if (ncomp < 1 || ncomp > 3) return FL_ERR_ARG_OUTOFRANGE;
   fl_poisson *h = m->gp;
   FL_HIP(hipSetDevice(h->device));
-  if (m->nactive > 0) hipLaunchKernelGGL(k_ibm_spread, dim3(m->nactive), dim3(256), 0, h->stream, m->P, m->i0, m->w, m->off, m->list, m->active, ncomp, h->ncell, F, dV, f);
+  if (m->nactive > 0) hipLaunchKernelGGL(k_ibm_spread, dim3(m->nactive), dim3(256), 0, h->stream, m->P, m->i0, m->w, m->off, m->list, m->active, ncomp, h->ncell, F, dV, f, ibm_dbg());
   FL_HIP(hipGetLastError());
   return FL_SUCCESS;
 }

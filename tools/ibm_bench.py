@@ -25,6 +25,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--loopback", type=int, default=0)
     ap.add_argument("--cells", type=int, default=512)
+    ap.add_argument("--markers", type=str, default="12868,51456,102944,205888,411776,1647104")
+    ap.add_argument("--sphere", type=int, default=0, help="1: the markers of config 4 (Fibonacci lattice on a sphere of diameter 64 h, spacing ~ h) instead of cylinders")
     a = ap.parse_args()
     os.environ["FLUCA_COMM_LOOPBACK"] = "1" if a.loopback else "0"
     from fluca_amd import capi
@@ -39,7 +41,7 @@ def main():
     f = torch.zeros(3 * P.ncell, dtype=torch.float64, device="cuda")
     ptr = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
     rows = []
-    for L in (12868, 51456, 102944, 205888, 411776, 1647104):
+    for L in [int(v) for v in a.markers.split(",")]:
         # markers on cylinders of radius 32 h around z (as many as L needs), spacing ~ h
         nth = int(round(2 * np.pi * 32))
         m = np.arange(L)
@@ -47,6 +49,12 @@ def main():
         ring = m // nth
         rad = (32 + 3 * (ring // n)) * h
         X = [torch.as_tensor(v, device="cuda") for v in (0.5 + rad * np.cos(th), 0.5 + rad * np.sin(th), ((ring % n) + 0.5) * h)]
+        if a.sphere:
+            R = 32 * h
+            L = int(round(4 * np.pi * R * R / (h * h)))
+            i = np.arange(L) + 0.5
+            phi, th = np.arccos(1 - 2 * i / L), np.pi * (1 + 5 ** 0.5) * i
+            X = [torch.as_tensor(v, device="cuda") for v in (0.5 + R * np.cos(th) * np.sin(phi), 0.5 + R * np.sin(th) * np.sin(phi), 0.5 + R * np.cos(phi))]
         F = torch.rand(3 * L, dtype=torch.float64, device="cuda")
         dV = torch.full((L,), h ** 3, dtype=torch.float64, device="cuda")
         U = torch.empty(3 * L, dtype=torch.float64, device="cuda")
@@ -68,7 +76,11 @@ def main():
         t_bin = timed(lambda: capi.check(capi.lib.fl_ibm_update(hm, ptr(X[0]), ptr(X[1]), ptr(X[2]))))
         t_int = timed(lambda: capi.check(capi.lib.fl_ibm_interp(hm, 3, ptr(u), ptr(U))))
         t_spr = timed(lambda: capi.check(capi.lib.fl_ibm_spread(hm, 3, ptr(F), ptr(dV), ptr(f))))
-        rows.append(dict(markers=L, rebin_ms=t_bin, interp_ms=t_int, spread_ms=t_spr, allreduce_bytes=24 * L if a.loopback else 0))
+        st = [C.c_int(), C.c_int(), C.c_int()]
+        capi.lib.fldbg_ibm_stats.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 3
+        capi.check(capi.lib.fldbg_ibm_stats(hm, *[C.byref(v) for v in st]))
+        rows.append(dict(markers=L, rebin_ms=t_bin, interp_ms=t_int, spread_ms=t_spr, allreduce_bytes=24 * L if a.loopback else 0, tiles_with_markers=st[0].value,
+                         bin_entries=st[1].value, largest_bin=st[2].value, env={k: v for k, v in os.environ.items() if k.startswith("FLUCA_IBM")}))
         capi.lib.fl_ibm_destroy(hm)
         print(json.dumps(rows[-1]), flush=True)
     P.close()
