@@ -190,8 +190,8 @@ __global__ void __launch_bounds__(256) k_ibm_interp(IbmP P, const int *__restric
 }
 
 // f[c*ncell + x] += sum_l w_l(x) F[c*L + l] dV_l / (hx hy hz), gather over the tile's bin, markers in ascending id order
-__global__ void __launch_bounds__(256) k_ibm_spread(IbmP P, const int *__restrict__ i0, const double *__restrict__ w, const int *__restrict__ off, const int *__restrict__ list, const int *__restrict__ active, int ncomp, int64_t ncell, const double *__restrict__ F,
-                                                      const double *__restrict__ dV, double *__restrict__ f, int dbg)
+__global__ void __launch_bounds__(256) k_ibm_spread_v1(IbmP P, const int *__restrict__ i0, const double *__restrict__ w, const int *__restrict__ off, const int *__restrict__ list, const int *__restrict__ active, int ncomp, int64_t ncell, const double *__restrict__ F,
+                                                      const double *__restrict__ dV, double *__restrict__ f)
 {
   __shared__ int    sraw[BIN_CHUNK];
   __shared__ int    si0[3][BIN_CHUNK];
@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(256) k_ibm_spread(IbmP P, const int *__restric
       for (int c = 0; c < 3; ++c) sF[c][threadIdx.x] = c < ncomp ? F[(int64_t)c * P.L + m] * dv : 0.;
     }
     __syncthreads();
-    if (ci < P.n[0] && cj < P.n[1] && !(dbg & 1)) {
+    if (ci < P.n[0] && cj < P.n[1]) {
       for (int e = 0; e < n; ++e) {
         int a = ci + P.lo[0] - si0[0][e], b = cj + P.lo[1] - si0[1][e];
         if (P.periodic[0]) { if (a < 0) a += P.ng[0]; else if (a >= P.ng[0]) a -= P.ng[0]; }
@@ -248,9 +248,75 @@ __global__ void __launch_bounds__(256) k_ibm_spread(IbmP P, const int *__restric
       }
     }
   }
-  if (ci < P.n[0] && cj < P.n[1] && !(dbg & 2))
+  if (ci < P.n[0] && cj < P.n[1])
     for (int half = 0; half < 2; ++half) {
       const int ck = tz * TB + lk + 4 * half;
+      if (ck >= P.n[2]) continue;
+      const int64_t cell = ((int64_t)ck * P.n[1] + cj) * P.n[0] + ci;
+      const double  vinv = uni ? 1. : P.idx[0][ci] * P.idx[1][cj] * P.idx[2][ck];
+      for (int c = 0; c < ncomp && c < 3; ++c)
+        if (acc[half][c] != 0.) f[(int64_t)c * ncell + cell] += acc[half][c] * vinv;
+    }
+}
+
+// Round 4.  The loop above is a chain of dependent LDS reads per marker (its first cell -> the index into its weights -> the weight) behind two
+// divergent tests, one wave per SIMD and block: about 300 cycles per marker and 150 markers per bin of config 4's sphere.  Here the staging step expands
+// every marker's 1-D weights onto the tile's eight cells per axis (zero outside the support, periodic wrap and all), so the loop reads four weights and
+// three forces at addresses that depend on nothing but the thread and the loop counter -- no test, no dependent read, unrolled.  A cell outside a marker's
+// support adds an exact zero, so the sums (ascending marker id per cell, as before) are the same bits.
+__global__ void __launch_bounds__(256) k_ibm_spread(IbmP P, const int *__restrict__ i0, const double *__restrict__ w, const int *__restrict__ off, const int *__restrict__ list, const int *__restrict__ active, int ncomp, int64_t ncell, const double *__restrict__ F,
+                                                    const double *__restrict__ dV, double *__restrict__ f)
+{
+  __shared__ double swl[3][BIN_CHUNK][TB];  // weight of marker e on the tile's cell c of axis d
+  __shared__ double sF[3][BIN_CHUNK];
+  const int tile = active[blockIdx.x];  // only tiles with a non-empty bin are launched
+  const int beg = off[tile], end = off[tile + 1];
+  if (beg == end) return;
+  const int tt[3] = {tile % P.nt[0], (tile / P.nt[0]) % P.nt[1], tile / (P.nt[0] * P.nt[1])};
+  const bool   uni = P.uniform[0] && P.uniform[1] && P.uniform[2];
+  const double ih  = uni ? 1. / (P.h[0] * P.h[1] * P.h[2]) : 1.;  // stretched grids: 1 / (volume of the target cell), applied per cell below
+  // this thread's two cells: (ci, cj, ck) and (ci, cj, ck + 4)
+  const int li = threadIdx.x & 7, lj = (threadIdx.x >> 3) & 7, lk = threadIdx.x >> 6;
+  const int ci = tt[0] * TB + li, cj = tt[1] * TB + lj;
+  double    acc[2][3] = {{0., 0., 0.}, {0., 0., 0.}};
+  for (int c0 = beg; c0 < end; c0 += BIN_CHUNK) {  // bins are sorted by marker id (k_ibm_sort_bins): chunks in list order keep the order
+    const int n = min(BIN_CHUNK, end - c0);
+    __syncthreads();
+    if ((int)threadIdx.x < n) {
+      const int m = list[c0 + threadIdx.x];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const int first = i0[d * P.L + m];
+        double    wd[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) wd[a] = w[(d * 4 + a) * P.L + m];
+#pragma unroll
+        for (int c = 0; c < TB; ++c) {
+          int a = tt[d] * TB + c + P.lo[d] - first;
+          if (P.periodic[d]) { if (a < 0) a += P.ng[d]; else if (a >= P.ng[d]) a -= P.ng[d]; }
+          swl[d][threadIdx.x][c] = (a < 0 || a >= P.S) ? 0. : (a == 0 ? wd[0] : (a == 1 ? wd[1] : (a == 2 ? wd[2] : wd[3])));
+        }
+      }
+      const double dv = dV[m] * ih;
+      for (int c = 0; c < 3; ++c) sF[c][threadIdx.x] = c < ncomp ? F[(int64_t)c * P.L + m] * dv : 0.;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int e = 0; e < n; ++e) {
+      const double wxy = swl[0][e][li] * swl[1][e][lj];
+      const double wt0 = wxy * swl[2][e][lk], wt1 = wxy * swl[2][e][lk + 4];
+      const double f0 = sF[0][e], f1 = sF[1][e], f2 = sF[2][e];
+      acc[0][0] += wt0 * f0;
+      acc[0][1] += wt0 * f1;
+      acc[0][2] += wt0 * f2;
+      acc[1][0] += wt1 * f0;
+      acc[1][1] += wt1 * f1;
+      acc[1][2] += wt1 * f2;
+    }
+  }
+  if (ci < P.n[0] && cj < P.n[1])
+    for (int half = 0; half < 2; ++half) {
+      const int ck = tt[2] * TB + lk + 4 * half;
       if (ck >= P.n[2]) continue;
       const int64_t cell = ((int64_t)ck * P.n[1] + cj) * P.n[0] + ci;
       const double  vinv = uni ? 1. : P.idx[0][ci] * P.idx[1][cj] * P.idx[2][ck];
@@ -412,14 +478,6 @@ extern "C" int fl_ibm_interp(fl_ibm *m, int ncomp, const double *u, double *U)
   return FL_SUCCESS;
 }
 
-static int ibm_dbg()
-{
-  static const int v = []() {
-    const char *e = std::getenv("FLUCA_IBM_DBG");  // experiments: bit 0 skips the marker loop of k_ibm_spread, bit 1 its read-modify-write of f
-    return e ? std::atoi(e) : 0;
-  }();
-  return v;
-}
 // bin statistics of the current marker positions (experiments): tiles with a non-empty bin, entries of all bins, the largest bin
 extern "C" int fldbg_ibm_stats(fl_ibm *m, int *nactive, int *entries, int *maxbin)
 {
@@ -441,7 +499,14 @@ extern "C" int fl_ibm_spread(fl_ibm *m, int ncomp, const double *F, const double
   if (ncomp < 1 || ncomp > 3) return FL_ERR_ARG_OUTOFRANGE;
   fl_poisson *h = m->gp;
   FL_HIP(hipSetDevice(h->device));
-  if (m->nactive > 0) hipLaunchKernelGGL(k_ibm_spread, dim3(m->nactive), dim3(256), 0, h->stream, m->P, m->i0, m->w, m->off, m->list, m->active, ncomp, h->ncell, F, dV, f, ibm_dbg());
+  static const bool v1 = []() {
+    const char *e = std::getenv("FLUCA_IBM_SPREAD");  // 1: round 1's loop over the bin (A/B runs)
+    return e && std::atoi(e) == 1;
+  }();
+  if (m->nactive > 0) {
+    if (v1) hipLaunchKernelGGL(k_ibm_spread_v1, dim3(m->nactive), dim3(256), 0, h->stream, m->P, m->i0, m->w, m->off, m->list, m->active, ncomp, h->ncell, F, dV, f);
+    else hipLaunchKernelGGL(k_ibm_spread, dim3(m->nactive), dim3(256), 0, h->stream, m->P, m->i0, m->w, m->off, m->list, m->active, ncomp, h->ncell, F, dV, f);
+  }
   FL_HIP(hipGetLastError());
   return FL_SUCCESS;
 }
