@@ -97,6 +97,10 @@ PROTOTYPES = {
     "fl_free": (C.c_int, [C.c_int, _P]),
     "fl_memcpy_h2d": (C.c_int, [C.c_int, _P, _P, C.c_size_t]),
     "fl_memcpy_d2h": (C.c_int, [C.c_int, _P, _P, C.c_size_t]),
+    "fl_malloc_host": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "fl_free_host": (C.c_int, [_P]),
+    "fl_poisson_upload": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "fl_poisson_upload_fence": (C.c_int, [_P]),
     "fl_tuning_set": (C.c_int, [C.c_char_p, C.c_int]),
     "fl_tuning_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
     "fl_poisson_tune_placement": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double)]),

@@ -243,6 +243,7 @@ extern "C" int fl_poisson_destroy(fl_poisson *h)
   if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
   if (h->ev_packed) (void)hipEventDestroy(h->ev_packed);
   if (h->ev_ghosts) (void)hipEventDestroy(h->ev_ghosts);
+  if (h->ev_upload) (void)hipEventDestroy(h->ev_upload);
   if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1424,6 +1425,36 @@ extern "C" int fl_memcpy_h2d(int device, void *dev, const void *host, size_t byt
   FL_HIP(hipDeviceSynchronize());  // whatever still reads or writes `dev` on a handle's stream finishes first
   FL_HIP(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice));
   FL_HIP(hipDeviceSynchronize());
+  return FL_SUCCESS;
+}
+// Page-locked host memory and a copy out of it that is ordered on the handle's stream like a kernel: no device-wide wait on either side (the C host
+// mirror hands over some thirty boundary planes per time step; fl_memcpy_h2d drains the device twice per plane).
+extern "C" int fl_malloc_host(size_t bytes, void **host_out)
+{
+  if (!host_out) return FL_ERR_ARG_NULL;
+  *host_out = nullptr;
+  if (hipHostMalloc(host_out, bytes ? bytes : 8, hipHostMallocDefault) != hipSuccess) return FL_ERR_MEM;
+  return FL_SUCCESS;
+}
+extern "C" int fl_free_host(void *host)
+{
+  if (!host) return FL_SUCCESS;
+  FL_HIP(hipHostFree(host));
+  return FL_SUCCESS;
+}
+extern "C" int fl_poisson_upload(fl_poisson *h, void *dev, const void *host, size_t bytes)
+{
+  if (!h || !dev || !host) return FL_ERR_ARG_NULL;
+  FL_HIP(hipSetDevice(h->device));
+  if (!h->ev_upload) FL_HIP(hipEventCreateWithFlags(&h->ev_upload, hipEventDisableTiming));
+  FL_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, h->stream));
+  FL_HIP(hipEventRecord(h->ev_upload, h->stream));
+  return FL_SUCCESS;
+}
+extern "C" int fl_poisson_upload_fence(fl_poisson *h)
+{
+  if (!h) return FL_ERR_ARG_NULL;
+  if (h->ev_upload) FL_HIP(hipEventSynchronize(h->ev_upload));
   return FL_SUCCESS;
 }
 extern "C" int fl_memcpy_d2h(int device, void *host, const void *dev, size_t bytes)

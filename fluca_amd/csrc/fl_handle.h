@@ -307,6 +307,7 @@ struct fl_poisson {
   // halo exchange overlapped with k_cg_B (fl_exchange_r_begin / _end): its own stream and the two events that order it
   hipStream_t comm_stream = nullptr;
   hipEvent_t  ev_packed = nullptr, ev_ghosts = nullptr;
+  hipEvent_t  ev_upload = nullptr;  // behind the last fl_poisson_upload (fl_poisson_upload_fence waits for it)
   fl_mg     *mg = nullptr;  // multigrid hierarchy, built by the first solve with FL_PC_MG (fl_mg.hip)
 };
 

@@ -1433,8 +1433,7 @@ static FlErrorCode NSSetUp_CNLinear(NS ns)
   }
   c->plane_cap = pmax;
   FLCHK(cnl_alloc(ns, &c->plane_dev, pmax));
-  for (int q = 0; q < 7; ++q)
-    if (!(c->plane_host[q] = (double *)malloc(sizeof(double) * (size_t)pmax))) return E_MEM;
+  for (int q = 0; q < 7; ++q) FLABI(fl_malloc_host(sizeof(double) * (size_t)pmax, (void **)&c->plane_host[q]));
   return 0;
 }
 
@@ -1450,7 +1449,10 @@ static FlErrorCode NSDestroy_CNLinear(NS ns)
     for (size_t a = 0; a < sizeof(f) / sizeof(f[0]); ++a)
       if (f[a]) fl_free(ns->device, f[a]);
   }
-  for (int q = 0; q < 7; ++q) free(c->plane_host[q]);
+  for (int q = 0; q < 7; ++q) fl_free_host(c->plane_host[q]);
+  for (int b = 0; b < 6; ++b)
+    for (int k = 0; k < 2; ++k)
+      for (int q = 0; q < 3; ++q) fl_free_host(c->bc_plane[b][k][q]);
   for (int i = -2; i < c->gm_cap; ++i) { /* every slot of the table: a failed allocation may have left a partly filled one */
     NSVec   *a = i == -2 ? &c->gm_w : i == -1 ? &c->gm_t : &c->gm_V[i];
     double *q[5] = {a->v, a->p, a->V[0], a->V[1], a->V[2]};
@@ -1509,15 +1511,31 @@ FlErrorCode NSGetSolutionArrays(NS ns, double **v, double *V[3], double **p)
   return 0;
 }
 
-/* boundary b touches this rank and carries a velocity condition: evaluate the callback at the face centres, out[c] =
- * component c on this rank's part of the boundary (cnlinearcart3d.c:690-698: xb = face coordinate, cell centres in plane) */
-static FlErrorCode cnl_eval_velocity(NS ns, int b, double t, double *out[3])
+/* boundary b touches this rank and carries a velocity condition: the callback at the face centres, out[c] = component c on this rank's part of
+ * the boundary (cnlinearcart3d.c:690-698: xb = face coordinate, cell centres in plane).  A step looks at the values at t and t + dt several times
+ * (the boundary-condition vectors of L, C, B and the wall faces of v0interp), and its t + dt is the next step's t: the planes of the two most recent
+ * times are kept (page-locked, so that they can be handed over as they are) -- a callback is a function of (t, x) by its contract, and a plane
+ * is evaluated again when the callback, its context or the time differ. */
+static FlErrorCode cnl_eval_velocity(NS ns, int b, double t, const double *out[3])
 {
+  NS_CNLinear     *c = (NS_CNLinear *)ns->data;
   Mesh_Cart       *cart = (Mesh_Cart *)ns->mesh->data;
   const fl_decomp *D    = &ns->mesh->decomp;
   const int        ax = b / 2, side = b % 2, a1 = ax == 0 ? 1 : 0, a2 = ax == 2 ? 1 : 2;
   const int64_t    n1 = D->len[a1], n2 = D->len[a2];
   if (!ns->bcs[b].velocity) return E_ARG_WRONGSTATE;
+  for (int k = 0; k < 2; ++k)
+    if (c->bc_have[b][k] && c->bc_time[b][k] == t && c->bc_fn[b][k] == ns->bcs[b].velocity && c->bc_ctx[b][k] == ns->bcs[b].ctx_velocity) {
+      for (int q = 0; q < 3; ++q) out[q] = c->bc_plane[b][k][q];
+      c->bc_old[b] = 1 - k;
+      return 0;
+    }
+  const int k = c->bc_old[b]; /* the slot not asked for last */
+  FLABI(fl_poisson_upload_fence(ns->poisson)); /* an upload out of that slot may still be under way */
+  c->bc_have[b][k] = 0;
+  for (int q = 0; q < 3; ++q)
+    if (!c->bc_plane[b][k][q]) FLABI(fl_malloc_host(sizeof(double) * (size_t)c->plane_cap, (void **)&c->bc_plane[b][k][q]));
+  double *p0 = c->bc_plane[b][k][0], *p1 = c->bc_plane[b][k][1], *p2 = c->bc_plane[b][k][2];
   for (int64_t j = 0; j < n2; ++j)
     for (int64_t i = 0; i < n1; ++i) {
       double xb[3], val[3] = {0., 0., 0.};
@@ -1525,8 +1543,16 @@ static FlErrorCode cnl_eval_velocity(NS ns, int b, double t, double *out[3])
       xb[a1] = cart->xc[a1][D->lo[a1] + i];
       xb[a2] = cart->xc[a2][D->lo[a2] + j];
       FLCHK(ns->bcs[b].velocity(3, t, xb, val, ns->bcs[b].ctx_velocity));
-      for (int c = 0; c < 3; ++c) out[c][j * n1 + i] = val[c];
+      p0[j * n1 + i] = val[0];
+      p1[j * n1 + i] = val[1];
+      p2[j * n1 + i] = val[2];
     }
+  c->bc_have[b][k] = 1;
+  c->bc_time[b][k] = t;
+  c->bc_fn[b][k]   = ns->bcs[b].velocity;
+  c->bc_ctx[b][k]  = ns->bcs[b].ctx_velocity;
+  c->bc_old[b]     = 1 - k;
+  for (int q = 0; q < 3; ++q) out[q] = c->bc_plane[b][k][q];
   return 0;
 }
 
@@ -1536,10 +1562,23 @@ static int cnl_touches(NS ns, int b)
   return b % 2 ? D->coord[b / 2] == D->ranks[b / 2] - 1 : D->coord[b / 2] == 0;
 }
 
+/* host (page-locked: a scratch plane of cnl_scratch or a kept boundary plane) -> plane_dev, ordered on the handle's stream behind the kernel that read
+ * the plane before and in front of the one that reads this one; the host plane stays untouched until the next fence */
 static FlErrorCode cnl_upload(NS ns, const double *host, int64_t n)
 {
   NS_CNLinear *c = (NS_CNLinear *)ns->data;
-  FLABI(fl_memcpy_h2d(ns->device, c->plane_dev, host, sizeof(double) * (size_t)n));
+  FLABI(fl_poisson_upload(ns->poisson, c->plane_dev, host, sizeof(double) * (size_t)n));
+  return 0;
+}
+/* the next of the seven page-locked scratch planes; once round, the uploads out of them are waited for */
+static FlErrorCode cnl_scratch(NS ns, double **plane)
+{
+  NS_CNLinear *c = (NS_CNLinear *)ns->data;
+  if (c->plane_next == 7) {
+    FLABI(fl_poisson_upload_fence(ns->poisson));
+    c->plane_next = 0;
+  }
+  *plane = c->plane_host[c->plane_next++];
   return 0;
 }
 
@@ -1795,7 +1834,7 @@ static FlErrorCode NSFormFunction_CNLinear(NS ns, const NSVec *x, NSVec *f)
     const fl_decomp *D = &ns->mesh->decomp;
     const int64_t    np = D->len[a1] * D->len[a2], n = cart->N[ax];
     const double    *xf = cart->xf[ax], *xc = cart->xc[ax];
-    double          *vb0[3] = {c->plane_host[0], c->plane_host[1], c->plane_host[2]}, *vb1[3] = {c->plane_host[3], c->plane_host[4], c->plane_host[5]};
+    const double    *vb0[3], *vb1[3];
     FLCHK(cnl_eval_velocity(ns, b, t, vb0));
     FLCHK(cnl_eval_velocity(ns, b, t + dt, vb1));
     /* coefficient of the wall value in the one-sided second-derivative row, :698-701 / :726-729 */
@@ -1807,9 +1846,10 @@ static FlErrorCode NSFormFunction_CNLinear(NS ns, const NSVec *x, NSVec *f)
       h1 = xf[n] - xc[n - 1]; h2 = xc[n - 1] - xc[n - 2]; h3 = xc[n - 1] - xc[n - 3]; hcell = xf[n] - xf[n - 1];
     }
     const double cl = 2. * (h2 + h3) / (h1 * (h1 + h2) * (h1 + h3)), sgn = side ? 0.5 : -0.5;
-    double      *tmp = c->plane_host[6];
     for (int q = 0; q < 3; ++q) {
       /* momrhs += cv (vbcL(t) + vbcL(t+dt)) - dt vbcC(t, t+dt), :2985-2998 with :698-701 and :1338 */
+      double *tmp;
+      FLCHK(cnl_scratch(ns, &tmp));
       for (int64_t a = 0; a < np; ++a) tmp[a] = cv * cl * (vb0[q][a] + vb1[q][a]) - dt * sgn * (vb1[q][a] * vb0[ax][a] + vb0[q][a] * vb1[ax][a]) / hcell;
       FLCHK(cnl_upload(ns, tmp, np));
       FLABI(fl_boundary_add_cells(h, b, 1., c->plane_dev, f->v + q * N));
@@ -1837,7 +1877,10 @@ static FlErrorCode NSFormFunction_CNLinear(NS ns, const NSVec *x, NSVec *f)
       const int64_t    n1 = D->len[a1], n2 = D->len[a2], np = n1 * n2, n = cart->N[ax];
       const double    *xf = cart->xf[ax], *xc = cart->xc[ax];
       if (!ns->bcs[b].pressure || n < 2) return !ns->bcs[b].pressure ? E_ARG_WRONGSTATE : E_SUP;
-      double *pq = c->plane_host[0], *pp = c->plane_host[1], *tmp = c->plane_host[2];
+      double *pq, *pp, *tmp;
+      FLCHK(cnl_scratch(ns, &pq));
+      FLCHK(cnl_scratch(ns, &pp));
+      FLCHK(cnl_scratch(ns, &tmp));
       int     differs = 0;
       for (int64_t j = 0; j < n2; ++j)
         for (int64_t i = 0; i < n1; ++i) {
@@ -1949,7 +1992,7 @@ static FlErrorCode NSStep_CNLinear(NS ns)
     const int        ax = b / 2, a1 = ax == 0 ? 1 : 0, a2 = ax == 2 ? 1 : 2;
     const fl_decomp *D = &ns->mesh->decomp;
     const int64_t    np = D->len[a1] * D->len[a2];
-    double          *vb0[3] = {c->plane_host[0], c->plane_host[1], c->plane_host[2]};
+    const double    *vb0[3];
     FLCHK(cnl_eval_velocity(ns, b, ns->t, vb0));
     for (int q = 0; q < 3; ++q) { /* v0interp on the wall faces = the wall velocity at t (INSERT), :1788 */
       FLCHK(cnl_upload(ns, vb0[q], np));

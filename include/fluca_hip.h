@@ -160,6 +160,13 @@ int fl_malloc(int device, size_t bytes, void **dev_out); /* zero-initialised */
 int fl_free(int device, void *dev);
 int fl_memcpy_h2d(int device, void *dev, const void *host, size_t bytes);
 int fl_memcpy_d2h(int device, void *host, const void *dev, size_t bytes);
+/* Page-locked host memory, and a copy out of it that is ordered on the handle's stream like a kernel launch (no device-wide wait; dev may be read by
+ * kernels enqueued before and after).  The host buffer must stay untouched until fl_poisson_upload_fence (waits for the LAST upload of the handle, hence
+ * for all of them) or fl_poisson_synchronize has returned.  host need not come from fl_malloc_host, but only page-locked memory copies asynchronously. */
+int fl_malloc_host(size_t bytes, void **host_out);
+int fl_free_host(void *host);
+int fl_poisson_upload(fl_poisson *h, void *dev, const void *host, size_t bytes);
+int fl_poisson_upload_fence(fl_poisson *h);
 
 /* y = a x + b z (z_dev may be NULL; y may alias x or z) and result = sum x y over all ranks (blocking; every rank passes its
  * owned entries) -- for hosts that run an outer iteration over device vectors and have no vector library of their own. */

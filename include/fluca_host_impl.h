@@ -116,8 +116,16 @@ typedef struct {
   int     have_sol0;                           /* "if (ns->sol0)" of NSFormJacobian (:2930): set by the first NSStep */
   double *W[9];                                /* cnl->v0interp */
   double *r_v, *r_V[3], *r_p, *d_v, *d_V[3], *d_p;
-  double *plane_dev, *plane_host[7];           /* boundary values: 3 components at two times + one scratch plane */
+  double *plane_dev, *plane_host[7];           /* page-locked scratch planes, handed out in turn (cnl_scratch) */
   int64_t plane_cap;
+  int     plane_next;                          /* planes handed out since the last fence */
+  /* values of the velocity callbacks on the boundary planes, kept for the two times a step looks at (t and t + dt: the second is the next step's
+   * first): bc_plane[b][slot][component], page-locked; valid for callback bc_fn / context bc_ctx at time bc_time */
+  double     *bc_plane[6][2][3];
+  double      bc_time[6][2];
+  int         bc_have[6][2], bc_old[6];
+  void       *bc_ctx[6][2];
+  NSBoundaryConditionFunction bc_fn[6][2];
   /* GMRES work vectors, kept from step to step (allocating and freeing ~70 GB of device memory per step at 512^3 left the
    * GPU idle for a third of the step): w, t and the Krylov basis, grown lazily up to restart + 1 */
   NSVec gm_w, gm_t, *gm_V;

@@ -412,3 +412,30 @@ def test_small_handles_are_not_placed():
     x1, i1 = P.solve(dev(b), history=True)
     assert i0["iters"] == i1["iters"] and torch.equal(x0, x1)
     P.close()
+
+
+def test_stream_ordered_upload_from_page_locked_memory():
+    """fl_malloc_host / fl_poisson_upload / fl_poisson_upload_fence: the plane lands between the kernels enqueued before and after it."""
+    import ctypes as C
+
+    import torch
+
+    from fluca_amd import capi
+    P, g = make_pair((16, 12, 8), CAVITY, kappa=1.0, nonuniform=False)
+    n = 12 * 8
+    hp = C.c_void_p()
+    capi.check(capi.lib.fl_malloc_host(8 * n, C.byref(hp)))
+    buf = np.ctypeslib.as_array(C.cast(hp, C.POINTER(C.c_double)), shape=(n,))
+    plane = torch.zeros(n, dtype=torch.float64, device="cuda")
+    cells = torch.zeros(g.ncell, dtype=torch.float64, device="cuda")
+    expect = np.zeros(g.ncell).reshape(8, 12, 16)
+    for rep in range(3):  # the same device plane and the same host plane three times over: each copy sits behind the kernel that read the plane before
+        buf[:] = np.arange(n) + 100.0 * rep
+        capi.check(capi.lib.fl_poisson_upload(P.h, C.c_void_p(plane.data_ptr()), hp, 8 * n))
+        capi.check(capi.lib.fl_boundary_add_cells(P.h, 0, 2.0, C.c_void_p(plane.data_ptr()), C.c_void_p(cells.data_ptr())))
+        capi.check(capi.lib.fl_poisson_upload_fence(P.h))       # before the host plane is written again
+        expect[:, :, 0] += 2.0 * (np.arange(n) + 100.0 * rep).reshape(8, 12)
+    P.synchronize()
+    assert np.array_equal(host(cells).reshape(8, 12, 16), expect)
+    capi.check(capi.lib.fl_free_host(hp))
+    P.close()
