@@ -643,25 +643,49 @@ __global__ void __launch_bounds__(256) k_scale_by(int64_t n, const double *__res
   }
 }
 // VecMDot / VecMAXPY on up to 8 vectors per launch: x is read once for all of them
-// max (SUM = false) or sum (SUM = true) over the owned cells of three padded components (one entry per block)
-template <bool SUM>
-__global__ void __launch_bounds__(256) k_max_owned(GridP g, int64_t cs, const double *__restrict__ v, double *__restrict__ partial)
+// max of a and sum of b over the owned cells of three padded components each (partial[2 * block], partial[2 * block + 1]; either array may be NULL):
+// four rows per pass, 16-byte loads -- eight loads in flight per thread (round 4; one row and 8-byte loads per pass ran at 3.2 TB/s)
+__global__ void __launch_bounds__(256) k_max_sum_owned(GridP g, int64_t cs, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ partial)
 {
-  __shared__ double red[4];
-  const int64_t rows = (int64_t)3 * g.nz * g.ny;
-  double        mx = 0.;
-  for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
-    const int     c = (int)(r / ((int64_t)g.nz * g.ny)), kj = (int)(r % ((int64_t)g.nz * g.ny)), k = kj / g.ny, j = kj % g.ny;
-    const double *row = v + (int64_t)c * cs + g.off0 + (int64_t)k * g.sxy + (int64_t)j * g.sx;
-    for (int i = threadIdx.x; i < g.nx; i += 256) mx = SUM ? mx + row[i] : fmax(mx, row[i]);
+  __shared__ double red[2][4];
+  const int64_t plane = (int64_t)g.nz * g.ny, rows = 3 * plane;
+  double        mx = 0., sm = 0.;
+  for (int64_t r0 = (int64_t)blockIdx.x * 4; r0 < rows; r0 += (int64_t)gridDim.x * 4) {
+    int64_t base[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t r = min(r0 + u, rows - 1);  // a repeated row changes neither the maximum nor (skipped below) the sum
+      const int     c = (int)(r / plane), kj = (int)(r % plane), k = kj / g.ny, j = kj % g.ny;
+      base[u] = (int64_t)c * cs + g.off0 + (int64_t)k * g.sxy + (int64_t)j * g.sx;
+    }
+    for (int i = 2 * threadIdx.x; i < g.nx; i += 512) {
+      const bool two = i + 1 < g.nx;
+      double2    va[4], vb[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        va[u] = a ? (two ? *reinterpret_cast<const double2 *>(a + base[u] + i) : make_double2(a[base[u] + i], 0.)) : make_double2(0., 0.);
+        vb[u] = b ? (two ? *reinterpret_cast<const double2 *>(b + base[u] + i) : make_double2(b[base[u] + i], 0.)) : make_double2(0., 0.);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        mx = fmax(mx, fmax(va[u].x, va[u].y));
+        if (r0 + u < rows) sm += vb[u].x + vb[u].y;
+      }
+    }
   }
   for (int off = 32; off > 0; off >>= 1) {
-    const double o = __shfl_down(mx, off, 64);
-    mx = SUM ? mx + o : fmax(mx, o);
+    mx = fmax(mx, __shfl_down(mx, off, 64));
+    sm += __shfl_down(sm, off, 64);
   }
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = mx;
+    red[1][threadIdx.x >> 6] = sm;
+  }
   __syncthreads();
-  if (threadIdx.x == 0) partial[blockIdx.x] = SUM ? (red[0] + red[1]) + (red[2] + red[3]) : fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x]     = fmax(fmax(red[0][0], red[0][1]), fmax(red[0][2], red[0][3]));
+    partial[2 * blockIdx.x + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
 }
 
 struct Vec8 {
@@ -1198,24 +1222,27 @@ extern "C" int fl_momentum_diagonal(fl_momentum *m, double *d_dev)
   return FL_SUCCESS;
 }
 
-// max, or sum, over the owned cells (all ranks) of three padded components: a set-up quantity, one host wait
-static int max_owned(fl_momentum *m, const double *v3, double *out, bool sum = false)
+// max of a and sum of b over the owned cells (all ranks) of three padded components each: set-up quantities, one launch and one host wait for both
+static int max_sum_owned(fl_momentum *m, const double *a3, const double *b3, double *mx_out, double *sum_out)
 {
   fl_poisson   *h = m->p;
   const int64_t rows = (int64_t)3 * h->g.nz * h->g.ny;
-  const int     nb = (int)std::max<int64_t>(1, std::min<int64_t>(rows, 1024));
-  FL_CHK(fl_ensure_partials(h, nb));
-  if (sum) hipLaunchKernelGGL(k_max_owned<true>, dim3(nb), dim3(256), 0, h->stream, h->g, (int64_t)h->padlen, v3, h->partial);
-  else hipLaunchKernelGGL(k_max_owned<false>, dim3(nb), dim3(256), 0, h->stream, h->g, (int64_t)h->padlen, v3, h->partial);
+  const int     nb = (int)std::max<int64_t>(1, std::min<int64_t>((rows + 3) / 4, 2048));
+  FL_CHK(fl_ensure_partials(h, 2 * nb));
+  hipLaunchKernelGGL(k_max_sum_owned, dim3(nb), dim3(256), 0, h->stream, h->g, (int64_t)h->padlen, a3, b3, h->partial);
   FL_HIP(hipGetLastError());
-  std::vector<double> part((size_t)nb);
-  FL_HIP(hipMemcpyAsync(part.data(), h->partial, sizeof(double) * (size_t)nb, hipMemcpyDeviceToHost, h->stream));
+  std::vector<double> part((size_t)(2 * nb));
+  FL_HIP(hipMemcpyAsync(part.data(), h->partial, sizeof(double) * (size_t)(2 * nb), hipMemcpyDeviceToHost, h->stream));
   FL_HIP(hipStreamSynchronize(h->stream));
-  double mx = 0.;
-  for (double v : part) mx = sum ? mx + v : std::max(mx, v);  // fixed order: the same number run to run
-  if (sum) FL_CHK(fl_allreduce_sum(h, &mx));
-  else FL_CHK(fl_allreduce_max(h, &mx));  // several ranks: the bound of the whole operator
-  *out = mx;
+  double mx = 0., sm = 0.;
+  for (int q = 0; q < nb; ++q) {  // fixed order: the same numbers run to run
+    mx = std::max(mx, part[(size_t)(2 * q)]);
+    sm += part[(size_t)(2 * q + 1)];
+  }
+  FL_CHK(fl_allreduce_max(h, &mx));  // several ranks: the bound of the whole operator
+  FL_CHK(fl_allreduce_sum(h, &sm));
+  if (mx_out) *mx_out = mx;
+  if (sum_out) *sum_out = sm;
   return 0;
 }
 
@@ -1232,9 +1259,8 @@ extern "C" int fl_momentum_gershgorin(fl_momentum *m, double *radius)
   if (m->gersh < 0.) {
     FL_CHK(mom_vec(m, 7));
     mom_apply_t<0, false, 3>(m, m->F, m->vec[7], nullptr, nullptr);  // x is not used for the row sums: any valid padded array
-    FL_CHK(max_owned(m, m->vec[7], &m->gersh));
     double dsum = 0.;
-    FL_CHK(max_owned(m, m->dg, &dsum, true));
+    FL_CHK(max_sum_owned(m, m->vec[7], m->dg, &m->gersh, &dsum));
     m->dmean = dsum / (3. * (double)h->ax[0].n * (double)h->ax[1].n * (double)h->ax[2].n);
   }
   *radius = m->gersh;
