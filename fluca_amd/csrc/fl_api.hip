@@ -1210,7 +1210,20 @@ static int solve_cg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts
     const char *e = std::getenv("FLUCA_CGBQ_CHUNKS");  // experiments: z chunks of k_cg_Bq (default: those of k_cg_A)
     return e ? std::atoi(e) : 0;
   }();
-  const PlanA planB = storeq ? plan_cg_B(g) : (bq_chunks_env > 0 ? plan_tiles(g, plan.ry, plan.nw, bq_chunks_env, 0) : plan);  // k_cg_Bq walks the tiles of k_cg_A
+  PlanA planB = storeq ? plan_cg_B(g) : (bq_chunks_env > 0 ? plan_tiles(g, plan.ry, plan.nw, bq_chunks_env, 0) : plan);  // k_cg_Bq walks the tiles of k_cg_A
+  {
+    struct Force { int ry = 0, nw = 0, nchunk = 0; };
+    static const Force fb = []() {
+      Force f;
+      if (const char *e = std::getenv("FLUCA_CGBQ_PLAN")) std::sscanf(e, "%d,%d,%d", &f.ry, &f.nw, &f.nchunk);  // experiments: a tiling of its own for k_cg_Bq
+      return f;
+    }();
+    if (!storeq && (fb.ry == 1 || fb.ry == 2) && (fb.nw == 4 || (fb.nw == 8 && fb.ry == 2)) && fb.nchunk > 0 && g.ny >= 8) {
+      const PlanA keep = planB;
+      planB            = plan_tiles(g, fb.ry, fb.nw, fb.nchunk, 0);
+      planB.pf = keep.pf; planB.nt = keep.nt; planB.remap = keep.remap; planB.sq = keep.sq; planB.qb = keep.qb;
+    }
+  }
   const int   nsb  = stream_blocks(g);
   const int   nab  = variant == 1 ? apply_dot_blocks(g) : plan.nblocks;
   FL_CHK(fl_ensure_partials(h, std::max(std::max(nsb, nab), planB.nblocks)));
