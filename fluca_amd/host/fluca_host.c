@@ -707,6 +707,7 @@ FlErrorCode NSCreate(NS *ns)
   n->max_steps = -1;
   n->max_time  = 1.7976931348623157e308;
   n->errorifstepfailed = 1;
+  n->bc_keep           = 1;
   fl_ksp_opts_default(&n->schur);
   fl_ksp_opts_default(&n->mom);
   n->mom.type = FL_KSP_BCGS; /* PETSc's own default for kspA is gmres + ilu: neither has a matrix-free form here */
@@ -832,6 +833,12 @@ FlErrorCode NSSetFromOptions(NS ns, int argc, char **argv)
     const int got = opt_flag(argc, argv, "-ns_error_if_step_failed", &flg); /* :188 */
     if (got < 0) return E_ARG_WRONG;
     if (got) ns->errorifstepfailed = flg;
+  }
+  {
+    int flg = 0;
+    const int got = opt_flag(argc, argv, "-ns_keep_boundary_values", &flg); /* mirror only: see fluca_host.h */
+    if (got < 0) return E_ARG_WRONG;
+    if (got) ns->bc_keep = flg;
   }
   /* sub-KSP of the Schur complement: prefix ns_ + abf_schur_ (nssol.c:19, abfpc.c:206) */
   if ((s = opt_find(argc, argv, "-ns_abf_schur_ksp_type"))) {
@@ -1975,6 +1982,8 @@ static FlErrorCode NSStep_CNLinear(NS ns)
   fl_poisson   *h = ns->poisson;
   const int64_t N = c->sz[0];
   FLCHK(ns_jacobian(ns));
+  if (!ns->bc_keep) /* -ns_keep_boundary_values false: nothing a callback returned in an earlier step is used again */
+    for (int b = 0; b < 6; ++b) c->bc_have[b][0] = c->bc_have[b][1] = 0;
   const int timing = step_timing();
   double    tm[6] = {0., 0., 0., 0., 0., 0.};
   if (timing) tm[0] = step_clock(ns);

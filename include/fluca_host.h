@@ -163,6 +163,10 @@ FlErrorCode NSGetTimeStepSize(NS ns, double *dt);
 FlErrorCode NSSetTime(NS ns, double t);
 FlErrorCode NSSetTimeStep(NS ns, int64_t step);
 /* -ns_error_if_step_failed (default true, nsbasic.c:46): a failed step makes NSStep return PETSC_ERR_NOT_CONVERGED (91) */
+/* -ns_keep_boundary_values (mirror only; default true): the values a VELOCITY callback returned on a boundary are kept for the two most recent times, so
+ * that the several boundary-condition vectors of a step and the next step's t (= this step's t + dt) do not sweep the callback again.  That presumes what
+ * the reference's own repeated sweeps presume within a step -- a callback is a function of (t, x) for a fixed context.  A caller that changes what ctx
+ * points to between steps passes false (values are then kept within a step only) or sets the boundary condition again. */
 FlErrorCode NSSetErrorIfStepFailed(NS ns, int flg);
 FlErrorCode NSGetErrorIfStepFailed(NS ns, int *flg);
 /* NSConvergedReason (flucans.h:13-18): 0 ITERATING, 1 CONVERGED_TIME, 2 CONVERGED_ITS, -1 DIVERGED_NONLINEAR_SOLVE */
