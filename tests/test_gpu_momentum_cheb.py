@@ -101,3 +101,25 @@ def test_chebyshev_refuses_what_it_cannot_bound():
         M.solve(b, type=fo.KSP_CHEBYSHEV, pc=fo.PC_JACOBI, norm_type=fo.NORM_NATURAL)
     M.close()
     P.close()
+
+
+def test_an_interval_that_is_too_short_ends_in_dtol_and_the_handle_recovers():
+    """emax below the spectrum: the iteration grows until KSPConvergedDefault's divergence test stops it (dtol 1e5), as the oracle's restatement does;
+    the next solve on the same handle is not affected by what the diverged one left in the work vectors."""
+    P, M, g = _pair((24, 20, 12), CAVITY, False)
+    V0, v0, dt, rho, mu = _state(g, 0.4)
+    W = g.apply_B(v0)
+    A = g.assemble_momentum(1.0, dt, -0.5 * mu * dt / rho, V0, W)
+    M.set_state(dt, rho, mu, [dev(a) for a in V0], M.interp_faces(dev(v0)), v0=dev(v0))
+    b = np.random.default_rng(2).standard_normal(3 * g.ncell)
+    lam = A.gershgorin(fo.PC_JACOBI)
+    xo, io = A.solve(b, ksp=fo.KSP_CHEBYSHEV, pc=fo.PC_JACOBI, nullspace=False, rtol=1e-8, maxit=400, emin=0.05, emax=0.45 * lam)
+    xg, ig = M.solve(dev(b), type=fo.KSP_CHEBYSHEV, pc=fo.PC_JACOBI, rtol=1e-8, maxit=400, emin=0.05, emax=0.45 * lam, check_every=1, history=True)
+    assert io["reason"] == -4 and ig["reason"] == -4, (io["reason"], ig["reason"])          # KSP_DIVERGED_DTOL
+    assert abs(ig["iters"] - io["iters"]) <= 1, (ig["iters"], io["iters"])
+    x2, i2 = M.solve(dev(b), type=fo.KSP_CHEBYSHEV, pc=fo.PC_JACOBI, rtol=1e-8, maxit=400)
+    xr, ir = A.solve(b, ksp=fo.KSP_CHEBYSHEV, pc=fo.PC_JACOBI, nullspace=False, rtol=1e-8, maxit=400, emin=M.chebyshev_interval()[0], emax=M.chebyshev_interval()[1])
+    assert i2["reason"] == ir["reason"] == 2 and i2["iters"] == ir["iters"]
+    assert np.linalg.norm(host(x2) - xr) <= 1e-9 * np.linalg.norm(xr)
+    M.close()
+    P.close()
