@@ -213,6 +213,17 @@ def pmc_traffic(kernel):
     return d.get("hbm_bytes_per_launch"), provenance.stale(kernel, d.get("sources_at_profiling"))
 
 
+def workload_traffic(workload):
+    """{kernel: (HBM bytes per launch, stale)} of the CG pair on another grid size than the headline's, from the launches of that size inside the last
+    committed counter passes of the bench command (profiles/pmc_workload_<workload>.json); None where no such record exists."""
+    from fluca_amd import provenance
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", f"pmc_workload_{workload}.json")))
+    except Exception:  # noqa: BLE001
+        return None
+    return {k: (d[k], provenance.stale(k, d.get("sources_at_profiling", {}).get(k))) for k in ("k_cg_A", "k_cg_Bq") if k in d}
+
+
 def _oracle_threads():
     from oracle import fluca_oracle as fo
     # a one-GPU box's CPU share is 16 cores; never spawn more OpenMP threads than that (or than the affinity mask)
@@ -355,7 +366,7 @@ def other_configs(stream, parity=True):
     (_, info), dt = timed(lambda: P.solve(b, x=x, maxit=K, profile=4, **kw))
     cfg["C2"] = {"workload": "256^3 lid-driven cavity, matrix-free Jacobi-PCG, fixed 400 iterations", "metric": "PCG iterations/s", "value": K / dt, "steps": K,
                  "ms_per_step": dt / K * 1e3, "iteration_algorithmic_GBps": B_ITER_ALGO * P.ncell * K / dt / 1e9,
-                 "roofline": cg_roofline(info, P.ncell, 0, dt / K * 1e3)}
+                 "roofline": cg_roofline(info, P.ncell, 0, dt / K * 1e3, workload_traffic("c2_256"))}
     P.close()
     del b, x
 
@@ -560,7 +571,7 @@ def other_configs(stream, parity=True):
                     f"Jacobi-PCG fixed {K} iterations; immersed cylinder D = 64 h along the span, {Lc} markers",
         "metric": "PCG iterations/s on the block", "value": K / dt, "steps": K, "ms_per_step": dt / K * 1e3,
         "ibm_interp_plus_spread_ms": dti / 20 * 1e3, "markers": Lc,
-        "roofline": cg_roofline(info, P.ncell, 0, dt / K * 1e3)}
+        "roofline": cg_roofline(info, P.ncell, 0, dt / K * 1e3, workload_traffic("c5_block"))}
     capi.lib.fl_ibm_destroy(mc)
     P.close()
     del b, x

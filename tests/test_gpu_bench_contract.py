@@ -95,3 +95,8 @@ def test_quoted_counter_passes_are_of_the_kernels_in_the_tree():
         traffic, stale = bench.pmc_traffic(kernel)
         assert traffic and traffic > 0, kernel
         assert stale is False, f"profiles/pmc_{kernel}.json was taken from other sources than the tree's: re-run the counter pass"
+    for workload in ("c2_256", "c5_block"):     # the same pair on the grids of config 2 and of the config-5 rehearsal
+        rec = bench.workload_traffic(workload)
+        assert rec and set(rec) == {"k_cg_A", "k_cg_Bq"}, workload
+        for kernel, (traffic, stale) in rec.items():
+            assert traffic > 0 and stale is False, (workload, kernel)

@@ -70,4 +70,28 @@ for k, name in (("fl::k_cg_A<2, 8, true, 1, 2, false>", "pmc_k_cg_A.json"), ("fl
                   "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `python3 bench.py --steps 8 --warmup 2 --skip-cpu --skip-extras` "
                             f"(tools/experiments/r0N_profile.sh, summarised by tools/experiments/pmc_summary.py, {tag}); FETCH_SIZE in KB doubled per MI355X_MICROARCH.md"})
         json.dump(o, open(os.path.join(ROOT, "profiles", name), "w"), indent=1)
+# the other sizes the same passes saw (bench.py's configs run behind the headline): 256^3 (config 2) and the 512 x 512 x 256 block of the config-5
+# rehearsal -- counter values near 1/8 and 1/2 of the 512^3 ones.  One record per workload: HBM bytes per launch of k_cg_A and of k_cg_Bq (mean of
+# the even- and odd-iteration instantiations), stamped like the others.
+for wl, lo, hi, cells in (("c2_256", 0.09, 0.16, 256 ** 3), ("c5_block", 0.45, 0.55, 512 * 512 * 256)):
+    rec = {}
+    for k in sorted(f):
+        if not ("k_cg_A<2, 8" in k or "k_cg_Bq<2, 8, true, 2, 0>" in k or "k_cg_Bq<2, 8, true, 2, 2>" in k):
+            continue
+        mf, mw = max(f[k]), max(w.get(k, [0.0]))
+        fv, wv = [v for v in f[k] if lo * mf <= v <= hi * mf], [v for v in w.get(k, []) if lo * mw <= v <= hi * mw]
+        if fv and wv:
+            rec[k] = {"launches_counted": len(fv), "fetch_GB": round(statistics.median(fv) * 2 * 1024 / 1e9, 4), "write_GB": round(statistics.median(wv) * 1024 / 1e9, 4),
+                      "hbm_bytes_per_launch": statistics.median(fv) * 2 * 1024 + statistics.median(wv) * 1024}
+            rec[k]["B_per_cell"] = round(rec[k]["hbm_bytes_per_launch"] / cells, 2)
+    a = [v for k, v in rec.items() if "k_cg_A" in k]
+    b = [v for k, v in rec.items() if "k_cg_Bq" in k]
+    if len(a) == 1 and len(b) == 2:
+        o = {"workload": wl, "cells": cells, "k_cg_A": a[0]["hbm_bytes_per_launch"], "k_cg_Bq": (b[0]["hbm_bytes_per_launch"] + b[1]["hbm_bytes_per_launch"]) / 2,
+             "B_per_cell_per_iteration": round((a[0]["hbm_bytes_per_launch"] + (b[0]["hbm_bytes_per_launch"] + b[1]["hbm_bytes_per_launch"]) / 2) / cells, 2),
+             "kernels": rec, "sources_at_profiling": {"k_cg_A": provenance.source_hashes("k_cg_A"), "k_cg_Bq": provenance.source_hashes("k_cg_Bq")},
+             "source": f"the launches of this size inside the FETCH_SIZE / WRITE_SIZE passes of the bench command (tools/experiments/pmc_summary.py, {tag})"}
+        json.dump(o, open(os.path.join(ROOT, "profiles", f"pmc_workload_{wl}.json"), "w"), indent=1)
+        out["workload " + wl] = {kk: o[kk] for kk in ("k_cg_A", "k_cg_Bq", "B_per_cell_per_iteration")}
+json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
