@@ -55,7 +55,7 @@ def build_host(force=False, verbose=False):
     hdrs = [os.path.normpath(os.path.join(HERE, "..", "include", h)) for h in ("fluca_host.h", "fluca_host_impl.h", "fluca_hip.h")]
     if force or _stale(HOST_LIB, [src, LIB] + hdrs):
         cmd = [os.environ.get("CC", "gcc"), "-std=gnu99", "-O2", "-fPIC", "-shared", "-Wall", "-o", HOST_LIB, src,
-               "-L" + LIBDIR, "-lflucahip", "-Wl,-rpath,$ORIGIN", "-lm", "-ldl"]
+               "-L" + LIBDIR, "-lflucahip", "-Wl,-rpath,$ORIGIN", "-lm", "-ldl", "-pthread"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

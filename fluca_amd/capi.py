@@ -88,6 +88,7 @@ PROTOTYPES = {
     "fl_poisson_synchronize": (C.c_int, [_P]),
     "fl_poisson_barrier": (C.c_int, [_P]),
     "fl_poisson_sizes": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "fl_poisson_allreduce_sum": (C.c_int, [_P, C.POINTER(C.c_double), C.c_int]),
     "fl_ksp_opts_default": (None, [C.POINTER(fl_ksp_opts)]),
     "fl_version": (C.c_char_p, []),
     "fl_abi_version": (C.c_int, []),

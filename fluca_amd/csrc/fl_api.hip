@@ -312,6 +312,22 @@ int fl_allreduce_sum(fl_poisson *h, double *v)
   return 0;
 }
 
+extern "C" int fl_poisson_allreduce_sum(fl_poisson *h, double *host_vals, int n)
+{
+  if (!h || !host_vals) return FL_ERR_ARG_NULL;
+  if (n < 0 || n > NSLOT) return FL_ERR_ARG_OUTOFRANGE;
+  if (!h->multi || n == 0) return FL_SUCCESS;
+  FL_HIP(hipSetDevice(h->device));
+  double host[NSLOT] = {0., 0., 0., 0., 0., 0., 0., 0.};
+  std::memcpy(host, host_vals, sizeof(double) * (size_t)n);
+  FL_HIP(hipMemcpyAsync(h->sums, host, sizeof(double) * NSLOT, hipMemcpyHostToDevice, h->stream));
+  FL_CHK(h->comm.allreduce(h->stream, h->sums, NSLOT));
+  FL_HIP(hipMemcpyAsync(host, h->sums, sizeof(double) * NSLOT, hipMemcpyDeviceToHost, h->stream));
+  FL_HIP(hipStreamSynchronize(h->stream));
+  std::memcpy(host_vals, host, sizeof(double) * (size_t)n);
+  return FL_SUCCESS;
+}
+
 extern "C" int fl_poisson_sizes(const fl_poisson *h, int64_t out[4])
 {
   if (!h || !out) return FL_ERR_ARG_NULL;
@@ -1505,6 +1521,7 @@ extern "C" int fl_poisson_comm_init_rccl(fl_poisson *h, const void *id128, int r
   h->comm.destroy();
   FL_NCCL(g_rccl.CommInitRank(&h->comm.nccl, nranks, id, rank));
   h->comm.kind   = Comm::RCCL;
+  h->cheb2_agreed[0] = h->cheb2_agreed[1] = -1;  // a new communicator: the ranks vote again (fl_cheb2_agree)
   h->comm.rank   = rank;
   h->comm.nranks = nranks;
   return FL_SUCCESS;
@@ -1518,6 +1535,7 @@ extern "C" int fl_poisson_comm_init_host(fl_poisson *h, fl_exchange_fn xchg, fl_
   if (nranks != h->dec.ranks[0] * h->dec.ranks[1] * h->dec.ranks[2] || rank < 0 || rank >= nranks) return FL_ERR_ARG_WRONG;
   h->comm.destroy();
   h->comm.kind   = Comm::HOST;
+  h->cheb2_agreed[0] = h->cheb2_agreed[1] = -1;  // a new communicator: the ranks vote again (fl_cheb2_agree)
   h->comm.xchg   = xchg;
   h->comm.allred = allred;
   h->comm.ctx    = ctx;

@@ -473,6 +473,24 @@ bool fl_cheb2_usable(const fl_poisson *h)
   return true;
 }
 
+// Several ranks: every rank must take the same branch -- the fused path exchanges TWO layers of x per pair of steps under its own tags, the
+// one-step path one layer per step, and fl_fill_ghosts_deep takes for granted that the NEIGHBOUR owns two layers too.  "Legal" and "large
+// enough" are per-block quantities (an uneven split can straddle the threshold: 64 x 32 x 31 over two z ranks is 32768 against 30720 cells), so
+// the ranks vote once per handle (and per multigrid level, whose handles borrow the communicator): fused only where nobody objects.
+int fl_cheb2_agree(fl_poisson *h)
+{
+  if (h->cheb2_agreed[0] >= 0) return 0;
+  const bool legal = fl_cheb2_usable(h);
+  double     no[2] = {legal ? 0. : 1., (legal && h->ncell >= 32768) ? 0. : 1.};  // objections, summed over the ranks
+  if (h->multi) {
+    FL_CHK(fl_allreduce_sum(h, &no[0]));
+    FL_CHK(fl_allreduce_sum(h, &no[1]));
+  }
+  h->cheb2_agreed[0] = no[0] == 0. ? 1 : 0;
+  h->cheb2_agreed[1] = no[1] == 0. ? 1 : 0;
+  return 0;
+}
+
 Cheb2Plan fl_cheb2_plan(const GridP &g)
 {
   Cheb2Plan p;

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <ctime>
 #include <limits>
+#include <mutex>
 #include <string>
 
 #include "fl_internal.h"
@@ -90,24 +91,27 @@ struct Rccl {
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   decltype(&ncclCommCount)      CommCount      = nullptr;
   decltype(&ncclCommUserRank)   CommUserRank   = nullptr;
-  int load()
+  std::mutex mu;  // handles of several host threads may reach their first RCCL call together
+  int        load()
   {
+    std::lock_guard<std::mutex> lock(mu);
     if (lib) return 0;
     // the soname: inside a process that already loaded torch this resolves to the very RCCL torch.distributed uses
-    lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!lib) {
+    void *l = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!l) l = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!l) {
       std::fprintf(stderr, "[flucahip] cannot dlopen librccl: %s\n", dlerror());
       return FL_ERR_LIB;
     }
 #define FL_SYM(n)                                                \
-  n = (decltype(n))dlsym(lib, "nccl" #n);                        \
+  n = (decltype(n))dlsym(l, "nccl" #n);                          \
   if (!n) {                                                      \
     std::fprintf(stderr, "[flucahip] librccl lacks nccl" #n "\n"); \
     return FL_ERR_LIB;                                           \
   }
     FL_SYM(GetUniqueId) FL_SYM(CommInitRank) FL_SYM(CommDestroy) FL_SYM(Send) FL_SYM(Recv) FL_SYM(AllReduce) FL_SYM(GroupStart) FL_SYM(GroupEnd) FL_SYM(GetErrorString) FL_SYM(CommCount) FL_SYM(CommUserRank)
 #undef FL_SYM
+    lib = l;  // last: a reader that sees lib != nullptr sees every symbol
     return 0;
   }
 };
@@ -275,6 +279,9 @@ struct fl_poisson {
   size_t      padlen = 0;
   int         nv_il = 1, sx0 = 0;  // row-interleave factor of the padded vectors and the un-interleaved row length
   int         gw = 1;              // ghost layers of the padded layout around the owned block (2 on several ranks: fl_fill_ghosts_deep)
+  // fused two-step Chebyshev (fl_cheb2.hip) on several ranks: the ranks' AGREED answers to "legal on my block" [0] and "legal and large
+  // enough to pay" [1], -1 = not asked yet (one all-reduce per handle / multigrid level: fl_cheb2_agree)
+  int         cheb2_agreed[2] = {-1, -1};
   // solver workspace (padded vectors)
   double *r = nullptr, *P0 = nullptr, *P1 = nullptr, *q = nullptr, *xp = nullptr, *w0 = nullptr, *w1 = nullptr, *w2 = nullptr;
   double *cd1 = nullptr;  // second d buffer of the fused two-step Chebyshev kernel (fl_cheb2.hip)
@@ -403,6 +410,7 @@ struct Cheb2Plan {
   int nw, tiles_x, tiles, nchunk, zc, nblocks;
 };
 bool      fl_cheb2_usable(const fl_poisson *h);
+int       fl_cheb2_agree(fl_poisson *h);  // collective on several ranks; fills h->cheb2_agreed
 Cheb2Plan fl_cheb2_plan(const GridP &g);
 void      fl_launch_cheb2(fl_poisson *h, const Cheb2Plan &p, bool jac, double *X0, double *X1, const double *B, double *D0, double *D1, bool mgdots = false);
 // fl_mg.hip

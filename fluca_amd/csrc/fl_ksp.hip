@@ -1055,11 +1055,14 @@ int &cheb_fuse_mode()
   }();
   return m;
 }
-bool cheb_fuse(const fl_poisson *h)
+// -> 1 fused, 0 one step per launch, < 0 error.  Collective on several ranks the first time a handle asks (fl_cheb2_agree): call it where every
+// rank passes, before any test that could differ between ranks.
+int cheb_fuse(fl_poisson *h)
 {
+  FL_CHK(fl_cheb2_agree(h));
   const int m = cheb_fuse_mode();
-  if (m <= 0 || !fl_cheb2_usable(h)) return false;
-  return m >= 2 || h->ncell >= 32768;
+  if (m <= 0) return 0;
+  return h->cheb2_agreed[m >= 2 ? 0 : 1];
 }
 
 // the scalar block handed over BY VALUE (kernel argument): nothing reads the host copy after the launch returns, so the next
@@ -1312,7 +1315,9 @@ int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero, bool
   S.cheb_rho  = 0.;
   S.cheb_c    = S.scale;
   hipLaunchKernelGGL(k_scal_set, dim3(1), dim3(1), 0, s, h->scal, S);
-  const bool fuse = cheb_fuse(h) && nu - (guess_zero ? 1 : 0) >= 2;
+  const int fuse_ok = cheb_fuse(h);
+  if (fuse_ok < 0) return fuse_ok;
+  const bool fuse = fuse_ok && nu - (guess_zero ? 1 : 0) >= 2;
   Cheb2Plan  cp{};
   if (fuse) {
     cp = fl_cheb2_plan(h->g);
@@ -1593,7 +1598,9 @@ int fl_solve_cheb(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *
   const int  every  = o->check_every > 0 ? o->check_every : 16;
   const int  total  = o->norm_type == FL_NORM_NONE ? o->maxit : o->maxit + 1;  // with a norm, launch maxit is only the final check
   // without a convergence test between the steps two of them share one sweep over memory (fl_cheb2.hip)
-  const bool fuse = o->norm_type == FL_NORM_NONE && total >= 2 && cheb_fuse(h);
+  const int fuse_ok = cheb_fuse(h);
+  if (fuse_ok < 0) return fuse_ok;
+  const bool fuse = o->norm_type == FL_NORM_NONE && total >= 2 && fuse_ok;
   Cheb2Plan  cp{};
   if (fuse) {
     cp = fl_cheb2_plan(g);

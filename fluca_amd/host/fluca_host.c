@@ -6,6 +6,7 @@
 #include "../../include/fluca_host_impl.h"
 
 #include <math.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -59,16 +60,18 @@ typedef struct {
   void *create;
 } TypeEntry;
 static TypeEntry MeshList[MAXTYPES], NSList[MAXTYPES];
-static int       nMeshTypes = 0, nNSTypes = 0, registered = 0;
+static int       nMeshTypes = 0, nNSTypes = 0;
+/* the type lists are the only process-wide state of this library: objects of several host threads (one rank each, tests/test_gpu_config5.py)
+ * may reach MeshCreate / NSCreate together, so the built-in types are registered exactly once and the lists are appended to under a lock */
+static pthread_once_t  register_once = PTHREAD_ONCE_INIT;
+static pthread_mutex_t register_lock = PTHREAD_MUTEX_INITIALIZER;
 
-
-static void RegisterAll(void)
+static void RegisterBuiltins(void)
 {
-  if (registered) return;
-  registered = 1;
   MeshRegister(MESHCART, MeshCreate_Cart); /* meshreg.c */
   NSRegister(NSCNLINEAR, NSCreate_CNLinear); /* nsreg.c:17 */
 }
+static void RegisterAll(void) { pthread_once(&register_once, RegisterBuiltins); }
 
 static const char *opt_find(int argc, char **argv, const char *name)
 {
@@ -200,9 +203,15 @@ static int viewer_is(FlucaViewer v, const char *type) { return v && v->type && !
 
 FlErrorCode MeshRegister(const char name[], FlErrorCode (*create)(Mesh))
 {
-  if (nMeshTypes >= MAXTYPES) return E_MEM;
+  pthread_mutex_lock(&register_lock);
+  if (nMeshTypes >= MAXTYPES) {
+    pthread_mutex_unlock(&register_lock);
+    return E_MEM;
+  }
   snprintf(MeshList[nMeshTypes].name, sizeof(MeshList[0].name), "%s", name);
-  MeshList[nMeshTypes++].create = (void *)create;
+  MeshList[nMeshTypes].create = (void *)create;
+  __atomic_store_n(&nMeshTypes, nMeshTypes + 1, __ATOMIC_RELEASE); /* readers (SetType) walk the list without the lock: the entry is complete before it counts */
+  pthread_mutex_unlock(&register_lock);
   return 0;
 }
 
@@ -221,7 +230,7 @@ FlErrorCode MeshCreate(Mesh *mesh)
 FlErrorCode MeshSetType(Mesh mesh, MeshType type)
 {
   if (!mesh || !type) return E_ARG_NULL;
-  for (int i = 0; i < nMeshTypes; ++i)
+  for (int i = 0, nt = __atomic_load_n(&nMeshTypes, __ATOMIC_ACQUIRE); i < nt; ++i)
     if (!strcmp(MeshList[i].name, type)) {
       if (mesh->ops->destroy) FLCHK(mesh->ops->destroy(mesh));
       memset(mesh->ops, 0, sizeof(mesh->ops));
@@ -689,9 +698,15 @@ FlErrorCode MeshDestroy(Mesh *mesh)
 
 FlErrorCode NSRegister(const char name[], FlErrorCode (*create)(NS))
 {
-  if (nNSTypes >= MAXTYPES) return E_MEM;
+  pthread_mutex_lock(&register_lock);
+  if (nNSTypes >= MAXTYPES) {
+    pthread_mutex_unlock(&register_lock);
+    return E_MEM;
+  }
   snprintf(NSList[nNSTypes].name, sizeof(NSList[0].name), "%s", name);
-  NSList[nNSTypes++].create = (void *)create;
+  NSList[nNSTypes].create = (void *)create;
+  __atomic_store_n(&nNSTypes, nNSTypes + 1, __ATOMIC_RELEASE); /* readers (SetType) walk the list without the lock: the entry is complete before it counts */
+  pthread_mutex_unlock(&register_lock);
   return 0;
 }
 
@@ -725,7 +740,7 @@ FlErrorCode NSCreate(NS *ns)
 FlErrorCode NSSetType(NS ns, NSType type)
 {
   if (!ns || !type) return E_ARG_NULL;
-  for (int i = 0; i < nNSTypes; ++i)
+  for (int i = 0, nt = __atomic_load_n(&nNSTypes, __ATOMIC_ACQUIRE); i < nt; ++i)
     if (!strcmp(NSList[i].name, type)) {
       if (ns->ops->destroy) FLCHK(ns->ops->destroy(ns));
       memset(ns->ops, 0, sizeof(ns->ops));
@@ -1917,6 +1932,18 @@ static FlErrorCode NSFormFunction_CNLinear(NS ns, const NSVec *x, NSVec *f)
         FLABI(fl_boundary_add_cells(h, b, kappa * cg, c->plane_dev, w + ax * N));     /* kappa (vbcGq - vbcGp), :3031-3032 */
         FLABI(fl_boundary_add_faces(h, b, kappa * cgst, c->plane_dev, f->V[ax]));     /* + kappa (vbcGstq - vbcGstp), :3034-3035 */
       }
+    }
+    /* MatMultAdd(negT, ...) is collective (ghost exchange of w): the ranks that do not touch an outlet, or whose part of it is steady, must take
+     * the same branch as the one that found a difference -- one flag summed over the ranks, only where the problem has an outlet at all (the
+     * boundary TYPES are known to every rank).  Found by the 2 x 2 x 2 run of tests/test_gpu_config5.py: rounds 1-4 never had an outlet on a
+     * split axis. */
+    int any_outlet = 0;
+    for (int b = 0; b < 6; ++b) any_outlet |= ns->bcs[b].type == NS_BC_PRESSURE_OUTLET;
+    if (any_outlet && ns->mesh->size > 1) {
+      double flag = (double)rhiechow;
+      FLABI(fl_poisson_allreduce_sum(h, &flag, 1));
+      if (flag > 0. && !rhiechow) FLABI(fl_vec_lincomb(h, 3 * N, 0., w, 0., NULL, w)); /* this rank's share of w is zero */
+      rhiechow = flag > 0.;
     }
     if (rhiechow) {
       /* interprhs += (-T) w, :3033 */

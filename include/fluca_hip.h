@@ -147,6 +147,9 @@ int fl_poisson_set_stream(fl_poisson *h, void *hip_stream);
 int fl_poisson_synchronize(fl_poisson *h);
 /* every rank of the handle's communicator has reached this call when it returns (MPI_Barrier on the object's comm) */
 int fl_poisson_barrier(fl_poisson *h);
+/* in-place sum of n <= 8 HOST doubles over the ranks of the handle's communicator (MPIU_Allreduce(..., MPI_SUM, comm) of a few scalars; a
+ * flag "does any rank ..." is a sum of 0 / 1).  Blocking; a no-op on one rank.  Every rank must call it. */
+int fl_poisson_allreduce_sum(fl_poisson *h, double *host_vals, int n);
 /* sizes of this rank's arrays: out[0]=cells, out[1..3]=x,y,z faces */
 int fl_poisson_sizes(const fl_poisson *h, int64_t out[4]);
 void fl_ksp_opts_default(fl_ksp_opts *o); /* PETSc defaults + cg/jacobi/preconditioned norm */

@@ -97,8 +97,28 @@ def lib():
         L.fo_apply_B.argtypes = [C.c_void_p, _dp, C.c_void_p]
         L.fo_ibm_phi.restype = C.c_double
         L.fo_ibm_phi.argtypes = [C.c_int, C.c_double]
+        # OpenMP sizes its team from the machine, not from this process's share of it: on a GPU box (hundreds of hardware threads, a CPU share
+        # of 16) a 360-iteration solve then spends minutes in oversubscribed barriers.  Unless the caller chose (OMP_NUM_THREADS), never more
+        # threads than the affinity mask, the cgroup quota or 16.
+        if not os.environ.get("OMP_NUM_THREADS"):
+            L.fo_set_num_threads(max(1, min(_cpu_share(), L.fo_num_threads())))
         _LIB = L
     return _LIB
+
+
+def _cpu_share():
+    n = 16
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:  # pragma: no cover
+        n = min(n, os.cpu_count() or 1)
+    try:   # cgroup v2 quota: "max 100000" or "<quota> <period>"
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 class Row1d(C.Structure):

@@ -1,0 +1,577 @@
+"""-m gpu: BASELINE config 5's rank grid -- 2 x 2 x 2, boundary types [VELOCITY inlet, PRESSURE_OUTLET, wall, wall, PERIODIC, PERIODIC],
+a cylinder of markers along the periodic span -- on the GPU path, against the single-domain CPU oracle.
+
+The reference's decomposition is DMStag's (fluca/src/mesh/impl/cart/cart.c:88-104; first / last-rank flags :548-562): here every rank has
+a face neighbour on each of the three axes, the z axis is periodic ACROSS ranks, the outlet removes the null space, and the two-deep
+exchange of the fused smoother (fl_fill_ghosts_deep) carries its shell's edge cells over three split axes.  One GPU box cannot hold eight
+processes (six at most on the card), so the eight ranks are eight host threads with one fl_poisson handle each (what include/fluca_hip.h
+promises), wired through fl_poisson_comm_init_host with the in-memory transport of tests/plugins/inproc_comm.c.  Everything behind the
+wire -- decomposition, pack / unpack kernels, ghost-aware stencil kernels, partial sums + all-reduce, device-side convergence logic -- is the
+production path; only ncclSend / ncclRecv / ncclAllReduce are replaced."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import inproc
+
+pytestmark = pytest.mark.gpu
+
+V, O, PER, SYM = 1, 2, 3, 4
+C5_BC = [V, O, V, V, PER, PER]
+
+
+def _stretched(n, lo, hi, beta):
+    s = np.linspace(0.0, 1.0, n + 1)
+    return lo + (hi - lo) * (np.tanh(beta * (2 * s - 1)) / np.tanh(beta) + 1) / 2
+
+
+def _coords(n, box, stretch_y):
+    xf = [np.linspace(box[d][0], box[d][1], n[d] + 1) for d in range(3)]
+    if stretch_y:
+        xf[1] = _stretched(n[1], box[1][0], box[1][1], 1.2)     # wall-normal clustering, as a channel grid has
+    return xf
+
+
+def _cylinder(box, h, radius_cells=5.0):
+    """markers on a cylinder along z (the periodic span), centred where the four x-y rank blocks meet: its supports straddle both split planes,
+    the rank boundary in z and the periodic seam"""
+    cx, cy = 0.5 * (box[0][0] + box[0][1]), 0.5 * (box[1][0] + box[1][1])
+    R = radius_cells * h
+    nth = max(8, int(round(2 * np.pi * R / h)))
+    th = (np.arange(nth) + 0.5) * 2 * np.pi / nth
+    nzs = int(round((box[2][1] - box[2][0]) / h))
+    zs = box[2][0] + (np.arange(nzs) + 0.25) * h
+    X = np.concatenate([cx + R * np.cos(th) for _ in zs])
+    Y = np.concatenate([cy + R * np.sin(th) for _ in zs])
+    Z = np.repeat(zs, nth)
+    return [X, Y, Z]
+
+
+class Case:
+    def __init__(self, n, ranks, bc, box, stretch_y=False, kappa=1e-3, own=None):
+        """own: ownership ranges per axis (MeshCartSetOwnershipRanges, cart.c:399-418), None = DMStag's default split"""
+        from oracle import fluca_oracle as fo
+        self.n, self.ranks, self.bc, self.box, self.kappa, self.own = n, ranks, bc, box, kappa, own
+        assert own is None or all(sum(own[d]) == n[d] and len(own[d]) == ranks[d] for d in range(3))
+        self.xf = _coords(n, box, stretch_y)
+        self.g = fo.Grid(n, self.xf, bc, kappa)
+        self.S = self.g.assemble_S()
+        self.nullspace = O not in bc
+        self.periodic = [bc[0] == PER, bc[2] == PER, bc[4] == PER]
+        self.shp = (n[2], n[1], n[0])
+        g = self.g
+        self.fshape = [(n[2], n[1], g.nf[0]), (n[2], g.nf[1], n[0]), (g.nf[2], n[1], n[0])]
+
+
+def _handle(R, case):
+    """this rank's fl_poisson on its own stream, attached to the in-process wire"""
+    import torch
+    from fluca_amd import capi
+    from fluca_amd.poisson import Poisson
+    from tests import mp_common as mpc
+    d = mpc.decomp_of(capi, case.n, case.ranks, R.rank)
+    if case.own is not None:      # user-set ownership: the rank grid and coordinates stay DMStag's (x fastest), the ranges are the caller's
+        for a in range(3):
+            d.len[a] = case.own[a][d.coord[a]]
+            d.lo[a] = sum(case.own[a][:d.coord[a]])
+    P = Poisson(case.n, case.xf, case.bc, case.kappa, decomp=d)
+    s = torch.cuda.Stream()
+    P.set_stream(s)
+    R.attach(P.h)
+    return P, d, s
+
+
+def _blk(case, d, a):
+    from tests import mp_common as mpc
+    return np.ascontiguousarray(a.reshape(case.shp)[mpc.block(d)]).ravel()
+
+
+def _fblk(case, d, a, ax):
+    from tests import mp_common as mpc
+    return np.ascontiguousarray(a.reshape(case.fshape[ax])[mpc.face_block(d, ax, case.periodic)]).ravel()
+
+
+def _rel_global(R, got, want_block, want_global_sq):
+    """|| got - want || / || want || over all ranks"""
+    v = np.array([((got - want_block) ** 2).sum()])
+    R.allreduce(v)
+    return float(np.sqrt(v[0] / want_global_sq))
+
+
+# ------------------------------------------------------------------------------------------------ operator + Krylov solvers
+
+def _operator_worker(R, case, ref):
+    import torch
+    P, d, s = _handle(R, case)
+    with torch.cuda.stream(s):
+        dev = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64).ravel(), device="cuda")
+        info = P.comm_info()
+        # 2 x 2 x 2 with a periodic z: the x and y axes have ONE neighbouring rank each (the other side is a physical boundary), z has the same
+        # rank on both sides -- three distinct neighbours, four exchanged faces
+        assert info["transport"] == 2 and info["nranks"] == R.size and info["rank"] == R.rank
+        if tuple(case.ranks) == (2, 2, 2) and case.bc == C5_BC:
+            assert info["neighbours"] == 3 and info["messages"] == 4, info
+        # y = S x
+        y = P.apply(dev(_blk(case, d, ref["p"])))
+        s.synchronize()
+        want = _blk(case, d, ref["b"])
+        assert abs(y.cpu().numpy() - want).max() <= 1e-12 * abs(ref["b"]).max(), ("apply", R.rank)
+        # diagonal
+        dg = P.diagonal()
+        s.synchronize()
+        assert abs(dg.cpu().numpy() - _blk(case, d, ref["diag"])).max() <= 1e-13 * abs(ref["diag"]).max(), ("diag", R.rank)
+        # b = -D V, stage 2
+        Vl = [dev(_fblk(case, d, ref["V"][a], a)) for a in range(3)]
+        assert tuple(P.nface) == tuple(int(v.numel()) for v in Vl)
+        rb = P.rhs(*Vl)
+        s.synchronize()
+        want = _blk(case, d, ref["rhs"])
+        assert abs(rb.cpu().numpy() - want).max() <= 1e-12 * max(1.0, abs(ref["rhs"]).max()), ("rhs", R.rank)
+        vl = [dev(_blk(case, d, ref["v"][c])) for c in range(3)]
+        P.project(dev(_blk(case, d, ref["p"])), v=vl, V=Vl)
+        s.synchronize()
+        for a in range(3):
+            want = _fblk(case, d, ref["V"][a] - ref["Gst"][a], a)
+            assert abs(Vl[a].cpu().numpy() - want).max() <= 1e-12 * max(1.0, abs(want).max()), ("project V", R.rank, a)
+            want = _blk(case, d, ref["v"][a] - ref["G"][a])
+            assert abs(vl[a].cpu().numpy() - want).max() <= 1e-12 * max(1.0, abs(want).max()), ("project v", R.rank, a)
+        # KSPSolve to rtol 1e-10: CG, CG with -ksp_cg_single_reduction, BiCGStab -- histories and the solution
+        bd = dev(_blk(case, d, ref["b"]))
+        for name in ("cg", "cg_sr", "bcgs"):
+            xo, io = ref[name]
+            kw = dict(type=1 if name == "bcgs" else 0, cg_single_reduction=int(name == "cg_sr"))
+            before = R.stats()["allreduces"]
+            xg, ig = P.solve(bd, history=True, remove_nullspace=int(case.nullspace), rtol=ref["rtol"][name], maxit=4000, check_every=8, **kw)
+            s.synchronize()
+            made = R.stats()["allreduces"] - before
+            assert ig["reason"] == io["reason"], (name, ig["reason"], io["reason"])
+            assert abs(ig["iters"] - io["iters"]) <= (2 if name != "bcgs" else max(3, io["iters"] // 10)), (name, ig["iters"], io["iters"])
+            if name == "cg_sr" and io["reason"] == -10:
+                # On a stretched axis S = -kappa D Gst is symmetric only in the volume-weighted inner product (rows carry 1 / dx_i): KSPCG gets
+                # through, the single-reduction recurrence (which forms p.Sp from differences) reports KSP_DIVERGED_INDEFINITE_MAT -- on the
+                # oracle and on eight ranks at the same iteration.  Same behaviour is what is checked; there is no solution to compare.
+                assert not np.allclose(case.xf[1][1:] - case.xf[1][:-1], case.xf[1][1] - case.xf[1][0])
+                continue
+            assert ig["reason"] == 2
+            m = min(len(ig["history"]), len(io["history"]))
+            k = m if name != "bcgs" else min(m, 10)      # BiCGStab's history is not stable against reduction order beyond the first iterations
+            # residual history against the oracle: relative to the initial norm (late entries are 1e-10 of it and carry the reduction order)
+            assert np.abs(ig["history"][:k] - io["history"][:k]).max() <= 1e-8 * io["history"][0], (name, "history")
+            assert np.allclose(ig["history"][:min(k, 12)], io["history"][:min(k, 12)], rtol=1e-9), (name, "history head")
+            if name == "cg_sr":     # ONE all-reduce per iteration (+ iteration 0, + at most check_every - 1 enqueued behind the converged one)
+                assert ig["iters"] + 1 <= made <= ig["iters"] + 8, (made, ig["iters"])
+            xg = xg.cpu().numpy()
+            xref = xo
+            if case.nullspace:
+                sm = np.array([xg.sum(), float(xg.size)])
+                R.allreduce(sm)
+                xg = xg - sm[0] / sm[1]
+                xref = xo - xo.mean()
+            err = _rel_global(R, xg, _blk(case, d, xref), float((xref ** 2).sum()))
+            assert err <= 1e-6, (name, "solution", err)
+    P.close()
+    return True
+
+
+def _reference(case, seed=20260313):
+    from oracle import fluca_oracle as fo
+    g, S = case.g, case.S
+    rng = np.random.default_rng(seed)
+    p = rng.uniform(-1, 1, g.ncell)
+    if case.nullspace:
+        p -= p.mean()
+    ref = dict(p=p, b=S.mult(p), diag=S.diag())
+    ref["V"] = [rng.standard_normal(nf) for nf in g.nface]
+    ref["v"] = [rng.standard_normal(g.ncell) for _ in range(3)]
+    ref["rhs"] = g.rhs(*ref["V"])
+    ref["Gst"] = g.apply_gst(p)
+    ref["G"] = g.apply_G(p)
+    # two solves that each stop at rtol agree to about cond(S) * rtol: BiCGStab's last residuals are less regular than CG's, one decade more
+    ref["rtol"] = dict(cg=1e-10, cg_sr=1e-10, bcgs=1e-11)
+    kw = dict(nullspace=case.nullspace, maxit=4000)
+    ref["cg"] = S.solve(ref["b"], rtol=ref["rtol"]["cg"], **kw)
+    ref["cg_sr"] = S.solve(ref["b"], single_reduction=True, rtol=ref["rtol"]["cg_sr"], **kw)
+    ref["bcgs"] = S.solve(ref["b"], ksp=fo.KSP_BCGS, rtol=ref["rtol"]["bcgs"], **kw)
+    return ref
+
+
+CASES = {
+    # config 5 scaled down: 2 x 2 x 2, equal blocks of 32 x 24 x 16 (one 128-wide tile row per block, several z chunks)
+    "c5_even": dict(n=(64, 48, 32), ranks=(2, 2, 2), bc=C5_BC, box=[(0.0, 2.0), (0.0, 1.5), (0.0, 1.0)]),
+    # uneven ownership (DMStag gives the first N % m ranks one cell more: 21 + 20, 19 + 18, 15 + 14) on a wall-clustered y axis
+    "c5_uneven_stretched": dict(n=(41, 37, 29), ranks=(2, 2, 2), bc=C5_BC, box=[(0.0, 2.0), (0.0, 1.0), (0.0, 0.7)], stretch_y=True),
+    # user-set ownership ranges (uneven AND coarsenable: multigrid keeps the fine decomposition, so every range must stay even)
+    "c5_own_ranges": dict(n=(44, 36, 28), ranks=(2, 2, 2), bc=C5_BC, box=[(0.0, 2.2), (0.0, 1.0), (0.0, 0.7)], stretch_y=True,
+                          own=[(24, 20), (20, 16), (16, 12)]),
+    # all three axes periodic across ranks (pure null-space problem, every rank has six neighbours' worth of faces)
+    "periodic_222": dict(n=(32, 32, 32), ranks=(2, 2, 2), bc=[PER] * 6, box=[(0.0, 1.0)] * 3),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_operator_and_krylov_solvers_on_the_2x2x2_rank_grid(name):
+    case = Case(**CASES[name])
+    ref = _reference(case)
+    assert all(inproc.run_threads(8, _operator_worker, case, ref))
+
+
+# ------------------------------------------------------------------------------------------------ fused two-deep smoother, multigrid
+
+def _smoother_worker(R, case, ref, levels, fuse_modes):
+    import torch
+    from fluca_amd import capi
+    P, d, s = _handle(R, case)
+    out = {}
+    with torch.cuda.stream(s):
+        dev = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64).ravel(), device="cuda")
+        bd = dev(_blk(case, d, ref["b"]))
+        lam = ref["lam"]
+        for steps in (2, 7):
+            xo = ref["cheb"][steps]
+            res = {}
+            for mode in fuse_modes:
+                # process-wide knob, every rank thread sets the same value between two barriers: nobody is inside a solve while it changes
+                R.barrier()
+                capi.check(capi.lib.fl_tuning_set(b"cheb_fuse", mode))
+                R.barrier()
+                xg, ig = P.solve(bd, type=2, pc=1, norm_type=3, remove_nullspace=int(case.nullspace), maxit=steps, emin=0.1 * lam, emax=1.1 * lam, profile=1)
+                s.synchronize()
+                assert ig["iters"] == steps and ig["reason"] == 4
+                res[mode] = (xg.cpu().numpy(), ig["kernel_launches"])
+                err = _rel_global(R, res[mode][0], _blk(case, d, xo), float((xo ** 2).sum()))
+                assert err <= 1e-11, ("chebyshev sweep", steps, mode, err)
+            if 0 in res and 2 in res:
+                assert res[0][1] == steps and res[2][1] == steps // 2, ("which kernel ran", res[0][1], res[2][1])
+                pair = np.array([((res[2][0] - res[0][0]) ** 2).sum(), (res[0][0] ** 2).sum()])
+                R.allreduce(pair)
+                assert np.sqrt(pair[0] / pair[1]) <= 1e-13
+            out[steps] = {m: r[1] for m, r in res.items()}
+        # multigrid-preconditioned CG: iteration count and history against MgOracle, with the fused smoother wherever it is legal and without
+        xo, io = ref["mg"]
+        hist = {}
+        for mode in fuse_modes:
+            R.barrier()
+            capi.check(capi.lib.fl_tuning_set(b"cheb_fuse", mode))
+            R.barrier()
+            xg, ig = P.solve(bd, history=True, type=0, pc=2, remove_nullspace=int(case.nullspace), rtol=1e-10, maxit=60, mg_levels=levels)
+            s.synchronize()
+            assert ig["reason"] == io["reason"] == 2, (ig["reason"], io["reason"])
+            assert abs(ig["iters"] - io["iters"]) <= 1, (mode, ig["iters"], io["iters"])
+            m = min(len(ig["history"]), len(io["history"]))
+            assert np.allclose(ig["history"][:4], io["history"][:4], rtol=1e-7), (mode, ig["history"][:4], io["history"][:4])
+            assert np.allclose(ig["history"][:m], io["history"][:m], rtol=2e-2)
+            xg = xg.cpu().numpy()
+            xref = xo
+            if case.nullspace:
+                sm = np.array([xg.sum(), float(xg.size)])
+                R.allreduce(sm)
+                xg, xref = xg - sm[0] / sm[1], xo - xo.mean()
+            err = _rel_global(R, xg, _blk(case, d, xref), float((xref ** 2).sum()))
+            assert err <= 1e-6, ("multigrid solution", mode, err)
+            hist[mode] = (ig["iters"], np.asarray(ig["history"]))
+        if 0 in hist and 2 in hist:
+            assert hist[0][0] == hist[2][0] and np.allclose(hist[0][1], hist[2][1], rtol=1e-9)
+        R.barrier()
+        capi.check(capi.lib.fl_tuning_set(b"cheb_fuse", 1))
+        R.barrier()
+    P.close()
+    return out
+
+
+def _smoother_reference(case, levels, seed=78):
+    from fluca_amd import capi
+    from fluca_amd.poisson import Poisson
+    from oracle import fluca_oracle as fo
+    g, S = case.g, case.S
+    rng = np.random.default_rng(seed)
+    p = rng.standard_normal(g.ncell)
+    if case.nullspace:
+        p -= p.mean()
+    b = S.mult(p)
+    lam = S.gershgorin(fo.PC_JACOBI)
+    ref = dict(b=b, lam=lam, cheb={})
+    for steps in (2, 7):
+        ref["cheb"][steps], _ = S.solve(b, ksp=fo.KSP_CHEBYSHEV, pc=fo.PC_JACOBI, norm=fo.NORM_NONE, nullspace=case.nullspace, maxit=steps, emin=0.1 * lam, emax=1.1 * lam)
+    mg = fo.MgOracle(g, max_levels=levels, nullspace=case.nullspace)
+    assert mg.nlevels == levels
+    bounds = []
+    for gl in mg.grids:      # the product's eigenvalue bounds per level (host-only query on single-domain handles of the same grids)
+        Q = Poisson(gl.n, gl.xf, gl.bc, gl.kappa)
+        lb = C.c_double()
+        capi.check(capi.lib.fl_poisson_gershgorin(Q.h, capi.PC_JACOBI, C.byref(lb)))
+        bounds.append(lb.value)
+        Q.close()
+    ref["mg"] = fo.MgOracle(g, max_levels=levels, nullspace=case.nullspace, bounds=bounds, prolong="linear").pcg(b, rtol=1e-10, maxit=60)
+    return ref
+
+
+@pytest.mark.parametrize("name,levels", [("c5_even", 3), ("c5_own_ranges", 2), ("periodic_222", 3)])
+def test_fused_smoother_and_multigrid_on_the_2x2x2_rank_grid(name, levels):
+    """fl_fill_ghosts_deep across three split axes: fixed-length Chebyshev-Jacobi sweeps through the fused two-step kernel ("cheb_fuse" = 2) and
+    through the one-step kernel (0) against the oracle's KSPCHEBYSHEV, and multigrid-PCG (tri-linear prolongation: edge and corner ghosts from
+    the neighbours) against MgOracle."""
+    case = Case(**CASES[name])
+    ref = _smoother_reference(case, levels)
+    res = inproc.run_threads(8, _smoother_worker, case, ref, levels, (0, 2))
+    assert all(r == res[0] for r in res)          # every rank ran the same kernels
+
+
+def test_fuse_decision_is_collective_on_an_uneven_split():
+    """ADVICE (round 4): with the default "cheb_fuse" = 1 the fused kernel runs on blocks of >= 32768 cells -- a per-rank quantity.  64 x 32 x 31
+    over two z ranks gives 32768 against 30720 cells: the ranks must agree (all fused or none), or their message counts stop pairing up."""
+    case = Case(n=(64, 32, 31), ranks=(1, 1, 2), bc=[V, V, V, V, PER, PER], box=[(0.0, 2.0), (0.0, 1.0), (0.0, 1.0)])
+    ref = _smoother_reference(case, 2)
+    res = inproc.run_threads(2, _smoother_worker, case, ref, 2, (1,))
+    assert res[0] == res[1], res          # the same number of launches on both ranks: one decision
+    assert res[0][2][1] == 2 and res[0][7][1] == 7, res   # ... and it is "not fused": one rank is below the threshold
+
+
+# ------------------------------------------------------------------------------------------------ IBM: the cylinder along the span
+
+def _ibm_worker(R, case, ref, kind):
+    import torch
+    from fluca_amd import capi
+    P, d, s = _handle(R, case)
+    with torch.cuda.stream(s):
+        dev = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64).ravel(), device="cuda")
+        X, L = ref["X"], ref["X"][0].size
+        Xd = [dev(a) for a in X]
+        m = C.c_void_p()
+        capi.check(capi.lib.fl_ibm_create(P.h, kind, L, *[C.c_void_p(t.data_ptr()) for t in Xd], C.byref(m)))
+        ul = dev(np.stack([_blk(case, d, ref["u"][c]) for c in range(3)]))
+        U = torch.empty(3 * L, dtype=torch.float64, device="cuda")
+        capi.check(capi.lib.fl_ibm_interp(m, 3, C.c_void_p(ul.data_ptr()), C.c_void_p(U.data_ptr())))
+        s.synchronize()
+        assert np.allclose(U.cpu().numpy().reshape(3, L), ref["U"], rtol=1e-12, atol=1e-13), ("interp", R.rank)
+        fl = dev(np.stack([_blk(case, d, ref["f0"][c]) for c in range(3)]))
+        Fd, dVd = dev(ref["F"]), dev(ref["dV"])
+        capi.check(capi.lib.fl_ibm_spread(m, 3, C.c_void_p(Fd.data_ptr()), C.c_void_p(dVd.data_ptr()), C.c_void_p(fl.data_ptr())))
+        s.synchronize()
+        want = np.stack([_blk(case, d, ref["f"][c]) for c in range(3)])
+        got = fl.cpu().numpy().reshape(3, -1)
+        assert np.allclose(got, want, rtol=1e-12, atol=1e-12 * abs(ref["f"]).max()), ("spread", R.rank)
+        # conservation over the ranks: sum_x f dV_cell = sum_l F dV_l (uniform grid: the cell volume is a constant)
+        tot = np.array([(got[c] - np.stack([_blk(case, d, ref["f0"][c]) for c in range(3)])[c]).sum() for c in range(3)])
+        R.allreduce(tot)
+        capi.lib.fl_ibm_destroy(m)
+    P.close()
+    return tot
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_cylinder_markers_along_the_span_on_the_2x2x2_rank_grid(kind):
+    """Config 5's immersed cylinder: markers replicated on every rank, interpolation all-reduced over the owners of the support
+    cells, spreading into owned cells only; supports straddle both split planes, the z rank boundary and the periodic seam."""
+    case = Case(**CASES["c5_even"])
+    g = case.g
+    h = case.box[0][1] / case.n[0]
+    X = _cylinder(case.box, h)
+    L = X[0].size
+    rng = np.random.default_rng(17)
+    u = rng.standard_normal((3, g.ncell))
+    F = rng.standard_normal((3, L))
+    dV = rng.uniform(0.5, 1.5, L) * h ** 3
+    f0 = rng.standard_normal((3, g.ncell))
+    ref = dict(X=X, u=u, F=F, dV=dV, f0=f0, U=g.ibm_interp(kind, X, u), f=g.ibm_spread(kind, X, dV, F, f0.copy()))
+    tots = inproc.run_threads(8, _ibm_worker, case, ref, kind)
+    cellvol = h ** 3
+    want = (F * dV[None, :]).sum(axis=1) / cellvol
+    assert np.allclose(tots[0], want, rtol=1e-9, atol=1e-9 * np.abs(F).sum()), (tots[0], want)
+
+
+# ------------------------------------------------------------------------------------------------ thread independence of the handles
+
+def _independent_worker(R, n, bc, seed, iters_out):
+    """no communicator at all: every thread owns a whole (different) problem; the answers must be those of a run on one thread"""
+    import torch
+    from fluca_amd.poisson import Poisson
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        P = Poisson.uniform(n, [(0.0, 1.0), (0.0, 1.0), (0.0, 0.5)], bc, 1e-3)
+        P.set_stream(s)
+        rng = np.random.default_rng(seed)
+        x = rng.standard_normal(P.ncell)
+        x -= x.mean()
+        xd = torch.as_tensor(x, device="cuda")
+        b = P.apply(xd)
+        outs = []
+        for _ in range(iters_out):
+            y, info = P.solve(b, rtol=1e-9, maxit=3000, history=True)
+            s.synchronize()
+            outs.append((y.cpu().numpy().copy(), info["iters"], np.asarray(info["history"])))
+        P.close()
+    return outs
+
+
+def test_two_threads_drive_two_handles_without_colliding():
+    """include/fluca_hip.h: "a handle is driven by one host thread; different handles are independent".  Eight threads, eight different
+    problems, three solves each, all at once on one device -- every answer equals, bit for bit, the one the same problem gives when it
+    runs alone (partial sums, tickets, scalars and work vectors are per handle; nothing of a solve lives in a global)."""
+    specs = [((24 + 4 * r, 20, 16), [V, V, V, V, SYM, V] if r % 2 == 0 else [PER, PER, V, V, PER, PER], 100 + r) for r in range(8)]
+
+    def worker(R):
+        return _independent_worker(R, *specs[R.rank], 3)
+
+    together = inproc.run_threads(8, worker)
+    for r in range(8):
+        alone = inproc.run_threads(1, lambda R: _independent_worker(R, *specs[r], 1))[0][0]
+        for y, its, hist in together[r]:
+            assert its == alone[1] and np.array_equal(hist, alone[2]) and np.array_equal(y, alone[0]), r
+
+
+# ------------------------------------------------------------------------------------------------ whole time steps through the C host mirror
+
+CH_BOX = (2.0, 1.5, 1.0)      # Lx, Ly, Lz of the channel below (uniform spacing 1/16: the direct-forcing IBM of the mirror wants it)
+
+
+def _mirror_run(R, n, ranks, nsteps, ibm):
+    """NSSolve of the C host mirror on config 5's set-up (parabolic VELOCITY inlet, PRESSURE_OUTLET with a pressure that varies in space and
+    time, no-slip walls in y, periodic span; optionally the cylinder of markers held at rest by direct forcing): this rank's blocks of v, V, p.
+    R = None: the undecomposed run."""
+    from fluca_amd import capi, hostapi as H
+    P = C.c_void_p
+    Lx, Ly, Lz = CH_BOX
+    rank, size = (0, 1) if R is None else (R.rank, R.size)
+    rk = ranks if size > 1 else (1, 1, 1)
+    mesh = P()
+    assert H.lib.MeshCartCreate3d(0, 0, 1, n[0], n[1], n[2], rk[0], rk[1], rk[2], None, None, None, C.byref(mesh)) == 0
+    assert H.lib.MeshSetRank(mesh, rank, size) == 0
+    assert H.lib.MeshSetUp(mesh) == 0
+    assert H.lib.MeshCartSetUniformCoordinates(mesh, 0., Lx, 0., Ly, 0., Lz) == 0
+    ns = P()
+    assert H.lib.NSCreate(C.byref(ns)) == 0 and H.lib.NSSetType(ns, b"cnlinear") == 0 and H.lib.NSSetMesh(ns, mesh) == 0
+    assert H.lib.NSSetDensity(ns, 1.0) == 0 and H.lib.NSSetViscosity(ns, 0.05) == 0
+
+    @H.BCFunc
+    def inlet(dim, t, x, val, ctx):
+        val[0], val[1], val[2] = 4.0 * x[1] * (Ly - x[1]) / Ly ** 2 * (1.0 + 0.3 * np.sin(2 * np.pi * x[2] / Lz)), 0.0, 0.0
+        return 0
+
+    @H.BCFunc
+    def wall(dim, t, x, val, ctx):
+        val[0] = val[1] = val[2] = 0.0
+        return 0
+
+    @H.BCFunc
+    def outlet(dim, t, x, val, ctx):
+        val[0] = 0.3 * np.sin(3.0 * t) + 0.1 * x[1]
+        return 0
+
+    bcs = [H.NSBoundaryCondition(type=H.NS_BC_VELOCITY, velocity=inlet), H.NSBoundaryCondition(type=H.NS_BC_PRESSURE_OUTLET, pressure=outlet),
+           H.NSBoundaryCondition(type=H.NS_BC_VELOCITY, velocity=wall), H.NSBoundaryCondition(type=H.NS_BC_VELOCITY, velocity=wall),
+           H.NSBoundaryCondition(type=H.NS_BC_PERIODIC), H.NSBoundaryCondition(type=H.NS_BC_PERIODIC)]
+    for b in range(6):
+        assert H.lib.NSSetBoundaryCondition(ns, b, bcs[b]) == 0
+    argc, av = H.argv("-ns_time_step_size", 5e-3, "-ns_max_steps", nsteps, "-ns_ksp_rtol", 1e-10, "-ns_abf_schur_ksp_type", "bcgs",
+                      "-ns_abf_schur_ksp_rtol", 1e-12, "-ns_abf_momentum_ksp_rtol", 1e-12)
+    assert H.lib.NSSetFromOptions(ns, argc, av) == 0 and H.lib.NSSetUp(ns) == 0
+    hp = P()
+    assert H.lib.NSGetPoisson(ns, C.byref(hp)) == 0
+    if R is not None:
+        R.attach(hp)
+    keep = []
+    if ibm:
+        h = Lx / n[0]
+        X = _cylinder([(0.0, Lx), (0.0, Ly), (0.0, Lz)], h, radius_cells=3.0)
+        L = X[0].size
+        arrs = X + [np.full(L, h ** 3)]
+        for a in arrs:
+            dptr = P()
+            capi.check(capi.lib.fl_malloc(0, a.size * 8, C.byref(dptr)))
+            capi.check(capi.lib.fl_memcpy_h2d(0, dptr, np.ascontiguousarray(a).ctypes.data_as(C.c_void_p), a.size * 8))
+            keep.append(dptr)
+        assert H.lib.NSSetImmersedBoundary(ns, 0, L, keep[0], keep[1], keep[2], keep[3], None) == 0
+    assert H.lib.NSSolve(ns) == 0
+    sz = (C.c_int64 * 4)()
+    assert H.lib.NSGetLocalSizes(ns, sz) == 0
+    cc = [C.c_int64() for _ in range(6)]
+    assert H.lib.MeshCartGetCorners(mesh, *[C.byref(q) for q in cc]) == 0
+    lo, ln = [q.value for q in cc[:3]], [q.value for q in cc[3:]]
+    v, p, Vp = P(), P(), (C.c_void_p * 3)()
+    assert H.lib.NSGetSolutionArrays(ns, C.byref(v), Vp, C.byref(p)) == 0
+
+    def get(ptr, m):
+        out = np.empty(m)
+        capi.check(capi.lib.fl_memcpy_d2h(0, out.ctypes.data_as(C.c_void_p), ptr, m * 8))
+        return out
+
+    res = dict(lo=lo, ln=ln, v=get(v, 3 * sz[0]), p=get(p, sz[0]), V=[get(C.c_void_p(Vp[d]), sz[1 + d]) for d in range(3)])
+    its = (C.c_int(), C.c_int())
+    assert H.lib.NSGetInnerIterations(ns, C.byref(its[0]), C.byref(its[1])) == 0
+    res["inner"] = (its[0].value, its[1].value)
+    H.lib.NSDestroy(C.byref(ns))
+    H.lib.MeshDestroy(C.byref(mesh))
+    for dptr in keep:
+        capi.lib.fl_free(0, dptr)
+    return res
+
+
+def _gather(parts, n):
+    """blocks of the ranks -> global v (3, nz, ny, nx), V[d] on the global face arrays, p"""
+    nfx = [n[0] + 1, n[1] + 1, n[2]]           # x outlet / y wall: one face more than cells; z periodic: as many
+    v = np.full((3, n[2], n[1], n[0]), np.nan)
+    p = np.full((n[2], n[1], n[0]), np.nan)
+    V = [np.full((n[2], n[1], nfx[0]), np.nan), np.full((n[2], nfx[1], n[0]), np.nan), np.full((nfx[2], n[1], n[0]), np.nan)]
+    for r in parts:
+        lo, ln = r["lo"], r["ln"]
+        sl = (slice(lo[2], lo[2] + ln[2]), slice(lo[1], lo[1] + ln[1]), slice(lo[0], lo[0] + ln[0]))
+        v[(slice(None),) + sl] = r["v"].reshape(3, ln[2], ln[1], ln[0])
+        p[sl] = r["p"].reshape(ln[2], ln[1], ln[0])
+        for d in range(3):
+            f = list(ln)
+            f[d] = r["V"][d].size // (ln[(d + 1) % 3] * ln[(d + 2) % 3])
+            fs = [slice(lo[a], lo[a] + f[a]) for a in (2, 1, 0)]
+            V[d][tuple(fs)] = r["V"][d].reshape(f[2], f[1], f[0])
+    assert not (np.isnan(v).any() or np.isnan(p).any() or any(np.isnan(a).any() for a in V)), "the blocks do not tile the grid"
+    return v, V, p
+
+
+def test_nsstep_on_the_2x2x2_rank_grid_matches_the_oracle_step():
+    """Two whole CNLinear steps (NSStep_CNLinear_Cart3d_Internal, cnlinearcart3d.c:2807-2863) of config 5's channel on 2 x 2 x 2 ranks -- momentum
+    solve, Rhie-Chow interpolation, Schur solve, projection, pressure update, every boundary-condition vector evaluated by the rank that touches
+    the boundary -- against StepOracle's composition of the reference formulas on the undecomposed grid: v, V, p to 1e-6."""
+    from oracle import fluca_oracle as fo
+    n, ranks, nsteps, dt, rho, mu = (32, 24, 16), (2, 2, 2), 2, 5e-3, 1.0, 0.05
+    Lx, Ly, Lz = CH_BOX
+    parts = inproc.run_threads(8, _mirror_run, n, ranks, nsteps, False)
+    v, V, p = _gather(parts, n)
+    g = fo.Grid.uniform(n, [(0, Lx), (0, Ly), (0, Lz)], C5_BC, dt / rho)
+
+    def velocity(b, t, X):
+        if b == 0:
+            return np.stack([4.0 * X[:, 1] * (Ly - X[:, 1]) / Ly ** 2 * (1.0 + 0.3 * np.sin(2 * np.pi * X[:, 2] / Lz)), np.zeros(len(X)), np.zeros(len(X))])
+        return np.zeros((3, len(X)))
+
+    pressure = lambda b, t, X: 0.3 * np.sin(3.0 * t) + 0.1 * X[:, 1]
+    so = fo.StepOracle(g, dt, rho, mu, velocity, krylov_rtol=1e-12, outer_rtol=1e-10, pressure=pressure)
+    so.S_ksp = fo.KSP_BCGS
+    vo, Vo, po = np.zeros(3 * g.ncell), [np.zeros(nf) for nf in g.nface], np.zeros(g.ncell)
+    for _ in range(nsteps):
+        vo, Vo, po, info = so.step_once(vo, Vo, po)
+    assert np.abs(vo).max() > 0.5
+    assert np.linalg.norm(v.ravel() - vo) <= 1e-6 * np.linalg.norm(vo)
+    for d in range(3):
+        assert np.linalg.norm(V[d].ravel() - Vo[d]) <= 1e-6 * max(np.linalg.norm(Vo[d]), 1e-12), d
+    assert np.linalg.norm(p.ravel() - po) <= 1e-6 * np.linalg.norm(po)
+    # continuity of the projected face velocity (||D V||_inf <= 10 rtol ||b||_inf; here against the inlet flux scale)
+    assert np.abs(g.rhs(*[a.ravel() for a in V])).max() <= 1e-6 * np.abs(Vo[0]).max() / (Lx / n[0])
+    assert all(r["inner"] == parts[0]["inner"] for r in parts)        # every rank counted the same inner iterations
+
+
+def test_nsstep_with_the_immersed_cylinder_on_the_2x2x2_rank_grid():
+    """The same steps with the cylinder of markers along the span held at rest by direct forcing (IBM interpolation + spreading inside every
+    step; no oracle for the forcing loop, so: eight ranks against the undecomposed run of the same library, whose pieces the tests above and
+    tests/test_gpu_ibm.py pin to the oracle)."""
+    n, ranks, nsteps = (32, 24, 16), (2, 2, 2), 3
+    parts = inproc.run_threads(8, _mirror_run, n, ranks, nsteps, True)
+    v, V, p = _gather(parts, n)
+    one = inproc.run_threads(1, lambda R: _mirror_run(None, n, ranks, nsteps, True))
+    v1, V1, p1 = _gather(one, n)
+    free = inproc.run_threads(1, lambda R: _mirror_run(None, n, ranks, nsteps, False))
+    vf, _, _ = _gather(free, n)
+    assert np.linalg.norm(v1 - vf) >= 1e-3 * np.linalg.norm(vf)           # the forcing does something
+    assert np.linalg.norm(v - v1) <= 1e-8 * np.linalg.norm(v1)
+    for d in range(3):
+        assert np.linalg.norm(V[d] - V1[d]) <= 1e-8 * max(np.linalg.norm(V1[d]), 1e-12), d
+    assert np.linalg.norm(p - p1) <= 1e-7 * np.linalg.norm(p1)
