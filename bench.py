@@ -10,7 +10,9 @@ iteration count (rtol = atol = 0), inputs resident in HBM before the timed regio
 One JSON line on rank 0.  value = (cells of the whole job / 512^3) * K / seconds  ==  iterations/s of a 512^3 grid at N=1.
 At N = 1 the line also carries "configs": driver-timed lines for the other single-GPU configurations of BASELINE.json (C2 256^3
 cavity CG, C3 512^3 channel Chebyshev-Jacobi sweeps, C4 512^3 with the IBM kernels on an immersed sphere), each with its own
-roofline object, "C5_rank_rehearsal" (one rank's share of config 5 without the halo exchange), and "value_unplaced": the same K steps on plainly allocated vectors (see "placement" in include/fluca_hip.h).
+roofline object, "C1" (config 1: the 64^3 cavity's CPU KSP CG + Jacobi, iterations / seconds / cores), "C5_rank_rehearsal" (one rank's share of config 5
+without the halo exchange, with its parity against the oracle's assembled block), "flow_step" (a whole 512^3 time step, and the velocity-field parity of two
+steps at 128^3), and "value_unplaced": the same K steps on plainly allocated vectors (see "placement" in include/fluca_hip.h).
 For N > 1 the halo transport is RCCL; if RCCL cannot be initialised the run FAILS (a host-staged curve would be worthless) --
 the host-staged rehearsal has to be asked for with --transport host.
 """
@@ -40,41 +42,48 @@ CG_KERNELS = {0: (("k_cg_A (p-update + S*p + dot; q never stored)", 40, 24), ("k
 B_ITER_REAL = {0: 60, 2: 72, 1: 136}
 
 
+def phys(bytes_counted, bytes_floor, bytes_textbook, ms):
+    """The roofline entries of one kernel launch.  `frac` is a FRACTION of the HBM roofline: bytes that crossed the HBM interface per launch
+    (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE from the last committed counter pass, profiles/pmc_*.json; where no pass exists for the workload, the
+    bytes the kernel must move by construction -- its own floor) / the launch's duration (HIP events inside the timed region) / 8 TB/s.
+    Never above 1.  SURVEY 8(d)'s textbook figure (the bytes of the BLAS-1 / SpMV steps the kernel REPLACES, which it no longer moves: q is
+    never stored, x is touched every second iteration, two Chebyshev steps share one sweep) is kept beside it as achieved_textbook /
+    frac_textbook: a speed-up over the textbook sequence, not a bandwidth."""
+    used = bytes_counted if bytes_counted else bytes_floor
+    g = used / (ms * 1e-3) / 1e9 if ms and ms > 0 else None
+    gt = bytes_textbook / (ms * 1e-3) / 1e9 if ms and ms > 0 else None
+    return {"achieved": g, "frac": g / HBM_PEAK_GBS if g else None, "bytes_per_launch": used,
+            "bytes_source": "rocprofv3 PMC pass (profiles/)" if bytes_counted else "the kernel's own byte floor x cells (no counter pass for this workload)",
+            "traffic": bytes_counted, "traffic_GBps": g, "traffic_frac": g / HBM_PEAK_GBS if g else None,
+            "floor_bytes_per_launch": bytes_floor, "floor_GBps": bytes_floor / (ms * 1e-3) / 1e9 if ms and ms > 0 else None,
+            "achieved_textbook": gt, "frac_textbook": gt / HBM_PEAK_GBS if gt else None, "avg_launch_ms": ms}
+
+
+FRAC_NOTE = ("frac = achieved / peak with achieved = bytes that crossed the HBM interface per launch (counter pass; the kernel's byte floor where none exists) / "
+             "HIP-event duration: the physical fraction of the 8 TB/s roofline, <= 1.  *_textbook = SURVEY 8(d)'s algorithmic bytes of the steps the kernel "
+             "replaces / the same duration (exceeds the peak once a kernel stops moving bytes the textbook sequence moves)")
+
+
 def cg_roofline(info, ncell, variant, ms_per_iter, traffic=None):
     """roofline object of a CG run: the kernel with the larger share of the iteration is the headline entry ("dominant kernel"), the other
     one and the whole iteration (every kernel, driver-timed) are listed beside it.  Durations: HIP events around each launch inside the
-    timed region (fl_ksp_opts.profile).
-
-    Two kinds of fraction, never to be confused:
-      achieved / frac          SURVEY 8(d)'s ALGORITHMIC bytes of the textbook steps a kernel replaces / its duration (the contract's
-                               figure; it exceeds 1 once a kernel stops moving bytes the textbook sequence moves -- q is never stored, x is
-                               touched every second iteration);
-      traffic_GBps / traffic_frac   bytes that actually crossed the HBM interface (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE per launch from the
-                               last committed counter pass, profiles/pmc_*.json; the kernel's own moved-byte count x cells where no pass
-                               exists for the workload) / the same duration / 8 TB/s: the PHYSICAL fraction of the roofline, <= 1."""
+    timed region (fl_ksp_opts.profile).  Fractions as phys() defines them."""
     ks = []
     for (name, algo, moved), ms, n in zip(CG_KERNELS[variant], (info["kernel_ms"], info["kernel2_ms"]), (info["kernel_launches"], info["kernel2_launches"])):
-        ach = algo * ncell / (ms * 1e-3) / 1e9 if ms > 0 else None
         tr, tstale = traffic.get(name.split(" ")[0], (None, None)) if isinstance(traffic, dict) else (None, None)
-        tb, src = (tr, "rocprofv3 PMC pass (profiles/)") if tr else (moved * ncell, "moved bytes per cell x cells (no counter pass for this workload)")
-        tg = tb / (ms * 1e-3) / 1e9 if ms > 0 else None
-        ks.append({"kernel": name, "algorithmic_bytes_per_cell": algo, "moved_bytes_per_cell": moved, "avg_launch_ms": ms, "launches_timed": n, "achieved": ach,
-                   "frac": ach / HBM_PEAK_GBS if ach else None, "moved_GBps": moved * ncell / (ms * 1e-3) / 1e9 if ms > 0 else None,
-                   "traffic": tr, "traffic_stale": tstale, "traffic_bytes_used": tb, "traffic_source": src, "traffic_GBps": tg, "traffic_frac": tg / HBM_PEAK_GBS if tg else None})
+        k = {"kernel": name, "algorithmic_bytes_per_cell": algo, "moved_bytes_per_cell": moved, "launches_timed": n, "traffic_stale": tstale}
+        k.update(phys(tr, moved * ncell, algo * ncell, ms))
+        ks.append(k)
     dom = max(ks, key=lambda k: k["avg_launch_ms"] or 0.0)
-    it_ach = B_ITER_ALGO * ncell / (ms_per_iter * 1e-3) / 1e9
-    it_tb = sum(k["traffic_bytes_used"] for k in ks)
-    it_tg = it_tb / (ms_per_iter * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": dom["traffic"],
-            "traffic_stale": (any(k["traffic_stale"] for k in ks) if any(k["traffic"] for k in ks) else None),
-            "traffic_GBps": dom["traffic_GBps"], "traffic_frac": dom["traffic_frac"], "traffic_source": dom["traffic_source"],
-            "frac_note": "frac = algorithmic bytes of the textbook steps this kernel replaces / time / peak (SURVEY 8d; may exceed 1); traffic_frac = bytes that crossed "
-                         "the HBM interface / time / peak: the physical fraction",
-            "algorithmic_bytes_per_cell": dom["algorithmic_bytes_per_cell"], "moved_bytes_per_cell": dom["moved_bytes_per_cell"],
-            "avg_launch_ms": dom["avg_launch_ms"], "launches_timed": dom["launches_timed"], "moved_GBps": dom["moved_GBps"], "kernels": ks,
-            "iteration": {"algorithmic_bytes_per_cell": B_ITER_ALGO, "moved_bytes_per_cell": B_ITER_REAL.get(variant), "ms": ms_per_iter, "achieved": it_ach,
-                          "frac": it_ach / HBM_PEAK_GBS, "traffic_bytes": it_tb, "traffic_GBps": it_tg, "traffic_frac": it_tg / HBM_PEAK_GBS,
-                          "note": "all kernels of one iteration, driver-timed (ms_per_step)"}}
+    it_tb = sum(k["bytes_per_launch"] for k in ks)
+    it = phys(it_tb if any(k["traffic"] for k in ks) else None, sum(k["floor_bytes_per_launch"] for k in ks), B_ITER_ALGO * ncell, ms_per_iter)
+    it.update({"algorithmic_bytes_per_cell": B_ITER_ALGO, "moved_bytes_per_cell": B_ITER_REAL.get(variant), "ms": ms_per_iter,
+               "note": "all kernels of one iteration, driver-timed (ms_per_step)"})
+    out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac_note": FRAC_NOTE,
+           "traffic_stale": (any(k["traffic_stale"] for k in ks) if any(k["traffic"] for k in ks) else None)}
+    out.update({k: v for k, v in dom.items() if k != "traffic_stale"})
+    out.update({"kernels": ks, "iteration": it})
+    return out
 B_CHEB_ALGO = 40               # algorithmic bytes / cell / Chebyshev-Jacobi step: read x, b, d; write x', d'
 IBM_B_PER_MARKER = 1584        # SURVEY 8d: L * (4^3 * 3 * 8 + 6 * 8) bytes per interp or spread of three components
 RANK_GRIDS = {1: (1, 1, 1), 2: (1, 1, 2), 4: (1, 2, 2), 8: (2, 2, 2)}
@@ -304,6 +313,59 @@ def momentum_parity(n1=256, its=5):
     return out
 
 
+def c1_cpu_ksp():
+    """BASELINE config 1 (fluca/tests/cavity_flow/cavity_flow_3d.c:39-42,72-77 at -cart_grid 64): the 64^3 lid-driven cavity's
+    KSPSolve(kspS) as the reference runs it on the CPU -- KSPCG + PCJACOBI, PETSc defaults (rtol 1e-5, preconditioned norm, constant null space
+    removed) -- here the oracle's restatement on the host cores (PETSc is absent), on the SURVEY 8(d) right-hand side; and the same solve on
+    the GPU path beside it."""
+    fo = _oracle_threads()
+    from fluca_amd import poisson as flp
+    n, box, bc = (64,) * 3, [(0.0, 1.0), (0.0, 1.0), (0.0, 0.5)], [1, 1, 1, 1, 4, 1]
+    g = fo.Grid.uniform(n, box, bc, 1e-3)
+    S = g.assemble_S()
+    rng = np.random.default_rng(20260313)
+    p = rng.uniform(-1, 1, g.ncell)
+    p -= p.mean()
+    b = S.mult(p)
+    S.solve(b, history=False)                      # warm caches / thread team
+    xo, io = S.solve(b, history=False)
+    P = flp.Poisson.uniform(n, box, bc, 1e-3)
+    bd = torch.as_tensor(b, device="cuda")
+    P.solve(bd)
+    xg, ig = P.solve(bd)
+    xg = xg.cpu().numpy()
+    P.close()
+    return {"workload": "64^3 lid-driven cavity (cavity_flow_3d.c:39-42,72-77), KSPCG + PCJACOBI to PETSc's default rtol 1e-5 (preconditioned norm, constant null space), "
+                        "b = S p* seeded; CPU = the oracle's restatement (PETSc absent from the image), not the reference binary",
+            "metric": "KSPSolve seconds (CPU reference plumbing)", "value": io["seconds"], "higher_is_better": False, "cores": fo.num_threads(),
+            "iterations": io["iters"], "reason": io["reason"], "its_per_s": io["iters"] / io["seconds"], "rnorm_over_rnorm0": io["rnorm"] / io["rnorm0"],
+            "gpu": {"iterations": ig["iters"], "reason": ig["reason"], "seconds": ig["seconds"], "its_per_s": ig["iters"] / ig["seconds"],
+                    "rel_l2_diff_x": float(np.linalg.norm((xg - xg.mean()) - (xo - xo.mean())) / np.linalg.norm(xo - xo.mean()))}}
+
+
+def c5_block_parity(P, b, nb, box, bc, its=20):
+    """One rank's 512 x 512 x 256 block of config 5 against the oracle's ASSEMBLED S of that block (as c3_parity does for config 3): `its`
+    Jacobi-PCG iterations on the right-hand side the timed run used, no null space (the outlet)."""
+    mem = _host_mem_available_gb()
+    if not (mem and mem >= 24.0):
+        return {"skipped": f"host memory {mem} GB < 24 GB for the 67 M-row CSR"}
+    fo = _oracle_threads()
+    t0 = time.perf_counter()
+    g = fo.Grid.uniform(nb, box, bc, 1e-3)
+    S = g.assemble_S()
+    P.synchronize()
+    bh = b.cpu().numpy()
+    xo, io = S.solve(bh, nullspace=False, rtol=0.0, atol=0.0, maxit=its, history=True)
+    xg, ig = P.solve(b, rtol=0.0, atol=0.0, maxit=its, remove_nullspace=0, history=True)
+    P.synchronize()
+    xg = xg.cpu().numpy()
+    hg, ho = np.asarray(ig["history"][:its + 1]), np.asarray(io["history"][:its + 1])
+    return {"iters_gpu": ig["iters"], "iters_cpu": io["iters"], "rel_max_diff_x": float(np.abs(xg - xo).max() / np.abs(xo).max()),
+            "rel_max_diff_history": float(np.abs(hg - ho).max() / np.abs(ho).max()), "rnorm_gpu": ig["rnorm"], "rnorm_cpu": io["rnorm"],
+            "oracle_seconds": io["seconds"], "seconds_total": time.perf_counter() - t0,
+            "oracle": "assembled CSR of the 512 x 512 x 256 block (oracle/fluca_oracle.c), KSPCG + PCJACOBI restatement"}
+
+
 def measured_stream_rates():
     import ctypes as C
 
@@ -379,20 +441,16 @@ def other_configs(stream, parity=True):
     K = 100
     (_, info), dt = timed(lambda: P.solve(b, x=x, maxit=K, profile=1, **kw))
     fused = info["kernel_launches"] * 2 == K            # the fused kernel applies two steps per launch
-    per_launch = (2 if fused else 1) * B_CHEB_ALGO * P.ncell
-    ach = per_launch / (info["kernel_ms"] * 1e-3) / 1e9
+    spl = 2 if fused else 1
     traffic, tstale = pmc_traffic("k_cheb2") if fused else (None, None)
+    # floor of a launch: x, b, d read, x', d' written once = 40 B/cell whether it applies one step or two; textbook: 40 B/cell per STEP
+    r3 = {"bound": "hbm", "kernel": "k_cheb2 (two fused Chebyshev-Jacobi steps per launch)" if fused else "k_cheb_st", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+          "traffic_stale": tstale, "frac_note": FRAC_NOTE, "algorithmic_bytes_per_cell_per_step": B_CHEB_ALGO, "floor_bytes_per_cell_per_launch": B_CHEB_ALGO,
+          "steps_per_launch": spl, "launches_timed": info["kernel_launches"]}
+    r3.update(phys(traffic, B_CHEB_ALGO * P.ncell, spl * B_CHEB_ALGO * P.ncell, info["kernel_ms"]))
     cfg["C3"] = {"workload": "512^3 channel [VELOCITY, PRESSURE_OUTLET, wall, wall, PERIODIC, PERIODIC], Chebyshev-Jacobi, KSP_NORM_NONE, fixed 100 steps",
                  "metric": "Chebyshev-Jacobi steps/s", "value": K / dt, "steps": K, "ms_per_step": dt / K * 1e3,
-                 "step_algorithmic_GBps": B_CHEB_ALGO * P.ncell * K / dt / 1e9,
-                 "roofline": {"bound": "hbm", "kernel": "k_cheb2 (two fused Chebyshev-Jacobi steps per launch)" if fused else "k_cheb", "achieved": ach, "peak": HBM_PEAK_GBS,
-                              "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_stale": tstale,
-                              "traffic_GBps": (traffic or B_CHEB_ALGO * P.ncell) / (info["kernel_ms"] * 1e-3) / 1e9,
-                              "traffic_frac": (traffic or B_CHEB_ALGO * P.ncell) / (info["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                              "traffic_source": "rocprofv3 PMC pass (profiles/pmc_k_cheb2.json)" if traffic else "40 B x cells per launch (x, b, d read; x', d' written once)",
-                              "frac_note": "frac counts 40 algorithmic B/cell per STEP, two steps per launch; traffic_frac is the physical fraction",
-                              "algorithmic_bytes_per_cell_per_launch": per_launch / P.ncell,
-                              "steps_per_launch": 2 if fused else 1, "avg_launch_ms": info["kernel_ms"], "launches_timed": info["kernel_launches"]}}
+                 "step_algorithmic_GBps": B_CHEB_ALGO * P.ncell * K / dt / 1e9, "roofline": r3}
     if parity:
         try:
             cfg["C3"]["parity_on_full_grid"] = c3_parity(P, b, box, [1, 2, 1, 1, 3, 3])
@@ -432,7 +490,7 @@ def other_configs(stream, parity=True):
     cfg["C4"] = {"workload": f"512^3 grid, immersed sphere D = 64 h, {L} markers (Peskin 4-point): interpolation + spreading of 3 components per step",
                  "metric": "IBM interpolate+spread steps/s", "value": K / dt, "steps": K, "ms_per_step": dt / K * 1e3, "markers": L,
                  "roofline": {"bound": "hbm", "kernel": "k_ibm_interp + k_ibm_spread", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                              "traffic": None, "algorithmic_bytes_per_marker": IBM_B_PER_MARKER,
+                              "traffic": None, "algorithmic_bytes_per_marker": IBM_B_PER_MARKER, "bytes_source": "SURVEY 8(d): 1584 B per marker and pass (no counter pass)",
                               "note": "latency-bound by construction (20 MB of traffic per step): reported, not a roofline target (SURVEY 8d)"}}
     capi.lib.fl_ibm_destroy(m)
     P.close()
@@ -471,18 +529,16 @@ def other_configs(stream, parity=True):
         # (one also reads the shadow residual) + 3 vector updates
         B_APPLY, B_BCGS = 96, 552
         tr, trstale = pmc_traffic("k_mom3")
-        ach = B_APPLY * P.ncell / (kms["plain"] * 1e-3) / 1e9
-        tg = (tr or B_APPLY * P.ncell) / (kms["plain"] * 1e-3) / 1e9
+        rm = {"bound": "hbm", "kernel": "k_mom3 (MatMult(A): two cells per lane on 128 x 8 tiles, v0interp formed from v0 in the kernel)", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+              "traffic_stale": trstale, "frac_note": FRAC_NOTE, "algorithmic_bytes_per_cell": B_APPLY, "launches_timed": 10}
+        rm.update(phys(tr, B_APPLY * P.ncell, B_APPLY * P.ncell, kms["plain"]))
+        itg = B_BCGS * P.ncell * info["iters"] / dt / 1e9
+        rm["iteration"] = {"algorithmic_bytes_per_cell": B_BCGS, "ms": dt / max(info["iters"], 1) * 1e3, "achieved": itg, "frac": itg / HBM_PEAK_GBS,
+                           "bytes_source": "552 B/cell: what the iteration's kernels move by construction (2 products + 3 vector updates; no counter pass of the whole iteration)"}
         cfg["momentum"] = {"workload": "512^3 cavity grid, momentum block A = I + dt C - (mu dt / 2 rho) L matrix-free (3 velocity components; V0 on faces, v0interp = B v0 formed in the kernel), "
                                        f"Jacobi-BiCGStab (KSPBCGS + PCJACOBI) fixed {K} iterations",
                            "metric": "momentum BiCGStab iterations/s", "value": info["iters"] / dt, "steps": info["iters"], "ms_per_step": dt / max(info["iters"], 1) * 1e3,
-                           "iteration_algorithmic_GBps": B_BCGS * P.ncell * info["iters"] / dt / 1e9, "kernel_ms": kms,
-                           "roofline": {"bound": "hbm", "kernel": "k_mom3 (MatMult(A): two cells per lane on 128 x 8 tiles, v0interp formed from v0 in the kernel)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                        "frac": ach / HBM_PEAK_GBS, "traffic": tr, "traffic_stale": trstale, "traffic_GBps": tg, "traffic_frac": tg / HBM_PEAK_GBS,
-                                        "traffic_source": "rocprofv3 PMC pass (profiles/pmc_k_mom3.json)" if tr else "96 B x cells",
-                                        "algorithmic_bytes_per_cell": B_APPLY, "avg_launch_ms": kms["plain"], "launches_timed": 10,
-                                        "iteration": {"algorithmic_bytes_per_cell": B_BCGS, "ms": dt / max(info["iters"], 1) * 1e3,
-                                                      "achieved": B_BCGS * P.ncell * info["iters"] / dt / 1e9, "frac": B_BCGS * P.ncell * info["iters"] / dt / 1e9 / HBM_PEAK_GBS}}}
+                           "iteration_algorithmic_GBps": itg, "kernel_ms": kms, "roofline": rm}
         # the two Krylov methods to rtol 1e-5 on the viscous-dominated operator of the 512^3 flow configurations (nu dt / h^2 = 2.56; the state
         # above has 0.25): Jacobi-BiCGStab against KSPCHEBYSHEV fused into the product (k_mom3, OUT 4: 144 B/cell per step against 552 per iteration)
         try:
@@ -572,10 +628,23 @@ def other_configs(stream, parity=True):
         "metric": "PCG iterations/s on the block", "value": K / dt, "steps": K, "ms_per_step": dt / K * 1e3,
         "ibm_interp_plus_spread_ms": dti / 20 * 1e3, "markers": Lc,
         "roofline": cg_roofline(info, P.ncell, 0, dt / K * 1e3, workload_traffic("c5_block"))}
+    if parity:
+        try:
+            cfg["C5_rank_rehearsal"]["parity"] = c5_block_parity(P, b, nb, [(0, 0.5), (0, 0.5), (0, 0.25)], [1, 2, 1, 1, 3, 3])
+        except Exception as e:  # noqa: BLE001
+            cfg["C5_rank_rehearsal"]["parity"] = {"error": repr(e)}
+    cfg["C5_rank_rehearsal"]["rank_grid_parity"] = ("the 2 x 2 x 2 rank grid itself (halo exchange over three split axes, fused smoother, multigrid, IBM cylinder, "
+                                                    "whole time steps) runs against the single-domain oracle in tests/test_gpu_config5.py: eight handles on eight "
+                                                    "host threads of one process, in-memory transport")
     capi.lib.fl_ibm_destroy(mc)
     P.close()
     del b, x
     torch.cuda.empty_cache()
+    if parity:
+        try:
+            cfg["C1"] = c1_cpu_ksp()
+        except Exception as e:  # noqa: BLE001
+            cfg["C1"] = {"error": repr(e)}
 
     # A whole time step of the reference's integrator on the C host mirror (examples/flow_configs.c, a child process: it opens the GPU itself):
     # 512^3 channel with the immersed sphere of config 4, fractional step (-ns_ksp_type preonly: one PCApply_ABF per step -- BiCGStab + Jacobi on the
@@ -603,6 +672,14 @@ def other_configs(stream, parity=True):
             cfg["flow_step"]["with_momentum_chebyshev"] = {"error": repr(e)[:300]}
     except Exception as e:  # noqa: BLE001
         cfg["flow_step"] = {"error": repr(e)[:500]}
+    if parity and isinstance(cfg.get("flow_step"), dict):
+        # velocity-field parity of whole steps (north_star: "residual and velocity field"): the same set-up at 128^3, two converged steps through the
+        # C host mirror against the oracle's step (tests/flow_parity.py; the 512^3 step above is a fractional step, this one iterates to 1e-9)
+        try:
+            from tests import flow_parity
+            cfg["flow_step"]["parity"] = flow_parity.channel_sphere(n=128, nsteps=2)
+        except Exception as e:  # noqa: BLE001
+            cfg["flow_step"]["parity"] = {"error": repr(e)[:500]}
     return cfg
 
 

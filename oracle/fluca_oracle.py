@@ -595,9 +595,11 @@ class StepOracle:
     velocity(b, t, X) -> (3, npoints) array: the wall velocity callback of boundary b at the face centres X (npoints, 3).
     """
 
-    def __init__(self, g, dt, rho, mu, velocity=None, krylov_rtol=1e-12, outer_rtol=1e-8, outer_maxit=50, pressure=None):
+    def __init__(self, g, dt, rho, mu, velocity=None, krylov_rtol=1e-12, outer_rtol=1e-8, outer_maxit=50, pressure=None, ibm=None):
+        """ibm = dict(kind, X=[x, y, z], dV, Ut=None): explicit direct forcing, momrhs += spread(Ut - interp(v0)) -- build-defined (the
+        reference only promises an IBM, THEORY_GUIDE.md:130-132), the rule of NSSetImmersedBoundary in include/fluca_host.h."""
         assert abs(g.kappa - dt / rho) < 1e-15 * max(1.0, g.kappa)
-        self.g, self.dt, self.rho, self.mu, self.velocity, self.pressure = g, dt, rho, mu, velocity, pressure
+        self.g, self.dt, self.rho, self.mu, self.velocity, self.pressure, self.ibm = g, dt, rho, mu, velocity, pressure, ibm
         self.S = g.assemble_S()
         self.L = g.assemble_momentum(0.0, 0.0, 1.0)
         self.krtol, self.ortol, self.omaxit = krylov_rtol, outer_rtol, outer_maxit
@@ -682,12 +684,20 @@ class StepOracle:
         if np.any(wG != 0.0):
             Tw = g.apply_T(wG)
             interprhs = [interprhs[d] - Tw[d] for d in range(3)]
+        if self.ibm is not None:
+            ib = self.ibm
+            U = g.ibm_interp(ib["kind"], ib["X"], v0.reshape(3, N))
+            F = (0.0 if ib.get("Ut") is None else np.asarray(ib["Ut"]).reshape(3, -1)) - U
+            momrhs = momrhs + g.ibm_spread(ib["kind"], ib["X"], ib["dV"], F).ravel()
         A = g.assemble_momentum(1.0, dt, -cv, V0, W)
 
         def pcapply(fv, fV, fp):      # abfpc.c:71-101
             vs, _ = A.solve(fv, ksp=KSP_BCGS, pc=PC_JACOBI, nullspace=False, rtol=self.krtol, maxit=2000, history=False)
             Vs = g.apply_T(vs, fV)
-            ps, _ = self.S.solve(g.rhs(*Vs, contrhs=fp), ksp=getattr(self, "S_ksp", KSP_CG), nullspace=self.nullspace, rtol=self.krtol, maxit=20000, history=False)
+            bS = g.rhs(*Vs, contrhs=fp)
+            if fp is None:
+                self.b_inf = float(np.abs(bS).max())   # || b ||_inf of the step's first Schur solve, b = -D V* (SURVEY 8d's scale for || D V ||_inf)
+            ps, _ = self.S.solve(bS, ksp=getattr(self, "S_ksp", KSP_CG), nullspace=self.nullspace, rtol=self.krtol, maxit=20000, history=False)
             Gst = g.apply_gst(ps)
             return vs - np.concatenate(g.apply_G(ps)), [Vs[d] - Gst[d] for d in range(3)], ps
 

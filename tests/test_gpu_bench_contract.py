@@ -31,9 +31,15 @@ def test_single_gpu_line_has_the_contract_keys():
     assert d["value"] > 0 and abs(d["ms_per_step"] * d["value"] * (512 / 64) ** 3 / 1e3 - 1.0) < 1e-6      # value = 512^3-equivalent iterations/s
     r, c = d["roofline"], d["cpu_baseline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    # the physical fraction (bytes that crossed the HBM interface / time / peak) can never exceed 1, whatever the algorithmic one says
-    assert 0 < r["traffic_frac"] <= 1.0 and 0 < r["iteration"]["traffic_frac"] <= 1.0 and all(0 < k["traffic_frac"] <= 1.0 for k in r["kernels"])
-    assert abs(r["traffic_frac"] - r["traffic_GBps"] / r["peak"]) < 1e-12 and r["measured_copy_GBps"] > 3000.0 and r["measured_3r3w_GBps"] > 3000.0
+    # frac IS a fraction of the roofline: bytes that crossed the HBM interface (counter pass, or the kernel's own floor where the workload has
+    # none, as at this toy size) / time / peak -- never above 1, in the headline entry, in the whole iteration and in every kernel; the
+    # textbook figure of SURVEY 8(d) travels beside it under its own name
+    for e in [r, r["iteration"]] + r["kernels"]:
+        assert 0 < e["frac"] <= 1.0 and abs(e["frac"] - e["achieved"] / r["peak"]) < 1e-12, e
+        assert e["frac"] == e["traffic_frac"] and e["frac_textbook"] > 0 and e["bytes_source"], e
+        assert e["frac_textbook"] >= e["frac"] * 0.999      # the textbook steps move at least the bytes the fused kernels move
+    assert r["traffic_stale"] in (None, False)
+    assert r["measured_copy_GBps"] > 3000.0 and r["measured_3r3w_GBps"] > 3000.0
     assert d["placement"]["mode"] == "auto" and d["hbm_bytes_held"] > 0
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and "petsc_cpu" in c
     assert c["parity_on_sample"]["iters_gpu"] == c["parity_on_sample"]["iters_cpu"] and c["parity_on_sample"]["rel_max_diff_x"] < 1e-9
