@@ -9,7 +9,8 @@ import os
 import torch  # noqa: F401  (loads the process-wide HIP runtime first)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libflucahip.so")
+# FLUCA_LIB_DIR: another build of the library than the product's (lib_kbench/, fluca_amd/build.py) -- measurement tools only
+LIB_PATH = os.path.join(os.environ.get("FLUCA_LIB_DIR") or os.path.join(_HERE, "lib"), "libflucahip.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -2,6 +2,9 @@
 // and the two halo transports (RCCL Send/Recv; host-staged callbacks).
 #include <new>
 
+#include <cctype>
+#include <mutex>
+
 #include "fl_handle.h"
 
 int fl_dev_alloc(fl_poisson *h, void **p, size_t bytes, bool zero)
@@ -32,7 +35,12 @@ static int plane_size(const fl_poisson *h, int d)
 // "abi N": bumped whenever a struct of include/fluca_hip.h grows or an entry point changes its meaning (FL_ABI_VERSION there): a caller built
 // against another header must not be handed this library.  5: fl_ksp_opts carries cg_single_reduction (round 3's trailing field), the
 // momentum solve accepts FL_KSP_CHEBYSHEV, fl_momentum_gershgorin / fl_momentum_chebyshev_interval exist.
-extern "C" const char *fl_version(void) { return "fluca_amd 0.2 (gfx950, abi 5)"; }
+extern "C" const char *fl_build_id(void);  // lib/fl_build_id.cpp, written by fluca_amd/build.py: a hash over every source, header and compiler flag
+extern "C" const char *fl_version(void)
+{
+  static const std::string v = std::string("fluca_amd 0.3 (gfx950, abi 5, sources ") + fl_build_id() + ")";
+  return v.c_str();
+}
 extern "C" int fl_abi_version(void) { return FL_ABI_VERSION; }
 
 extern "C" void fl_ksp_opts_default(fl_ksp_opts *o)
@@ -82,8 +90,7 @@ static int poisson_init(fl_poisson *h, const fl_grid *grid, const int bc[6], dou
   }
   h->multi = h->dec.ranks[0] * h->dec.ranks[1] * h->dec.ranks[2] > 1;
   {
-    const char *e = std::getenv("FLUCA_COMM_LOOPBACK");
-    if (e && std::atoi(e) != 0 && !h->multi && (periodic[0] || periodic[1] || periodic[2])) {
+    if (knob(K_comm_loopback) != 0 && !h->multi && (periodic[0] || periodic[1] || periodic[2])) {
       h->loopback = h->comm.loopback = true;
       h->multi    = true;
       for (int d = 0; d < 3; ++d) h->wrap_local[d] = false;
@@ -115,8 +122,7 @@ static int poisson_init(fl_poisson *h, const fl_grid *grid, const int bc[6], dou
   // same row of all NV solver vectors is contiguous in memory and a kernel that streams several vectors sweeps ONE
   // address range instead of NV ranges a gigabyte apart.  Kernels only ever see (pointer, row stride, plane stride).
   {
-    const char *e = std::getenv("FLUCA_INTERLEAVE");
-    h->nv_il      = e ? std::atoi(e) : FL_DEFAULT_INTERLEAVE;
+    h->nv_il = FL_VARIANT(interleave, FL_DEFAULT_INTERLEAVE);
     if (h->nv_il < 2) h->nv_il = 1;
     if (h->nv_il > 8) h->nv_il = 8;
   }
@@ -125,8 +131,8 @@ static int poisson_init(fl_poisson *h, const fl_grid *grid, const int bc[6], dou
   // two-step smoother (k_cheb2) can run on several ranks.  Kernels only ever see (off0, sx, sxy): the width is a property of the handle,
   // not of the kernels.  FLUCA_GHOST_WIDTH=2 forces the wide layout on a single rank (tests: the whole suite must not care).
   {
-    const char *e = std::getenv("FLUCA_GHOST_WIDTH");
-    h->gw         = e ? std::atoi(e) : (h->multi && !h->loopback ? 2 : 1);
+    const int forced = knob(K_ghost_width);
+    h->gw            = forced > 0 ? forced : (h->multi && !h->loopback ? 2 : 1);
     if (h->gw < 1 || h->gw > 2 || h->nv_il > 1) h->gw = 1;
   }
   const int gw = h->gw;
@@ -351,23 +357,69 @@ extern "C" int fl_poisson_sizes(const fl_poisson *h, int64_t out[4])
 // was fastest; the vectors outside the window come alternately from the arena's two sides.  Done once per handle, by the
 // first fl_ensure_vec of a large handle (tuning knob "placement", default 1) or explicitly by fl_poisson_tune_placement.
 
-// "cg_xbatch" (fl_tuning_set; initial value from FLUCA_CG_XBATCH): 1 (default) k_cg_Bq applies both x-updates of an iteration pair on
-// the odd iteration, 0 one per iteration.  Same x bit for bit.
-int &fl_cg_xbatch_mode()
+// ------------------------------------------------------------------------------------------------ knobs (fl_knobs.h)
+namespace fl {
+namespace {
+struct KnobEntry {
+  const char      *name;
+  int              dflt;
+  std::atomic<int> v;
+};
+KnobEntry g_knobs[K_COUNT + 1] = {
+#define X(n, d) {#n, (d), {(d)}},
+    FL_PUBLIC_KNOBS(X) FL_VARIANT_KNOBS(X)
+#undef X
+        {nullptr, 0, {0}}};
+// the one place where the library reads its environment: FLUCA_<NAME> gives a knob its initial value
+void knob_table_init()
 {
-  static int m = []() {
-    const char *e = std::getenv("FLUCA_CG_XBATCH");
-    return e ? std::atoi(e) : 1;
-  }();
-  return m;
+  static std::once_flag once;
+  std::call_once(once, []() {
+    for (int k = 0; k < K_COUNT; ++k) {
+      std::string env = "FLUCA_";
+      for (const char *c = g_knobs[k].name; *c; ++c) env.push_back((char)std::toupper((unsigned char)*c));
+      if (const char *e = std::getenv(env.c_str())) g_knobs[k].v.store(std::atoi(e), std::memory_order_relaxed);
+    }
+  });
 }
-int &fl_placement_mode()
+}  // namespace
+int knob(Knob k)
 {
-  static int m = []() {
-    const char *e = std::getenv("FLUCA_PLACEMENT");
-    return e ? std::atoi(e) : 0;  // opt-in since round 3 (1 - 2 % of the CG rate for a search of ~0.15 s per handle): fl_poisson_tune_placement, or this knob
-  }();
-  return m;
+  knob_table_init();
+  return g_knobs[k].v.load(std::memory_order_relaxed);
+}
+void knob_set(Knob k, int v)
+{
+  knob_table_init();
+  g_knobs[k].v.store(v, std::memory_order_relaxed);
+}
+int knob_find(const char *name)
+{
+  for (int k = 0; k < K_COUNT; ++k)
+    if (std::strcmp(g_knobs[k].name, name) == 0) return k;
+  return -1;
+}
+const char *knob_name(int k) { return k >= 0 && k < K_COUNT ? g_knobs[k].name : nullptr; }
+#ifdef FL_KBENCH_VARIANTS
+const char *variant_env(const char *name) { return std::getenv(name); }
+#endif
+}  // namespace fl
+
+extern "C" int fl_tuning_set(const char *name, int value)
+{
+  if (!name) return FL_ERR_ARG_NULL;
+  const int k = knob_find(name);
+  if (k < 0) return FL_ERR_ARG_WRONG;
+  knob_set((Knob)k, value);
+  return FL_SUCCESS;
+}
+extern "C" int fl_tuning_get(const char *name, int *value)
+{
+  if (!name || !value) return FL_ERR_ARG_NULL;
+  const int k = knob_find(name);
+  if (k < 0) return FL_ERR_ARG_WRONG;
+  *value = knob((Knob)k);
+  return FL_SUCCESS;
 }
 // An arena whose physical memory is a row of separately created chunks mapped into one reserved address range (HIP virtual memory
 // management).  The search below slides its window through it like through a plain allocation; afterwards the chunks the chosen window
@@ -493,10 +545,7 @@ int place_vectors(fl_poisson *h)
     }
     FL_HIP(hipMemcpy(sc.p, S2, sizeof(S2), hipMemcpyHostToDevice));
   }
-  static const int verbose = []() {
-    const char *e = std::getenv("FLUCA_PLACEMENT_VERBOSE");
-    return e ? std::atoi(e) : 0;
-  }();
+  const int verbose = knob(K_placement_verbose);
   // probe = the pair the solver runs: k_cg_A (r, p -> p') and the odd-iteration k_cg_Bq (p', p_old, r, x -> r, x: every window vector but q)
   auto probe = [&](void *arena, size_t b, double *ms_out) -> int {
     auto vec = [&](int k) { return (double *)((char *)arena + b + (size_t)k * vecb); };
@@ -523,10 +572,7 @@ int place_vectors(fl_poisson *h)
   // found 16 GiB in; on some the whole arena answers flat).  A flat arena is kept allocated -- so that the next one comes from other
   // physical memory -- and the search repeated, at most PL_ARENAS times; the losers are freed at the end.
   constexpr int PL_ARENAS = 3;
-  static const int use_vmm = []() {
-    const char *e = std::getenv("FLUCA_PLACEMENT_VMM");  // 1 (default): chunk-mapped arenas, everything but the chosen window is released
-    return e ? std::atoi(e) : 1;
-  }();
+  const int use_vmm = knob(K_placement_vmm);  // 1 (default): chunk-mapped arenas, everything but the chosen window is released
   void  *arena = nullptr;
   size_t want = 0, best = 0;
   double first_ms = 0., best_ms = 0.;
@@ -580,10 +626,8 @@ int place_vectors(fl_poisson *h)
       best    = abest;
       best_ms = abest_ms;
     }
-    static const double thresh = []() {
-      const char *e = std::getenv("FLUCA_PLACEMENT_THRESH");  // experiments: 0 walks through all PL_ARENAS arenas
-      return e ? std::atof(e) : 0.97;
-    }();
+    const char  *te = variant_env("FLUCA_PLACEMENT_THRESH");  // experiments: 0 walks through all PL_ARENAS arenas
+    const double thresh = te ? std::atof(te) : 0.97;
     if (best_ms <= thresh * first_ms) break;  // a seam was found
   }
   if (!arena) return 0;  // no memory for an arena: plain allocations
@@ -713,7 +757,7 @@ extern "C" int fl_poisson_vector_bytes(fl_poisson *h, int64_t *bytes_out)
 int fl_ensure_vec(fl_poisson *h, double **v)
 {
   if (*v) return 0;
-  if (h->nv_il == 1 && !h->placed && h->nvec == 0 && fl_placement_mode() > 0 && sizeof(double) * h->padlen >= PL_MIN_VEC) {
+  if (h->nv_il == 1 && !h->placed && h->nvec == 0 && knob(K_placement) > 0 && sizeof(double) * h->padlen >= PL_MIN_VEC) {
     // carves r, P0, P1, q, xp out of one allocation (see "placement" above).  A failure in there (memory short, a probe launch refused)
     // is no reason to fail the caller's solve: whatever the search held is released and the vectors become plain allocations.
     if (place_vectors(h) != 0) {
@@ -737,17 +781,10 @@ int fl_ensure_vec(fl_poisson *h, double **v)
     *v = (double *)h->slab + (size_t)h->sx0 * (size_t)h->nvec++;
     return 0;
   }
-  static const long gap = []() {
-    const char *e = std::getenv("FLUCA_GAP");
-    long        s = e ? std::atol(e) : FL_DEFAULT_GAP;
-    return (s / 128) * 128;
-  }();
+  const long gap = ((long)FL_VARIANT(gap, FL_DEFAULT_GAP) / 128) * 128;
   constexpr int NSLOTS = 8;
   const size_t  slot   = ((sizeof(double) * h->padlen + 127) / 128) * 128 + (size_t)gap;
-  static const bool use_slab = []() {
-    const char *e = std::getenv("FLUCA_SLAB");
-    return e ? std::atoi(e) != 0 : false;  // default: one hipMalloc per vector (placement)
-  }();
+  const bool use_slab = FL_VARIANT(slab, 0) != 0;  // default: one hipMalloc per vector (placement)
   if (!use_slab) {
     void *base = nullptr;
     FL_CHK(fl_dev_alloc(h, &base, slot, true));
@@ -1081,10 +1118,9 @@ extern "C" int fl_poisson_project(fl_poisson *h, const double *p_dev, double *vx
   if (!h || !p_dev) return FL_ERR_ARG_NULL;
   FL_HIP(hipSetDevice(h->device));
   double *v[3] = {vx, vy, vz}, *V[3] = {Vx, Vy, Vz};
-  static const int fused = []() {
-    const char *e = std::getenv("FLUCA_PROJECT_FUSED");  // A/B runs.  0: one kernel per output array (round 1); 1: k_project_all (round 3);
-    return e ? std::atoi(e) : 3;                         // 2: k_project_six on the padded p; 3 (default): on the caller's p where one rank holds the grid
-  }();
+  // A/B runs.  0: one kernel per output array (round 1); 1: k_project_all (round 3); 2: k_project_six on the padded p; 3 (shipped): on the caller's p where
+  // one rank holds the grid
+  const int fused = FL_VARIANT(project_fused, 3);
   // all six arrays (PCApply_ABF's call), one rank: k_project_six reads the caller's p itself -- no padded copy, no ghost layers
   if (fused >= 3 && !h->multi && project_six_usable(h->g, p_dev, v, V)) {
     int per = 0;
@@ -1101,12 +1137,17 @@ extern "C" int fl_poisson_project(fl_poisson *h, const double *p_dev, double *vx
     FL_HIP(hipGetLastError());
     return FL_SUCCESS;
   }
-  if (fused) launch_project_all(h->stream, h->g, h->w0, v, V);  // the six updates in one pass over p
-  else
+#ifdef FL_KBENCH_VARIANTS
+  if (!fused) {
     for (int d = 0; d < 3; ++d) {
       if (v[d]) launch_project_cells(h->stream, h->g, h->w0, v[d], d);
       if (V[d]) launch_project_faces(h->stream, h->g, h->w0, V[d], d);
     }
+    FL_HIP(hipGetLastError());
+    return FL_SUCCESS;
+  }
+#endif
+  launch_project_all(h->stream, h->g, h->w0, v, V);  // any subset of the six arrays, one pass over p
   FL_HIP(hipGetLastError());
   return FL_SUCCESS;
 }
@@ -1209,31 +1250,22 @@ static int solve_cg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts
   FL_CHK(fl_ensure_vec(h, &h->xp));
   // variant 0 (default): k_cg_A<SQ = false> + k_cg_Bq, q = S p' formed twice and never stored (64 B/cell/iteration);
   // variant 2: k_cg_A stores q, k_cg_B reads it back (72 B/cell; the default until round 2); variant 1: one kernel per step
-  static const int variant_env = []() {
-    const char *e = std::getenv("FLUCA_CG_VARIANT");
-    return e ? std::atoi(e) : -1;
-  }();
-  const int variant = (o->variant == 0 && variant_env >= 0) ? variant_env : o->variant;
+  const int variant_forced = FL_VARIANT(cg_variant, -1);
+  const int variant = (o->variant == 0 && variant_forced >= 0) ? variant_forced : o->variant;
+#ifndef FL_KBENCH_VARIANTS
+  if (variant != 0) return FL_ERR_SUP;  // variants 1 and 2 (superseded, A/B material) live in the kbench build only (include/fluca_hip.h, fl_ksp_opts.variant)
+#endif
   const bool storeq = variant != 0;  // variants 1 and 2 keep q in memory and update r with k_cg_B
   PlanA       plan = plan_cg_A(g, 0, 0);
   plan.sq          = storeq ? 1 : 0;
-  static const int qb_env = []() {
-    const char *e = std::getenv("FLUCA_CG_QB");  // experiments (only with FLUCA_OVERLAP=0): 0 = k_cg_A stores no q at all
-    return e ? std::atoi(e) : 1;
-  }();
+  const int qb_env = FL_VARIANT(cg_qb, 1);  // experiments (only with "overlap" = 0): 0 = k_cg_A stores no q at all
   plan.qb          = (!storeq && h->multi && qb_env) ? 1 : 0;  // several ranks: q of the boundary layers is kept for the overlapped exchange of r
-  static const int bq_chunks_env = []() {
-    const char *e = std::getenv("FLUCA_CGBQ_CHUNKS");  // experiments: z chunks of k_cg_Bq (default: those of k_cg_A)
-    return e ? std::atoi(e) : 0;
-  }();
+  const int bq_chunks_env = FL_VARIANT(cgbq_chunks, 0);  // experiments: z chunks of k_cg_Bq (default: those of k_cg_A)
   PlanA planB = storeq ? plan_cg_B(g) : (bq_chunks_env > 0 ? plan_tiles(g, plan.ry, plan.nw, bq_chunks_env, 0) : plan);  // k_cg_Bq walks the tiles of k_cg_A
   {
     struct Force { int ry = 0, nw = 0, nchunk = 0; };
-    static const Force fb = []() {
-      Force f;
-      if (const char *e = std::getenv("FLUCA_CGBQ_PLAN")) std::sscanf(e, "%d,%d,%d", &f.ry, &f.nw, &f.nchunk);  // experiments: a tiling of its own for k_cg_Bq
-      return f;
-    }();
+    Force fb;
+    if (const char *e = variant_env("FLUCA_CGBQ_PLAN")) std::sscanf(e, "%d,%d,%d", &fb.ry, &fb.nw, &fb.nchunk);  // experiments: a tiling of its own for k_cg_Bq
     if (!storeq && (fb.ry == 1 || fb.ry == 2) && (fb.nw == 4 || (fb.nw == 8 && fb.ry == 2)) && fb.nchunk > 0 && g.ny >= 8) {
       const PlanA keep = planB;
       planB            = plan_tiles(g, fb.ry, fb.nw, fb.nchunk, 0);
@@ -1247,7 +1279,7 @@ static int solve_cg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts
   FL_CHK(fl_ensure_hist(h, nhist));
   hipStream_t s = h->stream;
 
-  const bool xbatch_env = fl_cg_xbatch_mode() != 0;
+  const bool xbatch_env = knob(K_cg_xbatch) != 0;
   // q-free pair with batched x-updates: the padded x is not zeroed -- the first pair of updates (iteration 1) writes it without reading
   // it, and until then KspScal::x_valid = 0 tells k_cg_finish that it stands for 0
   const bool xlazy = !storeq && xbatch_env;
@@ -1279,14 +1311,8 @@ static int solve_cg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts
   const bool ghosts = fl_any_ghost_exchange(h);
   if (ghosts) FL_CHK(fl_fill_ghosts(h, h->r));
   // single rank: the last block of k_cg_A / k_cg_B performs the scalar update itself (no k_cg_fin launches)
-  static const bool fusedfin_env = []() {
-    const char *e = std::getenv("FLUCA_FUSEDFIN");
-    return e ? std::atoi(e) != 0 : true;
-  }();
-  static const bool overlap_env = []() {
-    const char *e = std::getenv("FLUCA_OVERLAP");  // 0: pack / transfer / unpack after k_cg_B, on the handle's stream (A/B measurements)
-    return e ? std::atoi(e) != 0 : true;
-  }();
+  const bool fusedfin_env = FL_VARIANT(fusedfin, 1) != 0;
+  const bool overlap_env  = knob(K_overlap) != 0;  // 0: pack / transfer / unpack after the update kernel, on the handle's stream (A/B measurements, tests)
   const bool fusedfin = !h->multi && variant != 1 && fusedfin_env;
   // several ranks: the last block of k_cg_A / k_cg_B still reduces the rank's partial sums (no k_reduce launch); the
   // all-reduce and the scalar kernel follow
@@ -1578,6 +1604,9 @@ extern "C" int fl_poisson_comm_info(fl_poisson *h, fl_comm_info *out)
 extern "C" int fldbg_bench(fl_poisson *h, int kernel, int ry, int pf, int nchunk, int reps, const double *src_dev, double *ms_out, int *nblocks_out)
 {
   if (!h || !ms_out) return FL_ERR_ARG_NULL;
+#ifndef FL_KBENCH_VARIANTS
+  if (kernel != 0 && kernel != 2 && kernel != 3) return FL_ERR_SUP;  // the product keeps what bench.py measures with: k_cg_A and the streaming probes
+#endif
   FL_HIP(hipSetDevice(h->device));
   const GridP &g = h->g;
   if (kernel == 8) {
@@ -1629,7 +1658,7 @@ extern "C" int fldbg_bench(fl_poisson *h, int kernel, int ry, int pf, int nchunk
   std::memset(&S, 0, sizeof(S));
   S.beta = 0.5; S.alpha = 1e-3; S.zshift = 1e-4; S.ncell_global = (double)h->ncell; S.maxit = 1 << 30; S.pending_x = 1; S.nullspace = 1; S.rz = 1.;
   FL_HIP(hipMemcpyAsync(h->scal, h->scal_host, sizeof(KspScal), hipMemcpyHostToDevice, s));
-  if (std::getenv("FLUCA_PRINT_PTRS") && kernel == 0)
+  if (FL_VARIANT(print_ptrs, 0) && kernel == 0)
     std::fprintf(stderr, "[ptrs] r=%p P0=%p P1=%p q=%p xp=%p w0=%p\n", (void *)h->r, (void *)h->P0, (void *)h->P1, (void *)h->q, (void *)h->xp, (void *)h->w0);
   auto once = [&]() {
     if (kernel == 0) launch_cg_A(s, g, true, plan, h->r, h->P0, h->P1, h->q, h->xp, h->scal, h->partial, nullptr, nullptr, 0);
@@ -1654,6 +1683,7 @@ extern "C" int fldbg_bench(fl_poisson *h, int kernel, int ry, int pf, int nchunk
   return FL_SUCCESS;
 }
 
+#ifdef FL_KBENCH_VARIANTS  // experiments behind the placement notes of DESIGN.md: not in the product
 // Experiment behind fl_poisson_tune_placement (tools/experiments/pool_probe.py): K vectors allocated once, M random
 // assignments of five of them to the roles (r, p0, p1, q, x) of k_cg_A, probe time of each.
 extern "C" int fldbg_pool_probe(fl_poisson *h, int K, int M, unsigned seed, double *ms_out, int *sel_out)
@@ -1823,3 +1853,4 @@ extern "C" int fldbg_kernel_ptrs(fl_poisson *h, int kernel, void *const *ptrs, i
   *ms_out = ms / (2 * reps);
   return FL_SUCCESS;
 }
+#endif  // FL_KBENCH_VARIANTS

@@ -494,10 +494,7 @@ int fl_cheb2_agree(fl_poisson *h)
 Cheb2Plan fl_cheb2_plan(const GridP &g)
 {
   Cheb2Plan p;
-  static const int force_nw = []() {
-    const char *e = std::getenv("FLUCA_CHEB2_NW");  // experiments: 4 = 128 x 8 tiles (two 256-thread blocks per CU), 8 = 128 x 16
-    return e ? std::atoi(e) : 0;
-  }();
+  const int force_nw = FL_VARIANT(cheb2_nw, 0);  // experiments: 4 = 128 x 8 tiles (two 256-thread blocks per CU), 8 = 128 x 16
   p.nw      = (force_nw == 4 || force_nw == 8) ? force_nw : (g.ny > 8 ? 8 : 4);
   p.tiles_x = (g.nx + 127) / 128;
   const int ty    = 2 * p.nw;
@@ -505,10 +502,7 @@ Cheb2Plan fl_cheb2_plan(const GridP &g)
   p.tiles         = tiles;
   // one block per CU is resident (120 KB of LDS): aim at one full wave of 256 blocks; a chunk re-reads 4 planes of x and 2 of
   // b and d, so chunks stay >= 16 planes
-  static const int force = []() {
-    const char *e = std::getenv("FLUCA_CHEB2_NCHUNK");
-    return e ? std::atoi(e) : 0;
-  }();
+  const int force = FL_VARIANT(cheb2_nchunk, 0);
   int nchunk = force > 0 ? force : std::max(1, (256 + tiles / 2) / tiles);
   if (force <= 0 && tiles * nchunk > 256 && tiles <= 256) nchunk = std::max(1, 256 / tiles);  // never a second round of blocks (384^3: 72 tiles x 4 chunks = 288 -> 216;
                                                                                              // the CG pair gained 35 % from the same rule, profiles/r04_cg_plans.txt)

@@ -13,13 +13,7 @@
 #include <string>
 
 #include "fl_internal.h"
-
-#ifndef FL_DEFAULT_GAP
-#define FL_DEFAULT_GAP 0
-#endif
-#ifndef FL_DEFAULT_INTERLEAVE
-#define FL_DEFAULT_INTERLEAVE 0
-#endif
+#include "fl_knobs.h"
 
 namespace fl {
 
@@ -168,12 +162,11 @@ struct Comm {
     }
     if (kind == HOST) {
       const int n = (int)m.size();
-      static const bool trace = []() { const char *e = std::getenv("FLUCA_COMM_TRACE"); return e && std::atoi(e) != 0; }();
-      if (trace) {
-        static long seq = 0;
+      if (knob(K_comm_trace) != 0) {
+        static std::atomic<long> seq{0};
         struct timespec ts;
         clock_gettime(CLOCK_MONOTONIC, &ts);
-        std::fprintf(stderr, "[%.3f comm r%d #%ld] exchange %d msgs:", ts.tv_sec % 1000 + 1e-9 * ts.tv_nsec, rank, seq++, n);
+        std::fprintf(stderr, "[%.3f comm r%d #%ld] exchange %d msgs:", ts.tv_sec % 1000 + 1e-9 * ts.tv_nsec, rank, seq.fetch_add(1), n);
         for (const Msg &x : m) std::fprintf(stderr, " (peer %d stag %d rtag %d n %lld%s%s)", x.peer, x.sendtag, x.recvtag, (long long)x.count, x.send ? " S" : "", x.recv ? " R" : "");
         std::fprintf(stderr, "\n");
         std::fflush(stderr);
@@ -371,11 +364,7 @@ struct ProfEvents {
 // shared host helpers (fl_api.hip)
 int  fl_dev_alloc(fl_poisson *h, void **p, size_t bytes, bool zero);
 int  fl_ensure_vec(fl_poisson *h, double **v);
-int &fl_placement_mode();
 void fl_vmm_destroy(fl_poisson *h);
-int &fl_cg_xbatch_mode();
-int &fl_mg_prolong_mode();  // fl_mg.hip: 0 piecewise constant, 1 tri-linear
-int &fl_mg_flexible_mode(); // fl_mg.hip: 0 KSPCG's beta, 1 the Polak-Ribiere form (flexible CG)
 int  fl_ensure_partials(fl_poisson *h, int nblocks);
 int  fl_ensure_hist(fl_poisson *h, int nhist);
 int  fl_zero_vec(fl_poisson *h, double *v);
@@ -393,7 +382,7 @@ int fl_residual(fl_poisson *h, const double *x, const double *b, double *r);
 int fl_residual_padded(fl_poisson *h, double *xpad, const double *bpad, double *rpad);
 int fl_residual_restrict_padded(fl_poisson *h, double *xpad, const double *bpad, const double *wx, const double *wy, const double *wz, fl_poisson *hc, double *cpad);
 int fl_apply_padded_dot(fl_poisson *h, double *xpad, double *ypad, double *xy);
-int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero, bool *mgdots = nullptr, const double *subq = nullptr, double suba = 0.);
+int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero, bool *mgdots = nullptr, const double *subq = nullptr, const double *suba_dev = nullptr);
 int fl_solve_bcgs(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *o, fl_ksp_stats *st);
 int fl_solve_cg_sr(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *o, fl_ksp_stats *st);
 int fl_ksp_begin(fl_poisson *h, const fl_ksp_opts *o);

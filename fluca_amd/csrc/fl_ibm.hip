@@ -190,6 +190,7 @@ __global__ void __launch_bounds__(256) k_ibm_interp(IbmP P, const int *__restric
 }
 
 // f[c*ncell + x] += sum_l w_l(x) F[c*L + l] dV_l / (hx hy hz), gather over the tile's bin, markers in ascending id order
+#ifdef FL_KBENCH_VARIANTS  // round 1's spreading loop (A/B runs)
 __global__ void __launch_bounds__(256) k_ibm_spread_v1(IbmP P, const int *__restrict__ i0, const double *__restrict__ w, const int *__restrict__ off, const int *__restrict__ list, const int *__restrict__ active, int ncomp, int64_t ncell, const double *__restrict__ F,
                                                       const double *__restrict__ dV, double *__restrict__ f)
 {
@@ -258,6 +259,7 @@ __global__ void __launch_bounds__(256) k_ibm_spread_v1(IbmP P, const int *__rest
         if (acc[half][c] != 0.) f[(int64_t)c * ncell + cell] += acc[half][c] * vinv;
     }
 }
+#endif  // FL_KBENCH_VARIANTS
 
 // Round 4.  The loop above is a chain of dependent LDS reads per marker (its first cell -> the index into its weights -> the weight) behind two
 // divergent tests, one wave per SIMD and block: about 300 cycles per marker and 150 markers per bin of config 4's sphere.  Here the staging step expands
@@ -479,6 +481,7 @@ extern "C" int fl_ibm_interp(fl_ibm *m, int ncomp, const double *u, double *U)
 }
 
 // bin statistics of the current marker positions (experiments): tiles with a non-empty bin, entries of all bins, the largest bin
+#ifdef FL_KBENCH_VARIANTS  // bin statistics for tools/ibm_bench.py
 extern "C" int fldbg_ibm_stats(fl_ibm *m, int *nactive, int *entries, int *maxbin)
 {
   if (!m) return FL_ERR_ARG_NULL;
@@ -492,6 +495,7 @@ extern "C" int fldbg_ibm_stats(fl_ibm *m, int *nactive, int *entries, int *maxbi
   if (maxbin) *maxbin = mx;
   return FL_SUCCESS;
 }
+#endif  // FL_KBENCH_VARIANTS
 
 extern "C" int fl_ibm_spread(fl_ibm *m, int ncomp, const double *F, const double *dV, double *f)
 {
@@ -499,13 +503,13 @@ extern "C" int fl_ibm_spread(fl_ibm *m, int ncomp, const double *F, const double
   if (ncomp < 1 || ncomp > 3) return FL_ERR_ARG_OUTOFRANGE;
   fl_poisson *h = m->gp;
   FL_HIP(hipSetDevice(h->device));
-  static const bool v1 = []() {
-    const char *e = std::getenv("FLUCA_IBM_SPREAD");  // 1: round 1's loop over the bin (A/B runs)
-    return e && std::atoi(e) == 1;
-  }();
   if (m->nactive > 0) {
-    if (v1) hipLaunchKernelGGL(k_ibm_spread_v1, dim3(m->nactive), dim3(256), 0, h->stream, m->P, m->i0, m->w, m->off, m->list, m->active, ncomp, h->ncell, F, dV, f);
-    else hipLaunchKernelGGL(k_ibm_spread, dim3(m->nactive), dim3(256), 0, h->stream, m->P, m->i0, m->w, m->off, m->list, m->active, ncomp, h->ncell, F, dV, f);
+#ifdef FL_KBENCH_VARIANTS
+    if (FL_VARIANT(ibm_spread, 0) == 1)  // round 1's loop over the bin (A/B runs)
+      hipLaunchKernelGGL(k_ibm_spread_v1, dim3(m->nactive), dim3(256), 0, h->stream, m->P, m->i0, m->w, m->off, m->list, m->active, ncomp, h->ncell, F, dV, f);
+    else
+#endif
+      hipLaunchKernelGGL(k_ibm_spread, dim3(m->nactive), dim3(256), 0, h->stream, m->P, m->i0, m->w, m->off, m->list, m->active, ncomp, h->ncell, F, dV, f);
   }
   FL_HIP(hipGetLastError());
   return FL_SUCCESS;

@@ -16,6 +16,7 @@
 //           pair moves 40 + 24 = 64 B/cell/iteration (+ tile rings).  The solver's default since round 2.
 #include "fl_internal.h"
 #include "fl_stencil.h"
+#include "fl_knobs.h"
 
 #ifndef FL_CGA_WPE
 #define FL_CGA_WPE 2  // waves per SIMD the register allocator must leave room for: 2 = up to 256 VGPRs (one 512-thread block per CU), 4 = at most 128 (two blocks)
@@ -274,6 +275,7 @@ __global__ void k_face_plane0(GridP g, const double *__restrict__ V, double *__r
 }
 
 // V_d -= kappa * Gst p on the owned faces of axis d (p padded with ghosts)
+#ifdef FL_KBENCH_VARIANTS  // round 1: one projection kernel per output array
 __global__ void k_project_faces(GridP g, const double *__restrict__ p, double *__restrict__ V, int axis)
 {
   const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
@@ -303,6 +305,7 @@ __global__ void k_project_cells(GridP g, const double *__restrict__ p, double *_
   if (v2 != 0.) gr += v2 * p[pc + 2 * st];
   v[((int64_t)k * g.ny + j) * g.nx + i] -= g.kappa * gr;
 }
+#endif  // FL_KBENCH_VARIANTS
 
 // The whole stage-2 update of PCApply_ABF (abfpc.c:79-101) in ONE pass over p:  v_d -= kappa (G p)_d on the cells and V_d -= kappa (Gst p)_d on the
 // owned faces of all three axes -- the rows and the arithmetic of k_project_cells / k_project_faces (same products, same order: bit-identical), but p is
@@ -840,6 +843,7 @@ __global__ void __launch_bounds__(256) k_cg_init(GridP g, const double *__restri
 // r -= alpha q ; partial sums of the new r.  24 B/cell.  Same 128 x (4*RY) x zc tiling as k_cg_A (no integer division in
 // the loop); loads are unconditional on clamped, always-valid addresses so that the compiler can count them (a load
 // inside a divergent branch costs an s_waitcnt vmcnt(0)); only the stores and the sums are masked.
+#ifdef FL_KBENCH_VARIANTS  // variant 2 of the CG pair: the r-update that reads a stored q
 template <int RY, bool JAC, int NT>
 __global__ void __launch_bounds__(256) k_cg_B(GridP g, const double *__restrict__ q, double *__restrict__ r, KspScal *__restrict__ s, double *__restrict__ partial, int stride, int nchunk, int zc, int tiles_x, FinCtx fin)
 {
@@ -920,6 +924,7 @@ __global__ void __launch_bounds__(256) k_cg_B(GridP g, const double *__restrict_
 #pragma unroll
     for (int a = 0; a < 5; ++a) partial[(int64_t)a * stride + blockIdx.x] = acc[a];
 }
+#endif  // FL_KBENCH_VARIANTS
 
 // the x-update still owed when the iteration stops, fused with the copy into the caller's (unpadded) array:
 //   xout = x + alpha p   (p = the current direction; plain copy when nothing is pending).  The padded x is not updated: the
@@ -1419,6 +1424,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_cg_Bq_probe(FL_CG_BQ_ARGS)
 // ------------------------------------------------------------------------------------------------ unfused CG pieces (variant 1)
 
 // p = (r/diag - mean) + beta p on the owned cells
+#ifdef FL_KBENCH_VARIANTS  // variant 1 of the CG solver: one kernel per BLAS-1 / SpMV step
 template <bool JAC>
 __global__ void k_cg_pupdate(GridP g, const double *__restrict__ r, double *__restrict__ P0, double *__restrict__ P1, const KspScal *__restrict__ s)
 {
@@ -1458,6 +1464,7 @@ __global__ void __launch_bounds__(256) k_cg_apply_dot(GridP g, const double *__r
     if (lin == 0) partial[((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
   }
 }
+#endif  // FL_KBENCH_VARIANTS
 
 // ------------------------------------------------------------------------------------------------ bandwidth reference
 // NR input streams, NW output streams, 16 B per lane per access, grid-stride: the realistic HBM ceiling for a kernel with
@@ -1614,8 +1621,10 @@ void launch_face_plane0(hipStream_t st, const GridP &g, const double *V, double 
 }
 void launch_project_faces(hipStream_t st, const GridP &g, const double *p, double *V, int axis)
 {
+#ifdef FL_KBENCH_VARIANTS
   const int lx = axis == 0 ? g.fx : g.nx, ly = axis == 1 ? g.fy : g.ny, lz = axis == 2 ? g.fz : g.nz;
   if (lz > 0) hipLaunchKernelGGL(k_project_faces, grid3(lx, ly, lz), blk3(), 0, st, g, p, V, axis);
+#endif
 }
 void launch_project_all(hipStream_t st, const GridP &g, const double *p, double *const v[3], double *const V[3])
 {
@@ -1653,11 +1662,8 @@ void launch_project_six(hipStream_t st, const GridP &g, const double *p, bool di
   // per XCD 2.69 ms, 256: 2.97, 16384 (a row per wave): 2.87; without the slabs (nxcd 1) 2.76 - 2.86; without the hint 2.78; two rows per pass
   // (244 VGPRs) 2.86; capped at 128 VGPRs 2.85
   struct Var { int nt = 1, nxcd = 8, nbx = 1024; };
-  static const Var var = []() {
-    Var x;
-    if (const char *e = std::getenv("FLUCA_PROJECT_VAR")) std::sscanf(e, "%d,%d,%d", &x.nt, &x.nxcd, &x.nbx);
-    return x;
-  }();
+  Var var;
+  if (const char *e = variant_env("FLUCA_PROJECT_VAR")) std::sscanf(e, "%d,%d,%d", &var.nt, &var.nxcd, &var.nbx);
   const int nseg = (g.nx + 127) / 128;
   const int nxcd = (var.nxcd == 1 || g.ny < 8) ? 1 : 8;
   // blocks of four waves per XCD: a multiple of nseg (a wave keeps its segment), no more than the rows of a slab need
@@ -1673,7 +1679,12 @@ void launch_project_six(hipStream_t st, const GridP &g, const double *p, bool di
     else hipLaunchKernelGGL((k_project_six<false, 0, 1>), gr, bl, 0, st, g, p, o, per, nxcd);
   }
 }
-void launch_project_cells(hipStream_t st, const GridP &g, const double *p, double *v, int axis) { hipLaunchKernelGGL(k_project_cells, grid3(g.nx, g.ny, g.nz), blk3(), 0, st, g, p, v, axis); }
+void launch_project_cells(hipStream_t st, const GridP &g, const double *p, double *v, int axis)
+{
+#ifdef FL_KBENCH_VARIANTS
+  hipLaunchKernelGGL(k_project_cells, grid3(g.nx, g.ny, g.nz), blk3(), 0, st, g, p, v, axis);
+#endif
+}
 void launch_gst_bc(hipStream_t st, const GridP &g, const double *pb, double *V, int axis, int side, double coeff, int add)
 {
   const int na = axis == 0 ? g.ny : g.nx, nb = axis == 2 ? g.ny : g.nz;
@@ -1757,10 +1768,7 @@ constexpr int MIN_BLOCKS = 256;  // one per CU
 // round-1 plan of 128 x 16 x 16 chunks: 164), k_cg_B 128 x 4 x 4 chunks (70 us; round 1: 128 x 16 x 32 chunks, 108).
 PlanA plan_cg_A(const GridP &g, int ry_force, int nchunk_force)
 {
-  static const int target_env = []() {
-    const char *e = std::getenv("FLUCA_CGA_TARGET");
-    return e ? std::atoi(e) : 0;
-  }();
+  const int target_env = FL_VARIANT(cga_target, 0);
   const int target = target_env > 0 ? target_env : 256;
   const int ry = ry_force > 0 ? ry_force : (g.ny >= 8 ? 2 : 1);
   // 128 x 16 tiles (8 waves) when they alone nearly fill the chip, 128 x 8 (4 waves) below that
@@ -1782,11 +1790,8 @@ PlanA plan_cg_A(const GridP &g, int ry_force, int nchunk_force)
   p.nt         = 2;
   // experiments (tools/experiments/r04_cg256.sh): FLUCA_CG_PLAN="ry,nw,nchunk" replaces the tiling of k_cg_A / k_cg_Bq on every grid
   struct Force { int ry = 0, nw = 0, nchunk = 0; };
-  static const Force force = []() {
-    Force f;
-    if (const char *e = std::getenv("FLUCA_CG_PLAN")) std::sscanf(e, "%d,%d,%d", &f.ry, &f.nw, &f.nchunk);
-    return f;
-  }();
+  Force force;
+  if (const char *e = variant_env("FLUCA_CG_PLAN")) std::sscanf(e, "%d,%d,%d", &force.ry, &force.nw, &force.nchunk);
   if (ry_force <= 0 && nchunk_force <= 0 && (force.ry == 1 || force.ry == 2) && (force.nw == 4 || (force.nw == 8 && force.ry == 2)) && g.ny >= 8) {
     p    = plan_tiles(g, force.ry, force.nw, std::max(force.nchunk, 1), 0);
     p.pf = 1;
@@ -1827,8 +1832,13 @@ static void launch_cg_A_q(hipStream_t st, const GridP &g, bool jac, const PlanA 
 template <int RY, int NW, int PF, int NT>
 static void launch_cg_A_t(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const double *r, double *P0, double *P1, double *q, double *x, KspScal *s, double *partial, const FinCtx &fin)
 {
-  if (p.sq) launch_cg_A_q<RY, NW, PF, NT, true>(st, g, jac, p, r, P0, P1, q, x, s, partial, fin);
-  else launch_cg_A_q<RY, NW, PF, NT, false>(st, g, jac, p, r, P0, P1, q, x, s, partial, fin);
+#ifdef FL_KBENCH_VARIANTS
+  if (p.sq) {  // variant 2: q stored
+    launch_cg_A_q<RY, NW, PF, NT, true>(st, g, jac, p, r, P0, P1, q, x, s, partial, fin);
+    return;
+  }
+#endif
+  launch_cg_A_q<RY, NW, PF, NT, false>(st, g, jac, p, r, P0, P1, q, x, s, partial, fin);
 }
 template <int RY, int NW>
 static void launch_cg_A_v(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const double *r, double *P0, double *P1, double *q, double *x, KspScal *s, double *partial, const FinCtx &fin)
@@ -1864,6 +1874,7 @@ void launch_cg_A(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const
   }
 }
 
+#ifdef FL_KBENCH_VARIANTS  // variant 2 of the CG pair (q stored, k_cg_B reads it back)
 template <int RY>
 static void launch_cg_B_ry(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const double *q, double *r, KspScal *s, double *partial, int stride, const FinCtx &fin)
 {
@@ -1876,8 +1887,10 @@ static void launch_cg_B_ry(hipStream_t st, const GridP &g, bool jac, const PlanA
     else hipLaunchKernelGGL((k_cg_B<RY, false, 0>), gr, bl, 0, st, g, q, r, s, partial, stride, p.nchunk, p.zc, p.tiles_x, fin);
   }
 }
+#endif  // FL_KBENCH_VARIANTS
 void launch_cg_B(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const double *q, double *r, KspScal *s, double *partial, int stride, unsigned *counter, double *hist, int nhist, double *sums)
 {
+#ifdef FL_KBENCH_VARIANTS
   FinCtx fin;
   fin.sums    = sums;
   fin.counter = counter;
@@ -1889,6 +1902,7 @@ void launch_cg_B(hipStream_t st, const GridP &g, bool jac, const PlanA &p, const
   case 2: launch_cg_B_ry<2>(st, g, jac, p, q, r, s, partial, stride, fin); break;
   default: launch_cg_B_ry<1>(st, g, jac, p, q, r, s, partial, stride, fin); break;
   }
+#endif
 }
 
 // k_cg_Bq on the tiling of k_cg_A (plan_cg_A).  xmode: 0 no x-update, 1 x += alpha p', 2 the two updates owed on odd iterations
@@ -1965,13 +1979,17 @@ void launch_stream_par(hipStream_t st, int nr, int nw, int u, int nt, int nblock
 
 void launch_cg_pupdate(hipStream_t st, const GridP &g, bool jac, const double *r, double *P0, double *P1, const KspScal *s)
 {
+#ifdef FL_KBENCH_VARIANTS
   if (jac) hipLaunchKernelGGL(k_cg_pupdate<true>, grid3(g.nx, g.ny, g.nz), blk3(), 0, st, g, r, P0, P1, s);
   else hipLaunchKernelGGL(k_cg_pupdate<false>, grid3(g.nx, g.ny, g.nz), blk3(), 0, st, g, r, P0, P1, s);
+#endif
 }
 int  apply_dot_blocks(const GridP &g) { return ((g.nx + 63) / 64) * ((g.ny + 3) / 4) * g.nz; }
 void launch_cg_apply_dot(hipStream_t st, const GridP &g, const double *P0, const double *P1, double *q, double *x, const KspScal *s, double *partial)
 {
+#ifdef FL_KBENCH_VARIANTS
   hipLaunchKernelGGL(k_cg_apply_dot, grid3(g.nx, g.ny, g.nz), blk3(), 0, st, g, P0, P1, q, x, s, partial);
+#endif
 }
 
 }  // namespace fl

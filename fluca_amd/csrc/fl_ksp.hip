@@ -815,12 +815,14 @@ __global__ void __launch_bounds__(256) k_cheb(GridP g, const double *X0, const d
 // The first step from a zero initial guess (rho = 0, x = 0): z = M b ; d = c z ; x' = d.  The same numbers k_cheb produces
 // from a zeroed x (S 0 = +0, b - 0 = b, 0 + d = d), without zeroing x, reading it and d, or the stencil: 8 B/cell read and
 // 16 written instead of 8 (memset) + 24 + 16.  No sums: only for the smoother call (KSP_NORM_NONE, no null space).
-// SUB: the right-hand side is updated on the way, b -= suba * subq (the outer CG's r -= alpha q in front of a multigrid cycle)
+// SUB: the right-hand side is updated on the way, b -= suba * subq (the outer CG's r -= alpha q in front of a multigrid cycle); the step length
+// is read from DEVICE memory (the outer iteration's scalars never visit the host between two cycles, fl_mg.hip)
 template <bool JAC, bool SUB = false>
 __global__ void __launch_bounds__(256) k_cheb_first(GridP g, double *X0w, double *X1w, double *__restrict__ b, double *D0, double *D1, const KspScal *__restrict__ s, const double *__restrict__ subq = nullptr,
-                                                    double suba = 0.)
+                                                    const double *__restrict__ suba_dev = nullptr)
 {
   if (s->reason != 0) return;
+  const double suba = SUB ? *suba_dev : 0.;
   double       *xn = s->cur ? X0w : X1w;
   double *__restrict__ d = s->dcur ? D1 : D0;
   const double  cc = s->cheb_c;
@@ -1012,15 +1014,9 @@ void cheb_st_t(fl_poisson *h, const PlanA &p, bool jac, double *X0, double *X1, 
   if (jac) hipLaunchKernelGGL((k_cheb_st<RY, NW, true>), gr, bl, 0, h->stream, h->g, X0, X1, X0, X1, B, D0, D1, h->scal, h->partial, h->partial_stride, p.nchunk, p.zc, p.tiles_x, tiles, p.remap);
   else hipLaunchKernelGGL((k_cheb_st<RY, NW, false>), gr, bl, 0, h->stream, h->g, X0, X1, X0, X1, B, D0, D1, h->scal, h->partial, h->partial_stride, p.nchunk, p.zc, p.tiles_x, tiles, p.remap);
 }
-// "cheb_staged" (initial value from FLUCA_CHEB_STAGED): 1 (default) the one-step kernel on the LDS-staged walk (k_cheb_st), 0 round 1's k_cheb
-int &cheb_staged_mode()
-{
-  static int m = []() {
-    const char *e = std::getenv("FLUCA_CHEB_STAGED");
-    return e ? std::atoi(e) : 1;
-  }();
-  return m;
-}
+// variant switch "cheb_staged": 1 (shipped) the one-step kernel on the LDS-staged walk (k_cheb_st), 0 round 1's k_cheb (kbench build only; the product keeps
+// k_cheb for the one case the staged walk does not cover: more blocks than partial-sum slots)
+static inline int cheb_staged_mode() { return FL_VARIANT(cheb_staged, 1); }
 // one Chebyshev step; returns the number of blocks whose partial sums the scalar kernel has to add up
 int launch_cheb(fl_poisson *h, const TP &tp, bool jac, double *X0, double *X1, const double *B, double *D0, double *D1)
 {
@@ -1045,16 +1041,9 @@ int launch_cheb(fl_poisson *h, const TP &tp, bool jac, double *X0, double *X1, c
   return tp.nblocks;
 }
 
-// "cheb_fuse" (fl_tuning_set; initial value from FLUCA_CHEB_FUSE): 0 never use the fused two-step kernel, 1 (default) where it
-// pays (grids of at least 32^3 cells), 2 wherever it is legal (tests)
-int &cheb_fuse_mode()
-{
-  static int m = []() {
-    const char *e = std::getenv("FLUCA_CHEB_FUSE");
-    return e ? std::atoi(e) : 1;
-  }();
-  return m;
-}
+// "cheb_fuse" (fl_tuning_set): 0 never use the fused two-step kernel, 1 (default) where it pays (grids of at least 32^3 cells), 2 wherever it is
+// legal (tests)
+static inline int cheb_fuse_mode() { return knob(K_cheb_fuse); }
 // -> 1 fused, 0 one step per launch, < 0 error.  Collective on several ranks the first time a handle asks (fl_cheb2_agree): call it where every
 // rank passes, before any test that could differ between ranks.
 int cheb_fuse(fl_poisson *h)
@@ -1119,64 +1108,6 @@ int finish_stats(fl_poisson *h, const fl_ksp_opts *o, fl_ksp_stats *st)
 
 }  // namespace
 
-extern "C" int fl_tuning_set(const char *name, int value)
-{
-  if (!name) return FL_ERR_ARG_NULL;
-  if (std::strcmp(name, "cheb_fuse") == 0) {
-    cheb_fuse_mode() = value;
-    return FL_SUCCESS;
-  }
-  if (std::strcmp(name, "placement") == 0) {
-    fl_placement_mode() = value;
-    return FL_SUCCESS;
-  }
-  if (std::strcmp(name, "cg_xbatch") == 0) {
-    fl_cg_xbatch_mode() = value;
-    return FL_SUCCESS;
-  }
-  if (std::strcmp(name, "cheb_staged") == 0) {
-    cheb_staged_mode() = value;
-    return FL_SUCCESS;
-  }
-  if (std::strcmp(name, "mg_flexible") == 0) {
-    fl_mg_flexible_mode() = value != 0;
-    return FL_SUCCESS;
-  }
-  if (std::strcmp(name, "mg_prolong") == 0) {
-    fl_mg_prolong_mode() = value;
-    return FL_SUCCESS;
-  }
-  return FL_ERR_ARG_WRONG;
-}
-extern "C" int fl_tuning_get(const char *name, int *value)
-{
-  if (!name || !value) return FL_ERR_ARG_NULL;
-  if (std::strcmp(name, "cheb_fuse") == 0) {
-    *value = cheb_fuse_mode();
-    return FL_SUCCESS;
-  }
-  if (std::strcmp(name, "cg_xbatch") == 0) {
-    *value = fl_cg_xbatch_mode();
-    return FL_SUCCESS;
-  }
-  if (std::strcmp(name, "cheb_staged") == 0) {
-    *value = cheb_staged_mode();
-    return FL_SUCCESS;
-  }
-  if (std::strcmp(name, "placement") == 0) {
-    *value = fl_placement_mode();
-    return FL_SUCCESS;
-  }
-  if (std::strcmp(name, "mg_flexible") == 0) {
-    *value = fl_mg_flexible_mode();
-    return FL_SUCCESS;
-  }
-  if (std::strcmp(name, "mg_prolong") == 0) {
-    *value = fl_mg_prolong_mode();
-    return FL_SUCCESS;
-  }
-  return FL_ERR_ARG_WRONG;
-}
 
 int fl_apply_tiled(fl_poisson *h, const double *xpad, double *y, int unpadded_y)
 {
@@ -1236,10 +1167,7 @@ int fl_residual_padded(fl_poisson *h, double *xpad, const double *bpad, double *
 // children pair (two rows per wave, even z chunks); returns 1 where it does not apply (the caller runs the residual and the restriction).
 int fl_residual_restrict_padded(fl_poisson *h, double *xpad, const double *bpad, const double *wx, const double *wy, const double *wz, fl_poisson *hc, double *cpad)
 {
-  static const int on = []() {
-    const char *e = std::getenv("FLUCA_MG_FUSED_RESTRICT");  // 0: residual and restriction as two passes (A/B runs)
-    return e ? std::atoi(e) : 1;
-  }();
+  const int on = FL_VARIANT(mg_fused_restrict, 1);  // 0: residual and restriction as two passes (A/B runs)
   const GridP &g = h->g, &gc = hc->g;
   const PlanA  p = plan_cg_A(g, 0, 0);
   if (!on || cheb_staged_mode() == 0 || p.ry != 2 || (p.nw != 8 && p.nw != 4) || (p.nchunk > 1 && (p.zc & 1))) return 1;
@@ -1268,6 +1196,7 @@ int fl_apply_padded_dot(fl_poisson *h, double *xpad, double *ypad, double *xy)
   } else launch_apply_pc(h, tp, false, xpad, ypad, nullptr, nullptr, h->partial, 0);
   launch_reduce(h->stream, h->partial, nbl, h->partial_stride, 4, h->sums);
   if (h->multi) FL_CHK(h->comm.allreduce(h->stream, h->sums, NSLOT));
+  if (!xy) return 0;  // the caller takes x.y from h->sums[2] on the device (no host wait)
   FL_HIP(hipMemcpyAsync(xy, h->sums + 2, sizeof(double), hipMemcpyDeviceToHost, h->stream));
   FL_HIP(hipStreamSynchronize(h->stream));
   return 0;
@@ -1279,8 +1208,9 @@ int fl_apply_padded_dot(fl_poisson *h, double *xpad, double *ypad, double *xy)
 // never waits.  Spectrum bounds as in fl_solve_cheb.
 // mgdots (in: the caller wants the five sums of k_mg_dots over the result and the right-hand side; out: whether h->sums holds them -- only
 // when the last sweep is the fused Jacobi kernel, which forms them on its way, fl_cheb2.hip)
-// subq / suba: the right-hand side h->r is first updated in place, r -= suba * subq (padded), on the first step's pass (guess_zero only)
-int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero, bool *mgdots, const double *subq, double suba)
+// subq / suba: the right-hand side h->r is first updated in place, r -= *suba * subq (padded; suba points to DEVICE memory), on the first step's
+// pass (guess_zero only)
+int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero, bool *mgdots, const double *subq, const double *suba)
 {
   if (subq && !(guess_zero && nu > 0)) return FL_ERR_ARG_WRONGSTATE;
   const bool want = mgdots && *mgdots;
@@ -1301,8 +1231,8 @@ int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero, bool
   o.maxit            = nu;
   o.remove_nullspace = 0;
   // PETSc's -mg_levels_ksp_chebyshev_esteig 0,0.1,0,1.1 applied to the bound (experiments: FLUCA_MG_CHEB_LO / _HI, fractions of the bound)
-  static const double flo = []() { const char *e = std::getenv("FLUCA_MG_CHEB_LO"); return e ? std::atof(e) : 0.1; }();
-  static const double fhi = []() { const char *e = std::getenv("FLUCA_MG_CHEB_HI"); return e ? std::atof(e) : 1.1; }();
+  const char  *elo = variant_env("FLUCA_MG_CHEB_LO"), *ehi = variant_env("FLUCA_MG_CHEB_HI");
+  const double flo = elo ? std::atof(elo) : 0.1, fhi = ehi ? std::atof(ehi) : 1.1;
   const double lam = fl_gershgorin_bound(h, jac), emin = flo * lam, emax = fhi * lam;
   init_scal(h, &o);
   KspScal &S = *h->scal_host;
@@ -1329,10 +1259,10 @@ int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero, bool
   auto       finl = [=](const double *partial, int nb, int stride, const double *sums) { hipLaunchKernelGGL(k_cheb_fin, dim3(1), dim3(256), 0, s, partial, nb, stride, sums, h->scal, h->hist, nhist); };
   auto       fin2 = [=](const double *partial, int nb, int stride, const double *sums) { hipLaunchKernelGGL(k_cheb_fin2, dim3(1), dim3(256), 0, s, partial, nb, stride, sums, h->scal); };
   int        cur = 0, dcur = 0;
-  static const bool trace = []() { const char *e = std::getenv("FLUCA_COMM_TRACE"); return e && std::atoi(e) != 0; }();
+  const int trace = knob(K_comm_trace);
   auto mark = [&](const char *what, int j) {  // debugging aid: where a sweep stops making progress (each mark waits for the stream)
     if (!trace) return;
-    static const bool sync = []() { const char *e = std::getenv("FLUCA_COMM_TRACE"); return e && std::atoi(e) >= 2; }();
+    const bool sync = trace >= 2;
     const hipError_t e = sync ? hipStreamSynchronize(s) : hipSuccess;
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -1351,8 +1281,8 @@ int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero, bool
       if (subq) {
         if (jac) hipLaunchKernelGGL((k_cheb_first<true, true>), dim3(nb), dim3(256), 0, s, h->g, X0, X1, B, D0, D1, h->scal, subq, suba);
         else hipLaunchKernelGGL((k_cheb_first<false, true>), dim3(nb), dim3(256), 0, s, h->g, X0, X1, B, D0, D1, h->scal, subq, suba);
-      } else if (jac) hipLaunchKernelGGL((k_cheb_first<true>), dim3(nb), dim3(256), 0, s, h->g, X0, X1, B, D0, D1, h->scal, (const double *)nullptr, 0.);
-      else hipLaunchKernelGGL((k_cheb_first<false>), dim3(nb), dim3(256), 0, s, h->g, X0, X1, B, D0, D1, h->scal, (const double *)nullptr, 0.);
+      } else if (jac) hipLaunchKernelGGL((k_cheb_first<true>), dim3(nb), dim3(256), 0, s, h->g, X0, X1, B, D0, D1, h->scal, (const double *)nullptr, (const double *)nullptr);
+      else hipLaunchKernelGGL((k_cheb_first<false>), dim3(nb), dim3(256), 0, s, h->g, X0, X1, B, D0, D1, h->scal, (const double *)nullptr, (const double *)nullptr);
       finl(h->partial, tp.nblocks, h->partial_stride, (const double *)nullptr);  // no norm, no null space: the sums are not looked at, only the recurrence advances -- nothing to all-reduce
       j += 1;
     } else if (fuse && j + 2 <= nu && !(want && jac && !h->multi && ((nu - j) & 1))) {  // (asked for the sums: an odd step count takes its single step first, so that a fused sweep ends the call)
@@ -1395,11 +1325,8 @@ int fl_solve_bcgs(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *
 {
   // variant 0 (default): V0 = M S P and T0 = M S S0 are formed wherever they are needed and never stored (k_bcgs_st, 120 B/cell/iteration);
   // any other value: the stored products of round 1 (k_apply_pc + k_bcgs_pw, 152 B/cell)
-  static const int variant_env = []() {
-    const char *e = std::getenv("FLUCA_BCGS_VARIANT");
-    return e ? std::atoi(e) : -1;
-  }();
-  const int variant = (o->variant == 0 && variant_env >= 0) ? variant_env : o->variant;
+  const int variant_forced = FL_VARIANT(bcgs_variant, -1);
+  const int variant = (o->variant == 0 && variant_forced >= 0) ? variant_forced : o->variant;
   if (variant == 0) {
     const GridP &g   = h->g;
     const bool   jac = o->pc == FL_PC_JACOBI;
@@ -1449,7 +1376,9 @@ int fl_solve_bcgs(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *
     launch_unpad_copy(s, g, X, x, nullptr);
     return finish_stats(h, o, st);
   }
-
+#ifndef FL_KBENCH_VARIANTS
+  return FL_ERR_SUP;  // the stored-product form of round 1 lives in the kbench build only (include/fluca_hip.h, fl_ksp_opts.variant)
+#else
   const GridP &g   = h->g;
   const bool   jac = o->pc == FL_PC_JACOBI;
   // vectors: r=R, P0=RP, P1=P, q=V0, xp=X, w0=S0, w1=T0
@@ -1494,6 +1423,7 @@ int fl_solve_bcgs(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *
   }
   launch_unpad_copy(s, g, X, x, nullptr);
   return finish_stats(h, o, st);
+#endif
 }
 
 // KSPCG with -ksp_cg_single_reduction (fl_ksp_opts.cg_single_reduction): one reduction point, hence one all-reduce and one scalar
@@ -1524,11 +1454,8 @@ int fl_solve_cg_sr(fl_poisson *h, const double *b, double *x, const fl_ksp_opts 
   };
   // several ranks: the ghost exchange of the new residual runs on a second stream behind the update kernel (MODE 10), as the pair hides it behind
   // k_cg_Bq -- MODE 9 keeps S = A z on the block's boundary layers in the r buffer that is dead until MODE 10 refills it, and the pack forms
-  // r - a (S + b W) there.  FLUCA_OVERLAP=0 restores the sequential order (A/B runs).  (Periodic axes inside the block are wrapped at the end.)
-  static const bool overlap_env = []() {
-    const char *e = std::getenv("FLUCA_OVERLAP");
-    return e ? std::atoi(e) != 0 : true;
-  }();
+  // r - a (S + b W) there.  "overlap" = 0 restores the sequential order (A/B runs).  (Periodic axes inside the block are wrapped at the end.)
+  const bool overlap_env = knob(K_overlap) != 0;
   const bool overlap = h->multi && overlap_env;
   launch_bcgs_st<9>(h, pa, jac, R, nullptr, nullptr, nullptr, overlap ? Rn : nullptr, nullptr);
   FL_CHK(fin_step(h, pa.nblocks, 7, fin(0)));

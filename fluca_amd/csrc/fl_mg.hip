@@ -21,7 +21,9 @@
 // (the same polynomial in the residual as "e = smooth(b - S x); x += e", without forming the residual).  The constant null
 // space is handled once per cycle, algebraically: the outer CG needs z' = z - mean(z) only inside inner products and in
 // the direction update, so one pass over (z, r) yields sum z, z.z, r.z, sum r, r.r and the shift is folded into
-// p = (z - m) + beta p.  Scalars of the outer CG live on the host: two waits per iteration (p.q, and the five sums).
+// p = (z - m) + beta p.  Scalars of the outer CG live on the DEVICE (MgScal, round 5): alpha, beta, the shift m and r.z are formed by one-thread
+// kernels from the reduced sums and read from there by the kernels that use them; the host looks at the monitored norm once per iteration, through
+// a page-locked slot, and by then the GPU already holds the first third of the next iteration (one deferred wait, none on the critical path).
 // Several ranks: every level keeps the fine decomposition (block boundaries coincide with coarse faces), so restriction
 // and prolongation stay local; an axis is coarsened only while every rank's share stays even and >= 8 cells; the levels
 // borrow the fine handle's communicator for their halo exchanges and reductions.
@@ -336,6 +338,194 @@ __global__ void __launch_bounds__(256) k_mg_pw(GridP g, double a, double b, doub
   }
 }
 
+// ---- scalars of the outer (flexible) CG, device-resident --------------------------------------------------------------------------------------
+struct MgScal {
+  double alpha, beta, m, rz, rz_old, pq, dp, N;
+  int    ns, pnorm, bad_pq, pad_;
+};
+// what the host reads once per iteration (page-locked, one slot per iteration parity)
+struct MgSlot {
+  double dp, rz, pq;
+  int    bad_pq, pad_;
+};
+// STEP 0: after q = S p and the reduction of p.q (sums[2]):  alpha = r.z / p.q.  A non-positive or NaN p.q is flagged and alpha set to 0, so that the
+//         cycle already enqueued behind this kernel changes nothing (r -= 0 q) until the host has seen the flag.
+// STEP 1: after a cycle, sums = {sum z, z.z, r.z, sum r, r.r} of k_mg_dots:  m = mean(z) (null space), the monitored norm, r.z' with the shift folded in;
+//         the previous r.z moves to rz_old.  FIRST: the cycle in front of the loop (no previous r.z).
+// STEP 2: after the dots of (z, q):  beta = -alpha q.z' / (z_old.r_old)  (Polak-Ribiere);  STEP 3: beta = r.z / rz_old (KSPCG's form, no dots needed)
+template <int STEP, bool FIRST = false>
+__global__ void k_mg_scal(MgScal *__restrict__ S, const double *__restrict__ sums, MgSlot *__restrict__ slot_dev)
+{
+  if (STEP == 0) {
+    const double pq = sums[2];
+    S->pq     = pq;
+    S->bad_pq = !(pq > 0.);
+    S->alpha  = pq > 0. ? S->rz / pq : 0.;
+  } else if (STEP == 1) {
+    const double d0 = sums[0], d1 = sums[1], d2 = sums[2], d3 = sums[3], d4 = sums[4], N = S->N;
+    const double m  = S->ns ? d0 / N : 0.;
+    const double zz = d1 - N * m * m;
+    double       dp = S->pnorm ? sqrt(zz > 0. ? zz : 0.) : sqrt(d4);
+    if (isnan(d1)) dp = d1;
+    if (!FIRST) S->rz_old = S->rz;
+    S->m  = m;
+    S->dp = dp;
+    S->rz = d2 - m * d3;
+    slot_dev->dp     = dp;
+    slot_dev->rz     = S->rz;
+    slot_dev->pq     = S->pq;
+    slot_dev->bad_pq = FIRST ? 0 : S->bad_pq;
+  } else if (STEP == 2) {
+    S->beta = -S->alpha * (sums[2] - S->m * sums[3]) / S->rz_old;
+  } else {
+    S->beta = S->rz / S->rz_old;
+  }
+}
+
+__global__ void k_mg_scal_set(MgScal *dst, MgScal v) { *dst = v; }
+
+// The coarsest level's Jacobi-PCG (KSPCG + PCJACOBI, preconditioned norm, KSPConvergedDefault with rtol / maxit, constant null space removed from every
+// preconditioner output: the algorithm of fl_poisson_solve and of the oracle's fo_ksp_solve) as ONE workgroup: a coarsest grid of a few thousand cells
+// is a handful of waves' worth of work per iteration, and through the public solver it cost about sixty launches and a host poll per cycle.  x, r and
+// 1 / diag live in registers (CPT cells per thread), the direction p in LDS (its six neighbours are read from there; a periodic axis wraps its index, a
+// wall's coefficient is 0), two block reductions per iteration.  b: padded right-hand side; x: padded answer (owned cells written, zero initial guess).
+constexpr int MG_COARSE_MAX = 4096, MG_COARSE_CPT = MG_COARSE_MAX / 256;
+__global__ void __launch_bounds__(256) k_mg_coarse_cg(GridP g, int perbits, int ns, double rtol, double atol, double dtol, int maxit, const double *__restrict__ b, double *__restrict__ x)
+{
+  constexpr int CPT = MG_COARSE_CPT;
+  __shared__ double P[MG_COARSE_MAX];
+  __shared__ double red[4 * 4], bc[4];
+  const int tid = threadIdx.x, n = g.nx * g.ny * g.nz;
+  double    xr[CPT], rr[CPT], di[CPT];
+  int       cell_i[CPT], cell_j[CPT], cell_k[CPT];
+  // block-wide sums of up to four numbers, the same bits in every thread
+  auto sum4 = [&](double (&v)[4]) {
+    block_sum<4>(v, red);
+    if (tid == 0)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) bc[a] = v[a];
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 4; ++a) v[a] = bc[a];
+    __syncthreads();
+  };
+#pragma unroll
+  for (int m = 0; m < CPT; ++m) {
+    const int c = tid + 256 * m, cc = min(c, n - 1);
+    const int i = cc % g.nx, t = cc / g.nx, j = t % g.ny, k = t / g.ny;
+    cell_i[m] = i;
+    cell_j[m] = j;
+    cell_k[m] = k;
+    di[m]     = 1. / (g.sc[0][i] + g.sc[1][j] + g.sc[2][k]);
+    xr[m]     = 0.;
+    rr[m]     = c < n ? b[pidx(g, i, j, k)] : 0.;
+  }
+  const double N = (double)n;
+  double       beta, betaold = 1., mz, dp, rnorm0, ttol;
+  // z = M r with the constant removed, folded into the sums:  z' = z - m,  r.z' = r.z - m sum r,  z'.z' = z.z - N m^2
+  auto pc_sums = [&]() {
+    double v[4] = {0., 0., 0., 0.};
+#pragma unroll
+    for (int m = 0; m < CPT; ++m)
+      if (tid + 256 * m < n) {
+        const double z = rr[m] * di[m];
+        v[0] += z;
+        v[1] += z * z;
+        v[2] += rr[m] * z;
+        v[3] += rr[m];
+      }
+    sum4(v);
+    mz              = ns ? v[0] / N : 0.;
+    const double zz = v[1] - N * mz * mz;
+    dp              = sqrt(zz > 0. ? zz : 0.);
+    if (isnan(v[1])) dp = v[1];
+    beta = v[2] - mz * v[3];
+  };
+  pc_sums();
+  rnorm0     = dp;
+  ttol       = fmax(rtol * dp, atol);
+  auto done = [&](double v) { return isnan(v) || isinf(v) || v <= ttol || v >= dtol * rnorm0; };
+  int  it   = 0;
+  bool stop = done(dp);
+  while (!stop && it < maxit && !(beta < 0.)) {
+    // p = z' + (beta / betaold) p
+    const double bb = it == 0 ? 0. : beta / betaold;
+#pragma unroll
+    for (int m = 0; m < CPT; ++m) {
+      const int c = tid + 256 * m;
+      if (c < n) P[c] = (rr[m] * di[m] - mz) + (it == 0 ? 0. : bb * P[c]);
+    }
+    betaold = beta;
+    __syncthreads();
+    // w = S p ; p.w
+    double wv[CPT], v[4] = {0., 0., 0., 0.};
+#pragma unroll
+    for (int m = 0; m < CPT; ++m) {
+      const int c = tid + 256 * m;
+      wv[m]       = 0.;
+      if (c < n) {
+        const int i = cell_i[m], j = cell_j[m], k = cell_k[m];
+        const int im = i > 0 ? i - 1 : ((perbits & 1) ? g.nx - 1 : i), ip = i < g.nx - 1 ? i + 1 : ((perbits & 1) ? 0 : i);
+        const int jm = j > 0 ? j - 1 : ((perbits & 2) ? g.ny - 1 : j), jp = j < g.ny - 1 ? j + 1 : ((perbits & 2) ? 0 : j);
+        const int km = k > 0 ? k - 1 : ((perbits & 4) ? g.nz - 1 : k), kp = k < g.nz - 1 ? k + 1 : ((perbits & 4) ? 0 : k);
+        const int row = (k * g.ny + j) * g.nx;
+        double    acc = (g.sc[0][i] + g.sc[1][j] + g.sc[2][k]) * P[c];
+        acc += g.sl[0][i] * P[row + im] + g.sh[0][i] * P[row + ip];
+        acc += g.sl[1][j] * P[(k * g.ny + jm) * g.nx + i] + g.sh[1][j] * P[(k * g.ny + jp) * g.nx + i];
+        acc += g.sl[2][k] * P[(km * g.ny + j) * g.nx + i] + g.sh[2][k] * P[(kp * g.ny + j) * g.nx + i];
+        wv[m] = acc;
+        v[0] += P[c] * acc;
+      }
+    }
+    sum4(v);
+    const double dpi = v[0];
+    if (!(dpi > 0.)) break;  // KSP_DIVERGED_INDEFINITE_MAT / NaN: the correction found so far is what the cycle gets
+    const double a = beta / dpi;
+#pragma unroll
+    for (int m = 0; m < CPT; ++m) {
+      const int c = tid + 256 * m;
+      if (c < n) {
+        xr[m] += a * P[c];
+        rr[m] -= a * wv[m];
+      }
+    }
+    pc_sums();
+    ++it;
+    stop = done(dp);
+  }
+#pragma unroll
+  for (int m = 0; m < CPT; ++m)
+    if (tid + 256 * m < n) x[pidx(g, cell_i[m], cell_j[m], cell_k[m])] = xr[m];
+}
+
+// k_mg_pw with its scalars read from MgScal.  OP 2: y0 = x0 - m ;  OP 4: y1 += alpha y0 ; y0 = (x0 - m) + beta y0 ;  OP 5: y1 -= alpha x1
+template <int OP>
+__global__ void __launch_bounds__(256) k_mg_pwd(GridP g, const MgScal *__restrict__ S, const double *__restrict__ x0, const double *__restrict__ x1, double *__restrict__ y0, double *__restrict__ y1)
+{
+  const double  a = S->alpha, b = S->beta, c = S->m;
+  const int     lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  const int     nseg = (g.nx + 127) / 128;
+  const int64_t nitem = (int64_t)nseg * g.ny * g.nz;
+  for (int64_t it = (int64_t)blockIdx.x * nw + w; it < nitem; it += (int64_t)gridDim.x * nw) {
+    const int seg = (int)(it % nseg), row = (int)(it / nseg);
+    const int j = row % g.ny, k = row / g.ny, i = seg * 128 + 2 * lane;
+    if (i >= g.nx) continue;
+    const bool    two = i + 1 < g.nx;
+    const int64_t off = g.off0 + (int64_t)k * g.sxy + (int64_t)j * g.sx + i;
+    if (OP == 2) {
+      const double2 xv = ldp(x0, off, two);
+      stp(y0, off, two, make_double2(xv.x - c, xv.y - c));
+    } else if (OP == 4) {
+      const double2 zv = ldp(x0, off, two), pv = ldp(y0, off, two), xv = ldp(y1, off, two);
+      stp(y1, off, two, make_double2(xv.x + a * pv.x, xv.y + a * pv.y));
+      stp(y0, off, two, make_double2((zv.x - c) + b * pv.x, (zv.y - c) + b * pv.y));
+    } else {
+      const double2 qv = ldp(x1, off, two), rv = ldp(y1, off, two);
+      stp(y1, off, two, make_double2(rv.x - a * qv.x, rv.y - a * qv.y));
+    }
+  }
+}
+
 }  // namespace fl
 
 using namespace fl;
@@ -351,36 +541,30 @@ struct MgLevel {
 
 struct fl_mg {
   std::vector<MgLevel> lv;
+  MgScal              *scal = nullptr;      // device: the outer CG's scalars
+  MgSlot              *slot_dev = nullptr;  // device staging of what the host reads ...
+  MgSlot              *slot_host = nullptr; // ... and its page-locked copies, one per iteration parity
+  hipEvent_t           ev_slot[2] = {nullptr, nullptr};
 };
 
 void fl_mg_destroy(fl_poisson *h);
 
-// "mg_prolong" (fl_tuning_set; initial value from FLUCA_MG_PROLONG): 1 (default since round 3) tri-linear prolongation, 0 piecewise
+// "mg_prolong" (fl_tuning_set): 1 (default since round 3) tri-linear prolongation, 0 piecewise
 // constant.  512^3 cavity, rtol 1e-8, nu = 3: 7 iterations / 0.078 - 0.080 s against 8 / 0.082 - 0.083 s on the same box; nu = 2: 10 against 22
 // iterations, nu = 1: 20 against 132 (profiles/r03_mg_bench.txt)
-int &fl_mg_prolong_mode()
-{
-  static int m = []() {
-    const char *e = std::getenv("FLUCA_MG_PROLONG");
-    return e ? std::atoi(e) : 1;
-  }();
-  return m;
-}
+static inline int fl_mg_prolong_mode() { return knob(K_mg_prolong); }
 
-// "mg_flexible" (fl_tuning_set; initial value from FLUCA_MG_FLEXIBLE): 1 (default since round 4) the outer CG takes the Polak-Ribiere form
+// "mg_flexible" (fl_tuning_set): 1 (default since round 4) the outer CG takes the Polak-Ribiere form
 // of beta, beta = z_new . (r_new - r_old) / (z_old . r_old) = -alpha (q . z_new) / (z_old . r_old) -- KSPFCG truncated to one direction
 // (-ksp_fcg_mmax 1) --, 0 the Fletcher-Reeves form of KSPCG, r_new . z_new / (r_old . z_old).  The two agree for a fixed symmetric
 // preconditioner; the V-cycle is neither once the restriction is not a multiple of the transposed prolongation (tri-linear against
 // volume-weighted; any transfer pair on a stretched grid): with two smoothing steps a stretched channel needed 100 iterations with the
 // KSPCG form and 17 with this one (oracle study, profiles/r04_mg_flexible.txt).  Costs one more pass over (z, q) per iteration.
-int &fl_mg_flexible_mode()
-{
-  static int m = []() {
-    const char *e = std::getenv("FLUCA_MG_FLEXIBLE");
-    return e ? std::atoi(e) : 1;
-  }();
-  return m;
-}
+static inline int fl_mg_flexible_mode() { return knob(K_mg_flexible); }
+
+// "mg_coarse" (fl_tuning_set): 1 (default) a coarsest level of at most 4096 cells on one rank is solved by one workgroup (k_mg_coarse_cg); 0: through
+// the public Jacobi-PCG like every other size (A/B runs; the same algorithm, other summation order)
+static inline int fl_mg_coarse_mode() { return knob(K_mg_coarse); }
 
 namespace {
 
@@ -514,13 +698,18 @@ int mg_build_levels(fl_poisson *h, fl_mg *mg, int max_levels)
     FL_CHK(fl_ensure_partials(hl, MG_BLOCKS));
   }
   for (double **v : {&h->w0, &h->w1, &h->w2}) FL_CHK(fl_ensure_vec(h, v));  // outer CG: x, p, q
+  FL_HIP(hipMalloc((void **)&mg->scal, sizeof(MgScal)));
+  FL_HIP(hipMalloc((void **)&mg->slot_dev, 2 * sizeof(MgSlot)));
+  FL_HIP(hipHostMalloc((void **)&mg->slot_host, 2 * sizeof(MgSlot)));
+  for (hipEvent_t &e : mg->ev_slot) FL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   return 0;
 }
 
 // V-cycle on level l: right-hand side in the level handle's h->r, answer (zero initial guess) in its h->xp -- both padded
 // sums (level 0 only; in: asked for, out: delivered): the five sums of k_mg_dots over (answer, right-hand side) left in h->sums by the last sweep
-// subq / suba (level 0 only): the right-hand side is first updated in place, b -= suba * subq, on the first smoothing step's pass over it
-int vcycle(fl_mg *mg, size_t l, const fl_ksp_opts *o, bool *sums = nullptr, const double *subq = nullptr, double suba = 0.)
+// subq (level 0 only): the right-hand side is first updated in place, b -= alpha * subq with the outer CG's alpha read from mg->scal on the device, on the
+// first smoothing step's pass over it
+int vcycle(fl_mg *mg, size_t l, const fl_ksp_opts *o, bool *sums = nullptr, const double *subq = nullptr)
 {
   const bool want = sums && *sums;
   if (sums) *sums = false;
@@ -536,7 +725,13 @@ int vcycle(fl_mg *mg, size_t l, const fl_ksp_opts *o, bool *sums = nullptr, cons
     so.pc    = FL_PC_JACOBI;
     so.rtol  = 1e-2;
     so.maxit = 200;
-    if (subq) hipLaunchKernelGGL(k_mg_pw<5>, dim3(nblk_pairs(h->g)), dim3(256), 0, h->stream, h->g, suba, 0., 0., (const double *)nullptr, subq, (double *)nullptr, h->r);
+    if (subq) hipLaunchKernelGGL(k_mg_pwd<5>, dim3(nblk_pairs(h->g)), dim3(256), 0, h->stream, h->g, (const MgScal *)mg->scal, (const double *)nullptr, subq, (double *)nullptr, h->r);
+    if (!h->multi && h->ncell <= MG_COARSE_MAX && h->nv_il == 1 && fl_mg_coarse_mode() != 0) {
+      // one workgroup, no host poll, straight from the padded right-hand side into the padded answer
+      const int per = (h->ax[0].periodic ? 1 : 0) | (h->ax[1].periodic ? 2 : 0) | (h->ax[2].periodic ? 4 : 0);
+      hipLaunchKernelGGL(k_mg_coarse_cg, dim3(1), dim3(256), 0, h->stream, h->g, per, so.remove_nullspace, so.rtol, so.atol, so.dtol, so.maxit, (const double *)h->r, h->xp);
+      return 0;
+    }
     launch_unpad_copy(h->stream, h->g, h->r, L.b, nullptr);
     // a one-level hierarchy runs this solve on the OUTER handle, whose h->r is the outer residual and is the inner
     // solve's work vector as well: keep it aside
@@ -551,7 +746,7 @@ int vcycle(fl_mg *mg, size_t l, const fl_ksp_opts *o, bool *sums = nullptr, cons
   }
   const int nu = o->mg_smooth_its > 0 ? o->mg_smooth_its : 3;
   MgLevel  &C  = mg->lv[l + 1];
-  FL_CHK(fl_cheb_smooth_padded(h, nu, true, true, nullptr, subq, suba));             // x = smooth(b), zero initial guess
+  FL_CHK(fl_cheb_smooth_padded(h, nu, true, true, nullptr, subq, subq ? &mg->scal->alpha : nullptr));  // x = smooth(b), zero initial guess
   int fused = 1;
   if (L.r[0] == 2 && L.r[1] == 2 && L.r[2] == 2) {
     fused = fl_residual_restrict_padded(h, h->xp, h->r, L.w[0], L.w[1], L.w[2], C.h, C.h->r);       // coarse b = R (b - S x) in one pass
@@ -569,10 +764,7 @@ int vcycle(fl_mg *mg, size_t l, const fl_ksp_opts *o, bool *sums = nullptr, cons
       t.pn[d] = L.pn[d];
       t.pw[d] = L.pw[d];
     }
-    static const int tiled = []() {
-      const char *e = std::getenv("FLUCA_MG_PROLONG_TILE");  // 2 (default): parent-centred where every axis is halved, else 1: the tile walk; 0: the grid-stride kernel
-      return e ? std::atoi(e) : 2;
-    }();
+    const int tiled = FL_VARIANT(mg_prolong_tile, 2);  // 2 (shipped): parent-centred where every axis is halved, else 1: the tile walk; 0: the grid-stride kernel
     if (tiled >= 2 && L.r[0] == 2 && L.r[1] == 2 && L.r[2] == 2) {
       const int  kc = 4;
       const GridP &gcs = C.h->g;
@@ -604,6 +796,11 @@ void fl_mg_destroy(fl_poisson *h)
       if (p) (void)hipFree(p);
     if (l > 0 && L.h) fl_poisson_destroy(L.h);
   }
+  if (mg->scal) (void)hipFree(mg->scal);
+  if (mg->slot_dev) (void)hipFree(mg->slot_dev);
+  if (mg->slot_host) (void)hipHostFree(mg->slot_host);
+  for (hipEvent_t e : mg->ev_slot)
+    if (e) (void)hipEventDestroy(e);
   delete mg;
   h->mg = nullptr;
 }
@@ -644,33 +841,57 @@ int fl_solve_cg_mg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts 
   hipEvent_t e0 = ev.a, e1 = ev.b;
   FL_HIP(hipEventRecord(e0, s));
   double *X = h->w0, *P = h->w1, *Q = h->w2;  // padded; r = h->r (the cycle's right-hand side), z = h->xp after the cycle
-  double  d[5], rz = 0., rz_old = 1., dp = 0., pq = 0., m = 0.;
+  double  d[5], rz = 0., dp = 0., pq = 0.;
+  int     bad_pq = 0;
   std::vector<double> hist;
-  // z' = z - m 1 with m = mean(z):  z'.z' = z.z - N m^2,  r.z' = r.z - m sum r
-  static const bool fused_dots = []() {
-    const char *e = std::getenv("FLUCA_MG_FUSED_DOTS");  // 0: always the separate k_mg_dots pass (A/B runs)
-    return e ? std::atoi(e) != 0 : true;
-  }();
-  const double *subq = nullptr;  // r -= suba * subq is owed (taken care of inside the next cycle)
-  double        suba = 0.;
-  auto cycle_and_sums = [&]() -> int {
+  // z' = z - m 1 with m = mean(z):  z'.z' = z.z - N m^2,  r.z' = r.z - m sum r   (k_mg_scal<1>)
+  const bool fused_dots = FL_VARIANT(mg_fused_dots, 1) != 0;  // 0: always the separate k_mg_dots pass (A/B runs)
+  MgScal *S = mg->scal;
+  {
+    MgScal init;
+    std::memset(&init, 0, sizeof(init));
+    init.N      = N;
+    init.ns     = ns ? 1 : 0;
+    init.pnorm  = pnorm ? 1 : 0;
+    init.rz_old = 1.;
+    hipLaunchKernelGGL(k_mg_scal_set, dim3(1), dim3(1), 0, s, S, init);  // by value: nothing reads the stack frame after the launch
+  }
+  // the five sums of k_mg_dots over all ranks, left in h->sums (no host wait)
+  auto dots_dev = [&](const double *z, const double *r) -> int {
+    hipLaunchKernelGGL(k_mg_dots, dim3(nb), dim3(256), 0, s, g, z, r, h->partial, h->partial_stride);
+    launch_reduce(s, h->partial, nb, h->partial_stride, 5, h->sums);
+    if (h->multi) FL_CHK(h->comm.allreduce(s, h->sums, NSLOT));
+    return 0;
+  };
+  const double *subq = nullptr;  // r -= alpha * subq is owed (taken care of inside the next cycle, alpha from the device)
+  // [r -= alpha q ;] z = M^-1 r, the five sums, the scalars that follow from them, and their copy on the way to the host (slot `it & 1`)
+  auto cycle_and_sums = [&](int it, bool first) -> int {
     bool got = fused_dots;
-    FL_CHK(vcycle(mg, 0, o, &got, subq, suba));                            // [r -= alpha q ;] z = M^-1 r
-    if (got) {  // the cycle's last smoothing sweep formed the sums on its way
-      FL_HIP(hipMemcpyAsync(d, h->sums, sizeof(double) * 5, hipMemcpyDeviceToHost, h->stream));
-      FL_HIP(hipStreamSynchronize(h->stream));
-    } else FL_CHK(dots(h, h->xp, h->r, d));
-    m = ns ? d[0] / N : 0.;
-    const double zz = d[1] - N * m * m;
-    dp = pnorm ? std::sqrt(zz > 0. ? zz : 0.) : std::sqrt(d[4]);
-    if (std::isnan(d[1])) dp = d[1];
-    rz = d[2] - m * d[3];
+    FL_CHK(vcycle(mg, 0, o, &got, subq));
+    if (!got) FL_CHK(dots_dev(h->xp, h->r));  // (else the cycle's last smoothing sweep formed the sums on its way)
+    const int a = it & 1;
+    if (first) hipLaunchKernelGGL((k_mg_scal<1, true>), dim3(1), dim3(1), 0, s, S, (const double *)h->sums, mg->slot_dev + a);
+    else hipLaunchKernelGGL((k_mg_scal<1, false>), dim3(1), dim3(1), 0, s, S, (const double *)h->sums, mg->slot_dev + a);
+    FL_HIP(hipMemcpyAsync(mg->slot_host + a, mg->slot_dev + a, sizeof(MgSlot), hipMemcpyDeviceToHost, s));
+    FL_HIP(hipEventRecord(mg->ev_slot[a], s));
+    return 0;
+  };
+  // the host's one look per iteration: by now the GPU holds the work that follows the cycle, so it does not idle while the host decides
+  auto look = [&](int it) -> int {
+    const int a = it & 1;
+    FL_HIP(hipEventSynchronize(mg->ev_slot[a]));
+    const MgSlot &L = mg->slot_host[a];
+    dp     = L.dp;
+    rz     = L.rz;
+    pq     = L.pq;
+    bad_pq = L.bad_pq;
     return 0;
   };
   launch_pad_copy(s, g, b, h->r);                                           // r = b (x = 0)
   FL_CHK(fl_zero_vec(h, X));
-  FL_CHK(cycle_and_sums());
-  hipLaunchKernelGGL(k_mg_pw<2>, dim3(nb), dim3(256), 0, s, g, 0., 0., m, (const double *)h->xp, (const double *)nullptr, P, (double *)nullptr);  // p = z'
+  FL_CHK(cycle_and_sums(0, true));
+  hipLaunchKernelGGL(k_mg_pwd<2>, dim3(nb), dim3(256), 0, s, g, (const MgScal *)S, (const double *)h->xp, (const double *)nullptr, P, (double *)nullptr);  // p = z'
+  FL_CHK(look(0));
   const double rnorm0 = dp, ttol = std::max(o->rtol * dp, o->atol);
   hist.push_back(dp);
   int  it = 0, reason = 0;
@@ -682,35 +903,31 @@ int fl_solve_cg_mg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts 
   };
   reason = converged(dp);
   if (!reason && o->maxit <= 0) reason = FL_DIVERGED_ITS;
+  const bool flexible = fl_mg_flexible_mode() != 0;
   while (!reason) {
-    FL_CHK(fl_apply_padded_dot(h, P, Q, &pq));                              // q = S p ; p.q
-    if (!(pq > 0.)) {
+    FL_CHK(fl_apply_padded_dot(h, P, Q, nullptr));                          // q = S p ; p.q stays in h->sums[2]
+    hipLaunchKernelGGL((k_mg_scal<0>), dim3(1), dim3(1), 0, s, S, (const double *)h->sums, (MgSlot *)nullptr);  // alpha = r.z / p.q
+    // x += alpha p ; r -= alpha q -- neither as a pass of its own: r on the first smoothing step of the cycle that follows, x together with p below
+    subq = Q;
+    FL_CHK(cycle_and_sums(it + 1, false));                                  // r -= alpha q, z = M^-1 r, the five sums, m, ||z'||, r.z'
+    subq = nullptr;
+    // The direction update is enqueued BEFORE the host has looked at the norm: x += alpha p is owed whether the iteration stops or not, and a
+    // p that is rewritten after the last iteration is never read.  beta in the Polak-Ribiere way: z'.(r_new - r_old) = -alpha q.z'
+    if (flexible) {
+      FL_CHK(dots_dev(h->xp, Q));
+      hipLaunchKernelGGL((k_mg_scal<2>), dim3(1), dim3(1), 0, s, S, (const double *)h->sums, (MgSlot *)nullptr);
+    } else hipLaunchKernelGGL((k_mg_scal<3>), dim3(1), dim3(1), 0, s, S, (const double *)h->sums, (MgSlot *)nullptr);
+    hipLaunchKernelGGL(k_mg_pwd<4>, dim3(nb), dim3(256), 0, s, g, (const MgScal *)S, (const double *)h->xp, (const double *)nullptr, P, X);  // x += alpha p ; p = z' + beta p
+    FL_CHK(look(it + 1));
+    if (bad_pq) {  // p.q <= 0 or NaN: alpha was 0 on the device, the cycle and the update behind it changed nothing; the iteration does not count
       reason = std::isnan(pq) ? FL_DIVERGED_NANORINF : FL_DIVERGED_INDEFINITE_MAT;
       break;
     }
-    const double alpha = rz / pq;
-    // x += alpha p ; r -= alpha q -- neither as a pass of its own: r on the first smoothing step of the cycle that follows, x together with p below
-    subq = Q;
-    suba = alpha;
-    rz_old = rz;
-    FL_CHK(cycle_and_sums());                                               // r -= alpha q, z = M^-1 r and the five sums
-    subq = nullptr;
     ++it;
     hist.push_back(dp);
     reason = converged(dp);
     if (!reason && it >= o->maxit) reason = FL_DIVERGED_ITS;
     if (!reason && !(rz > 0.)) reason = std::isnan(rz) ? FL_DIVERGED_NANORINF : FL_DIVERGED_INDEFINITE_PC;
-    if (reason) {
-      hipLaunchKernelGGL(k_mg_pw<3>, dim3(nb), dim3(256), 0, s, g, alpha, 0., 0., (const double *)P, (const double *)nullptr, X, (double *)nullptr);  // x += alpha p
-      break;
-    }
-    double beta = rz / rz_old;
-    if (fl_mg_flexible_mode()) {  // z' . (r_new - r_old) = -alpha q . z',  q . z' = q . z - m sum q
-      double d2[5];
-      FL_CHK(dots(h, h->xp, Q, d2));
-      beta = -alpha * (d2[2] - m * d2[3]) / rz_old;
-    }
-    hipLaunchKernelGGL(k_mg_pw<4>, dim3(nb), dim3(256), 0, s, g, alpha, beta, m, (const double *)h->xp, (const double *)nullptr, P, X);  // x += alpha p ; p = z' + beta p
   }
   // answer, with the constant removed on the way out (the shift is handed over in device memory)
   double *shift = nullptr;

@@ -133,6 +133,7 @@ struct MomLds {
 //    faces are exchanged through LDS (double-buffered, one barrier per plane); z neighbours ride in registers.
 //  * Software pipeline: while plane k is computed, the loads of plane k+1 (faces, ring) and k+2 (velocity, z-faces) are
 //    in flight; they are consumed by the register rotation at the end of the iteration.
+#ifdef FL_KBENCH_VARIANTS  // round 1 / 2's momentum product (A/B runs)
 template <bool DOT, bool JAC, int OUT>
 __global__ void __launch_bounds__(MOM_NT, FL_MOM_WPE) k_mom_apply(GridP g, MomP m, const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ F, int64_t cs, const double *__restrict__ o,
                                                                 const KspScal *__restrict__ s, double *__restrict__ partial, int pstride, int tiles_x, int nchunk, int zc, int order)
@@ -397,6 +398,7 @@ __global__ void __launch_bounds__(MOM_NT, FL_MOM_WPE) k_mom_apply(GridP g, MomP 
     }
   }
 }
+#endif  // FL_KBENCH_VARIANTS
 
 }  // namespace fl
 #include "fl_stencil.h"
@@ -409,6 +411,7 @@ namespace fl {
 // OP 1: S = R - alpha V
 // OP 2: X += alpha P + omega S ; R = S - omega T          slots: 0 R.R  1 R.RP  2 sum R
 // OP 3: R = RP = b / diag (b unpadded, component-major)    slots: 0 sum R  1 R.R        (dg NULL: no preconditioner)
+#ifdef FL_KBENCH_VARIANTS  // round 1's vector updates (A/B runs)
 template <int OP>
 __global__ void __launch_bounds__(256) k_mom_pw(GridP g, int64_t cs, const double *__restrict__ a0, const double *__restrict__ a1, const double *__restrict__ a2, const double *__restrict__ a3, double *__restrict__ w0,
                                                 double *__restrict__ w1, const KspScal *__restrict__ s, double *__restrict__ partial, int pstride, int tiles_x, int nchunk, int zc)
@@ -454,10 +457,12 @@ __global__ void __launch_bounds__(256) k_mom_pw(GridP g, int64_t cs, const doubl
       for (int a = 0; a < 3; ++a) partial[(int64_t)a * pstride + blockIdx.x] = acc[a];
   }
 }
+#endif  // FL_KBENCH_VARIANTS
 
 // The same four updates on 128-cell row segments, two x-adjacent cells per lane (16-byte accesses, non-temporal where a value is not read
 // again before it would be evicted anyway): one wave per segment, grid-stride over the segments of the block.  Padded rows start on
 // a 128-byte boundary (PADX), so every pair is 16-byte aligned; the unpadded b of OP 3 is read in pairs when nx is even (pairs != 0).
+#ifdef FL_KBENCH_VARIANTS  // round 2's vector updates (A/B runs)
 template <int OP>
 __global__ void __launch_bounds__(256) k_mom_pw2(GridP g, int64_t cs, const double *__restrict__ a0, const double *__restrict__ a1, const double *__restrict__ a2, const double *__restrict__ a3, double *__restrict__ w0,
                                                  double *__restrict__ w1, const KspScal *__restrict__ s, double *__restrict__ partial, int pstride, int pairs)
@@ -527,6 +532,7 @@ __global__ void __launch_bounds__(256) k_mom_pw2(GridP g, int64_t cs, const doub
       for (int a = 0; a < 3; ++a) partial[(int64_t)a * pstride + blockIdx.x] = acc[a];
   }
 }
+#endif  // FL_KBENCH_VARIANTS
 
 // The tile walk of k_mom2 for the vector updates (experiment FLUCA_MOM_PW=3): a block marches a 128 x 8 tile through a z chunk, blocks in
 // the XCD-contiguous order -- the access pattern at which the stencil kernels move 6 TB/s where the grid-stride form above moves 5.3.
@@ -872,30 +878,20 @@ int mom_ghosts(fl_momentum *m, double *v3)
 
 int mom_order()
 {
-  static const int o = []() {
-    const char *e = std::getenv("FLUCA_MOM_ORDER");  // 1 (default): chunk-major, XCD-contiguous; 0: chunk fastest (round 1's order)
-    return e ? std::atoi(e) : 1;                     // three alternating rounds at 512^3: apply 5.83 against 6.03 ms (profiles/r02c_mom_order.txt)
-  }();
-  return o;
+  // 1 (shipped): chunk-major, XCD-contiguous; 0: chunk fastest (round 1's order); three alternating rounds at 512^3: apply 5.83 against 6.03 ms
+  // (profiles/r02c_mom_order.txt)
+  return FL_VARIANT(mom_order, 1);
 }
 
 int mom_kernel()
 {
-  static const int o = []() {
-    // 3 (default): k_mom3 (v0interp formed in the kernel) when the state came with v0 (fl_momentum_set_state_v0), else k_mom2;
-    // 2: always k_mom2, two cells per lane on 128 x 8 tiles, all twelve face fields read; 1: round 1/2's k_mom_apply (A/B runs)
-    const char *e = std::getenv("FLUCA_MOM_KERNEL");
-    return e ? std::atoi(e) : 3;
-  }();
-  return o;
+  // 3 (shipped): k_mom3 (v0interp formed in the kernel) when the state came with v0 (fl_momentum_set_state_v0), else k_mom2;
+  // 2: always k_mom2, two cells per lane on 128 x 8 tiles, all twelve face fields read; 1: round 1/2's k_mom_apply (kbench build)
+  return FL_VARIANT(mom_kernel, 3);
 }
 int mom_nt()
 {
-  static const int o = []() {
-    const char *e = std::getenv("FLUCA_MOM_NT");  // non-temporal stores of k_mom2
-    return e ? std::atoi(e) : 1;
-  }();
-  return o;
+  return FL_VARIANT(mom_nt, 1);  // non-temporal stores of k_mom2
 }
 
 // DOT: 0 no inner products, 1 sum y and y.o (slots 0, 1), 2 x.y and y.y (slots 2, 3), 3 all four (k_mom_apply always forms all four)
@@ -915,7 +911,9 @@ void mom_apply_t(fl_momentum *m, const double *x, double *y, const double *o, co
     else hipLaunchKernelGGL((k_mom2<8, DOT, JAC, OUT, 0>), dim3(m->t2blocks), dim3(512), 0, h->stream, h->g, coeffs ? *coeffs : m->mp, x, y, m->F, (int64_t)h->padlen, o, s, h->partial, h->partial_stride, m->t2x, m->t2chunk, m->t2zc, flags);
     return;
   }
+#ifdef FL_KBENCH_VARIANTS
   hipLaunchKernelGGL((k_mom_apply<(DOT != 0), JAC, OUT>), dim3(m->ablocks), dim3(MOM_NT), 0, h->stream, h->g, coeffs ? *coeffs : m->mp, x, y, m->F, (int64_t)h->padlen, o, s, h->partial, h->partial_stride, m->tiles_x, m->anchunk, m->azc, mom_order());
+#endif
 }
 // the scaled, cell-major tables of k_mom2 for the coefficients in p (stream-ordered; slot 0: the handle's own, slot 1: a one-off operator)
 int mom_scale_tables(fl_momentum *m, int slot, MomP &p)
@@ -935,11 +933,7 @@ int mom_apply_blocks(const fl_momentum *m) { return mom_kernel() >= 2 ? m->t2blo
 
 int mom_pw_kernel()
 {
-  static const int o = []() {
-    const char *e = std::getenv("FLUCA_MOM_PW");  // 3 (default): k_mom_pw3, the tile walk; 2: k_mom_pw2, 16-byte row segments; 1: round 1's k_mom_pw (A/B runs)
-    return e ? std::atoi(e) : 3;
-  }();
-  return o;
+  return FL_VARIANT(mom_pw, 3);  // 3 (shipped): k_mom_pw3, the tile walk; 2: k_mom_pw2, 16-byte row segments; 1: round 1's k_mom_pw (kbench build)
 }
 // blocks of the vector-update kernels = entries of their partial sums
 int mom_pw_blocks(const fl_momentum *m) { return mom_pw_kernel() >= 3 ? m->t2blocks : (mom_pw_kernel() == 2 ? m->pw2blocks : m->nblocks); }
@@ -953,12 +947,14 @@ void mom_pw(fl_momentum *m, const double *a0, const double *a1, const double *a2
     hipLaunchKernelGGL((k_mom_pw3<OP>), dim3(m->t2blocks), dim3(512), 0, h->stream, h->g, (int64_t)h->padlen, a0, a1, a2, a3, w0, w1, h->scal, h->partial, h->partial_stride, pairs, m->t2x, m->t2chunk, m->t2zc);
     return;
   }
+#ifdef FL_KBENCH_VARIANTS
   if (mom_pw_kernel() >= 2) {
     const int pairs = (h->g.nx & 1) == 0 && (reinterpret_cast<uintptr_t>(a0) & 15) == 0;
     hipLaunchKernelGGL((k_mom_pw2<OP>), dim3(m->pw2blocks), dim3(256), 0, h->stream, h->g, (int64_t)h->padlen, a0, a1, a2, a3, w0, w1, h->scal, h->partial, h->partial_stride, pairs);
     return;
   }
   hipLaunchKernelGGL((k_mom_pw<OP>), dim3(m->nblocks), dim3(256), 0, h->stream, h->g, (int64_t)h->padlen, a0, a1, a2, a3, w0, w1, h->scal, h->partial, h->partial_stride, m->tiles_x, m->nchunk, m->zc);
+#endif
 }
 
 int mom_init(fl_momentum *m, fl_poisson *h)
@@ -1038,8 +1034,7 @@ int mom_init(fl_momentum *m, fl_poisson *h)
     const int atiles = m->tiles_x * ((g.ny + MOM_RY - 1) / MOM_RY);
     int       nc = std::max(1, (2048 + atiles / 2) / atiles);
     nc         = std::max(1, std::min(std::min(nc, std::max(1, g.nz / 8)), g.nz));
-    if (const char *e = std::getenv("FLUCA_MOM_CHUNKS"))  // experiments: z chunks of k_mom_apply
-      if (std::atoi(e) > 0) nc = std::min(std::atoi(e), g.nz);
+    if (FL_VARIANT(mom_chunks, 0) > 0) nc = std::min(FL_VARIANT(mom_chunks, 0), g.nz);  // experiments: z chunks of k_mom_apply
     if (atiles * nc > MAX_PARTIAL_BLOCKS) nc = std::max(1, MAX_PARTIAL_BLOCKS / atiles);
     m->azc     = (g.nz + nc - 1) / nc;
     m->anchunk = (g.nz + m->azc - 1) / m->azc;
@@ -1053,8 +1048,7 @@ int mom_init(fl_momentum *m, fl_poisson *h)
     const int tiles = m->t2x * ((g.ny + 7) / 8);
     int       nc    = std::max(1, (1024 + tiles / 2) / tiles);
     nc              = std::max(1, std::min(std::min(nc, std::max(1, g.nz / 8)), g.nz));
-    if (const char *e = std::getenv("FLUCA_MOM_CHUNKS"))
-      if (std::atoi(e) > 0) nc = std::min(std::atoi(e), g.nz);
+    if (FL_VARIANT(mom_chunks, 0) > 0) nc = std::min(FL_VARIANT(mom_chunks, 0), g.nz);
     if (tiles * nc > MAX_PARTIAL_BLOCKS) nc = std::max(1, MAX_PARTIAL_BLOCKS / tiles);
     m->t2zc     = (g.nz + nc - 1) / nc;
     m->t2chunk  = (g.nz + m->t2zc - 1) / m->t2zc;
@@ -1064,8 +1058,7 @@ int mom_init(fl_momentum *m, fl_poisson *h)
   {
     const int64_t nseg = (int64_t)((g.nx + 127) / 128) * g.ny * g.nz;
     int           nb   = 2048;  // 8 blocks of 4 waves per CU
-    if (const char *e = std::getenv("FLUCA_MOM_PW_BLOCKS"))
-      if (std::atoi(e) > 0) nb = std::atoi(e);
+    if (FL_VARIANT(mom_pw_blocks, 0) > 0) nb = FL_VARIANT(mom_pw_blocks, 0);
     m->pw2blocks = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((nseg + 3) / 4, nb), MAX_PARTIAL_BLOCKS));
   }
   FL_CHK(fl_ensure_partials(h, std::max(std::max(m->nblocks, m->ablocks), m->t2blocks)));
@@ -1287,7 +1280,10 @@ extern "C" int fl_momentum_chebyshev_interval(fl_momentum *m, double *emin, doub
 
 // KSPCHEBYSHEV on the momentum block (-ns_abf_momentum_ksp_type chebyshev, a PETSc option the reference's kspA accepts like any other):
 // PETSc's three-term recurrence with PCJACOBI / PCNONE, zero initial guess.  Interval: opts->emin / emax (-ksp_chebyshev_eigenvalues), or, with
-// PCJACOBI, fl_momentum_chebyshev_interval: [max(1 - g, 0.9 / max a_ii), 1 + g], g the Gershgorin radius of D^-1 A.
+// PCJACOBI, fl_momentum_chebyshev_interval: [max(1 - g, 0.9 / mean a_ii), 1 + g], g the Gershgorin radius of D^-1 A -- a heuristic for emin, a bound for
+// emax, and a REAL interval for a spectrum that is not (the convective part of g is imaginary): PETSc would have estimated the spectrum with GMRES.
+// So a solve on the default interval is never left unwatched: with -ksp_norm_type none it still forms the preconditioned norm and stops with
+// KSP_DIVERGED_DTOL / NANORINF like any KSP (dtol 1e5) instead of returning garbage after maxit steps.
 // One fused launch per step where the state came with v0 (k_mom3, OUT == 4: 144 B/cell), the product and a vector update otherwise.
 static int momentum_cheb(fl_momentum *m, const double *b_dev, double *x_dev, const fl_ksp_opts *opts, fl_ksp_stats *stats)
 {
@@ -1300,9 +1296,11 @@ static int momentum_cheb(fl_momentum *m, const double *b_dev, double *x_dev, con
   std::memset(stats, 0, sizeof(*stats));
   const bool jac = opts->pc == FL_PC_JACOBI;
   double     emin = opts->emin, emax = opts->emax;
+  bool       default_interval = false;
   if (emin == 0. && emax == 0.) {
     if (!jac) return FL_ERR_SUP;  // no bound of the unscaled operator is formed: give -ksp_chebyshev_eigenvalues
     FL_CHK(fl_momentum_chebyshev_interval(m, &emin, &emax));
+    default_interval = true;
   }
   if (!(emax > emin) || !(emin > 0.)) return FL_ERR_ARG_OUTOFRANGE;
   const bool fused = mom_kernel() >= 3 && m->fly && h->g.ny > 8;
@@ -1314,6 +1312,12 @@ static int momentum_cheb(fl_momentum *m, const double *b_dev, double *x_dev, con
   FL_CHK(fl_ensure_partials(h, std::max(std::max(m->nblocks, m->ablocks), m->t2blocks)));
   fl_ksp_opts o = *opts;
   o.remove_nullspace = 0;  // A = I + ... is non-singular
+  const bool watched = default_interval && o.norm_type == FL_NORM_NONE;
+  if (watched) {  // the heuristic interval with no norm asked for: watch the preconditioned norm anyway, stop on divergence only
+    o.norm_type = FL_NORM_PRECONDITIONED;
+    o.rtol      = 0.;
+    o.atol      = 0.;
+  }
   FL_CHK(fl_cheb_begin(h, &o, emin, emax));
   const size_t bytes = sizeof(double) * 3 * h->padlen;
   // x_0 = 0 and "x_-1" (multiplied by rho_0 = 0) must be finite numbers
@@ -1349,7 +1353,9 @@ static int momentum_cheb(fl_momentum *m, const double *b_dev, double *x_dev, con
   FL_CHK(fl_poll_scal(h));
   const double *ans = h->scal_host->cur ? X1 : X0;
   for (int c = 0; c < 3; ++c) launch_unpad_copy(h->stream, h->g, ans + (size_t)c * h->padlen, x_dev + (size_t)c * h->ncell, nullptr);
-  return fl_ksp_finish(h, &o, stats);
+  FL_CHK(fl_ksp_finish(h, &o, stats));
+  if (watched && stats->reason == FL_DIVERGED_ITS) stats->reason = FL_CONVERGED_ITS;  // what KSP_NORM_NONE reports after maxit steps
+  return 0;
 }
 
 static int momentum_gmres(fl_momentum *m, const double *b_dev, double *x_dev, const fl_ksp_opts *opts, fl_ksp_stats *stats);
@@ -1872,6 +1878,7 @@ extern "C" int fl_vec_maxpy(fl_poisson *h, int64_t n, double *x_dev, const doubl
 
 // ------------------------------------------------------------------------------------------------ diagnostics
 // Streaming ceiling of the access mix of k_mom_apply: 15 read streams + 3 write streams, flat, 16 B per lane.
+#ifdef FL_KBENCH_VARIANTS  // flat streaming probe with the product's read / write mix (tools/mom_bench.py)
 namespace fl {
 __global__ void __launch_bounds__(256) k_mom_stream(const double *__restrict__ F, const double *__restrict__ x, double *__restrict__ y, int64_t cs, int64_t n2)
 {
@@ -1912,6 +1919,7 @@ extern "C" int fldbg_mom_stream(fl_momentum *m, int reps, int blocks, double *ms
   *ms_out = ms / reps;
   return 0;
 }
+#endif  // FL_KBENCH_VARIANTS
 
 // the operator kernel alone on padded work vectors (no pad / unpad copies): mode 0 plain, 1 Jacobi, 2 Jacobi + y.o (the first product of a
 // BiCGStab iteration), 3 Jacobi + x.y, y.y (the second)

@@ -13,7 +13,7 @@
 #include <strings.h>
 
 /* positive PETSC_ERR_* values */
-enum { E_MEM = 55, E_SUP = 56, E_ARG_WRONG = 62, E_FILE_OPEN = 65, E_ARG_OUTOFRANGE = 63, E_ARG_WRONGSTATE = 73, E_ARG_NULL = 85, E_ARG_UNKNOWN_TYPE = 86, E_ARG_TYPENOTSET = 89 };
+enum { E_MEM = 55, E_SUP = 56, E_ARG_WRONG = 62, E_FILE_OPEN = 65, E_FILE_WRITE = 67 /* PETSC_ERR_FILE_WRITE (66 is FILE_READ) */, E_ARG_OUTOFRANGE = 63, E_ARG_WRONGSTATE = 73, E_ARG_NULL = 85, E_ARG_UNKNOWN_TYPE = 86, E_ARG_TYPENOTSET = 89 };
 
 #define FLCHK(call)             \
   do {                          \
@@ -129,7 +129,7 @@ static FlErrorCode ViewerVPrintf_ASCII(FlucaViewer v, const char *fmt, va_list a
 {
   FILE *f = (FILE *)v->data;
   for (int i = 0; i < v->tab; ++i) fputs("  ", f); /* PetscViewerASCIIPrintf indents by two blanks per tab level */
-  return vfprintf(f, fmt, ap) < 0 ? 66 /* PETSC_ERR_FILE_WRITE */ : 0;
+  return vfprintf(f, fmt, ap) < 0 ? E_FILE_WRITE : 0;
 }
 static FlErrorCode ViewerDestroy_ASCII(FlucaViewer v)
 {
@@ -820,6 +820,12 @@ FlErrorCode NSSetBoundaryCondition(NS ns, int index, NSBoundaryCondition bc)
   if (!ns->mesh) return E_ARG_WRONGSTATE; /* "Mesh not set" */
   if (index < 0 || index >= ns->nb) return E_ARG_OUTOFRANGE;
   ns->bcs[index] = bc;
+  /* the kept boundary planes of this boundary were evaluated with the condition that is being replaced (same function and context pointers are no
+   * proof of the same values: a caller may have changed what ctx points to and say so by setting the condition again) */
+  if (ns->data && !strcmp(ns->type_name, NSCNLINEAR)) {
+    NS_CNLinear *c = (NS_CNLinear *)ns->data;
+    if (index < 6) c->bc_have[index][0] = c->bc_have[index][1] = 0;
+  }
   return 0;
 }
 FlErrorCode NSGetBoundaryCondition(NS ns, int index, NSBoundaryCondition *bc)
@@ -956,19 +962,21 @@ FlErrorCode NSSetFromOptions(NS ns, int argc, char **argv)
 #include <dlfcn.h>
 static int (*roctx_push)(const char *) = NULL;
 static int (*roctx_pop)(void)          = NULL;
-static void trace_init(void)
+static pthread_once_t trace_once = PTHREAD_ONCE_INIT;
+static void trace_load(void)
 {
-  static int tried = 0;
-  if (tried) return;
-  tried = 1;
   void *lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
   if (!lib) lib = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
   if (!lib) lib = dlopen("/opt/rocm/lib/libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
   if (!lib) return;
-  roctx_push = (int (*)(const char *))dlsym(lib, "roctxRangePushA");
-  roctx_pop  = (int (*)(void))dlsym(lib, "roctxRangePop");
-  if (!roctx_push || !roctx_pop) roctx_push = NULL, roctx_pop = NULL;
+  int (*push)(const char *) = (int (*)(const char *))dlsym(lib, "roctxRangePushA");
+  int (*pop)(void)          = (int (*)(void))dlsym(lib, "roctxRangePop");
+  if (push && pop) {
+    roctx_pop  = pop;
+    roctx_push = push; /* last: trace_begin tests this one */
+  }
 }
+static void trace_init(void) { pthread_once(&trace_once, trace_load); }
 static void trace_begin(const char *name)
 {
   trace_init();
@@ -1092,11 +1100,21 @@ FlErrorCode NSView(NS ns, FlucaViewer viewer)
 }
 
 /* nssol.c:130-150.  The three field links of NSSetUp (nsbasic.c:180-182) in their order, then the type's own vectors. */
-FlErrorCode NSViewSolution(NS ns, FlucaViewer viewer)
+static FlErrorCode NSViewSolution_Body(NS ns, FlucaViewer viewer)
 {
-  if (!ns || !viewer) return E_ARG_NULL;
   if (!ns->setupcalled) return E_ARG_WRONGSTATE;
   if (viewer->mode != 'w') return E_ARG_WRONGSTATE;
+  if (viewer_is(viewer, FLUCAVIEWERASCII)) {
+    /* nssol.c:130-150 VecViews each field on whatever viewer it is given; an ASCII dump of 10^8 numbers serves nobody, so the ASCII viewer gets
+     * what VecView prints first -- the field names and their sizes -- and the numbers go to a CGNS viewer */
+    int64_t sz[4];
+    FLCHK(NSGetLocalSizes(ns, sz));
+    FLCHK(FlucaViewerASCIIPrintf(viewer, "NS solution at step %lld, time %g:\n", (long long)ns->step, ns->t));
+    FLCHK(FlucaViewerASCIIPrintf(viewer, "  Velocity: 3 x %lld cell values\n  FaceNormalVelocity: %lld + %lld + %lld face values\n  Pressure: %lld cell values\n", (long long)sz[0],
+                                 (long long)sz[1], (long long)sz[2], (long long)sz[3], (long long)sz[0]));
+    if (ns->ops->viewsolution && !strcmp(ns->type_name, NSCNLINEAR)) FLCHK(FlucaViewerASCIIPrintf(viewer, "  PressureHalfStep: %lld cell values\n", (long long)sz[0]));
+    return 0;
+  }
   if (!viewer->ops->solutionbegin || !viewer->ops->cellfield || !viewer->ops->facefield || !viewer->ops->solutionend) return E_SUP;
   double *v, *V[3], *p;
   FLCHK(NSGetSolutionArrays(ns, &v, V, &p));
@@ -1107,6 +1125,11 @@ FlErrorCode NSViewSolution(NS ns, FlucaViewer viewer)
   if (ns->ops->viewsolution) FLCHK(ns->ops->viewsolution(ns, viewer)); /* PetscTryTypeMethod(ns, viewsolution, viewer) */
   return viewer->ops->solutionend(viewer, ns);
 }
+FlErrorCode NSViewSolution(NS ns, FlucaViewer viewer) /* viewer NULL = PetscViewerASCIIGetStdout, as in the reference (nssol.c:136-137) */
+{
+  if (!ns) return E_ARG_NULL;
+  WITH_STDOUT_VIEWER(viewer, NSViewSolution_Body(ns, viewer));
+}
 /* nssol.c:174-203 */
 FlErrorCode NSLoadSolution(NS ns, FlucaViewer viewer)
 {
@@ -1114,6 +1137,7 @@ FlErrorCode NSLoadSolution(NS ns, FlucaViewer viewer)
   if (!ns->setupcalled) return E_ARG_WRONGSTATE; /* "This function must be called after NSSetUp()" */
   if (viewer->mode != 'r') return E_ARG_WRONGSTATE; /* PetscViewerCheckReadable */
   if (!viewer->ops->solutionbegin || !viewer->ops->cellfield || !viewer->ops->facefield || !viewer->ops->solutionend) return E_SUP;
+  if (!ns->ops->loadsolution) return E_SUP; /* PetscUseTypeMethod(ns, loadsolution, viewer): checked before anything is read into ns->sol */
   double *v, *V[3], *p;
   FLCHK(NSGetSolutionArrays(ns, &v, V, &p));
   viewer->seqnum = -1; /* MeshSetOutputSequenceNumber(ns->mesh, -1, 0.): "reset here and will be set in VecLoad()" */
@@ -1122,7 +1146,6 @@ FlErrorCode NSLoadSolution(NS ns, FlucaViewer viewer)
   FLCHK(viewer->ops->cellfield(viewer, ns, "Velocity", 3, v));
   FLCHK(viewer->ops->facefield(viewer, ns, "FaceNormalVelocity", V));
   FLCHK(viewer->ops->cellfield(viewer, ns, "Pressure", 1, p));
-  if (!ns->ops->loadsolution) return E_SUP; /* PetscUseTypeMethod(ns, loadsolution, viewer) */
   FLCHK(ns->ops->loadsolution(ns, viewer));
   FLCHK(viewer->ops->solutionend(viewer, ns));
   if (viewer->seqnum < 0) return 76; /* PETSC_ERR_LIB: the file held no solution */

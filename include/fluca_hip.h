@@ -5,8 +5,11 @@
  * Plain C, no PETSc / torch / C++ types.  Every function returns int: 0 = success,
  * negative = -(PETSC_ERR_* class) so a PETSc-side caller can SETERRQ(-rc).
  * Device pointers are raw HIP device addresses owned by the caller unless stated.
- * A handle is driven by one host thread; different handles (one per GPU / process)
- * are independent.  All arithmetic is IEEE fp64 (PetscScalar = double).
+ * A handle is driven by one host thread; different handles (one per GPU / process, or several
+ * per process on several host threads) are independent: nothing of a solve lives in a global
+ * (tests/test_gpu_config5.py drives eight handles from eight threads).  The only process-wide
+ * state are the tuning knobs below (atomics) and the lazily loaded RCCL entry points (guarded).
+ * All arithmetic is IEEE fp64 (PetscScalar = double).
  *
  * Reference interfaces replaced (file:line relative to thecasterian/fluca):
  *   fl_poisson_create    PCSetUp_ABF: S = D((-T)Ainv G - (-R)), Ainv = ID         fluca/src/ns/utils/abfpc/abfpc.c:113-182
@@ -101,10 +104,11 @@ typedef struct fl_ksp_opts {
   int     maxit;            /* -ksp_max_it   (PETSc default 10000) */
   double  rtol, atol, dtol; /* -ksp_rtol 1e-5, -ksp_atol 1e-50, -ksp_divtol 1e5 */
   double  emin, emax;       /* Chebyshev bounds of the preconditioned operator; 0,0 = Gershgorin bound * (0.1, 1.1) */
-  int     variant;          /* CG: 0 = fused kernels, q = S p formed twice and never stored, x updated every second iteration (default;
-                               60 B/cell/iteration), 1 = one kernel per BLAS-1/SpMV step (A/B + debugging), 2 = fused kernels with q stored
-                               and read back (72 B/cell).  BiCGStab: 0 = M S p and M S s formed where they are needed and never stored
-                               (default; 120 B/cell/iteration), other = stored (152 B/cell) */
+  int     variant;          /* 0 (the only value the product accepts): CG = fused kernels, q = S p formed twice and never stored, x updated
+                               every second iteration (60 B/cell/iteration); BiCGStab = M S p and M S s formed where they are needed and never stored
+                               (120 B/cell/iteration).  Other values select superseded implementations kept for A/B measurements (CG 1 = one kernel
+                               per BLAS-1 / SpMV step, 2 = q stored and read back, 72 B/cell; BiCGStab: products stored, 152 B/cell): they exist in
+                               a -DFL_KBENCH_VARIANTS build of the library only, here the solve returns FL_ERR_SUP. */
   int     check_every;      /* host polls the device-side convergence flag every this many iterations (0 = default 16);
                              * < 0 with FL_NORM_NONE (Chebyshev): never -- exactly maxit steps, no statistics (smoother use) */
   int     profile;          /* n > 0: bracket the kernels of every n-th pair of CG iterations (every Chebyshev launch) with HIP events ->
@@ -180,21 +184,32 @@ int fl_vec_dot(fl_poisson *h, int64_t n, const double *x_dev, const double *y_de
 int fl_vec_mdot(fl_poisson *h, int64_t n, const double *x_dev, const double *const *ys_dev, int k, double *out);
 int fl_vec_maxpy(fl_poisson *h, int64_t n, double *x_dev, const double *alphas, const double *const *ys_dev, int k);
 
-/* Build-specific tuning knobs (no reference counterpart; results never change beyond round-off).  Names:
+/* Build-specific tuning knobs (no reference counterpart; results never change beyond round-off).  ONE table (fluca_amd/csrc/fl_knobs.h); a knob's
+ * initial value is its default or, if set, the environment variable FLUCA_<NAME IN CAPITALS>, which the library reads once per process.  Names:
  *   "cheb_fuse"  0 = one kernel launch per Chebyshev step; 1 (default) = two steps per sweep over memory wherever no convergence
  *                test sits between them (KSP_NORM_NONE sweeps, the multigrid smoother) and the grid is large enough to gain;
- *                2 = the same on every grid where it is legal.
+ *                2 = the same on every grid where it is legal.  On several ranks the ranks vote once per handle: fused only where all agree.
  *   "placement"  0 (default since round 3) = one plain allocation per vector; 1 = the first solve on a handle whose padded vectors are
  *                >= 256 MiB runs the placement search of fl_poisson_tune_placement by itself (about 0.15 s, once per handle; worth
  *                1 - 2 % of the CG iteration rate at 512^3).  A failure inside the search never fails the solve: plain allocations.
+ *                "placement_vmm" (1): its arenas live in chunk-mapped virtual memory; "placement_verbose" (0): it narrates on stderr.
  *   "cg_xbatch"  1 (default) = the CG solver updates x every second iteration (both updates of the pair at once, while the older
  *                direction is still in its buffer); 0 = one update per iteration.  The same x bit for bit.
- *   "cheb_staged" 1 (default) = the one-step Chebyshev kernel walks LDS-staged tiles like the CG kernels (k_cheb_st); 0 = round 1's k_cheb.
  *   "mg_prolong" 1 (default) = tri-linear prolongation of the FL_PC_MG cycle; 0 = piecewise constant.  (This one and the next change the
  *                preconditioner, i.e. iteration counts -- not the converged answer.)
  *   "mg_flexible" 1 (default) = the CG around the FL_PC_MG cycle forms beta in the Polak-Ribiere way (flexible CG, KSPFCG with
  *                -ksp_fcg_mmax 1): robust against the cycle not being a symmetric operator; 0 = KSPCG's beta.
- * Returns FL_ERR_ARG_WRONG for an unknown name.  Process-wide; set before the solve it should affect. */
+ *   "mg_coarse"  1 (default) = a coarsest multigrid level of at most 4096 cells on one rank is solved by ONE workgroup (no launches per CG iteration,
+ *                no host poll inside the cycle); 0 = through the public Jacobi-PCG like every other size.  Same algorithm, other summation order.
+ *   "overlap"    1 (default) = on several ranks the exchange of the new residual runs behind the update kernel on a second stream; 0 = after it.
+ *   "comm_loopback" 1 = a handle created on ONE rank sends the ghost layers of its periodic axes to itself through the communicator instead of
+ *                copying them (exercises RCCL on a one-GPU box; looked at by fl_poisson_create).  "comm_trace" 1 / 2 = exchanges narrated on stderr.
+ *   "ghost_width" 0 (default) = automatic: two ghost layers where a neighbouring rank exists, else one; 1 / 2 = forced (looked at by fl_poisson_create).
+ *   "allreduce"  0 (default) = scalar reductions through ncclAllReduce / the host callback; 1 = the one-shot all-reduce through peer-mapped buffers
+ *                (fl_poisson_comm_init_oneshot below).
+ * Returns FL_ERR_ARG_WRONG for an unknown name.  Process-wide atomics: handles on several host threads may read them while they run; set a knob
+ * before the solves it should affect.  (Switches between a shipped code path and a superseded one -- round 1's kernels, stored-q CG, ... -- are
+ * compile-time constants in this library; a -DFL_KBENCH_VARIANTS build turns them into knobs of the same table for A/B measurements.) */
 int fl_tuning_set(const char *name, int value);
 int fl_tuning_get(const char *name, int *value);
 

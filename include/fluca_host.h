@@ -114,6 +114,10 @@ FlErrorCode MeshDestroy(Mesh *mesh);
 
 /* ---- NS ---- */
 typedef enum { NS_BC_NONE, NS_BC_VELOCITY, NS_BC_PRESSURE_OUTLET, NS_BC_PERIODIC, NS_BC_SYMMETRY } NSBoundaryConditionType;
+/* PURITY CONTRACT (mirror only): a callback is a function of (t, x) and of what ctx pointed to when the condition was SET.  The mirror keeps the
+ * boundary values of the two most recent times (a step's t + dt is the next step's t) and evaluates a plane again only when the time, the function
+ * pointer or the ctx pointer differ, or after NSSetBoundaryCondition on that boundary -- which is how a caller that changes the data behind ctx
+ * between steps says so.  -ns_keep_boundary_values false restores the reference's behaviour (every use evaluates the callback). */
 typedef FlErrorCode (*NSBoundaryConditionFunction)(int dim, double t, const double x[], double val[], void *ctx);
 typedef struct {
   NSBoundaryConditionType     type;
@@ -188,7 +192,8 @@ FlErrorCode NSGetSolverVectors(NS ns, NSVec *x, NSVec *r); /* ns->x, ns->r (the 
 FlErrorCode NSView(NS ns, FlucaViewer viewer);
 /* nssol.c:130-150: VecView of the field links Velocity, FaceNormalVelocity, Pressure, then PetscTryTypeMethod(viewsolution)
  * (CNLinear: PressureHalfStep, cnlinear.c:146-153).  With a FlucaViewerCGNS: FlowSolution<step> of the current step and
- * time; writes the mesh first if the file is new.  Collective over the ranks. */
+ * time; writes the mesh first if the file is new.  viewer NULL = stdout; an ASCII viewer prints the fields' names and sizes (not 10^8 numbers).
+ * Collective over the ranks. */
 FlErrorCode NSViewSolution(NS ns, FlucaViewer viewer);
 /* nssol.c:174-203: FlucaVecLoad of the same fields from the LAST FlowSolution of the file, PetscUseTypeMethod(loadsolution),
  * then step and time from the viewer's output sequence.  After NSSetUp; the mesh sizes must match. */

@@ -37,3 +37,14 @@ def mean_free_rhs(S, ncell, seed=20260313):
     p = rng.uniform(-1.0, 1.0, ncell)
     p -= p.mean()
     return p, S.mult(p)
+
+
+def kbench_build():
+    """True when the loaded libflucahip.so is a -DFL_KBENCH_VARIANTS build (superseded solver variants compiled in, fluca_amd/csrc/fl_knobs.h)"""
+    from fluca_amd import capi
+    return b"+kbench" in capi.lib.fl_version()
+
+
+def variants(*vs):
+    """the solver variants a test may ask for: all of them in a kbench build, the shipped one (0) in the product"""
+    return [v for v in vs if v == 0 or kbench_build()]

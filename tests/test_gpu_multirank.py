@@ -98,12 +98,12 @@ def test_decomposed_solve_matches_single_domain_oracle(world, n, ranks, bc, ksp)
 
 
 def _overlap_worker(rank, world, n, ranks, bc, overlap, outdir):
-    """One CG solve on the decomposed grid with the halo exchange of r overlapped with k_cg_Bq (FLUCA_OVERLAP=1, the default) or run
+    """One CG solve on the decomposed grid with the halo exchange of r overlapped with k_cg_Bq ("overlap" = 1, the default) or run
     after it (0); the residual history and the block of x go to a file for the comparison."""
     import os
-    os.environ["FLUCA_OVERLAP"] = str(overlap)      # read once per process, before the first solve
     import torch
     from fluca_amd import capi
+    capi.check(capi.lib.fl_tuning_set(b"overlap", int(overlap)))
     from fluca_amd.poisson import Poisson
     from oracle import fluca_oracle as fo
     d = mpc.decomp_of(capi, n, ranks, rank)

@@ -1,4 +1,5 @@
-"""-m gpu: the RCCL transport on a one-GPU box.  With FLUCA_COMM_LOOPBACK=1 a single rank does not copy the ghost layers of
+"""-m gpu: the RCCL transport on a one-GPU box.  With the tuning knob "comm_loopback" = 1 (fl_tuning_set; FLUCA_COMM_LOOPBACK=1 gives it its
+initial value) a single rank does not copy the ghost layers of
 its periodic axes locally but sends them to ITSELF through the communicator -- dlopen of librccl, ncclCommInitRank,
 grouped ncclSend/ncclRecv of the packed faces on the handle's stream, ncclAllReduce of the partial sums: the calls the
 N-GPU bench makes, minus a second device.  (RCCL refuses two ranks on one device, so the genuine multi-rank tests use the
@@ -14,10 +15,17 @@ from tests.gpu_common import PER, V, dev, host
 pytestmark = pytest.mark.gpu
 
 
+def _loop(on):
+    from fluca_amd import capi
+    capi.check(capi.lib.fl_tuning_set(b"comm_loopback", int(on)))
+
+
 @pytest.fixture
-def loopback(monkeypatch):
-    monkeypatch.setenv("FLUCA_COMM_LOOPBACK", "1")
+def loopback():
+    # the knob is looked at when a handle is created (the environment only once per process, for its initial value)
+    _loop(1)
     yield
+    _loop(0)
 
 
 @pytest.mark.parametrize("bc", [[PER] * 6, [PER, PER, V, V, PER, PER]])
@@ -72,8 +80,7 @@ def test_multigrid_levels_share_the_rccl_communicator(loopback):
     p -= p.mean()
     res = []
     for loop in (True, False):
-        if not loop:
-            os.environ.pop("FLUCA_COMM_LOOPBACK", None)
+        _loop(loop)
         P = flp.Poisson.uniform(n, box, bc, 1e-3)
         if loop:
             P.comm_init_rccl(flp.rccl_unique_id(), 0, 1)
@@ -97,8 +104,7 @@ def test_whole_time_steps_through_rccl(loopback):
     L, n = 2 * np.pi, 16
 
     def run(loop):
-        if not loop:
-            os.environ.pop("FLUCA_COMM_LOOPBACK", None)
+        _loop(loop)
         mesh = P()
         assert H.lib.MeshCartCreate3d(1, 1, 1, n, n, 8, 1, 1, 1, None, None, None, C.byref(mesh)) == 0 and H.lib.MeshSetUp(mesh) == 0
         assert H.lib.MeshCartSetUniformCoordinates(mesh, 0., L, 0., L, 0., L * 8 / n) == 0
