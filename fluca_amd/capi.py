@@ -122,6 +122,9 @@ PROTOTYPES = {
     "fl_comm_unique_id": (C.c_int, [_P]),
     "fl_poisson_comm_init_rccl": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "fl_poisson_comm_init_host": (C.c_int, [_P, EXCHANGE_FN, ALLREDUCE_FN, _P, C.c_int, C.c_int]),
+    "fl_poisson_comm_oneshot_handle": (C.c_int, [_P, _P, C.POINTER(_P)]),
+    "fl_poisson_comm_oneshot_attach": (C.c_int, [_P, _P, C.POINTER(_P)]),
+    "fl_poisson_comm_oneshot_error": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "fl_halo_plan": (C.c_int, [C.POINTER(fl_decomp), C.POINTER(C.c_int), C.POINTER(fl_halo_msg)]),
     "fl_decomp_default": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int), C.c_int, C.POINTER(fl_decomp)]),
     "fl_decomp_neighbor": (C.c_int, [C.POINTER(fl_decomp), C.POINTER(C.c_int), C.c_int]),

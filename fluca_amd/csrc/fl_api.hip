@@ -228,6 +228,8 @@ extern "C" int fl_poisson_destroy(fl_poisson *h)
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   fl_mg_destroy(h);
   h->comm.destroy();
+  for (SmoothSeq &q : h->smooth_seq)
+    if (q.dev) (void)hipFree(q.dev);
   for (void *p : h->tables) (void)hipFree(p);
   for (void *p : h->vec_bases) (void)hipFree(p);
   fl_vmm_destroy(h);
@@ -1567,6 +1569,109 @@ extern "C" int fl_poisson_comm_init_host(fl_poisson *h, fl_exchange_fn xchg, fl_
   h->comm.ctx    = ctx;
   h->comm.rank   = rank;
   h->comm.nranks = nranks;
+  return FL_SUCCESS;
+}
+
+// ------------------------------------------------------------------------------------------------ one-shot all-reduce (fl_handle.h: OneShotBox)
+namespace fl {
+// One wave.  Lane l < nranks delivers to peer l and later fetches rank l's slot; every store that a peer waits for is a system-scope release, every
+// load of a flag a system-scope acquire (the mailboxes are fine-grained memory, possibly of another device).  A wait gives up after about two
+// seconds of wall clock and raises the mailbox's error flag -- a kernel that spins for ever would take the GPU (and its neighbours) down with it.
+__global__ void __launch_bounds__(64) k_oneshot_allreduce(OneShotBox *const *boxes, int rank, int nranks, unsigned long long number, double *vals, int n)
+{
+  const int lane = threadIdx.x, par = (int)(number & 1ull);
+  __shared__ double got[NSLOT][NSLOT];
+  if (lane < nranks) {
+    OneShotBox *peer = boxes[lane];
+    for (int a = 0; a < n; ++a) __hip_atomic_store(&peer->slot[par][rank][a], vals[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&peer->seq[par][rank], number, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    OneShotBox     *mine = boxes[rank];
+    const long long t0 = wall_clock64();  // 100 MHz
+    bool            ok = mine->error == 0;  // sticky: after one timed-out wait every later call gives up at once (NaN sums end the solve)
+    while (ok && __hip_atomic_load(&mine->seq[par][lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != number) {
+      if (wall_clock64() - t0 > 200000000ll) {
+        ok = false;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    if (!ok) mine->error = 1;
+    for (int a = 0; a < n; ++a) got[lane][a] = ok ? __hip_atomic_load(&mine->slot[par][lane][a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : nan("");
+  }
+  __syncthreads();
+  if (lane < n) {
+    double sum = 0.;
+    for (int r = 0; r < nranks; ++r) sum += got[r][lane];  // rank order: the same bits on every rank
+    vals[lane] = sum;
+  }
+}
+void launch_oneshot_allreduce(hipStream_t st, OneShotBox *const *boxes, int rank, int nranks, unsigned long long number, double *vals, int n)
+{
+  hipLaunchKernelGGL(k_oneshot_allreduce, dim3(1), dim3(64), 0, st, boxes, rank, nranks, number, vals, n);
+}
+}  // namespace fl
+
+// This rank's mailbox (created by the first call) as a 64-byte hipIpcMemHandle_t for the other PROCESSES, and its address for other handles of
+// this process.  The host gathers the handles of all ranks (torch.distributed, MPI, ...) and hands every rank the whole list.
+extern "C" int fl_poisson_comm_oneshot_handle(fl_poisson *h, void *ipc_handle64, void **address)
+{
+  if (!h) return FL_ERR_ARG_NULL;
+  if (h->comm.kind == Comm::NONE) return FL_ERR_ARG_WRONGSTATE;
+  if (h->comm.nranks > NSLOT) return FL_ERR_SUP;
+  FL_HIP(hipSetDevice(h->device));
+  if (!h->comm.box) {
+    FL_HIP(hipExtMallocWithFlags((void **)&h->comm.box, sizeof(OneShotBox), hipDeviceMallocFinegrained));
+    FL_HIP(hipMemset(h->comm.box, 0, sizeof(OneShotBox)));
+  }
+  if (ipc_handle64) {
+    static_assert(sizeof(hipIpcMemHandle_t) == FL_IPC_HANDLE_BYTES, "hipIpcMemHandle_t size");
+    hipIpcMemHandle_t hd;
+    FL_HIP(hipIpcGetMemHandle(&hd, h->comm.box));
+    std::memcpy(ipc_handle64, &hd, sizeof(hd));
+  }
+  if (address) *address = h->comm.box;
+  return FL_SUCCESS;
+}
+// handles: nranks x 64 bytes in rank order (NULL entries are not allowed), or -- same process -- addresses: nranks mailbox addresses as
+// fl_poisson_comm_oneshot_handle returned them.  Exactly one of the two is given.  From then on "allreduce" = 1 routes this handle's scalar
+// reductions through the mailboxes (the multigrid levels keep the communicator's own all-reduce).
+extern "C" int fl_poisson_comm_oneshot_attach(fl_poisson *h, const void *handles, void *const *addresses)
+{
+  if (!h || (!handles == !addresses)) return FL_ERR_ARG_NULL;
+  Comm &c = h->comm;
+  if (c.kind == Comm::NONE || !c.box) return FL_ERR_ARG_WRONGSTATE;
+  FL_HIP(hipSetDevice(h->device));
+  std::vector<OneShotBox *> peers((size_t)c.nranks, nullptr);
+  for (int r = 0; r < c.nranks; ++r) {
+    if (r == c.rank) peers[(size_t)r] = c.box;
+    else if (addresses) peers[(size_t)r] = (OneShotBox *)addresses[r];
+    else {
+      hipIpcMemHandle_t hd;
+      std::memcpy(&hd, (const char *)handles + (size_t)r * FL_IPC_HANDLE_BYTES, sizeof(hd));
+      void *p = nullptr;
+      FL_HIP(hipIpcOpenMemHandle(&p, hd, hipIpcMemLazyEnablePeerAccess));
+      c.ipc_opened.push_back(p);
+      peers[(size_t)r] = (OneShotBox *)p;
+    }
+    if (!peers[(size_t)r]) return FL_ERR_ARG_NULL;
+  }
+  if (!c.peers_dev) FL_HIP(hipMalloc((void **)&c.peers_dev, sizeof(OneShotBox *) * NSLOT));
+  FL_HIP(hipMemcpy(c.peers_dev, peers.data(), sizeof(OneShotBox *) * peers.size(), hipMemcpyHostToDevice));
+  c.oneshot_calls = 0;
+  c.oneshot_ready = true;
+  return FL_SUCCESS;
+}
+// 1 if a wait of a one-shot all-reduce on this handle ever ran into its time limit (the sums of that call are NaN)
+extern "C" int fl_poisson_comm_oneshot_error(fl_poisson *h, int *error)
+{
+  if (!h || !error) return FL_ERR_ARG_NULL;
+  *error = 0;
+  if (!h->comm.box) return FL_SUCCESS;
+  FL_HIP(hipSetDevice(h->device));
+  OneShotBox host;
+  FL_HIP(hipStreamSynchronize(h->stream));
+  FL_HIP(hipMemcpy(&host, h->comm.box, sizeof(host), hipMemcpyDeviceToHost));
+  *error = host.error;
   return FL_SUCCESS;
 }
 

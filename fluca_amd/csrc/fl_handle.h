@@ -9,6 +9,7 @@
 #include <cstring>
 #include <ctime>
 #include <limits>
+#include <list>
 #include <mutex>
 #include <string>
 
@@ -120,8 +121,28 @@ inline Rccl g_rccl;
     }                                                                                                              \
   } while (0)
 
+// One-shot all-reduce of up to NSLOT doubles: every rank owns a MAILBOX in fine-grained device memory --
+// two parities of nranks slots of NSLOT doubles and nranks sequence numbers each -- that its peers have mapped (hipIpc handles exchanged once
+// through the control plane, or plain pointers between handles of one process).  An all-reduce is ONE single-wave kernel per rank: write my
+// numbers into my slot of every peer's mailbox, release the sequence number, wait until my own mailbox holds the current sequence number of
+// every rank, add the slots in rank order (the same bits on every rank).  No rendezvous through the host, no ring: at 256^3 per GPU the two
+// 64-byte ncclAllReduce of a CG iteration cost as much as its kernels.  Opt-in (tuning knob "allreduce" = 1); RCCL stays the default.
+struct OneShotBox {
+  double             slot[2][NSLOT][NSLOT];  // [parity][rank][value]  (nranks <= NSLOT)
+  unsigned long long seq[2][NSLOT];          // [parity][rank]: the all-reduce number the slot belongs to
+  int                error;                  // a wait ran into its time limit
+  int                pad_;
+};
+void launch_oneshot_allreduce(hipStream_t st, OneShotBox *const *boxes, int rank, int nranks, unsigned long long number, double *vals, int n);
+
 struct Comm {
   enum Kind { NONE, RCCL, HOST } kind = NONE;
+  // one-shot all-reduce (fl_poisson_comm_oneshot_*): my mailbox, the peers' mailboxes as this process sees them (device array), the call counter
+  OneShotBox          *box = nullptr;
+  OneShotBox         **peers_dev = nullptr;
+  std::vector<void *>  ipc_opened;
+  unsigned long long   oneshot_calls = 0;
+  bool                 oneshot_ready = false;
   int             rank = 0, nranks = 1;
   ncclComm_t      nccl = nullptr;
   fl_exchange_fn  xchg = nullptr;
@@ -140,6 +161,8 @@ struct Comm {
     destroy();
     kind = o.kind; rank = o.rank; nranks = o.nranks; nccl = o.nccl; xchg = o.xchg; allred = o.allred; ctx = o.ctx;
     owns = false;
+    // NOT the one-shot mailboxes: the call counter lives in the Comm, and two Comms counting on one mailbox would disagree about the
+    // sequence numbers -- the coarse levels' reductions go through the borrowed RCCL / host wire
   }
 
   int exchange(hipStream_t st, const std::vector<Msg> &m)
@@ -208,6 +231,10 @@ struct Comm {
   int  allreduce(hipStream_t st, double *dev, int n)
   {
     if (nranks == 1 && !loopback) return 0;
+    if (oneshot_ready && n <= NSLOT && knob(K_allreduce) == 1) {
+      launch_oneshot_allreduce(st, peers_dev, rank, nranks, ++oneshot_calls, dev, n);
+      return 0;
+    }
     if (kind == RCCL) {
       FL_NCCL(g_rccl.AllReduce(dev, dev, (size_t)n, ncclDouble, ncclSum, nccl, st));
       return 0;
@@ -227,8 +254,26 @@ struct Comm {
     return FL_ERR_ARG_WRONGSTATE;
   }
 
+  void destroy_oneshot()
+  {
+    if (!owns) {  // a multigrid level: the mailboxes belong to the fine handle
+      box = nullptr;
+      peers_dev = nullptr;
+      oneshot_ready = false;
+      return;
+    }
+    for (void *p : ipc_opened) (void)hipIpcCloseMemHandle(p);
+    ipc_opened.clear();
+    if (peers_dev) (void)hipFree(peers_dev);
+    if (box) (void)hipFree(box);
+    peers_dev = nullptr;
+    box = nullptr;
+    oneshot_ready = false;
+    oneshot_calls = 0;
+  }
   void destroy()
   {
+    destroy_oneshot();
     if (kind == RCCL && nccl && owns) g_rccl.CommDestroy(nccl);
     for (double *p : hsend)
       if (p) (void)hipHostFree(p);
@@ -253,6 +298,15 @@ using namespace fl;
 // ------------------------------------------------------------------------------------------------ handle
 
 struct fl_mg;
+
+// the scalar blocks of every sweep of one kind of smoothing call (fl_cheb_smooth_padded), precomputed on the host and kept on the device
+struct SmoothSeq {
+  int                  nu = 0;
+  bool                 guess_zero = false, jac = false, fuse = false, want = false;
+  double               emin = 0., emax = 0.;
+  std::vector<KspScal> host;
+  KspScal             *dev = nullptr;
+};
 
 struct fl_poisson {
   int         device = 0;
@@ -309,6 +363,7 @@ struct fl_poisson {
   hipEvent_t  ev_packed = nullptr, ev_ghosts = nullptr;
   hipEvent_t  ev_upload = nullptr;  // behind the last fl_poisson_upload (fl_poisson_upload_fence waits for it)
   fl_mg     *mg = nullptr;  // multigrid hierarchy, built by the first solve with FL_PC_MG (fl_mg.hip)
+  std::list<SmoothSeq> smooth_seq;  // (a list: entries are never moved once a sweep has been pointed at their host copy)
 };
 
 

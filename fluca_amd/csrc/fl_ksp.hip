@@ -1235,16 +1235,15 @@ int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero, bool
   const double flo = elo ? std::atof(elo) : 0.1, fhi = ehi ? std::atof(ehi) : 1.1;
   const double lam = fl_gershgorin_bound(h, jac), emin = flo * lam, emax = fhi * lam;
   init_scal(h, &o);
-  KspScal &S = *h->scal_host;
-  S.scale     = 2. / (emax + emin);
-  const double alpha = 1. - S.scale * emin;
-  S.mu        = 1. / alpha;
-  S.omegaprod = 2. / alpha;
-  S.ckm1      = 1.;
-  S.ck        = S.mu;
-  S.cheb_rho  = 0.;
-  S.cheb_c    = S.scale;
-  hipLaunchKernelGGL(k_scal_set, dim3(1), dim3(1), 0, s, h->scal, S);
+  KspScal S0 = *h->scal_host;
+  S0.scale     = 2. / (emax + emin);
+  const double alpha = 1. - S0.scale * emin;
+  S0.mu        = 1. / alpha;
+  S0.omegaprod = 2. / alpha;
+  S0.ckm1      = 1.;
+  S0.ck        = S0.mu;
+  S0.cheb_rho  = 0.;
+  S0.cheb_c    = S0.scale;
   const int fuse_ok = cheb_fuse(h);
   if (fuse_ok < 0) return fuse_ok;
   const bool fuse = fuse_ok && nu - (guess_zero ? 1 : 0) >= 2;
@@ -1256,8 +1255,6 @@ int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero, bool
   }
   double    *X0 = h->xp, *X1 = h->P0, *B = h->r, *D0 = h->q, *D1 = fuse ? h->cd1 : h->q;
   const bool ghosts = fl_any_ghost_exchange(h);
-  auto       finl = [=](const double *partial, int nb, int stride, const double *sums) { hipLaunchKernelGGL(k_cheb_fin, dim3(1), dim3(256), 0, s, partial, nb, stride, sums, h->scal, h->hist, nhist); };
-  auto       fin2 = [=](const double *partial, int nb, int stride, const double *sums) { hipLaunchKernelGGL(k_cheb_fin2, dim3(1), dim3(256), 0, s, partial, nb, stride, sums, h->scal); };
   int        cur = 0, dcur = 0;
   const int trace = knob(K_comm_trace);
   auto mark = [&](const char *what, int j) {  // debugging aid: where a sweep stops making progress (each mark waits for the stream)
@@ -1269,13 +1266,74 @@ int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero, bool
     std::fprintf(stderr, "[%.3f smooth r%d n=%dx%dx%d] %s j=%d cur=%d dcur=%d -> %s\n", ts.tv_sec % 1000 + 1e-9 * ts.tv_nsec, h->comm.rank, h->g.nx, h->g.ny, h->g.nz, what, j, cur, dcur, hipGetErrorString(e));
     std::fflush(stderr);
   };
+  // The smoother looks at no norm and carries no null space: what k_cheb_fin / k_cheb_fin2 would do between two sweeps -- flip the buffers, count
+  // the step, advance the Chebyshev recurrence -- depends on nothing the device computes.  So the scalar block of EVERY sweep of the call is formed
+  // here, once per (nu, first-step form, fused pattern, interval) and handle, kept on the device, and each sweep is launched on its own block: no scalar
+  // kernel between the sweeps (a 512^3 multigrid solve made 330 of them).  `kind`: 1 the first step from a zero guess, 2 a fused pair, 0 a single step.
+  auto kind_of = [&](int j) { return (j == 0 && guess_zero) ? 1 : ((fuse && j + 2 <= nu && !(want && jac && !h->multi && ((nu - j) & 1))) ? 2 : 0); };
+  const KspScal *seq = nullptr;
+  {
+    SmoothSeq *hit = nullptr;
+    for (SmoothSeq &q : h->smooth_seq)
+      if (q.nu == nu && q.guess_zero == guess_zero && q.jac == jac && q.fuse == fuse && q.want == want && q.emin == emin && q.emax == emax) hit = &q;
+    if (!hit) {
+      SmoothSeq q;
+      q.nu = nu; q.guess_zero = guess_zero; q.jac = jac; q.fuse = fuse; q.want = want; q.emin = emin; q.emax = emax;
+      KspScal S = S0;
+      auto advance = [](const KspScal &P, double ck, double ckm1, double &ck_out, double &ckm1_out, double &rho, double &c) {  // cheb_advance, on the host
+        const double ckp1 = 2. * P.mu * ck - ckm1, omega = P.omegaprod * ck / ckp1;
+        ckm1_out = ck;
+        ck_out   = ckp1;
+        rho      = omega - 1.;
+        c        = omega * P.scale;
+      };
+      for (int j = 0; j < nu;) {
+        q.host.push_back(S);
+        if (kind_of(j) == 2) {  // k_cheb_fin2: both steps accepted
+          double ck, ckm1, rho1, c1, rho2, c2;
+          advance(S, S.ck, S.ckm1, ck, ckm1, rho1, c1);
+          S.cur ^= 1;
+          S.dcur ^= 1;
+          S.it += 2;
+          advance(S, ck, ckm1, S.ck, S.ckm1, rho2, c2);
+          S.cheb_rho = rho2;
+          S.cheb_c   = c2;
+          j += 2;
+        } else {  // k_cheb_fin
+          double ck, ckm1, rho, c;
+          S.cur ^= 1;
+          S.it += 1;
+          advance(S, S.ck, S.ckm1, ck, ckm1, rho, c);
+          S.ck       = ck;
+          S.ckm1     = ckm1;
+          S.cheb_rho = rho;
+          S.cheb_c   = c;
+          j += 1;
+        }
+      }
+      FL_HIP(hipMalloc((void **)&q.dev, sizeof(KspScal) * q.host.size()));
+      h->smooth_seq.push_back(std::move(q));
+      hit = &h->smooth_seq.back();
+      // (the host copy lives as long as the handle: the asynchronous upload may read it whenever it likes)
+      FL_HIP(hipMemcpyAsync(hit->dev, hit->host.data(), sizeof(KspScal) * hit->host.size(), hipMemcpyHostToDevice, s));
+    }
+    seq = hit->dev;
+  }
+  // the launchers take the scalar block from h->scal: point it at the sweep's own block for the length of a launch
+  struct ScalGuard {
+    fl_poisson *h;
+    KspScal    *keep;
+    ~ScalGuard() { h->scal = keep; }
+  } guard{h, h->scal};
   // several ranks under the fused sweep: its ring comes from the ghost layers -- two of x with the shell's edges, one of d, one of b (b once
   // per call, after the first step has possibly updated it in place)
   const bool deep = fuse && h->multi;
   bool       bghost = false;
+  int        launch = 0;
   for (int j = 0; j < nu;) {
-    if (j == 0 && guess_zero) {
-      // the sums k_cheb_fin would look at are not used without a norm and a null space: it only advances the recurrence
+    h->scal = const_cast<KspScal *>(seq) + launch++;
+    const int kind = kind_of(j);
+    if (kind == 1) {
       const int64_t items = (int64_t)((h->g.nx + 127) / 128) * h->g.ny * h->g.nz;  // 128-cell row segments, one per wave and trip
       const int     nb    = (int)std::max<int64_t>(1, std::min<int64_t>((items + 3) / 4, 8192));
       if (subq) {
@@ -1283,9 +1341,8 @@ int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero, bool
         else hipLaunchKernelGGL((k_cheb_first<false, true>), dim3(nb), dim3(256), 0, s, h->g, X0, X1, B, D0, D1, h->scal, subq, suba);
       } else if (jac) hipLaunchKernelGGL((k_cheb_first<true>), dim3(nb), dim3(256), 0, s, h->g, X0, X1, B, D0, D1, h->scal, (const double *)nullptr, (const double *)nullptr);
       else hipLaunchKernelGGL((k_cheb_first<false>), dim3(nb), dim3(256), 0, s, h->g, X0, X1, B, D0, D1, h->scal, (const double *)nullptr, (const double *)nullptr);
-      finl(h->partial, tp.nblocks, h->partial_stride, (const double *)nullptr);  // no norm, no null space: the sums are not looked at, only the recurrence advances -- nothing to all-reduce
       j += 1;
-    } else if (fuse && j + 2 <= nu && !(want && jac && !h->multi && ((nu - j) & 1))) {  // (asked for the sums: an odd step count takes its single step first, so that a fused sweep ends the call)
+    } else if (kind == 2) {  // (asked for the sums: an odd step count takes its single step first, so that a fused sweep ends the call)
       // two steps in one sweep; on one rank it reads no ghost layer (fl_cheb2.hip)
       const bool md = want && jac && j + 2 == nu && !h->multi;
       if (deep) {
@@ -1298,7 +1355,6 @@ int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero, bool
       fl_launch_cheb2(h, cp, jac, X0, X1, B, D0, D1, md);
       mark("fused done", j);
       dcur ^= 1;
-      fin2(h->partial, cp.nblocks, h->partial_stride, (const double *)nullptr);  // without a norm and a null space the sums only advance the recurrence: no all-reduce on several ranks either
       if (md) {
         launch_reduce(s, h->partial, cp.nblocks, h->partial_stride, 5, h->sums);
         *mgdots = true;
@@ -1307,10 +1363,8 @@ int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero, bool
     } else {
       if (ghosts) FL_CHK(fl_fill_ghosts(h, cur ? X1 : X0));
       mark("before single", j);
-      const int nbc = launch_cheb(h, tp, jac, X0, X1, B, D0, D1);
+      (void)launch_cheb(h, tp, jac, X0, X1, B, D0, D1);
       mark("single done", j);
-      finl(h->partial, nbc, h->partial_stride, (const double *)nullptr);
-      mark("fin done", j);
       j += 1;
     }
     cur ^= 1;

@@ -290,6 +290,17 @@ int fl_poisson_comm_init_rccl(fl_poisson *h, const void *id128, int rank, int nr
 typedef int (*fl_exchange_fn)(void *ctx, int nmsg, const int *peer, const int *sendtag, const int *recvtag, void *const *send, void *const *recv, const int64_t *nbytes);
 typedef int (*fl_allreduce_fn)(void *ctx, double *vals, int n);
 int fl_poisson_comm_init_host(fl_poisson *h, fl_exchange_fn xchg, fl_allreduce_fn allred, void *ctx, int rank, int nranks);
+/* One-shot all-reduce (opt-in; tuning knob "allreduce" = 1): the scalar reductions of a solve -- 8 doubles, twice per CG iteration -- written
+ * straight into the peers' mailboxes (fine-grained device memory every rank has mapped) by one single-wave kernel per rank, instead of
+ * ncclAllReduce's rendezvous; the sums are added in rank order, the same bits on every rank.  Set-up, after fl_poisson_comm_init_*: every rank
+ * calls ..._oneshot_handle (its mailbox as a 64-byte hipIpcMemHandle_t, and as an address for handles of the same process), the host gathers
+ * them, every rank calls ..._oneshot_attach with the whole list (either nranks x 64 bytes of IPC handles, or nranks addresses).  At most 8 ranks.
+ * A wait that sees no peer for about two seconds gives up: the sums are NaN (the solve ends with KSP_DIVERGED_NANORINF) and ..._oneshot_error
+ * reports 1. */
+#define FL_IPC_HANDLE_BYTES 64
+int fl_poisson_comm_oneshot_handle(fl_poisson *h, void *ipc_handle64, void **address);
+int fl_poisson_comm_oneshot_attach(fl_poisson *h, const void *handles, void *const *addresses);
+int fl_poisson_comm_oneshot_error(fl_poisson *h, int *error);
 /* What the handle's communicator IS, for a caller (bench.py) that must prove which wire carried its halos: transport 0 none, 1 RCCL, 2 host
  * callbacks; rank / nranks as RCCL itself reports them (ncclCommUserRank / ncclCommCount) for transport 1, as given at init otherwise;
  * neighbours = ranks this one exchanges ghost layers with; halo_bytes = bytes this rank SENDS per ghost exchange of one cell vector. */

@@ -575,3 +575,70 @@ def test_nsstep_with_the_immersed_cylinder_on_the_2x2x2_rank_grid():
     for d in range(3):
         assert np.linalg.norm(V[d] - V1[d]) <= 1e-8 * max(np.linalg.norm(V1[d]), 1e-12), d
     assert np.linalg.norm(p - p1) <= 1e-7 * np.linalg.norm(p1)
+
+
+# ------------------------------------------------------------------------------------------------ one-shot all-reduce through peer mailboxes
+
+def _oneshot_worker(R, case, ref, shared):
+    import torch
+    from fluca_amd import capi
+    P, d, s = _handle(R, case)
+    out = {}
+    with torch.cuda.stream(s):
+        dev = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64).ravel(), device="cuda")
+        addr = C.c_void_p()
+        capi.check(capi.lib.fl_poisson_comm_oneshot_handle(P.h, None, C.byref(addr)))
+        shared[R.rank] = addr.value
+        R.barrier()
+        capi.check(capi.lib.fl_poisson_comm_oneshot_attach(P.h, None, (C.c_void_p * R.size)(*shared)))
+        bd = dev(_blk(case, d, ref["b"]))
+        for mode in (0, 1, 0, 1):          # the wire's all-reduce, the mailboxes, and once more each (sequence numbers carry on)
+            R.barrier()
+            capi.check(capi.lib.fl_tuning_set(b"allreduce", mode))
+            R.barrier()
+            before = R.stats()["allreduces"]
+            xg, ig = P.solve(bd, history=True, remove_nullspace=int(case.nullspace), rtol=1e-9, maxit=2000, check_every=8)
+            s.synchronize()
+            made = R.stats()["allreduces"] - before
+            out.setdefault(mode, []).append((ig["iters"], ig["reason"], np.asarray(ig["history"]), xg.cpu().numpy().copy(), made))
+        err = C.c_int()
+        capi.check(capi.lib.fl_poisson_comm_oneshot_error(P.h, C.byref(err)))
+        assert err.value == 0
+        R.barrier()
+        capi.check(capi.lib.fl_tuning_set(b"allreduce", 0))
+        R.barrier()
+    P.close()
+    return out
+
+
+def _oneshot_check(name):
+    case = Case(**CASES[name])
+    ref = _reference(case)
+    shared = [None] * 8
+    res = inproc.run_threads(8, _oneshot_worker, case, ref, shared)
+    for r in res:
+        (i0, r0, h0, x0, m0), (i1, r1, h1, x1, m1) = r[0][0], r[1][0]
+        assert (i0, r0) == (i1, r1) and r0 == 2
+        assert np.array_equal(h0, h1) and np.array_equal(x0, x1)
+        assert m0 >= 2 * i0 and m1 == 0, (m0, m1)          # two all-reduces per iteration on the wire, none with the mailboxes
+        for k in (0, 1):                                   # a second solve through each path repeats the first
+            assert np.array_equal(r[k][0][2], r[k][1][2]) and np.array_equal(r[k][0][3], r[k][1][3])
+
+
+@pytest.mark.parametrize("name", ["c5_even", "periodic_222"])
+def test_one_shot_allreduce_gives_the_wire_s_bits(name):
+    """Tuning knob "allreduce" = 1: the two 64-byte reductions of a CG iteration written straight into the peers' mailboxes by one single-wave
+    kernel per rank (fl_poisson_comm_oneshot_*), no rendezvous through RCCL / the host.  Both this and the test wire add the ranks' numbers in rank
+    order, so on eight ranks the residual history and the answer must be equal BIT FOR BIT, and the wire must not have been asked.
+
+    The kernels of the eight ranks WAIT for each other, so all eight must be able to run at once: true for one process per GPU (production) and
+    for eight processes on one GPU, not for eight streams of one process on the runtime's default of four hardware queues (a kernel behind a
+    waiting one in the same queue never starts; the wait then gives up after two seconds, the sums are NaN and the error flag is raised --
+    observed, and what fl_poisson_comm_oneshot_error is for).  Hence a child process with GPU_MAX_HW_QUEUES=16."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16")
+    code = f"import sys; sys.path.insert(0, {inproc.ROOT!r}); from tests import test_gpu_config5 as T; T._oneshot_check({name!r}); print('ONESHOT_OK')"
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=inproc.ROOT)
+    assert out.returncode == 0 and "ONESHOT_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]

@@ -547,3 +547,51 @@ def test_decomposed_cgns_dump_is_the_single_domain_file(tmp_path, world, n, rank
 ])
 def test_decomposed_time_steps_through_the_mirror(world, n, ranks, opts):
     mpc.run_ranks(world, _nsstep_worker, n, ranks, opts)
+
+
+def _oneshot_ipc_worker(rank, world, n, ranks, bc):
+    """Two PROCESSES on one GPU: the mailboxes travel as hipIpcMemHandle_t through the control plane (gloo all_gather), hipIpcOpenMemHandle maps the
+    peer's; the solve with "allreduce" = 1 against the same solve through the gloo callbacks."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    from fluca_amd import capi
+    from fluca_amd.poisson import Poisson
+    from oracle import fluca_oracle as fo
+    d = mpc.decomp_of(capi, n, ranks, rank)
+    box = [(0.0, 1.0), (0.0, 1.0), (0.0, 0.5)]
+    P = Poisson.uniform(n, box, bc, 1e-3, decomp=d)
+    P.comm_init_host(mpc.gloo_exchange, mpc.gloo_allreduce, rank, world)
+    hd = (C.c_char * 64)()
+    capi.check(capi.lib.fl_poisson_comm_oneshot_handle(P.h, hd, None))
+    every = [None] * world
+    dist.all_gather_object(every, bytes(hd))
+    blob = (C.c_char * (64 * world)).from_buffer_copy(b"".join(every))
+    capi.check(capi.lib.fl_poisson_comm_oneshot_attach(P.h, blob, None))
+    g = fo.Grid.uniform(n, box, bc, 1e-3)
+    rng = np.random.default_rng(20260313)
+    p = rng.uniform(-1, 1, g.ncell)
+    p -= p.mean()
+    b = g.assemble_S().mult(p)
+    shp = (n[2], n[1], n[0])
+    bd = torch.as_tensor(np.ascontiguousarray(b.reshape(shp)[mpc.block(d)]).ravel(), device="cuda")
+    res = {}
+    for mode in (0, 1):
+        dist.barrier()
+        capi.check(capi.lib.fl_tuning_set(b"allreduce", mode))
+        calls = mpc.allreduce_calls()
+        xg, ig = P.solve(bd, history=True, rtol=1e-8, maxit=600, check_every=6)
+        res[mode] = (ig["iters"], ig["reason"], np.asarray(ig["history"]), xg.cpu().numpy(), mpc.allreduce_calls() - calls)
+    err = C.c_int()
+    capi.check(capi.lib.fl_poisson_comm_oneshot_error(P.h, C.byref(err)))
+    assert err.value == 0
+    a, o = res[0], res[1]
+    assert a[0] == o[0] and a[1] == o[1] == 2
+    assert a[4] >= 2 * a[0] and o[4] == 0                  # the gloo callback was asked twice per iteration, then never
+    assert np.array_equal(a[2], o[2]) and np.array_equal(a[3], o[3])    # two ranks: a + b = b + a, the same bits either way
+    capi.check(capi.lib.fl_tuning_set(b"allreduce", 0))
+    P.close()
+
+
+def test_one_shot_allreduce_between_two_processes():
+    mpc.run_ranks(2, _oneshot_ipc_worker, (24, 20, 16), (1, 1, 2), [1, 1, 1, 1, 4, 1])
