@@ -77,8 +77,9 @@ def main():
         t_int = timed(lambda: capi.check(capi.lib.fl_ibm_interp(hm, 3, ptr(u), ptr(U))))
         t_spr = timed(lambda: capi.check(capi.lib.fl_ibm_spread(hm, 3, ptr(F), ptr(dV), ptr(f))))
         st = [C.c_int(), C.c_int(), C.c_int()]
-        capi.lib.fldbg_ibm_stats.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 3
-        capi.check(capi.lib.fldbg_ibm_stats(hm, *[C.byref(v) for v in st]))
+        if hasattr(capi.lib, "fldbg_ibm_stats"):   # bin statistics: kbench build of the library only (FLUCA_LIB_DIR=fluca_amd/lib_kbench)
+            capi.lib.fldbg_ibm_stats.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 3
+            capi.check(capi.lib.fldbg_ibm_stats(hm, *[C.byref(v) for v in st]))
         rows.append(dict(markers=L, rebin_ms=t_bin, interp_ms=t_int, spread_ms=t_spr, allreduce_bytes=24 * L if a.loopback else 0, tiles_with_markers=st[0].value,
                          bin_entries=st[1].value, largest_bin=st[2].value, env={k: v for k, v in os.environ.items() if k.startswith("FLUCA_IBM")}))
         capi.lib.fl_ibm_destroy(hm)

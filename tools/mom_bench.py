@@ -84,6 +84,9 @@ def main():
         out[f"kernel_ms_mode{mode}"] = ms.value
     out["kernel"] = os.environ.get("FLUCA_MOM_KERNEL", "3" if a.fly else "2")
     # streaming ceiling of the same access mix (15 reads + 3 writes, flat)
+    if not hasattr(lib, "fldbg_mom_stream"):   # the probe lives in the kbench build of the library only (FLUCA_LIB_DIR=fluca_amd/lib_kbench)
+        print(json.dumps(out))
+        return
     lib.fldbg_mom_stream.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
     for blocks in (2048, 8192):
         ms = C.c_double()
