@@ -777,7 +777,8 @@ int vcycle(fl_mg *mg, size_t l, const fl_ksp_opts *o, bool *sums = nullptr, cons
     } else hipLaunchKernelGGL(k_mg_prolong_lin_add, dim3(nblk_pairs(h->g)), dim3(256), 0, h->stream, h->g, C.h->g, L.r[0], L.r[1], L.r[2], t, (const double *)C.h->xp, h->xp);
   } else hipLaunchKernelGGL(k_mg_prolong_add, dim3(nblk_pairs(h->g)), dim3(256), 0, h->stream, h->g, C.h->g, L.r[0], L.r[1], L.r[2], C.h->xp, h->xp);  // x += P e_c
   bool got = want;
-  FL_CHK(fl_cheb_smooth_padded(h, nu, true, false, &got));                           // nu more steps from x
+  const int nu_post = knob(K_mg_post_smooth) > 0 ? knob(K_mg_post_smooth) : nu;
+  FL_CHK(fl_cheb_smooth_padded(h, nu_post, true, false, &got));                      // nu (or "mg_post_smooth") more steps from x
   if (sums) *sums = got;
   return 0;
 }

@@ -201,6 +201,8 @@ int fl_vec_maxpy(fl_poisson *h, int64_t n, double *x_dev, const double *alphas, 
  *                -ksp_fcg_mmax 1): robust against the cycle not being a symmetric operator; 0 = KSPCG's beta.
  *   "mg_coarse"  1 (default) = a coarsest multigrid level of at most 4096 cells on one rank is solved by ONE workgroup (no launches per CG iteration,
  *                no host poll inside the cycle); 0 = through the public Jacobi-PCG like every other size.  Same algorithm, other summation order.
+ *   "mg_post_smooth" 0 (default) = as many smoothing steps after the coarse correction as before it (fl_ksp_opts.mg_smooth_its); n > 0 = n steps
+ *                (V(3,2) is 3 % faster than V(3,3) at 512^3 and one iteration longer: profiles/r05_mg_nu.txt).
  *   "overlap"    1 (default) = on several ranks the exchange of the new residual runs behind the update kernel on a second stream; 0 = after it.
  *   "comm_loopback" 1 = a handle created on ONE rank sends the ghost layers of its periodic axes to itself through the communicator instead of
  *                copying them (exercises RCCL on a one-GPU box; looked at by fl_poisson_create).  "comm_trace" 1 / 2 = exchanges narrated on stderr.

@@ -52,7 +52,7 @@ def _worker(rank, world, n, ranks, bc, ksp):
         ksp = 0
     nullspace = 2 not in bc
     # (every iteration is two gloo all-reduces and a host-staged exchange: four processes make that slow, keep it short)
-    kw = dict(rtol=1e-6 if world < 4 else 1e-4, maxit=2000)
+    kw = dict(rtol=1e-9 if world < 4 else 1e-7, maxit=2000)
     if ksp == 2:
         lam = S.gershgorin(fo.PC_JACOBI)
         kw = dict(rtol=1e-3, maxit=40, emin=0.1 * lam, emax=1.1 * lam)
@@ -66,7 +66,7 @@ def _worker(rank, world, n, ranks, bc, ksp):
     assert ig["reason"] == io["reason"], (ig["reason"], io["reason"])
     assert abs(ig["iters"] - io["iters"]) <= (2 if ksp != 1 else max(3, io["iters"] // 10)), (ig["iters"], io["iters"])
     m = min(len(ig["history"]), len(io["history"]), 8)
-    assert np.allclose(ig["history"][:m], io["history"][:m], rtol=1e-6)
+    assert np.allclose(ig["history"][:m], io["history"][:m], rtol=1e-9 if ksp != 1 else 1e-6)   # (BiCGStab amplifies the reduction order from the start)
     xg = xg.cpu().numpy()
     xref = xo - xo.mean() if nullspace else xo
     if nullspace:
@@ -76,7 +76,9 @@ def _worker(rank, world, n, ranks, bc, ksp):
         xg = xg - sm[0] / sm[1]
     diff = np.array([((xg - xref.reshape(shp)[blk].ravel()) ** 2).sum(), (xref ** 2).sum() / world])
     mpc.gloo_allreduce(diff)
-    assert np.sqrt(diff[0] / diff[1]) <= (1e-3 if world < 4 else 1e-2), ("solution", np.sqrt(diff[0] / diff[1]))
+    # two solves that each stop at rtol agree to about cond(S) x rtol (round 5: rtol 1e-9 / 1e-7 instead of 1e-6 / 1e-4; the 2 x 2 x 2 grid of
+    # tests/test_gpu_config5.py goes to 1e-6 at rtol 1e-10 without the slow gloo wire)
+    assert np.sqrt(diff[0] / diff[1]) <= (1e-5 if world < 4 else 1e-3), ("solution", np.sqrt(diff[0] / diff[1]))
     P.close()
 
 
