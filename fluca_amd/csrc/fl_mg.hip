@@ -541,6 +541,7 @@ struct MgLevel {
 
 struct fl_mg {
   std::vector<MgLevel> lv;
+  int                  requested = 0;       // fl_ksp_opts.mg_levels the hierarchy was built for (0 = as deep as possible)
   MgScal              *scal = nullptr;      // device: the outer CG's scalars
   MgSlot              *slot_dev = nullptr;  // device staging of what the host reads ...
   MgSlot              *slot_host = nullptr; // ... and its page-locked copies, one per iteration parity
@@ -817,8 +818,13 @@ int fl_solve_cg_mg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts 
 {
   if (h->multi && h->comm.kind == Comm::NONE) return FL_ERR_ARG_WRONGSTATE;
   if (o->norm_type != FL_NORM_PRECONDITIONED && o->norm_type != FL_NORM_UNPRECONDITIONED) return FL_ERR_SUP;
-  if (h->mg && o->mg_levels > 0 && (int)h->mg->lv.size() != std::min<int>(o->mg_levels, (int)h->mg->lv.size()) ) fl_mg_destroy(h);
-  if (!h->mg) FL_CHK(mg_build(h, o->mg_levels));
+  // another depth than the hierarchy was built for: build again (round 5: comparing with the number of levels that EXIST never let a hierarchy grow
+  // back once a solve had asked for a shallower one)
+  if (h->mg && h->mg->requested != o->mg_levels) fl_mg_destroy(h);
+  if (!h->mg) {
+    FL_CHK(mg_build(h, o->mg_levels));
+    h->mg->requested = o->mg_levels;
+  }
   // the placement step (and nothing else) may have dropped the fine level's vectors since the hierarchy was built
   for (double **v : {&h->r, &h->P0, &h->q, &h->xp, &h->w0, &h->w1, &h->w2}) FL_CHK(fl_ensure_vec(h, v));
   fl_mg       *mg = h->mg;

@@ -84,6 +84,16 @@ def test_mg_vs_jacobi_iteration_counts_and_reuse():
     assert np.linalg.norm((a - a.mean()) - (c - c.mean())) <= 1e-5 * np.linalg.norm(a - a.mean())
     with pytest.raises(RuntimeError):
         P.solve(b, type=1, pc=2)                                      # BiCGStab + MG: not built
+    # -pc_mg_levels follows the request in BOTH directions: deep, shallow, deep again must give deep's history again (round 5: a hierarchy once
+    # built for fewer levels used to answer a later request for more)
+    hist = {}
+    for step, lev in enumerate((0, 2, 0, 3, 2)):
+        _, info = P.solve(b, type=0, pc=2, rtol=1e-8, maxit=100, mg_levels=lev, history=True)
+        assert info["reason"] == 2
+        if lev in hist:
+            assert np.array_equal(hist[lev], info["history"]), (step, lev)
+        hist[lev] = info["history"]
+    assert hist[2][0] != hist[0][0] and hist[3][0] != hist[0][0] and hist[2][0] != hist[3][0]     # three different cycles: ||M^-1 b|| differs
     P.close()
 
 
