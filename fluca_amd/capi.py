@@ -59,7 +59,8 @@ class fl_ksp_opts(C.Structure):
                 ("maxit", C.c_int), ("rtol", C.c_double), ("atol", C.c_double), ("dtol", C.c_double),
                 ("emin", C.c_double), ("emax", C.c_double), ("variant", C.c_int), ("check_every", C.c_int),
                 ("profile", C.c_int), ("history", C.POINTER(C.c_double)), ("nhistory", C.c_int),
-                ("mg_levels", C.c_int), ("mg_smooth_its", C.c_int), ("gmres_restart", C.c_int), ("cg_single_reduction", C.c_int)]
+                ("mg_levels", C.c_int), ("mg_smooth_its", C.c_int), ("gmres_restart", C.c_int), ("cg_single_reduction", C.c_int),
+                ("initial_guess_nonzero", C.c_int)]
 
 
 class fl_ksp_stats(C.Structure):

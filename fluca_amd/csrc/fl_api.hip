@@ -38,7 +38,7 @@ static int plane_size(const fl_poisson *h, int d)
 extern "C" const char *fl_build_id(void);  // lib/fl_build_id.cpp, written by fluca_amd/build.py: a hash over every source, header and compiler flag
 extern "C" const char *fl_version(void)
 {
-  static const std::string v = std::string("fluca_amd 0.3 (gfx950, abi 5, sources ") + fl_build_id() + ")";
+  static const std::string v = std::string("fluca_amd 0.3 (gfx950, abi 6, sources ") + fl_build_id() + ")";
   return v.c_str();
 }
 extern "C" int fl_abi_version(void) { return FL_ABI_VERSION; }
@@ -1415,6 +1415,7 @@ extern "C" int fl_poisson_solve(fl_poisson *h, const double *b_dev, double *x_de
   if (!h || !b_dev || !x_dev || !opts || !stats) return FL_ERR_ARG_NULL;
   if (opts->maxit < 0 || opts->maxit > 10000000) return FL_ERR_ARG_OUTOFRANGE;
   if (opts->pc != FL_PC_NONE && opts->pc != FL_PC_JACOBI && opts->pc != FL_PC_MG) return FL_ERR_SUP;
+  if (opts->initial_guess_nonzero) return FL_ERR_SUP;  // the Schur solvers start from zero, as the reference's kspS does (nsbasic.c:250-251)
   FL_HIP(hipSetDevice(h->device));
   std::memset(stats, 0, sizeof(*stats));
   if (opts->pc == FL_PC_MG) {

@@ -835,6 +835,7 @@ struct fl_momentum {
   double     *stabs[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};  // scaled tables: [0] the handle's coefficients, [1] fl_momentum_rhs
   std::vector<void *> ttabs;
   double     *srhs = nullptr;  // Schur right-hand side of fl_abf_apply
+  double     *gr = nullptr, *gd = nullptr;  // -ksp_initial_guess_nonzero: b - A x0 and the correction (3*cells each, unpadded)
   double     *tmpv = nullptr;  // 3*cells scratch of fl_abf_jacobian_mult
   double     *F = nullptr;   // 12 padded face fields: V0[0..2], v0interp[c*3+d] at 3 + c*3 + d
   double     *dg = nullptr;  // diag(A), 3 padded components (valid after set_state)
@@ -1102,6 +1103,8 @@ extern "C" int fl_momentum_destroy(fl_momentum *m)
     for (double *t : sl)
       if (t) (void)hipFree(t);
   if (m->srhs) (void)hipFree(m->srhs);
+  if (m->gr) (void)hipFree(m->gr);
+  if (m->gd) (void)hipFree(m->gd);
   if (m->tmpv) (void)hipFree(m->tmpv);
   if (m->F) (void)hipFree(m->F);
   if (m->dg) (void)hipFree(m->dg);
@@ -1362,10 +1365,53 @@ static int momentum_gmres(fl_momentum *m, const double *b_dev, double *x_dev, co
 
 // KSPSolve(kspA): left-preconditioned BiCGStab (KSPBCGS) or restarted GMRES (KSPGMRES, the reference's default type for kspA,
 // abfpc.c:72), zero initial guess, PCJACOBI or PCNONE
+namespace {
+void lincomb(fl_poisson *h, int64_t n, double a, const double *x, double b, const double *z, double *y);
+}
+// -ksp_initial_guess_nonzero on kspA: x_dev holds x0.  The Krylov methods here start from zero, and a Krylov method started from x0 is the same method
+// started from zero on the shifted system  A d = b - A x0,  x = x0 + d  (same residuals, same iterates).  What changes is the convergence test:
+// KSPConvergedDefault compares with the norm of the right-hand side b in the KSP's norm when the guess is non-zero (not with the initial residual),
+// so the shifted solve runs to the ABSOLUTE tolerance max(rtol ||M b||, atol).  Costs one product, a scaled norm of b and two vector updates in
+// front of the solve; saves every iteration the guess is worth -- in a time step, where x0 = the previous velocity, b - A x0 = O(dt) b.
+static int momentum_solve_from_guess(fl_momentum *m, const double *b_dev, double *x_dev, const fl_ksp_opts *opts, fl_ksp_stats *stats)
+{
+  fl_poisson *h = m->p;
+  FL_HIP(hipSetDevice(h->device));
+  const int64_t n3 = 3 * h->ncell;
+  if (!m->gr) FL_CHK(fl_dev_alloc(h, (void **)&m->gr, sizeof(double) * (size_t)n3, false));
+  if (!m->gd) FL_CHK(fl_dev_alloc(h, (void **)&m->gd, sizeof(double) * (size_t)n3, false));
+  // || M b || (M = 1 / diag with PCJACOBI and a preconditioned norm, else the identity): the update kernel that starts BiCGStab forms b / diag and
+  // its square sum in one pass (slot 1); its two outputs are scratch here
+  const bool scaled = opts->pc == FL_PC_JACOBI && opts->norm_type != FL_NORM_UNPRECONDITIONED;
+  for (int a = 0; a < 2; ++a) FL_CHK(mom_vec(m, a));
+  FL_CHK(fl_ensure_partials(h, std::max(std::max(m->nblocks, m->ablocks), m->t2blocks)));
+  mom_pw<3>(m, b_dev, scaled ? m->dg : nullptr, nullptr, nullptr, m->vec[0], m->vec[1]);
+  launch_reduce(h->stream, h->partial, mom_pw_blocks(m), h->partial_stride, 3, h->sums);
+  if (h->multi) FL_CHK(h->comm.allreduce(h->stream, h->sums, NSLOT));
+  double sums[NSLOT];
+  FL_HIP(hipMemcpyAsync(sums, h->sums, sizeof(sums), hipMemcpyDeviceToHost, h->stream));
+  FL_HIP(hipStreamSynchronize(h->stream));
+  const double bnorm = std::sqrt(sums[1] > 0. ? sums[1] : 0.);
+  // r = b - A x0
+  FL_CHK(fl_momentum_apply(m, x_dev, m->gr));
+  lincomb(h, n3, 1., b_dev, -1., m->gr, m->gr);
+  fl_ksp_opts o = *opts;
+  o.initial_guess_nonzero = 0;
+  o.rtol = 0.;
+  o.atol = std::max(opts->rtol * bnorm, opts->atol);
+  FL_CHK(fl_momentum_solve(m, m->gr, m->gd, &o, stats));
+  lincomb(h, n3, 1., x_dev, 1., m->gd, x_dev);  // x = x0 + d
+  FL_HIP(hipGetLastError());
+  if (stats->reason == FL_CONVERGED_ATOL && !(stats->rnorm < opts->atol)) stats->reason = FL_CONVERGED_RTOL;  // it was the relative test that was met
+  stats->rnorm0 = bnorm;  // what the relative tolerance refers to
+  return FL_SUCCESS;
+}
+
 extern "C" int fl_momentum_solve(fl_momentum *m, const double *b_dev, double *x_dev, const fl_ksp_opts *opts, fl_ksp_stats *stats)
 {
   if (!m || !b_dev || !x_dev || !opts || !stats) return FL_ERR_ARG_NULL;
   if (!m->have_state && m->mp.cC != 0.) return FL_ERR_ARG_WRONGSTATE;
+  if (opts->initial_guess_nonzero) return momentum_solve_from_guess(m, b_dev, x_dev, opts, stats);
   if (opts->type == FL_KSP_GMRES) return momentum_gmres(m, b_dev, x_dev, opts, stats);
   if (opts->type == FL_KSP_CHEBYSHEV) return momentum_cheb(m, b_dev, x_dev, opts, stats);
   if (opts->type != FL_KSP_BCGS) return FL_ERR_SUP;

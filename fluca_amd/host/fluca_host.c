@@ -935,6 +935,14 @@ FlErrorCode NSSetFromOptions(NS ns, int argc, char **argv)
     else if (!strcmp(s, "none")) ns->mom.norm_type = FL_NORM_NONE;
     else return !strcmp(s, "natural") ? E_SUP : E_ARG_UNKNOWN_TYPE;
   }
+  {
+    /* mirror only: the first PCApply_ABF of a time step starts kspA from the previous velocity (VecCopy(v0, v*) + KSPSetInitialGuessNonzero in front of
+     * abfpc.c:72); the other applications of the step (Richardson corrections) start from zero.  Same convergence test against || M momrhs ||. */
+    int flg = 0;
+    const int got = opt_flag(argc, argv, "-ns_abf_momentum_guess_previous", &flg);
+    if (got < 0) return E_ARG_WRONG;
+    if (got) ns->mom_guess_previous = flg;
+  }
   if (opt_real(argc, argv, "-ns_abf_momentum_ksp_rtol", &v)) ns->mom.rtol = v;
   if (opt_real(argc, argv, "-ns_abf_momentum_ksp_atol", &v)) ns->mom.atol = v;
   if (opt_real(argc, argv, "-ns_abf_momentum_ksp_divtol", &v)) ns->mom.dtol = v;
@@ -2073,8 +2081,14 @@ static FlErrorCode NSStep_CNLinear(NS ns)
     ns->reason  = 0;
     ns->mom_its = ns->schur_its = 0;
     FLCHK(cnl_gmres(ns, &f, &x));
-  } else
-  FLABI(fl_abf_apply(ns->momentum, &ns->mom, &ns->schur, c->f_v, fV, c->f_p, c->x_v, c->x_V, c->x_p, st));
+  } else {
+    fl_ksp_opts mom1 = ns->mom;
+    if (ns->mom_guess_previous) { /* -ns_abf_momentum_guess_previous: v* starts from v0 (the right-hand side is the whole momrhs here, not a residual) */
+      FLABI(fl_vec_lincomb(h, 3 * N, 1., c->sol0_v, 0., NULL, c->x_v));
+      mom1.initial_guess_nonzero = 1;
+    }
+    FLABI(fl_abf_apply(ns->momentum, &mom1, &ns->schur, c->f_v, fV, c->f_p, c->x_v, c->x_V, c->x_p, st));
+  }
   if (ns->ksp_type != 2) {
     ns->ksp_its   = 1;
     ns->reason    = 0;

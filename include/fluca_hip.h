@@ -123,6 +123,11 @@ typedef struct fl_ksp_opts {
                                ONE reduction -- one all-reduce and one scalar kernel per iteration on several ranks instead of two, for
                                72 instead of 60 B/cell/iteration (W = A p kept by recurrence).  0 (default) = off, as in PETSc.
                                With FL_PC_MG: FL_ERR_SUP (not built).  Other Krylov types ignore it, as PETSc ignores an option of another type. */
+  int     initial_guess_nonzero; /* -ksp_initial_guess_nonzero (KSPSetInitialGuessNonzero), fl_momentum_solve / fl_abf_apply's kspA only (ABI 6): the
+                               array handed over as x holds the initial guess.  Convergence as KSPConvergedDefault does it then: against the norm of
+                               the RIGHT-HAND SIDE (in the KSP's norm), not of the initial residual.  fl_poisson_solve: FL_ERR_SUP (its kernels
+                               start from zero).  The reference never sets it on kspA (PCApply_ABF's x holds no guess there); the host mirror
+                               offers it for the first PCApply_ABF of a time step, where the previous velocity is one (include/fluca_host.h). */
 } fl_ksp_opts;
 
 typedef struct fl_ksp_stats {
@@ -158,7 +163,7 @@ int fl_poisson_allreduce_sum(fl_poisson *h, double *host_vals, int n);
 int fl_poisson_sizes(const fl_poisson *h, int64_t out[4]);
 void fl_ksp_opts_default(fl_ksp_opts *o); /* PETSc defaults + cg/jacobi/preconditioned norm */
 const char *fl_version(void);
-#define FL_ABI_VERSION 5
+#define FL_ABI_VERSION 6
 int fl_abi_version(void); /* the FL_ABI_VERSION the library was built with */
 
 /* ---- device memory for hosts that have no allocator of their own (the C host mirror, a PETSc host without HIP Vecs) - */

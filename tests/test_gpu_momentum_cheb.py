@@ -123,3 +123,47 @@ def test_an_interval_that_is_too_short_ends_in_dtol_and_the_handle_recovers():
     assert np.linalg.norm(host(x2) - xr) <= 1e-9 * np.linalg.norm(xr)
     M.close()
     P.close()
+
+
+@pytest.mark.parametrize("ksp", [fo.KSP_BCGS, fo.KSP_CHEBYSHEV, 3])          # 3 = FL_KSP_GMRES
+@pytest.mark.parametrize("n,bc,nonuni", [((17, 9, 11), CAVITY, False), ((64, 48, 40), [V, O, V, V, PER, PER], False), ((9, 12, 7), [V, O, V, V, PER, PER], True)])
+def test_solve_from_a_nonzero_initial_guess(n, bc, nonuni, ksp):
+    """fl_ksp_opts.initial_guess_nonzero (-ksp_initial_guess_nonzero on kspA, round 5): x holds the guess; the convergence test compares with the norm of
+    the RIGHT-HAND SIDE (KSPConvergedDefault's rule for a non-zero guess).  (a) a zero guess reproduces the plain solve; (b) a guess that is close
+    needs fewer iterations, and its answer meets the same test -- the true preconditioned residual is below rtol || M b || -- and agrees with the
+    oracle's converged solution; (c) a guess that already meets the test costs no iteration."""
+    P, M, g = _pair(n, bc, nonuni)
+    V0, v0, dt, rho, mu = _state(g, 0.4)
+    W = g.apply_B(v0)
+    A = g.assemble_momentum(1.0, dt, -0.5 * mu * dt / rho, V0, W)
+    M.set_state(dt, rho, mu, [dev(a) for a in V0], M.interp_faces(dev(v0)), v0=dev(v0))
+    rng = np.random.default_rng(9)
+    b = rng.standard_normal(3 * g.ncell)
+    rtol = 1e-7
+    kw = dict(type=ksp, pc=fo.PC_JACOBI, rtol=rtol, maxit=400, check_every=3)
+    xo, _ = A.solve(b, ksp=fo.KSP_BCGS, pc=fo.PC_JACOBI, nullspace=False, rtol=1e-13, maxit=1000)     # the converged answer
+    dinv = 1.0 / A.diag()
+    bnorm = np.linalg.norm(dinv * b)
+
+    def pres(x):            # || M (b - A x) || / || M b ||
+        return np.linalg.norm(dinv * (b - A.mult(x))) / bnorm
+
+    xp, ip = M.solve(dev(b), **kw)                                                   # plain: zero guess
+    assert ip["reason"] == 2 and pres(host(xp)) <= 1.01 * rtol
+    x0, i0 = M.solve(dev(b), x=dev(np.zeros_like(b)), initial_guess_nonzero=1, **kw)  # (a)
+    assert i0["reason"] == 2 and i0["iters"] == ip["iters"]
+    assert np.linalg.norm(host(x0) - host(xp)) <= 1e-12 * np.linalg.norm(host(xp))
+    guess = xo + 1e-3 * np.linalg.norm(xo) / np.sqrt(xo.size) * rng.standard_normal(xo.size)
+    xg, ig = M.solve(dev(b), x=dev(guess), initial_guess_nonzero=1, **kw)              # (b)
+    assert ig["reason"] == 2 and 0 < ig["iters"] < ip["iters"], (ig["iters"], ip["iters"])
+    assert pres(host(xg)) <= 1.01 * rtol
+    assert np.linalg.norm(host(xg) - xo) <= 50 * rtol * np.linalg.norm(xo)
+    assert abs(ig["rnorm0"] - bnorm) <= 1e-10 * bnorm                                 # the reference norm of the test is || M b ||
+    xe, ie = M.solve(dev(b), x=dev(xo), initial_guess_nonzero=1, **kw)                # (c)
+    assert ie["iters"] == 0 and ie["reason"] in (2, 3) and np.linalg.norm(host(xe) - xo) <= 1e-12 * np.linalg.norm(xo)
+    # the Schur solvers start from zero, as the reference's kspS does: the flag is refused there
+    from fluca_amd.capi import FlucaError
+    with pytest.raises(FlucaError):
+        P.solve(dev(np.ones(g.ncell)), initial_guess_nonzero=1)
+    M.close()
+    P.close()
