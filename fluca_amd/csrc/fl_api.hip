@@ -733,7 +733,7 @@ extern "C" int fl_poisson_tune_placement(fl_poisson *h, int max_tries, double pr
     h->vec_bytes = 0;
     h->nvec = 0;
     h->slab = nullptr;
-    for (double **v : {&h->r, &h->P0, &h->P1, &h->q, &h->xp, &h->w0, &h->w1, &h->w2, &h->cd1}) *v = nullptr;
+    for (double **v : {&h->r, &h->P0, &h->P1, &h->q, &h->xp, &h->w0, &h->w1, &h->w2, &h->cd1, &h->rb}) *v = nullptr;
     FL_CHK(place_vectors(h));
   }
   if (probe_ms_out) {

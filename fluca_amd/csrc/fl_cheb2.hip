@@ -78,10 +78,19 @@ __device__ __forceinline__ int c2_xcd_remap(int b, int nblocks) { return (nblock
 // sums: 0 sum z  1 z.z  2 r.r of step 1;  3..5 the same of step 2
 // MGD (the last smoothing sweep of a multigrid cycle inside PCG): instead, the five sums the outer iteration wants of the sweep's result
 // x'' and its right-hand side b -- 0 sum x''  1 x''.x''  2 b.x''  3 sum b  4 b.b (slot 5 is 0) -- which saves a pass over both vectors
-template <int RY, int NW, bool JAC, int NT, bool MGD = false>
+// Z (round 5; the pre-smoother of a multigrid cycle, one rank): THREE steps from a zero initial guess in the one sweep.  The first step needs no
+// stencil -- x_1 = d_1 = c_0 M b -- so the sweep forms it wherever the regular kernel would LOAD x (tile + two rings, plane kk) from b loaded
+// there instead, takes d_1 = x_1 from the staged plane, and runs its two stencil steps as steps 2 and 3: reads b (tile + two rings), writes
+// x_3, d_3 -- 26 B/cell where k_cheb_first + the regular sweep move 16 + 24 + 44.  Z == 2: the right-hand side is first updated, b' = b - *za * zq
+// (the outer CG's r -= alpha q, alpha in device memory), read from b and zq with the rings and WRITTEN TO ANOTHER ARRAY bw on the tile -- a
+// neighbouring block still reads the old b of this tile's cells as its ring, so the update cannot be made in place: 42 B/cell for what took 84.
+template <int RY, int NW, bool JAC, int NT, bool MGD = false, int Z = 0>
 __global__ void __launch_bounds__(64 * NW) k_cheb2(GridP g, int perx, int pery, int perz, const double *X0, const double *X1, double *X0w, double *X1w, const double *__restrict__ b, const double *D0, const double *D1, double *D0w,
-                                                  double *D1w, const KspScal *__restrict__ s, double *__restrict__ partial, int stride, int zc, int tiles_x, int tiles, int remap)
+                                                  double *D1w, const KspScal *__restrict__ s, double *__restrict__ partial, int stride, int zc, int tiles_x, int tiles, int remap, const double *__restrict__ zq = nullptr,
+                                                  const double *__restrict__ za_dev = nullptr, double *__restrict__ bw = nullptr)
 {
+  constexpr bool ZR = Z != 0, ZS = Z == 2;
+  static_assert(!(ZR && MGD), "the three-step sweep is the pre-smoother: no sums of the outer iteration");
   constexpr int TX = 128, TY = NW * RY, LX = TX + 4, NTH = 64 * NW;
   constexpr int NTL = NT >= 2, NTS = NT >= 1;
   // XJ: x of planes kk, kk-1, kk-2 on the tile + two rings; row jj+2, column ii+2 for local (jj, ii)
@@ -95,11 +104,19 @@ __global__ void __launch_bounds__(64 * NW) k_cheb2(GridP g, int perx, int pery, 
   double       *xn = s->cur ? X0w : X1w;
   const double *d  = s->dcur ? D1 : D0;
   double       *dn = s->dcur ? D0w : D1w;
-  const double  rho0 = s->cheb_rho, c0 = s->cheb_c;
+  double        rho0 = s->cheb_rho, c0 = s->cheb_c;
   double        rho1, c1;
+  const double  cf = s->cheb_c;            // ZR: the factor of the first (stencil-free) step
+  const double  za = ZS ? *za_dev : 0.;
   {
     double ck, ckm1;
     cheb_advance(s, s->ck, s->ckm1, ck, ckm1, rho1, c1);
+    if (ZR) {  // the block is the one of the FIRST step: steps 2 and 3 take the next two sets of the recurrence
+      rho0 = rho1;
+      c0   = c1;
+      double ck2, ckm2;
+      cheb_advance(s, ck, ckm1, ck2, ckm2, rho1, c1);
+    }
   }
 
   const int bb    = remap ? c2_xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
@@ -140,6 +157,7 @@ __global__ void __launch_bounds__(64 * NW) k_cheb2(GridP g, int perx, int pery, 
     unsigned off;  // byte offset of the cell inside a plane, relative to cell (-2,-2) (a ghost cell may have negative coordinates)
     bool ok, in;
     int  lr, lc;  // XJ position
+    int  pi, pj;  // the cell that holds the value (ZR: its diagonal comes from the tables at these indices)
   };
   auto mk = [&](bool ok, int jj, int ii) {
     Halo      H;
@@ -150,6 +168,8 @@ __global__ void __launch_bounds__(64 * NW) k_cheb2(GridP g, int perx, int pery, 
     H.off = ok ? 8u * (unsigned)((pj + 2) * g.sx + (pi + 2)) : 8u * (unsigned)(2 * g.sx + 2);
     H.lr  = ok ? jj + 2 : 1;  // a thread without such a cell reads around (1, 1) and stages nothing
     H.lc  = ok ? ii + 2 : 1;
+    H.pi  = ok ? pi : 0;
+    H.pj  = ok ? pj : 0;
     return H;
   };
   const int  tb = tid - HB0, te = tid - HE0;
@@ -195,13 +215,20 @@ __global__ void __launch_bounds__(64 * NW) k_cheb2(GridP g, int perx, int pery, 
     cB[tb][4] = g.sc[0][cBi] + g.sc[1][cBj];
   }
   const int tbc = hBok ? tb : 0;
+  // ZR: x and y parts of the diagonal at this thread's ring cells (walls: any valid cell, the value is never used)
+  const double zrRy = ZR ? g.sc[1][rpj] : 0.;
+  const double zrBx = ZR ? g.sc[0][HB.pi] : 0., zrBy = ZR ? g.sc[1][HB.pj] : 0.;
+  const double zrEx = ZR ? g.sc[0][HE.pi] : 0., zrEy = ZR ? g.sc[1][HE.pj] : 0.;
 
   // inputs of one trip, fetched one trip ahead: x of plane kk (z-high neighbour of step 1), b and d of plane kk-1 (step 1 itself)
   struct Raw {
     double2 x[RY], b[RY], d[RY];
     double2 hxR, hbR, hdR;  // the wave's ring row: x (rows of ring 1 and 2), b and d (ring 1 only)
     double  hxB, hbB, hdB, hxE;
+    double  hqE;  // ZS: q at the E item
     double  zl, zc, zh;
+    double  zcw;  // ZR: the z part of the diagonal of the plane the values were read from
+    int64_t pl;   // ZS: the plane's offset
     bool    pin;
   };
   auto load = [&](int kk_, Raw &R) {
@@ -211,27 +238,51 @@ __global__ void __launch_bounds__(64 * NW) k_cheb2(GridP g, int perx, int pery, 
     const int     pk  = c2_wrap(kk, g.nz, perz, pin);
     const int     pkb = c2_wrap(min(max(kk - 1, k0 - 1), k1), g.nz, perz, dum);  // b, d of plane kk-1 (used on planes k0-1 .. k1 only)
     const int64_t pl = (int64_t)pk * g.sxy, plb = (int64_t)pkb * g.sxy;
-#pragma unroll
-    for (int m = 0; m < RY; ++m) {
-      R.x[m] = c2_LD2<NTL>(x + rob[m] + pl, lo);
-      R.b[m] = c2_LD2<NTL>(b + rob[m] + plb, lo);
-      R.d[m] = c2_LD2<NTL>(d + rob[m] + plb, lo);
-    }
     const int64_t hbase = g.off0 - 2 * (int64_t)g.sx - 2;  // cell (-2,-2) of plane 0: the origin of the items' offsets
-    const double *hx = x + hbase + pl, *hb = b + hbase + plb, *hd = d + hbase + plb;
-    R.hxB = R.hbB = R.hdB = R.hxE = 0.;
+    R.hxB = R.hbB = R.hdB = R.hxE = R.hqE = 0.;
     R.hxR = R.hbR = R.hdR = make_double2(0., 0.);
-    if (rowA || rowC) R.hxR = c2_LD2<0>(x + rrow + pl, lo);
-    if (rowA) {
-      R.hbR = c2_LD2<0>(b + rrow + plb, lo);
-      R.hdR = c2_LD2<0>(d + rrow + plb, lo);
+    if constexpr (ZR) {  // b (and q) of plane kk where the regular sweep reads x: the x and d slots carry them until convert() has run
+#pragma unroll
+      for (int m = 0; m < RY; ++m) {
+        R.x[m] = c2_LD2<NTL>(b + rob[m] + pl, lo);
+        if (ZS) R.d[m] = c2_LD2<NTL>(zq + rob[m] + pl, lo);
+        R.b[m] = make_double2(0., 0.);
+      }
+      const double *hb = b + hbase + pl, *hq = zq + hbase + pl;
+      if (rowA || rowC) {
+        R.hxR = c2_LD2<0>(b + rrow + pl, lo);
+        if (ZS) R.hdR = c2_LD2<0>(zq + rrow + pl, lo);
+      }
+      if (anyB) {
+        R.hxB = c2_LD1(hb, HB.off);
+        if (ZS) R.hdB = c2_LD1(hq, HB.off);
+      }
+      if (anyE) {
+        R.hxE = c2_LD1(hb, HE.off);
+        if (ZS) R.hqE = c2_LD1(hq, HE.off);
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < RY; ++m) {
+        R.x[m] = c2_LD2<NTL>(x + rob[m] + pl, lo);
+        R.b[m] = c2_LD2<NTL>(b + rob[m] + plb, lo);
+        R.d[m] = c2_LD2<NTL>(d + rob[m] + plb, lo);
+      }
+      const double *hx = x + hbase + pl, *hb = b + hbase + plb, *hd = d + hbase + plb;
+      if (rowA || rowC) R.hxR = c2_LD2<0>(x + rrow + pl, lo);
+      if (rowA) {
+        R.hbR = c2_LD2<0>(b + rrow + plb, lo);
+        R.hdR = c2_LD2<0>(d + rrow + plb, lo);
+      }
+      if (anyB) {
+        R.hxB = c2_LD1(hx, HB.off);
+        R.hbB = c2_LD1(hb, HB.off);
+        R.hdB = c2_LD1(hd, HB.off);
+      }
+      if (anyE) R.hxE = c2_LD1(hx, HE.off);
     }
-    if (anyB) {
-      R.hxB = c2_LD1(hx, HB.off);
-      R.hbB = c2_LD1(hb, HB.off);
-      R.hdB = c2_LD1(hd, HB.off);
-    }
-    if (anyE) R.hxE = c2_LD1(hx, HE.off);
+    R.zcw = ZR ? g.sc[2][pk] : 0.;
+    R.pl  = pl;
     const int kz = min(max(kk, -1), g.nz);
     R.zl  = g.sl[2][kz];
     R.zc  = g.sc[2][kz];
@@ -241,15 +292,61 @@ __global__ void __launch_bounds__(64 * NW) k_cheb2(GridP g, int perx, int pery, 
 
   double  acc[6] = {0., 0., 0., 0., 0., 0.};
   double2 sb2[RY], d1p[RY];  // b of plane kk-2; d' of plane kk-2
+  double2 zb1[RY], zb1R = make_double2(0., 0.);  // ZR: b' of plane kk-1 on the tile rows, the ring-1 row and the B item (formed one trip earlier)
+  double  zb1B = 0.;
   double  z1l = 0., z1c = 0., z1h = 0., z2l = 0., z2c = 0., z2h = 0.;  // z rows of planes kk-1, kk-2
   bool    pin1 = false;
 #pragma unroll
-  for (int m = 0; m < RY; ++m) sb2[m] = d1p[m] = make_double2(0., 0.);
+  for (int m = 0; m < RY; ++m) sb2[m] = d1p[m] = zb1[m] = make_double2(0., 0.);
 
   // DO1 / DO2: the first trips of a chunk only stage planes (kk = k0-2, k0-1), the next two form step 1 only
   auto step = [&](auto do1, auto do2, int kk, Raw &C, Raw &N) {
     constexpr bool DO1 = decltype(do1)::value, DO2 = decltype(do2)::value;
     load(kk + 1, N);
+    // ZR: plane kk arrived as b (and q): form b' = b - za q, store it on the owned tile cells, and turn the x slots into x_1 = cf M b'
+    double2 zbn[RY], zbnR = make_double2(0., 0.);
+    double  zbnB = 0.;
+    if constexpr (ZR) {
+      const bool ownk = kk >= k0 && kk < k1;
+#pragma unroll
+      for (int m = 0; m < RY; ++m) {
+        double2 bv = C.x[m];
+        if (ZS) {
+          bv.x -= za * C.d[m].x;
+          bv.y -= za * C.d[m].y;
+          if (ownk && rin[m] && in0) {
+            if (in1) c2_ST2<NTS>(bw + rob[m] + C.pl, lo, bv);
+            else c2_ST1(bw + rob[m] + C.pl, lo, bv.x);
+          }
+        }
+        zbn[m] = bv;
+        const double dyz = yc[m] + C.zcw;
+        C.x[m].x = 0. + cf * (JAC ? bv.x / (xc0 + dyz) : bv.x);
+        C.x[m].y = 0. + cf * (JAC ? bv.y / (xc1 + dyz) : bv.y);
+      }
+      if (rowA || rowC) {
+        double2 bv = C.hxR;
+        if (ZS) {
+          bv.x -= za * C.hdR.x;
+          bv.y -= za * C.hdR.y;
+        }
+        zbnR = bv;
+        const double dyz = zrRy + C.zcw;
+        C.hxR.x = 0. + cf * (JAC ? bv.x / (xc0 + dyz) : bv.x);
+        C.hxR.y = 0. + cf * (JAC ? bv.y / (xc1 + dyz) : bv.y);
+      }
+      if (anyB) {
+        double bv = C.hxB;
+        if (ZS) bv -= za * C.hdB;
+        zbnB  = bv;
+        C.hxB = 0. + cf * (JAC ? bv / (zrBx + (zrBy + C.zcw)) : bv);
+      }
+      if (anyE) {
+        double bv = C.hxE;
+        if (ZS) bv -= za * C.hqE;
+        C.hxE = 0. + cf * (JAC ? bv / (zrEx + (zrEy + C.zcw)) : bv);
+      }
+    }
     const int kc = kk - 1, k2 = kk - 2;
     const int lc = 2 * lane + 2;
     double2   x1v[RY], d1v[RY];
@@ -273,10 +370,11 @@ __global__ void __launch_bounds__(64 * NW) k_cheb2(GridP g, int perx, int pery, 
         const double  dyz = yc[m] + z1c;
         const double  v0 = (xc0 + dyz) * cen.x + xl0 * west + xh0 * cen.y + yl[m] * south.x + yh[m] * north.x + z1l * below.x + z1h * C.x[m].x;
         const double  v1 = (xc1 + dyz) * cen.y + xl1 * cen.x + xh1 * east + yl[m] * south.y + yh[m] * north.y + z1l * below.y + z1h * C.x[m].y;
-        const double  r0 = C.b[m].x - v0, r1 = C.b[m].y - v1;
+        const double2 bm = ZR ? zb1[m] : C.b[m], dm = ZR ? cen : C.d[m];  // ZR: d_1 = x_1
+        const double  r0 = bm.x - v0, r1 = bm.y - v1;
         const double  z0 = JAC ? r0 / (xc0 + dyz) : r0, z1 = JAC ? r1 / (xc1 + dyz) : r1;
-        const double  e0 = (rho0 != 0. ? rho0 * C.d[m].x : 0.) + c0 * z0;  // first step ever: d is not looked at
-        const double  e1 = (rho0 != 0. ? rho0 * C.d[m].y : 0.) + c0 * z1;
+        const double  e0 = (rho0 != 0. ? rho0 * dm.x : 0.) + c0 * z0;  // first step ever: d is not looked at
+        const double  e1 = (rho0 != 0. ? rho0 * dm.y : 0.) + c0 * z1;
         const bool    ok0 = pin1 && rin[m] && in0, ok1 = pin1 && rin[m] && in1;
         d1v[m].x = e0;
         d1v[m].y = e1;
@@ -302,18 +400,19 @@ __global__ void __launch_bounds__(64 * NW) k_cheb2(GridP g, int perx, int pery, 
         const double  dyz = Ayc + z1c;
         const double  v0 = (xc0 + dyz) * cen.x + xl0 * west + xh0 * cen.y + Ayl * south.x + Ayh * north.x + z1l * below.x + z1h * C.hxR.x;
         const double  v1 = (xc1 + dyz) * cen.y + xl1 * cen.x + xh1 * east + Ayl * south.y + Ayh * north.y + z1l * below.y + z1h * C.hxR.y;
-        const double  r0 = C.hbR.x - v0, r1 = C.hbR.y - v1;
+        const double2 bm = ZR ? zb1R : C.hbR, dm = ZR ? cen : C.hdR;
+        const double  r0 = bm.x - v0, r1 = bm.y - v1;
         const double  z0 = JAC ? r0 / (xc0 + dyz) : r0, z1 = JAC ? r1 / (xc1 + dyz) : r1;
-        const double  e0 = (rho0 != 0. ? rho0 * C.hdR.x : 0.) + c0 * z0;
-        const double  e1 = (rho0 != 0. ? rho0 * C.hdR.y : 0.) + c0 * z1;
+        const double  e0 = (rho0 != 0. ? rho0 * dm.x : 0.) + c0 * z0;
+        const double  e1 = (rho0 != 0. ? rho0 * dm.y : 0.) + c0 * z1;
         hx1R.x = (rinn0 && pin1) ? cen.x + e0 : 0.;
         hx1R.y = (rinn1 && pin1) ? cen.y + e1 : 0.;
       }
       if (anyB) {
         const double cen = XJ[bc][HB.lr][HB.lc], dyz = cB[tbc][4] + z1c;
         const double v = dyz * cen + cB[tbc][0] * XJ[bc][HB.lr][HB.lc - 1] + cB[tbc][1] * XJ[bc][HB.lr][HB.lc + 1] + cB[tbc][2] * XJ[bc][HB.lr - 1][HB.lc] + cB[tbc][3] * XJ[bc][HB.lr + 1][HB.lc] + z1l * XJ[bp][HB.lr][HB.lc] + z1h * C.hxB;
-        const double r = C.hbB - v, z = JAC ? r / dyz : r;
-        const double e = (rho0 != 0. ? rho0 * C.hdB : 0.) + c0 * z;
+        const double r = (ZR ? zb1B : C.hbB) - v, z = JAC ? r / dyz : r;
+        const double e = (rho0 != 0. ? rho0 * (ZR ? cen : C.hdB) : 0.) + c0 * z;
         hx1B = (HB.in && pin1) ? cen + e : 0.;
       }
     }
@@ -407,8 +506,13 @@ __global__ void __launch_bounds__(64 * NW) k_cheb2(GridP g, int perx, int pery, 
     __syncthreads();
 #pragma unroll
     for (int m = 0; m < RY; ++m) {
-      sb2[m] = C.b[m];
+      sb2[m] = ZR ? zb1[m] : C.b[m];
       d1p[m] = d1v[m];
+      if (ZR) zb1[m] = zbn[m];
+    }
+    if (ZR) {
+      zb1R = zbnR;
+      zb1B = zbnB;
     }
     z2l  = z1l;
     z2c  = z1c;
@@ -514,8 +618,8 @@ Cheb2Plan fl_cheb2_plan(const GridP &g)
   return p;
 }
 
-template <int NW, bool JAC, bool MGD = false>
-static void cheb2_t(fl_poisson *h, const Cheb2Plan &p, double *X0, double *X1, const double *B, double *D0, double *D1)
+template <int NW, bool JAC, bool MGD = false, int Z = 0>
+static void cheb2_t(fl_poisson *h, const Cheb2Plan &p, double *X0, double *X1, const double *B, double *D0, double *D1, const double *zq = nullptr, const double *za_dev = nullptr, double *bw = nullptr)
 {
   int per[3];
   for (int d = 0; d < 3; ++d) {  // per side: 0 wall, 1 periodic image inside the block, 2 a neighbouring rank (ghost layers)
@@ -523,7 +627,31 @@ static void cheb2_t(fl_poisson *h, const Cheb2Plan &p, double *X0, double *X1, c
     for (int side = 0; side < 2; ++side) m[side] = (h->multi && h->nbr[2 * d + side] >= 0 && !h->wrap_local[d]) ? 2 : (h->ax[d].periodic ? 1 : 0);
     per[d] = m[0] | (m[1] << 2);
   }
-  hipLaunchKernelGGL((k_cheb2<2, NW, JAC, 2, MGD>), dim3(p.nblocks), dim3(64 * NW), 0, h->stream, h->g, per[0], per[1], per[2], X0, X1, X0, X1, B, D0, D1, D0, D1, h->scal, h->partial, h->partial_stride, p.zc, p.tiles_x, p.tiles, 1);
+  hipLaunchKernelGGL((k_cheb2<2, NW, JAC, 2, MGD, Z>), dim3(p.nblocks), dim3(64 * NW), 0, h->stream, h->g, per[0], per[1], per[2], X0, X1, X0, X1, B, D0, D1, D0, D1, h->scal, h->partial, h->partial_stride, p.zc, p.tiles_x, p.tiles, 1,
+                     zq, za_dev, bw);
+}
+
+// three steps from a zero initial guess in one sweep (one rank): h->scal is the block of the FIRST step; the answer x_3 lands in the buffer the
+// block's `cur` does not name, d_3 likewise.  subq: b' = B - *suba_dev * subq is what the steps see, and it is written to Bw (never B itself)
+void fl_launch_cheb2_from_zero(fl_poisson *h, const Cheb2Plan &p, bool jac, double *X0, double *X1, const double *B, double *D0, double *D1, const double *subq, const double *suba_dev, double *Bw)
+{
+  if (subq) {
+    if (p.nw == 8) {
+      if (jac) cheb2_t<8, true, false, 2>(h, p, X0, X1, B, D0, D1, subq, suba_dev, Bw);
+      else cheb2_t<8, false, false, 2>(h, p, X0, X1, B, D0, D1, subq, suba_dev, Bw);
+    } else {
+      if (jac) cheb2_t<4, true, false, 2>(h, p, X0, X1, B, D0, D1, subq, suba_dev, Bw);
+      else cheb2_t<4, false, false, 2>(h, p, X0, X1, B, D0, D1, subq, suba_dev, Bw);
+    }
+    return;
+  }
+  if (p.nw == 8) {
+    if (jac) cheb2_t<8, true, false, 1>(h, p, X0, X1, B, D0, D1);
+    else cheb2_t<8, false, false, 1>(h, p, X0, X1, B, D0, D1);
+  } else {
+    if (jac) cheb2_t<4, true, false, 1>(h, p, X0, X1, B, D0, D1);
+    else cheb2_t<4, false, false, 1>(h, p, X0, X1, B, D0, D1);
+  }
 }
 
 void fl_launch_cheb2(fl_poisson *h, const Cheb2Plan &p, bool jac, double *X0, double *X1, const double *B, double *D0, double *D1, bool mgdots)

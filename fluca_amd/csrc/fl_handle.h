@@ -302,7 +302,7 @@ struct fl_mg;
 // the scalar blocks of every sweep of one kind of smoothing call (fl_cheb_smooth_padded), precomputed on the host and kept on the device
 struct SmoothSeq {
   int                  nu = 0;
-  bool                 guess_zero = false, jac = false, fuse = false, want = false;
+  bool                 guess_zero = false, jac = false, fuse = false, want = false, zero3 = false;
   double               emin = 0., emax = 0.;
   std::vector<KspScal> host;
   KspScal             *dev = nullptr;
@@ -332,6 +332,7 @@ struct fl_poisson {
   // solver workspace (padded vectors)
   double *r = nullptr, *P0 = nullptr, *P1 = nullptr, *q = nullptr, *xp = nullptr, *w0 = nullptr, *w1 = nullptr, *w2 = nullptr;
   double *cd1 = nullptr;  // second d buffer of the fused two-step Chebyshev kernel (fl_cheb2.hip)
+  double *rb = nullptr;   // where the three-step sweep from a zero guess writes the updated right-hand side; swaps roles with r afterwards
   std::vector<void *> vec_bases;
   void               *slab = nullptr;
   // placement (fl_api.hip): one arena, the five CG vectors in a window found by probing, two side pools for the rest
@@ -457,6 +458,7 @@ bool      fl_cheb2_usable(const fl_poisson *h);
 int       fl_cheb2_agree(fl_poisson *h);  // collective on several ranks; fills h->cheb2_agreed
 Cheb2Plan fl_cheb2_plan(const GridP &g);
 void      fl_launch_cheb2(fl_poisson *h, const Cheb2Plan &p, bool jac, double *X0, double *X1, const double *B, double *D0, double *D1, bool mgdots = false);
+void      fl_launch_cheb2_from_zero(fl_poisson *h, const Cheb2Plan &p, bool jac, double *X0, double *X1, const double *B, double *D0, double *D1, const double *subq, const double *suba_dev, double *Bw);
 // fl_mg.hip
 int  fl_solve_cg_mg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *o, fl_ksp_stats *st);
 void fl_mg_destroy(fl_poisson *h);

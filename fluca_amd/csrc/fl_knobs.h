@@ -23,6 +23,7 @@
   X(cheb_fuse, 1)         /* two Chebyshev steps per sweep: 0 never, 1 where it pays (>= 32768 cells per rank), 2 wherever legal */          \
   X(placement, 0)         /* 1: the first solve of a large handle runs the placement search of fl_poisson_tune_placement */                  \
   X(cg_xbatch, 1)         /* CG: both x-updates of an iteration pair on the odd iteration */                                                  \
+  X(cheb_zero3, 1)        /* a smoother call from a zero guess on one rank: its first three steps in one sweep (fl_cheb2.hip, Z) */          \
   X(mg_prolong, 1)        /* FL_PC_MG: 1 tri-linear prolongation, 0 piecewise constant */                                                     \
   X(mg_flexible, 1)       /* FL_PC_MG: 1 Polak-Ribiere beta (flexible CG), 0 KSPCG's */                                                      \
   X(mg_coarse, 1)         /* FL_PC_MG: 1 a coarsest level of <= 4096 cells on one rank is solved by one workgroup */                          \

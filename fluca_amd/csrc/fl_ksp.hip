@@ -1270,15 +1270,18 @@ int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero, bool
   // the step, advance the Chebyshev recurrence -- depends on nothing the device computes.  So the scalar block of EVERY sweep of the call is formed
   // here, once per (nu, first-step form, fused pattern, interval) and handle, kept on the device, and each sweep is launched on its own block: no scalar
   // kernel between the sweeps (a 512^3 multigrid solve made 330 of them).  `kind`: 1 the first step from a zero guess, 2 a fused pair, 0 a single step.
-  auto kind_of = [&](int j) { return (j == 0 && guess_zero) ? 1 : ((fuse && j + 2 <= nu && !(want && jac && !h->multi && ((nu - j) & 1))) ? 2 : 0); };
+  // 3 (round 5): the first THREE steps from a zero guess in one sweep -- the first step has no stencil, so the fused kernel forms it where it would
+  // load x (fl_cheb2.hip, Z); one rank only (the ring of b two deep is not exchanged)
+  const bool zero3 = fuse && guess_zero && nu >= 3 && !h->multi && knob(K_cheb_zero3) != 0;
+  auto kind_of = [&](int j) { return (j == 0 && guess_zero) ? (zero3 ? 3 : 1) : ((fuse && j + 2 <= nu && !(want && jac && !h->multi && ((nu - j) & 1))) ? 2 : 0); };
   const KspScal *seq = nullptr;
   {
     SmoothSeq *hit = nullptr;
     for (SmoothSeq &q : h->smooth_seq)
-      if (q.nu == nu && q.guess_zero == guess_zero && q.jac == jac && q.fuse == fuse && q.want == want && q.emin == emin && q.emax == emax) hit = &q;
+      if (q.nu == nu && q.guess_zero == guess_zero && q.jac == jac && q.fuse == fuse && q.want == want && q.zero3 == zero3 && q.emin == emin && q.emax == emax) hit = &q;
     if (!hit) {
       SmoothSeq q;
-      q.nu = nu; q.guess_zero = guess_zero; q.jac = jac; q.fuse = fuse; q.want = want; q.emin = emin; q.emax = emax;
+      q.nu = nu; q.guess_zero = guess_zero; q.jac = jac; q.fuse = fuse; q.want = want; q.zero3 = zero3; q.emin = emin; q.emax = emax;
       KspScal S = S0;
       auto advance = [](const KspScal &P, double ck, double ckm1, double &ck_out, double &ckm1_out, double &rho, double &c) {  // cheb_advance, on the host
         const double ckp1 = 2. * P.mu * ck - ckm1, omega = P.omegaprod * ck / ckp1;
@@ -1289,7 +1292,16 @@ int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero, bool
       };
       for (int j = 0; j < nu;) {
         q.host.push_back(S);
-        if (kind_of(j) == 2) {  // k_cheb_fin2: both steps accepted
+        if (kind_of(j) == 3) {  // one flip of each buffer pair, three steps of the recurrence
+          double ck, ckm1, ck2, ckm2, rho, c;
+          advance(S, S.ck, S.ckm1, ck, ckm1, rho, c);
+          advance(S, ck, ckm1, ck2, ckm2, rho, c);
+          S.cur ^= 1;
+          S.dcur ^= 1;
+          S.it += 3;
+          advance(S, ck2, ckm2, S.ck, S.ckm1, S.cheb_rho, S.cheb_c);
+          j += 3;
+        } else if (kind_of(j) == 2) {  // k_cheb_fin2: both steps accepted
           double ck, ckm1, rho1, c1, rho2, c2;
           advance(S, S.ck, S.ckm1, ck, ckm1, rho1, c1);
           S.cur ^= 1;
@@ -1333,7 +1345,20 @@ int fl_cheb_smooth_padded(fl_poisson *h, int nu, bool jac, bool guess_zero, bool
   for (int j = 0; j < nu;) {
     h->scal = const_cast<KspScal *>(seq) + launch++;
     const int kind = kind_of(j);
-    if (kind == 1) {
+    if (kind == 3) {
+      double *Bw = nullptr;
+      if (subq) {
+        FL_CHK(fl_ensure_vec(h, &h->rb));
+        Bw = h->rb;
+      }
+      fl_launch_cheb2_from_zero(h, cp, jac, X0, X1, B, D0, D1, subq, suba, Bw);
+      if (subq) {  // the updated right-hand side lives in the other array from here on
+        std::swap(h->r, h->rb);
+        B = h->r;
+      }
+      dcur ^= 1;
+      j += 3;
+    } else if (kind == 1) {
       const int64_t items = (int64_t)((h->g.nx + 127) / 128) * h->g.ny * h->g.nz;  // 128-cell row segments, one per wave and trip
       const int     nb    = (int)std::max<int64_t>(1, std::min<int64_t>((items + 3) / 4, 8192));
       if (subq) {

@@ -114,7 +114,7 @@ __device__ __forceinline__ void mom_axis(TF T, double um, double uc, double up, 
 }
 
 constexpr int MOM_RY = 8;            // grid rows per block = waves per block
-constexpr int MOM_NT = 64 * MOM_RY;
+[[maybe_unused]] constexpr int MOM_NT = 64 * MOM_RY;  // (the kbench build's k_mom_apply)
 
 // LDS image of one plane of a 64 x MOM_RY tile: what a cell needs from its x/y neighbours.
 struct MomLds {
@@ -1288,7 +1288,9 @@ extern "C" int fl_momentum_chebyshev_interval(fl_momentum *m, double *emin, doub
 // So a solve on the default interval is never left unwatched: with -ksp_norm_type none it still forms the preconditioned norm and stops with
 // KSP_DIVERGED_DTOL / NANORINF like any KSP (dtol 1e5) instead of returning garbage after maxit steps.
 // One fused launch per step where the state came with v0 (k_mom3, OUT == 4: 144 B/cell), the product and a vector update otherwise.
-static int momentum_cheb(fl_momentum *m, const double *b_dev, double *x_dev, const fl_ksp_opts *opts, fl_ksp_stats *stats)
+// from_guess: x_dev holds x_0 (the recurrence starts from any x_0: rho_0 = 0, the first step is x_1 = x_0 + c M (b - A x_0)); the first norm is then
+// the guess's residual norm, so the caller passes the tolerances it means in absolute terms (momentum_solve_from_guess)
+static int momentum_cheb(fl_momentum *m, const double *b_dev, double *x_dev, const fl_ksp_opts *opts, fl_ksp_stats *stats, bool from_guess = false)
 {
   if (opts->pc != FL_PC_JACOBI && opts->pc != FL_PC_NONE) return FL_ERR_SUP;
   if (opts->norm_type == FL_NORM_NATURAL) return FL_ERR_SUP;
@@ -1323,9 +1325,11 @@ static int momentum_cheb(fl_momentum *m, const double *b_dev, double *x_dev, con
   }
   FL_CHK(fl_cheb_begin(h, &o, emin, emax));
   const size_t bytes = sizeof(double) * 3 * h->padlen;
-  // x_0 = 0 and "x_-1" (multiplied by rho_0 = 0) must be finite numbers
+  // x_0 = 0 (or the caller's guess) and "x_-1" (multiplied by rho_0 = 0) must be finite numbers
   for (double *v : {X0, X1}) FL_HIP(hipMemsetAsync(v, 0, bytes, h->stream));
   for (int c = 0; c < 3; ++c) launch_pad_copy(h->stream, h->g, b_dev + (size_t)c * h->ncell, B + (size_t)c * h->padlen);
+  if (from_guess)
+    for (int c = 0; c < 3; ++c) launch_pad_copy(h->stream, h->g, x_dev + (size_t)c * h->ncell, X0 + (size_t)c * h->padlen);
   const int every = o.check_every > 0 ? o.check_every : 8;
   const int total = o.norm_type == FL_NORM_NONE ? o.maxit : o.maxit + 1;  // with a norm, launch maxit is only the final test
   int       j = 0, hostcur = 0;
@@ -1335,7 +1339,7 @@ static int momentum_cheb(fl_momentum *m, const double *b_dev, double *x_dev, con
     const int stop = std::min(total, j + every);
     for (; j < stop; ++j) {
       double *xin = hostcur ? X1 : X0, *xout = hostcur ? X0 : X1;
-      if (j > 0) FL_CHK(mom_ghosts(m, xin));
+      if (j > 0 || from_guess) FL_CHK(mom_ghosts(m, xin));
       if (fused) {
         if (jac) hipLaunchKernelGGL((k_mom3<8, 0, true, 4, 1>), dim3(m->t2blocks), dim3(512), 0, h->stream, h->g, m->mp, (const double *)xin, xout, m->F, (const double *)m->v0p, (int64_t)h->padlen, (const double *)B,
                                     (const KspScal *)h->scal, h->partial, h->partial_stride, m->t2x, m->t2chunk, m->t2zc, flags);
@@ -1378,8 +1382,6 @@ static int momentum_solve_from_guess(fl_momentum *m, const double *b_dev, double
   fl_poisson *h = m->p;
   FL_HIP(hipSetDevice(h->device));
   const int64_t n3 = 3 * h->ncell;
-  if (!m->gr) FL_CHK(fl_dev_alloc(h, (void **)&m->gr, sizeof(double) * (size_t)n3, false));
-  if (!m->gd) FL_CHK(fl_dev_alloc(h, (void **)&m->gd, sizeof(double) * (size_t)n3, false));
   // || M b || (M = 1 / diag with PCJACOBI and a preconditioned norm, else the identity): the update kernel that starts BiCGStab forms b / diag and
   // its square sum in one pass (slot 1); its two outputs are scratch here
   const bool scaled = opts->pc == FL_PC_JACOBI && opts->norm_type != FL_NORM_UNPRECONDITIONED;
@@ -1392,6 +1394,18 @@ static int momentum_solve_from_guess(fl_momentum *m, const double *b_dev, double
   FL_HIP(hipMemcpyAsync(sums, h->sums, sizeof(sums), hipMemcpyDeviceToHost, h->stream));
   FL_HIP(hipStreamSynchronize(h->stream));
   const double bnorm = std::sqrt(sums[1] > 0. ? sums[1] : 0.);
+  if (opts->type == FL_KSP_CHEBYSHEV) {  // the recurrence takes the guess as it is: no shifted system, no product and no vector update in front of it
+    fl_ksp_opts o = *opts;
+    o.initial_guess_nonzero = 0;
+    o.rtol = 0.;
+    o.atol = std::max(opts->rtol * bnorm, opts->atol);
+    FL_CHK(momentum_cheb(m, b_dev, x_dev, &o, stats, true));
+    if (stats->reason == FL_CONVERGED_ATOL && !(stats->rnorm < opts->atol)) stats->reason = FL_CONVERGED_RTOL;
+    stats->rnorm0 = bnorm;
+    return FL_SUCCESS;
+  }
+  if (!m->gr) FL_CHK(fl_dev_alloc(h, (void **)&m->gr, sizeof(double) * (size_t)n3, false));
+  if (!m->gd) FL_CHK(fl_dev_alloc(h, (void **)&m->gd, sizeof(double) * (size_t)n3, false));
   // r = b - A x0
   FL_CHK(fl_momentum_apply(m, x_dev, m->gr));
   lincomb(h, n3, 1., b_dev, -1., m->gr, m->gr);

@@ -942,6 +942,10 @@ FlErrorCode NSSetFromOptions(NS ns, int argc, char **argv)
     const int got = opt_flag(argc, argv, "-ns_abf_momentum_guess_previous", &flg);
     if (got < 0) return E_ARG_WRONG;
     if (got) ns->mom_guess_previous = flg;
+    /* ... or from the velocity extrapolated through the two previous steps, 2 v^n - v^(n-1) (the first step: v^n) */
+    const int got2 = opt_flag(argc, argv, "-ns_abf_momentum_guess_extrapolate", &flg);
+    if (got2 < 0) return E_ARG_WRONG;
+    if (got2 && flg) ns->mom_guess_previous = 2;
   }
   if (opt_real(argc, argv, "-ns_abf_momentum_ksp_rtol", &v)) ns->mom.rtol = v;
   if (opt_real(argc, argv, "-ns_abf_momentum_ksp_atol", &v)) ns->mom.atol = v;
@@ -2045,6 +2049,10 @@ static FlErrorCode NSStep_CNLinear(NS ns)
   const int timing = step_timing();
   double    tm[6] = {0., 0., 0., 0., 0., 0.};
   if (timing) tm[0] = step_clock(ns);
+  /* -ns_abf_momentum_guess_extrapolate: 2 v^n - v^(n-1) while sol0 still holds v^(n-1); fractional step only (what reads x_v as a guess below) */
+  const int guess = ns->ksp_type != 2 ? ns->mom_guess_previous : 0;
+  if (guess == 2 && c->have_sol0) FLABI(fl_vec_lincomb(h, 3 * N, 2., c->sol_v, -1., c->sol0_v, c->x_v));
+  else if (guess) FLABI(fl_vec_lincomb(h, 3 * N, 1., c->sol_v, 0., NULL, c->x_v));
   /* NSStep: VecCopy(sol, sol0), nsbasic.c:281-282 (the vectors are this type's device arrays, so the copy is made here) */
   FLABI(fl_vec_lincomb(h, 3 * N, 1., c->sol_v, 0., NULL, c->sol0_v));
   FLABI(fl_vec_lincomb(h, N, 1., c->sol_p, 0., NULL, c->sol0_p));
@@ -2083,10 +2091,9 @@ static FlErrorCode NSStep_CNLinear(NS ns)
     FLCHK(cnl_gmres(ns, &f, &x));
   } else {
     fl_ksp_opts mom1 = ns->mom;
-    if (ns->mom_guess_previous) { /* -ns_abf_momentum_guess_previous: v* starts from v0 (the right-hand side is the whole momrhs here, not a residual) */
-      FLABI(fl_vec_lincomb(h, 3 * N, 1., c->sol0_v, 0., NULL, c->x_v));
-      mom1.initial_guess_nonzero = 1;
-    }
+    /* -ns_abf_momentum_guess_previous / _extrapolate: v* starts from the guess left in x_v above (the right-hand side is the whole momrhs here, not a
+     * residual).  NSFormFunction and NSFormJacobian do not write x */
+    if (guess) mom1.initial_guess_nonzero = 1;
     FLABI(fl_abf_apply(ns->momentum, &mom1, &ns->schur, c->f_v, fV, c->f_p, c->x_v, c->x_V, c->x_p, st));
   }
   if (ns->ksp_type != 2) {

@@ -251,6 +251,7 @@ FlErrorCode NSSetPreviousState(NS ns, const double *const V0_dev[3], const doubl
  * -ns_abf_momentum_guess_previous (mirror only, NSStep with -ns_ksp_type preonly | richardson): the FIRST PCApply_ABF of a time step starts kspA from the
  * previous velocity instead of from zero (fl_ksp_opts.initial_guess_nonzero; convergence against || M momrhs || as KSPConvergedDefault does with a non-zero
  * guess): momrhs - A v0 = O(dt) momrhs, so the solve needs the iterations of a reduction by rtol / O(dt) only.  The answer meets the same test.
+ * -ns_abf_momentum_guess_extrapolate: the same with the guess 2 v^n - v^(n-1) (O(dt^2) away from the answer in a smooth flow; the first step uses v^n).
  * Options: -ns_abf_momentum_ksp_type bcgs|gmres|chebyshev (gmres = PETSc's default type for kspA, restart
  * -ns_abf_momentum_ksp_gmres_restart 30; chebyshev: -ns_abf_momentum_ksp_chebyshev_eigenvalues emin,emax or the Gershgorin disc,
  * -ns_abf_momentum_ksp_norm_type preconditioned|unpreconditioned|none), -ns_abf_momentum_pc_type jacobi|none (ilu, PETSc's default PC, has no

@@ -76,7 +76,7 @@ struct _p_NS {
   int64_t              step, max_steps;
   double               max_time; /* nsbasic.c:30: PETSC_MAX_REAL = not set */
   int                  errorifstepfailed; /* nsbasic.c:46: PETSC_TRUE */
-  int                  mom_guess_previous; /* -ns_abf_momentum_guess_previous (mirror only, default 0): see NSSetFromOptions */
+  int                  mom_guess_previous; /* -ns_abf_momentum_guess_previous (1) / -ns_abf_momentum_guess_extrapolate (2); mirror only, default 0: see NSSetFromOptions */
   int                  bc_keep;           /* -ns_keep_boundary_values (mirror only, default 1): a step's callback values at t + dt serve the next step's t */
   Mesh                 mesh;
   NSBoundaryCondition *bcs;

@@ -161,3 +161,45 @@ def test_flexible_beta_is_the_default_and_matches_the_oracle(n, bc, nonuni, null
         capi.check(capi.lib.fl_tuning_set(b"mg_prolong", 1))
         capi.check(capi.lib.fl_tuning_set(b"mg_flexible", 1))
     P.close()
+
+
+@pytest.mark.parametrize("n,bc,nonuni,nullspace,nu", [
+    ((160, 40, 36), CAVITY, False, True, 3),                       # two tiles in x (one partial), three in y, two z chunks
+    ((64, 48, 40), [V, O, V, V, PER, PER], True, False, 3),        # outlet, two periodic axes, stretched
+    ((32, 32, 32), [PER] * 6, False, True, 3),                     # the ring wraps on every axis
+    ((130, 18, 34), [V, V, PER, PER, SYM, V], True, True, 4),      # two cells past a tile in x and y; four steps: the sweep + a single step
+    ((34, 10, 12), CAVITY, False, True, 5),                        # a tile that is mostly ring; five steps: the sweep + a pair
+])
+def test_three_smoothing_steps_from_zero_in_one_sweep(n, bc, nonuni, nullspace, nu):
+    """Round 5: the pre-smoother of a cycle (zero initial guess) runs its first three steps -- the stencil-free first one included, and the outer CG's
+    r -= alpha q on the fine level -- in ONE sweep of the fused kernel (fl_cheb2.hip, Z; knob "cheb_zero3").  Same numbers as the separate first
+    step + fused pair: histories of a whole solve agree to rounding (the arithmetic is the same, only the order of the passes changed), and both
+    agree with the oracle."""
+    from fluca_amd import capi
+    P, g = make_pair(n, bc, kappa=1e-3, nonuniform=nonuni)
+    S = g.assemble_S()
+    p = np.random.default_rng(11).standard_normal(g.ncell)
+    if nullspace:
+        p -= p.mean()
+    b = S.mult(p)
+    mg0 = fo.MgOracle(g, nullspace=nullspace, nu=nu)
+    xo, io = fo.MgOracle(g, nullspace=nullspace, nu=nu, bounds=_bounds(mg0), prolong="linear").pcg(b, rtol=1e-9, maxit=100)
+    out = {}
+    try:
+        capi.check(capi.lib.fl_tuning_set(b"cheb_fuse", 2))          # fused wherever legal: these grids are below the size where it pays
+        for z3 in (1, 0):
+            capi.check(capi.lib.fl_tuning_set(b"cheb_zero3", z3))
+            xg, ig = P.solve(dev(b), history=True, type=0, pc=2, remove_nullspace=int(nullspace), rtol=1e-9, maxit=100, mg_smooth_its=nu)
+            assert ig["reason"] == 2, (z3, ig)
+            out[z3] = (host(xg), ig)
+    finally:
+        capi.check(capi.lib.fl_tuning_set(b"cheb_fuse", 1))
+        capi.check(capi.lib.fl_tuning_set(b"cheb_zero3", 1))
+    (x1, i1), (x0, i0) = out[1], out[0]
+    assert i1["iters"] == i0["iters"]
+    assert np.allclose(i1["history"], i0["history"], rtol=1e-9, atol=0.0)
+    assert np.linalg.norm(x1 - x0) <= 1e-10 * np.linalg.norm(x0)
+    assert abs(i1["iters"] - io["iters"]) <= 1, (i1["iters"], io["iters"])
+    assert np.allclose(i1["history"][:3], io["history"][:3], rtol=1e-6)
+    assert np.linalg.norm(b - S.mult(x1)) <= 1e-7 * np.linalg.norm(b)
+    P.close()

@@ -375,7 +375,7 @@ def test_full_pcapply_abf_through_the_mirror(H):
     assert H.lib.NSDestroy(C.byref(ns)) == 0 and H.lib.MeshDestroy(C.byref(mesh)) == 0
 
 
-def _tgv_mirror(H, n, nsteps, walls, t_final=0.4, rho=1.0, mu=0.1, ksp="richardson"):
+def _tgv_mirror(H, n, nsteps, walls, t_final=0.4, rho=1.0, mu=0.1, ksp="richardson", extra=(), info=None):
     """The reference's own check (fluca/tests/taylor_green_vortex/taylor_green_vortex.c) in 3-D: Taylor-Green vortex in
     x-y, periodic in z; walls=True puts time-dependent VELOCITY conditions from the exact solution on the four side walls
     (the boundary-condition vectors of L, C, B and T), walls=False is the fully periodic box."""
@@ -406,7 +406,7 @@ def _tgv_mirror(H, n, nsteps, walls, t_final=0.4, rho=1.0, mu=0.1, ksp="richards
         assert H.lib.NSSetBoundaryCondition(ns, b, H.NSBoundaryCondition(type=H.NS_BC_PERIODIC)) == 0
     dt = t_final / nsteps
     argc, av = H.argv("-ns_time_step_size", dt, "-ns_max_steps", nsteps, "-ns_ksp_type", ksp, "-ns_ksp_rtol", 1e-8,
-                      "-ns_abf_schur_ksp_rtol", 1e-10, "-ns_abf_momentum_ksp_rtol", 1e-10)
+                      "-ns_abf_schur_ksp_rtol", 1e-10, "-ns_abf_momentum_ksp_rtol", 1e-10, *extra)
     assert H.lib.NSSetFromOptions(ns, argc, av) == 0 and H.lib.NSSetUp(ns) == 0
     v, p, V = P(), P(), (C.c_void_p * 3)()
     assert H.lib.NSGetSolutionArrays(ns, C.byref(v), V, C.byref(p)) == 0
@@ -436,6 +436,10 @@ def _tgv_mirror(H, n, nsteps, walls, t_final=0.4, rho=1.0, mu=0.1, ksp="richards
     ue, we = ex(xc, xc, t_final)
     err = np.sqrt(((vh[0] - ue) ** 2 + (vh[1] - we) ** 2).mean())
     wmax = np.abs(vh[2]).max()
+    if info is not None:                        # the last step's inner iteration counts and the velocity itself
+        ma, ms = C.c_int(), C.c_int()
+        assert H.lib.NSGetInnerIterations(ns, C.byref(ma), C.byref(ms)) == 0
+        info.update(kspA_its=ma.value, kspS_its=ms.value, v=vh.copy())
     H.lib.NSDestroy(C.byref(ns))
     H.lib.MeshDestroy(C.byref(mesh))
     return err, wmax, its.value
@@ -457,6 +461,25 @@ def test_nssolve_preonly_is_the_fractional_step_method(H):
     e_p, _, its_p = _tgv_mirror(H, 32, 8, True, ksp="preonly")
     assert its_p == 1 and its_r > 1
     assert e_p < 3 * e_r + 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kspA", ["bcgs", "chebyshev"])
+def test_fractional_step_from_a_velocity_guess_is_the_same_step_in_fewer_iterations(H, kspA):
+    """-ns_abf_momentum_guess_previous / -ns_abf_momentum_guess_extrapolate (mirror only): kspA of the fractional step starts from v^n or from
+    2 v^n - v^(n-1) and stops at the same test (|| M r || <= rtol || M momrhs ||): the same velocity to the solver tolerance, in fewer iterations,
+    fewest with the extrapolated guess (the decaying vortex is smooth in time)."""
+    runs = {}
+    for name, extra in (("zero", ()), ("previous", ("-ns_abf_momentum_guess_previous",)), ("extrapolated", ("-ns_abf_momentum_guess_extrapolate",))):
+        runs[name] = {}
+        e, _, its = _tgv_mirror(H, 32, 8, True, ksp="preonly", extra=("-ns_abf_momentum_ksp_type", kspA) + extra, info=runs[name])
+        runs[name]["err"] = e
+        assert its == 1
+    ref = runs["zero"]["v"]
+    for name in ("previous", "extrapolated"):
+        assert np.abs(runs[name]["v"] - ref).max() <= 1e-8 * np.abs(ref).max(), name
+        assert abs(runs[name]["err"] - runs["zero"]["err"]) < 1e-8
+    assert runs["extrapolated"]["kspA_its"] < runs["previous"]["kspA_its"] < runs["zero"]["kspA_its"], {k: r["kspA_its"] for k, r in runs.items()}
 
 
 @pytest.mark.gpu
@@ -523,7 +546,8 @@ def test_c_cavity_driver_writes_cgns_like_the_reference_options(H, tmp_path):
                                   ("-ns_keep_boundary_values", "false"),           # the callbacks swept again in every step
                                   # the first PCApply_ABF of a step starts kspA from the previous velocity (round 5): same converged step
                                   ("-ns_ksp_type", "richardson", "-ns_abf_momentum_guess_previous"),
-                                  ("-ns_ksp_type", "richardson", "-ns_abf_momentum_guess_previous", "true", "-ns_abf_momentum_ksp_type", "chebyshev")])
+                                  ("-ns_ksp_type", "richardson", "-ns_abf_momentum_guess_previous", "true", "-ns_abf_momentum_ksp_type", "chebyshev"),
+                                  ("-ns_ksp_type", "richardson", "-ns_abf_momentum_guess_extrapolate")])
 def test_nsstep_matches_the_oracle_step(H, ainv):
     """Velocity, face velocity and pressure after two lid-driven-cavity steps: the C mirror on the GPU vs the CPU oracle's
     composition of the same reference formulas (StepOracle), including the wall terms of L, C, B and T."""
