@@ -337,7 +337,6 @@ __global__ void __launch_bounds__(256) k_project_all(GridP g, const double *__re
   const bool   xlast = il == g.nx - 1 && g.fx > g.nx;
   const int    xc0n = xlast ? g.gc0[0][g.nx] : 0;
   const double xa0n = xlast ? g.ga0[0][g.nx] : 0., xa1n = xlast ? g.ga1[0][g.nx] : 0.;
-  auto ld = [&](const double *a, int64_t q) { return pr2 ? *reinterpret_cast<const double2 *>(a + q) : make_double2(a[q], two ? a[q + 1] : 0.); };
   auto sub = [&](double *a, int64_t q, double2 d) {  // a[q], a[q + 1] -= kappa * d
     if (pr2) {
       double2 t = *reinterpret_cast<double2 *>(a + q);

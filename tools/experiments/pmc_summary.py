@@ -60,7 +60,7 @@ if len(bq) == 2:
         "B_per_cell": round((bq[0]["B_per_cell"] + bq[1]["B_per_cell"]) / 2, 2),
         "rocprof_avg_ms_512cubed_launches": round((bq[0]["rocprof_avg_ms_512cubed_launches"] + bq[1]["rocprof_avg_ms_512cubed_launches"]) / 2, 4)}
     json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json"), "w"), indent=1)
-for k, name in (("fl::k_cg_A<2, 8, true, 1, 2, false>", "pmc_k_cg_A.json"), ("fl::k_cheb2<2, 8, true, 2, false>", "pmc_k_cheb2.json"),
+for k, name in (("fl::k_cg_A<2, 8, true, 1, 2, false>", "pmc_k_cg_A.json"), ("fl::k_cheb2<2, 8, true, 2, false, 0>", "pmc_k_cheb2.json"),   # the two-step sweep of config 3 (Z = 0; round 5 added the template argument)
                 ("fl::k_cg_Bq (mean of the even- and odd-iteration launches)", "pmc_k_cg_Bq.json")):
     if k in out:
         o = dict(out[k])
