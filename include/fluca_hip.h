@@ -194,6 +194,9 @@ int fl_vec_maxpy(fl_poisson *h, int64_t n, double *x_dev, const double *alphas, 
  *   "cheb_fuse"  0 = one kernel launch per Chebyshev step; 1 (default) = two steps per sweep over memory wherever no convergence
  *                test sits between them (KSP_NORM_NONE sweeps, the multigrid smoother) and the grid is large enough to gain;
  *                2 = the same on every grid where it is legal.  On several ranks the ranks vote once per handle: fused only where all agree.
+ *   "cheb_zero3" 1 (default) = a smoother call that starts from a zero guess (the pre-smoother of a multigrid cycle) runs its first THREE steps in
+ *                one sweep, the outer CG's residual update included, where "cheb_fuse" applies and the handle has one rank; 0 = first step and
+ *                pair as separate launches (A/B, tests).  Same arithmetic either way.
  *   "placement"  0 (default since round 3) = one plain allocation per vector; 1 = the first solve on a handle whose padded vectors are
  *                >= 256 MiB runs the placement search of fl_poisson_tune_placement by itself (about 0.15 s, once per handle; worth
  *                1 - 2 % of the CG iteration rate at 512^3).  A failure inside the search never fails the solve: plain allocations.

@@ -197,8 +197,10 @@ def test_three_smoothing_steps_from_zero_in_one_sweep(n, bc, nonuni, nullspace, 
         capi.check(capi.lib.fl_tuning_set(b"cheb_zero3", 1))
     (x1, i1), (x0, i0) = out[1], out[0]
     assert i1["iters"] == i0["iters"]
-    assert np.allclose(i1["history"], i0["history"], rtol=1e-9, atol=0.0)
-    assert np.linalg.norm(x1 - x0) <= 1e-10 * np.linalg.norm(x0)
+    # (rounding differs in the last place -- other contractions of the same expressions -- and a Krylov iteration amplifies that: 6e-9 after 50 steps)
+    assert np.allclose(i1["history"][:8], i0["history"][:8], rtol=1e-10, atol=0.0)
+    assert np.allclose(i1["history"], i0["history"], rtol=1e-6, atol=0.0)
+    assert np.linalg.norm(x1 - x0) <= 1e-8 * np.linalg.norm(x0)
     assert abs(i1["iters"] - io["iters"]) <= 1, (i1["iters"], io["iters"])
     assert np.allclose(i1["history"][:3], io["history"][:3], rtol=1e-6)
     assert np.linalg.norm(b - S.mult(x1)) <= 1e-7 * np.linalg.norm(b)
