@@ -69,9 +69,24 @@ def _record(target, deps, cmd_words=()):
         json.dump(m, fh, indent=0, sort_keys=True)
 
 
+def _mapped(path):
+    """True when this process has `path` mapped (Linux)."""
+    try:
+        real = os.path.realpath(path)
+        with open("/proc/self/maps") as fh:
+            return any(line.rstrip().endswith(real) or line.rstrip().endswith(path) for line in fh)
+    except OSError:
+        return False
+
+
 def _link(cmd, target):
     """Run a link command whose output is `target` (after -o) into a temporary name and rename it over the target: a process that has the old file
     mapped (a test session that calls build() again) keeps the old inode instead of having its code pages rewritten under it."""
+    if _mapped(target):
+        # (the rename keeps the old pages alive, but the next dlopen of the name -- a dependent library, another ctypes handle -- would bring a SECOND copy
+        # of the library with its own globals into the process: handles made by one and destroyed by the other end in a segmentation fault)
+        raise RuntimeError(f"{target} is out of date with respect to the sources AND loaded in this process: rebuild it first "
+                           "(`python -m fluca_amd.build`, or tests/conftest.py, which builds before anything is loaded); it is not replaced under a live process")
     tmp = target + ".tmp%d" % os.getpid()
     i = cmd.index("-o")
     assert cmd[i + 1] == target

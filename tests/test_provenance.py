@@ -83,3 +83,22 @@ def test_fingerprints_do_not_depend_on_where_the_tree_lies(tmp_path, monkeypatch
     monkeypatch.setattr(build, "HERE", "/somewhere/else/repo/fluca_amd")
     b = build._fingerprint([src], ["hipcc", "-c", src.replace(root, "/somewhere/else/repo"), "-o", "/somewhere/else/repo/fluca_amd/lib/x.o"])
     assert a == b
+
+
+def test_a_library_this_process_has_loaded_is_never_replaced(tmp_path):
+    """build._link refuses to rename a fresh link over a library that is mapped in the calling process (round 5: a stale libflucahip.so rebuilt by a
+    test fixture on the GPU box put two copies of the library into the test process)."""
+    import ctypes
+
+    import pytest
+    from fluca_amd import build
+    src, so = tmp_path / "t.c", tmp_path / "libt.so"
+    src.write_text("int t_answer(void) { return 42; }\n")
+    cmd = ["gcc", "-shared", "-fPIC", "-o", str(so), str(src)]
+    build._link(cmd, str(so))                                    # not loaded yet: linked through a temporary name
+    assert so.exists() and not build._mapped(str(so))
+    lib = ctypes.CDLL(str(so))
+    assert lib.t_answer() == 42 and build._mapped(str(so))
+    with pytest.raises(RuntimeError, match="loaded in this process"):
+        build._link(cmd, str(so))
+    assert [p.name for p in tmp_path.iterdir() if ".tmp" in p.name] == []
