@@ -8,7 +8,7 @@ from tests import flow_parity
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n,D", [(32, 8), (64, 12)])
+@pytest.mark.parametrize("n,D", [(32, 8), (48, 10)])   # (bench.py runs the same check at 128^3 in every bench line: configs.flow_step.parity)
 def test_channel_with_immersed_sphere_matches_the_oracle_step(n, D):
     r = flow_parity.channel_sphere(n=n, nsteps=2, diameter_cells=D)
     assert r["max_abs_v"] > 0.5 and r["rms_speed_at_markers_over_inflow_peak"] < 0.9        # a flow, and a body that slows it down
