@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 KBENCH = bool(os.environ.get("FL_KBENCH_VARIANTS"))
 LIBDIR = os.path.join(HERE, "lib_kbench" if KBENCH else "lib")
 LIB = os.path.join(LIBDIR, "libflucahip.so")
-SOURCES = ["fl_coeff.cpp", "fl_kernels.hip", "fl_api.hip", "fl_ksp.hip", "fl_cheb2.hip", "fl_layout.hip", "fl_ibm.hip", "fl_momentum.hip", "fl_mg.hip"]
+SOURCES = ["fl_coeff.cpp", "fl_kernels.hip", "fl_api.hip", "fl_ksp.hip", "fl_cheb2.hip", "fl_layout.hip", "fl_ibm.hip", "fl_momentum.hip", "fl_mg.hip", "fl_schur_var.hip"]
 HEADERS = ["fl_internal.h", "fl_knobs.h", "fl_handle.h", "fl_device.h", "fl_stencil.h", "fl_mom_tile.h", "fl_mom_tile3.h", os.path.join("..", "..", "include", "fluca_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = (["-DFL_KBENCH_VARIANTS"] if KBENCH else []) + [f"-D{d}" for d in os.environ.get("FL_DEFINES", "").split()] + ([f"-DFL_MOM_WPE={int(os.environ['FL_MOM_WPE'])}"] if os.environ.get("FL_MOM_WPE") else []) + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",

@@ -332,6 +332,7 @@ struct fl_poisson {
   // solver workspace (padded vectors)
   double *r = nullptr, *P0 = nullptr, *P1 = nullptr, *q = nullptr, *xp = nullptr, *w0 = nullptr, *w1 = nullptr, *w2 = nullptr;
   double *cd1 = nullptr;  // second d buffer of the fused two-step Chebyshev kernel (fl_cheb2.hip)
+  void   *sv_pack[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // packed 1-D rows of the fused DIAG / ROWSUM Schur product (fl_schur_var.hip; freed with h->tables)
   double *rb = nullptr;   // where the three-step sweep from a zero guess writes the updated right-hand side; swaps roles with r afterwards
   std::vector<void *> vec_bases;
   void               *slab = nullptr;
@@ -458,6 +459,14 @@ bool      fl_cheb2_usable(const fl_poisson *h);
 int       fl_cheb2_agree(fl_poisson *h);  // collective on several ranks; fills h->cheb2_agreed
 Cheb2Plan fl_cheb2_plan(const GridP &g);
 void      fl_launch_cheb2(fl_poisson *h, const Cheb2Plan &p, bool jac, double *X0, double *X1, const double *B, double *D0, double *D1, bool mgdots = false);
+// the face-interpolation rows T (kind 0 of fl_momentum's FaceT) the fused DIAG / ROWSUM Schur product reads (fl_schur_var.hip)
+namespace fl {
+struct SchurVarT {
+  const double *w0[3], *w1[3];
+  const int    *c0[3];
+};
+}  // namespace fl
+int       fl_schur_var_apply_fused(fl_poisson *h, const fl::SchurVarT &t, const double *ainv, const double *p_pad, double *y);
 void      fl_launch_cheb2_from_zero(fl_poisson *h, const Cheb2Plan &p, bool jac, double *X0, double *X1, const double *B, double *D0, double *D1, const double *subq, const double *suba_dev, double *Bw);
 // fl_mg.hip
 int  fl_solve_cg_mg(fl_poisson *h, const double *b, double *x, const fl_ksp_opts *o, fl_ksp_stats *st);

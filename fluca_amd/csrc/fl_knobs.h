@@ -28,6 +28,7 @@
   X(mg_flexible, 1)       /* FL_PC_MG: 1 Polak-Ribiere beta (flexible CG), 0 KSPCG's */                                                      \
   X(mg_coarse, 1)         /* FL_PC_MG: 1 a coarsest level of <= 4096 cells on one rank is solved by one workgroup */                          \
   X(mg_post_smooth, 0)    /* FL_PC_MG: smoothing steps AFTER the coarse correction; 0 = as many as before it (fl_ksp_opts.mg_smooth_its) */           \
+  X(schur_var_fused, 1)   /* PCABF schurainv DIAG / ROWSUM on one rank: 1 the product S p in one pass (fl_schur_var.hip), 0 the composition of seven */   \
   X(overlap, 1)           /* several ranks: the exchange of the new residual hidden behind the update kernel; 0 sequential (A/B, tests) */   \
   X(comm_loopback, 0)     /* 1: a single rank sends the ghost layers of its periodic axes to itself through the communicator (tests) */      \
   X(comm_trace, 0)        /* 1: every host-staged exchange / smoother stage on stderr; 2: with a stream wait per stage */                     \

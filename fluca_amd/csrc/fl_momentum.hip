@@ -1652,6 +1652,18 @@ int schur_apply_var(fl_momentum *m, const double *p, double *y)
 {
   fl_poisson   *h = m->p;
   const int64_t N = h->ncell, n3 = 3 * N;
+  if (!h->multi && knob(K_schur_var_fused) != 0) {  // one pass over p and a^-1 (fl_schur_var.hip); several ranks keep the composition below
+    FL_CHK(fl_ensure_vec(h, &h->w0));
+    launch_pad_copy(h->stream, h->g, p, h->w0);
+    FL_CHK(fl_fill_ghosts(h, h->w0));
+    SchurVarT t;
+    for (int d = 0; d < 3; ++d) {
+      t.w0[d] = m->ft.w0[0][d];
+      t.w1[d] = m->ft.w1[0][d];
+      t.c0[d] = m->ft.c0[0][d];
+    }
+    return fl_schur_var_apply_fused(h, t, m->ainv[0], h->w0, y);
+  }
   FL_CHK(ensure_ainv_scratch(m));
   FL_HIP(hipMemsetAsync(m->gv, 0, sizeof(double) * (size_t)n3, h->stream));
   for (int d = 0; d < 3; ++d) FL_HIP(hipMemsetAsync(m->zV[d], 0, sizeof(double) * (size_t)h->nface[d], h->stream));

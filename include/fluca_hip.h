@@ -194,6 +194,8 @@ int fl_vec_maxpy(fl_poisson *h, int64_t n, double *x_dev, const double *alphas, 
  *   "cheb_fuse"  0 = one kernel launch per Chebyshev step; 1 (default) = two steps per sweep over memory wherever no convergence
  *                test sits between them (KSP_NORM_NONE sweeps, the multigrid smoother) and the grid is large enough to gain;
  *                2 = the same on every grid where it is legal.  On several ranks the ranks vote once per handle: fused only where all agree.
+ *   "schur_var_fused" 1 (default) = fl_abf_schur_apply / the Schur solve with schurainv DIAG or ROWSUM form S p in one pass on one rank
+ *                (fl_schur_var.hip); 0 = the composition of projection, scaling, face interpolation and divergence (A/B, tests; several ranks always)
  *   "cheb_zero3" 1 (default) = a smoother call that starts from a zero guess (the pre-smoother of a multigrid cycle) runs its first THREE steps in
  *                one sweep, the outer CG's residual update included, where "cheb_fuse" applies and the handle has one rank; 0 = first step and
  *                pair as separate launches (A/B, tests).  Same arithmetic either way.

@@ -233,7 +233,16 @@ def test_schur_complement_of_the_diag_and_rowsum_types(n, bc, nonuni, kind):
     want = fo.abf_schur_apply(g, ainv, p)
     # the oracle forms -T(a^-1 kGp) + T(kGp) term by term like MatMatMult + MatAXPY; the device scales by (a^-1 - 1) once: the two
     # differ by the cancellation in the former, relative to the size of the cancelling terms (larger than the result on stretched grids)
-    _close(host(M.schur_apply(dev(p))), want, tol=2e-10)
+    got = host(M.schur_apply(dev(p)))                                            # one pass (fl_schur_var.hip; round 5)
+    _close(got, want, tol=2e-10)
+    from fluca_amd import capi
+    capi.check(capi.lib.fl_tuning_set(b"schur_var_fused", 0))                    # ... and the composition of the seven kernels it replaces
+    try:
+        comp = host(M.schur_apply(dev(p)))
+    finally:
+        capi.check(capi.lib.fl_tuning_set(b"schur_var_fused", 1))
+    _close(comp, want, tol=2e-10)
+    _close(got, comp, tol=1e-12)
     M.set_ainv_types(schur=fo.AINV_ID)                                           # ID: the 7-point operator of the hot path
     _close(host(M.schur_apply(dev(p))), g.assemble_S().mult(p), tol=2e-13)
     _close(fo.abf_schur_apply(g, None, p), g.assemble_S().mult(p), tol=1e-9)     # and the oracle's composition cancels to it (abfpc.c:152-154,169)
