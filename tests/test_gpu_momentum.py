@@ -219,7 +219,7 @@ def _state(M, g, mu=0.05):
     return g.assemble_momentum(1.0, dt, -0.5 * mu * dt / rho, V0, W)
 
 
-@pytest.mark.parametrize("n,bc,nonuni", [CASES[0], CASES[2], CASES[3], CASES[5]])
+@pytest.mark.parametrize("n,bc,nonuni", [CASES[0], CASES[1], CASES[2], CASES[3], CASES[5], CASES[6], ((66, 4, 2), [PER] * 6, False)])   # ([1], [6], the last: the seam two cells deep on short axes)
 @pytest.mark.parametrize("kind", [fo.AINV_DIAG, fo.AINV_ROWSUM])
 def test_schur_complement_of_the_diag_and_rowsum_types(n, bc, nonuni, kind):
     """fl_abf_schur_apply == S = D ((-T) a^-1 kappa G - (-R)) of PCSetUp_ABF (abfpc.c:151-171), a = diag(A) or A 1."""
