@@ -353,7 +353,12 @@ __device__ __forceinline__ void st_body(const GridP &g, const double *__restrict
     for (int m = 0; m < RY; ++m) {
       R.v[m] = ld2<1>(stg + RO(m) + pl);
       if (NE >= 1) R.e[0][m] = ld2<1>(e0 + RO(m) + pr);
-      if (NE >= 2) R.e[1][m] = ld2<1>(e1 + RO(m) + pr);
+      if (NE >= 2) {
+        // MODE 6, first step of a recurrence (rho = 0: d is not looked at): its 8 B/cell are not fetched -- the post-smoother of every multigrid cycle
+        // starts with such a step
+        if (MODE == 6 && crho == 0.) R.e[1][m] = make_double2(0., 0.);
+        else R.e[1][m] = ld2<1>(e1 + RO(m) + pr);
+      }
       if (NE >= 3) R.e[NE >= 3 ? 2 : 0][m] = ld2<1>(e2 + RO(m) + pr);
     }
     R.hA = stg[tbase + pl + hAo];
