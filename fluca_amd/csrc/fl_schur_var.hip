@@ -79,13 +79,16 @@ __device__ __forceinline__ double sv_ldp(const double *__restrict__ p, int64_t p
 // composition); the rows pick their operands from the window by their first columns.
 // wraps: the axis is periodic inside this block -- face n is face 0 again, and a cell outside 0..n-1 is its image (ghost layers of p hold the
 // images of cells -1 and n; -2 and n+1 are fetched from where they live)
-__device__ __forceinline__ double sv_axis(const SvCell *__restrict__ ct, const SvFace *__restrict__ ft, const double *__restrict__ p, const double *__restrict__ ainv, int a, int n, bool wraps, int64_t pc0,
-                                          int64_t ps, int64_t uc0, int64_t us)
+// the rows an axis needs at cell a: of the cells a-1, a, a+1 (images across a periodic seam) and of the faces a, a+1
+struct SvRows {
+  SvCell c0, c1, c2;
+  SvFace r0, r1;
+  int    q0, q1, q2, f1;
+};
+__device__ __forceinline__ SvRows sv_rows(const SvCell *__restrict__ ct, const SvFace *__restrict__ ft, int a, int n, bool wraps)
 {
-  const double P0 = sv_ldp(p, pc0, ps, a - 2, n, wraps), P1 = sv_ldp(p, pc0, ps, a - 1, n, wraps), P2 = sv_ldp(p, pc0, ps, a, n, wraps), P3 = sv_ldp(p, pc0, ps, a + 1, n, wraps),
-               P4 = sv_ldp(p, pc0, ps, a + 2, n, wraps);
-  // the rows of the three cells and the two faces
-  int qw[3];
+  SvRows R;
+  int    qw[3];
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     const int q = a - 1 + r;
@@ -93,11 +96,25 @@ __device__ __forceinline__ double sv_axis(const SvCell *__restrict__ ct, const S
     if (q < 0) qw[r] = wraps ? q + n : 0;  // (a physical boundary: the T row carries no weight on a cell that does not exist)
     else if (q >= n) qw[r] = wraps ? q - n : n - 1;
   }
-  const SvCell c0 = ct[qw[0]], c1 = ct[qw[1]], c2 = ct[qw[2]];
-  const int    f1 = (a + 1 == n && wraps) ? 0 : a + 1;
-  const SvFace r0 = ft[a], r1 = ft[f1];
-  const double w0 = ainv[uc0 + qw[0] * us] - 1., w1 = ainv[uc0 + qw[1] * us] - 1., w2 = ainv[uc0 + qw[2] * us] - 1.;
-  const double hinv = c1.idx;
+  R.q0 = qw[0]; R.q1 = qw[1]; R.q2 = qw[2];
+  R.c0 = ct[qw[0]]; R.c1 = ct[qw[1]]; R.c2 = ct[qw[2]];
+  R.f1 = (a + 1 == n && wraps) ? 0 : a + 1;
+  R.r0 = ft[a];
+  R.r1 = ft[R.f1];
+  return R;
+}
+
+__device__ __forceinline__ double sv_axis(const SvRows &R, const double *__restrict__ p, const double *__restrict__ ainv, int a, int n, bool wraps, int64_t pc0,
+                                          int64_t ps, int64_t uc0, int64_t us)
+{
+  const double P0 = sv_ldp(p, pc0, ps, a - 2, n, wraps), P1 = sv_ldp(p, pc0, ps, a - 1, n, wraps), P2 = sv_ldp(p, pc0, ps, a, n, wraps), P3 = sv_ldp(p, pc0, ps, a + 1, n, wraps),
+               P4 = sv_ldp(p, pc0, ps, a + 2, n, wraps);
+  const SvCell &c0 = R.c0, &c1 = R.c1, &c2 = R.c2;
+  const SvFace &r0 = R.r0, &r1 = R.r1;
+  const int     f1 = R.f1;
+  const int     qw[3] = {R.q0, R.q1, R.q2};
+  const double  w0 = ainv[uc0 + qw[0] * us] - 1., w1 = ainv[uc0 + qw[1] * us] - 1., w2 = ainv[uc0 + qw[2] * us] - 1.;
+  const double  hinv = c1.idx;
   // first columns relative to the window / to the three gradients
   const int e0 = c0.gs - qw[0] + 1, e1 = c1.gs - qw[1] + 2, e2 = c2.gs - qw[2] + 3;   // G rows: 0, 1, 2 away from walls
   const int k0 = r0.gc0 - a + 2, k1 = r1.gc0 - f1 + 3;                                // Gst rows: 1, 2
@@ -139,14 +156,19 @@ __global__ void __launch_bounds__(256) k_schur_var(SvGrid g, int per, const doub
   const int     nseg = (g.nx + 63) / 64, nj = j1 - j0;
   const int64_t nitem = (int64_t)nseg * nj * g.nz, N = (int64_t)g.nx * g.ny * g.nz;
   const bool    wx = per & 1, wy = per & 2, wz = per & 4;
+  // a wave's stride is a multiple of the segments per row whenever the launch allows it: the wave then keeps ONE x segment for all its rows, and
+  // the x rows of its lanes' cells (15 16-byte loads per lane) are fetched once instead of once per row
+  const bool   fixed_seg = ((int64_t)nlb * nw) % nseg == 0;
+  const int    seg0 = (int)(((int64_t)lb * nw + w) % nseg), i0 = min(seg0 * 64 + lane, g.nx - 1);
+  const SvRows X0 = sv_rows(g.c[0], g.f[0], i0, g.nx, wx);
   for (int64_t it = (int64_t)lb * nw + w; it < nitem; it += (int64_t)nlb * nw) {
     const int seg = (int)(it % nseg), row = (int)(it / nseg);
     const int j = j0 + row % nj, k = row / nj, i = seg * 64 + lane;
     if (i >= g.nx) continue;
     const int64_t prow = g.off0 + (int64_t)k * g.sxy + (int64_t)j * g.sx, urow = ((int64_t)k * g.ny + j) * g.nx;
-    double acc = sv_axis(g.c[0], g.f[0], p, ainv, i, g.nx, wx, prow, 1, urow, 1);
-    acc += sv_axis(g.c[1], g.f[1], p, ainv + N, j, g.ny, wy, g.off0 + (int64_t)k * g.sxy + i, g.sx, (int64_t)k * g.ny * g.nx + i, g.nx);
-    acc += sv_axis(g.c[2], g.f[2], p, ainv + 2 * N, k, g.nz, wz, g.off0 + (int64_t)j * g.sx + i, g.sxy, (int64_t)j * g.nx + i, (int64_t)g.nx * g.ny);
+    double acc = sv_axis(fixed_seg ? X0 : sv_rows(g.c[0], g.f[0], i, g.nx, wx), p, ainv, i, g.nx, wx, prow, 1, urow, 1);
+    acc += sv_axis(sv_rows(g.c[1], g.f[1], j, g.ny, wy), p, ainv + N, j, g.ny, wy, g.off0 + (int64_t)k * g.sxy + i, g.sx, (int64_t)k * g.ny * g.nx + i, g.nx);
+    acc += sv_axis(sv_rows(g.c[2], g.f[2], k, g.nz, wz), p, ainv + 2 * N, k, g.nz, wz, g.off0 + (int64_t)j * g.sx + i, g.sxy, (int64_t)j * g.nx + i, (int64_t)g.nx * g.ny);
     y[urow + i] = -g.kappa * acc;
   }
 }
@@ -158,7 +180,7 @@ using namespace fl;
 // p_pad: padded, ghost layers filled (fl_fill_ghosts); ainv: 3 * cells, unpadded, component-major; y: cells, unpadded.  One rank.
 // t: the T rows (kind 0) of the caller's fl_momentum -- like the other tables a function of the grid and the boundary types only: packed once per handle
 #ifndef FL_SV_BLOCKS_PER_XCD
-#define FL_SV_BLOCKS_PER_XCD 128
+#define FL_SV_BLOCKS_PER_XCD 96
 #endif
 int fl_schur_var_apply_fused(fl_poisson *h, const SchurVarT &t, const double *ainv, const double *p_pad, double *y)
 {
