@@ -147,7 +147,10 @@ __device__ __forceinline__ double sv_axis(const SvRows &R, const double *__restr
 }
 
 // y (unpadded) = S p.  Grid: a multiple of 8 blocks; block b works for XCD b % 8 on the y band of that XCD.
-__global__ void __launch_bounds__(256) k_schur_var(SvGrid g, int per, const double *__restrict__ p, const double *__restrict__ ainv, double *__restrict__ y)
+#ifndef FL_SV_MINBLOCKS
+#define FL_SV_MINBLOCKS 4   // four blocks per CU: 128 blocks per XCD are resident and cover exactly one plane of the XCD's band per loop trip
+#endif
+__global__ void __launch_bounds__(256, FL_SV_MINBLOCKS) k_schur_var(SvGrid g, int per, const double *__restrict__ p, const double *__restrict__ ainv, double *__restrict__ y)
 {
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
   const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, nlb = gridDim.x >> 3;
@@ -180,7 +183,7 @@ using namespace fl;
 // p_pad: padded, ghost layers filled (fl_fill_ghosts); ainv: 3 * cells, unpadded, component-major; y: cells, unpadded.  One rank.
 // t: the T rows (kind 0) of the caller's fl_momentum -- like the other tables a function of the grid and the boundary types only: packed once per handle
 #ifndef FL_SV_BLOCKS_PER_XCD
-#define FL_SV_BLOCKS_PER_XCD 96
+#define FL_SV_BLOCKS_PER_XCD 128
 #endif
 int fl_schur_var_apply_fused(fl_poisson *h, const SchurVarT &t, const double *ainv, const double *p_pad, double *y)
 {
@@ -209,8 +212,10 @@ int fl_schur_var_apply_fused(fl_poisson *h, const SchurVarT &t, const double *ai
   int per = 0;
   for (int d = 0; d < 3; ++d) per |= h->wrap_local[d] ? (1 << d) : 0;
   const int64_t items = (int64_t)((g.nx + 63) / 64) * g.ny * g.nz;
-  // blocks per XCD: every block must be RESIDENT (4 per CU at 86 VGPRs, 32 CUs) -- the blocks of an XCD walk their band in step, and one that starts
-  // late walks it again alone, when the planes its neighbours brought in have left the L2 (256 per XCD: 67.7 B/cell fetched instead of 32)
+  // blocks per XCD: every block must be RESIDENT (four per CU, 32 CUs) -- the blocks of an XCD walk their band in step, and one that starts late walks
+  // it again alone, when the planes its neighbours brought in have left the L2 -- and the rows they cover per loop trip should divide the band (64 rows
+  // at 512^3), or the waves straddle two planes: 256 blocks 67.7 B/cell fetched, 96 (48 rows per trip) 84.1, 128 63.5, 64 43.7, 32 36.1 (32 compulsory;
+  // fewer blocks are slower all the same: profiles/r05_schur_var.txt)
   const int     per_xcd = (int)std::max<int64_t>(1, std::min<int64_t>((items / 8 + 3) / 4, FL_SV_BLOCKS_PER_XCD));
   hipLaunchKernelGGL(k_schur_var, dim3(8 * per_xcd), dim3(256), 0, h->stream, sg, per, p_pad, ainv, y);
   FL_HIP(hipGetLastError());
